@@ -1,0 +1,164 @@
+"""Generate the golden fixtures in tests/golden/*.npz by running the REFERENCE's own models/uit.py on torch CPU.
+
+Run only in the build container (needs /root/reference):
+    PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden.py
+
+The reference module is imported unmodified from where it lies (see _ref_shims.py for the three stand-in
+packages); the weights are the deterministic synthetic checkpoints of synth_weights.py loaded with
+`load_state_dict(strict=True)` (this pins the state_dict key set and shapes too).  Everything stored is data:
+inputs (int16 PCM; float input = pcm/32768, exact) and the reference's outputs at the stage boundaries of
+SURVEY.md section 8a.  Stage tensors are captured with forward hooks on the reference's own sub-modules.
+"""
+import sys
+from pathlib import Path
+
+import numpy as np
+import torch
+
+HERE = Path(__file__).resolve().parent
+sys.path.insert(0, str(HERE))
+# imported BEFORE the stand-in torchaudio module is installed (transformers probes for the real package)
+from transformers.audio_utils import mel_filter_bank, spectrogram  # noqa: E402
+import _ref_shims  # noqa: E402
+from synth_weights import make_state_dict, synth_pcm_i16  # noqa: E402
+
+REF = Path("/root/reference")
+uit = _ref_shims.import_reference_uit(str(REF))
+torch.set_num_threads(8)
+torch.manual_seed(0)
+
+
+def build_ref(name, seed, scale, outputdim=537, eval_avg="mean"):
+    m = getattr(uit, name)(outputdim=outputdim, target_length=102, eval_avg=eval_avg)
+    sd = {k: torch.from_numpy(np.asarray(v)) for k, v in make_state_dict(name, seed, scale, outputdim).items()}
+    missing = set(m.state_dict().keys()) ^ set(sd.keys())
+    assert not missing, missing
+    m.load_state_dict(sd, strict=True)
+    return m.eval()
+
+
+def run_ref(m, pcm_i16, stages_for=0):
+    """-> dict of reference outputs for wave = pcm/32768 (dataset.py:44-46 convention)."""
+    wave = torch.from_numpy(pcm_i16.astype(np.float32) / 32768.0)
+    cap = {}
+    hooks = [m.front_end.register_forward_hook(lambda mod, i, o: cap.__setitem__("mel_db", o.detach().clone()))]
+    toks = []
+    if stages_for:
+        # tokens entering blocks[0] == patch-embed + pos (+flatten); then the output of every block
+        hooks.append(m.blocks[0].register_forward_pre_hook(lambda mod, i: toks.append(i[0].detach().clone())))
+        for blk in m.blocks:
+            hooks.append(blk.register_forward_hook(lambda mod, i, o: toks.append(o.detach().clone())))
+    pre = []
+    hooks.append(m.outputlayer.register_forward_hook(lambda mod, i, o: pre.append(o.detach().clone())))
+    with torch.no_grad():
+        probs = m(wave)
+    for h in hooks:
+        h.remove()
+    out = dict(probs=probs.numpy(), mel_db=cap["mel_db"].numpy(),
+               logits=torch.stack(pre, 1).numpy())           # [B, ncrops, C]
+    if stages_for:
+        depth = len(m.blocks)
+        ncrops = len(pre)
+        st = torch.stack(toks, 0).reshape(ncrops, depth + 1, *toks[0].shape)   # [ncrops, depth+1, B, N, D]
+        out["stages"] = st.permute(2, 0, 1, 3, 4)[:stages_for].contiguous().numpy()
+    return out
+
+
+def read_wav_i16(path):
+    from scipy.io import wavfile
+    sr, data = wavfile.read(path)
+    assert sr == 16000 and data.dtype == np.int16 and data.ndim == 1
+    return data
+
+
+def crosscheck_frontend():
+    """Independent check of the torchaudio restatement against transformers.audio_utils (numpy)."""
+    pcm = read_wav_i16(REF / "samples/water_000.wav").astype(np.float32) / 32768.0
+    fe = torch.nn.Sequential(_ref_shims.MelSpectrogram(f_min=0, sample_rate=16000, win_length=512, center=True,
+                                                       n_fft=512, f_max=8000, hop_length=160, n_mels=64),
+                             _ref_shims.AmplitudeToDB(top_db=120))
+    ours = fe(torch.from_numpy(pcm)[None])[0].numpy()
+    fb = mel_filter_bank(257, 64, 0.0, 8000.0, 16000, norm=None, mel_scale="htk")
+    win = (0.5 - 0.5 * np.cos(2 * np.pi * np.arange(512) / 512))
+    theirs = spectrogram(pcm.astype(np.float64), win, 512, 160, fft_length=512, power=2.0, center=True,
+                         pad_mode="reflect", mel_filters=fb, log_mel="dB", reference=1.0, min_value=1e-10,
+                         db_range=120.0)
+    d_fb = np.abs(fe[0].mel_scale.fb.numpy() - fb).max()
+    d_db = np.abs(ours - theirs).max()
+    print(f"[crosscheck] transformers.audio_utils: fb max diff {d_fb:.2e}, dB max diff {d_db:.2e} {ours.shape}")
+    assert d_fb < 1e-4 and d_db < 5e-3
+    sd = make_state_dict("uit_xxxs", 0)
+    assert np.abs(sd["front_end.0.mel_scale.fb"] - fe[0].mel_scale.fb.numpy()).max() < 2e-5
+    assert np.abs(sd["front_end.0.spectrogram.window"] - fe[0].spectrogram.window.numpy()).max() < 1e-6
+    return float(d_fb), float(d_db)
+
+
+def main():
+    d_fb, d_db = crosscheck_frontend()
+    meta = dict(crosscheck_fb=d_fb, crosscheck_db=d_db)
+
+    # ---- case 1: synthetic 1 s batch (silent + loud + quiet clips -> batch-global top_db floor)
+    pcm = synth_pcm_i16(8, 16000, seed=0)
+    pcm[5] = 0                                               # a fully silent clip
+    for name, seed in (("uit_xxxs", 11), ("uit_xxs", 12), ("uit_xs", 13)):
+        m = build_ref(name, seed, 1.0)
+        r = run_ref(m, pcm, stages_for=2)
+        np.savez_compressed(HERE / f"synth1s_{name}.npz", pcm=pcm, seed=seed, scale=1.0, **r)
+        print(name, "probs", r["probs"].shape, "logit range", r["logits"].min(), r["logits"].max(),
+              "mel", r["mel_db"].min(), r["mel_db"].max())
+    # larger-magnitude weights (x3) for the precision modes
+    m = build_ref("uit_xs", 14, 3.0)
+    r = run_ref(m, pcm[:4])
+    np.savez_compressed(HERE / "synth1s_uit_xs_scale3.npz", pcm=pcm[:4], seed=14, scale=3.0,
+                        probs=r["probs"], logits=r["logits"])
+
+    # ---- case 2: the reference's sample clips (config #1: water_000 = 16384 samples -> 2 crops)
+    for name, seed in (("uit_xs", 13), ("uit_xxxs", 11)):
+        m = build_ref(name, seed, 1.0)
+        out = {}
+        for wav in ("water_000.wav", "water_003.wav", "85b877b5_nohash_0.wav"):
+            p = read_wav_i16(REF / "samples" / wav)
+            r = run_ref(m, p[None])
+            key = wav.split(".")[0]
+            out[f"{key}_pcm"] = p
+            out[f"{key}_probs"] = r["probs"][0]
+            out[f"{key}_logits"] = r["logits"][0]
+            print(name, wav, len(p), "crops", r["logits"].shape[1], "top3", np.argsort(-r["probs"][0])[:3])
+        # evaluate.py:56-64 pad rule on the 16000-sample GSC clip: diff = int((101 - T/160)*160) = 160
+        p = read_wav_i16(REF / "samples/85b877b5_nohash_0.wav")
+        diff = int((102 - 1 - len(p) / 160) * 160)
+        pp = np.concatenate([p, np.zeros(diff, np.int16)])
+        r = run_ref(m, pp[None])
+        out["gsc_padded_pcm"], out["gsc_padded_probs"], out["gsc_pad_diff"] = pp, r["probs"][0], diff
+        np.savez_compressed(HERE / f"samples_{name}.npz", seed=seed, **out)
+
+    # ---- case 3: long clip -> multi-crop with tail re-crop (313 frames -> 102,102,102,tail), mean and max
+    pcm_long = synth_pcm_i16(2, 50000, seed=3)
+    for avg in ("mean", "max"):
+        m = build_ref("uit_xxxs", 11, 1.0, eval_avg=avg)
+        r = run_ref(m, pcm_long)
+        np.savez_compressed(HERE / f"long_{avg}_uit_xxxs.npz", pcm=pcm_long, seed=11, probs=r["probs"],
+                            logits=r["logits"], mel_db=r["mel_db"])
+        print("long", avg, r["logits"].shape)
+
+    # ---- case 4: short clip (8000 samples -> 51 frames -> 3 time patches, 12 tokens), and 527 classes
+    pcm_short = synth_pcm_i16(3, 8000, seed=4)
+    m = build_ref("uit_xxxs", 11, 1.0)
+    r = run_ref(m, pcm_short, stages_for=1)
+    np.savez_compressed(HERE / "short_uit_xxxs.npz", pcm=pcm_short, seed=11, **r)
+    m = build_ref("uit_xxs", 15, 1.0, outputdim=527)
+    r = run_ref(m, pcm[:3])
+    np.savez_compressed(HERE / "synth1s_uit_xxs_527.npz", pcm=pcm[:3], seed=15, probs=r["probs"], logits=r["logits"])
+
+    # ---- pos-embed resize (models/uit.py:416-450): checkpoint with a longer time_pos_embed -> truncated
+    sd = make_state_dict("uit_xxxs", 11, 1.0, target_length=160)
+    m = getattr(uit, "uit_xxxs")(outputdim=537, target_length=102)
+    m.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()}, strict=True)
+    r = run_ref(m.eval(), pcm[:2])
+    np.savez_compressed(HERE / "posresize_uit_xxxs.npz", pcm=pcm[:2], seed=11, probs=r["probs"])
+    np.savez(HERE / "meta.npz", **meta)
+    print("done")
+
+
+if __name__ == "__main__":
+    main()

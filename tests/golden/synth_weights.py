@@ -1,0 +1,99 @@
+"""Deterministic synthetic checkpoints in the reference's state_dict layout (numpy only).
+
+No pretrained UiT checkpoint is reachable from the build container (zenodo, models/uit.py:643-653), so parity
+is pinned on seeded weights.  The SAME function is used by make_golden.py (to load the weights into the
+reference's own UITBase with strict=True -- which also pins the key set / shapes) and by the tests and bench
+(to feed the oracle and the HIP path), so the weights never have to be committed.
+
+Distributions follow the reference init (models/uit.py:329-336, 369-376; Conv2d default init) but with
+non-trivial biases, LayerNorm gains and BatchNorm running stats so every folded term is exercised; `scale`
+multiplies the matmul weights to mimic trained magnitudes.
+"""
+import math
+
+import numpy as np
+
+DEPTH = {"uit_xs": 12, "uit_xxs": 6, "uit_xxxs": 4}
+
+
+def hann_periodic(n):
+    return (0.5 - 0.5 * np.cos(2.0 * np.pi * np.arange(n, dtype=np.float64) / n)).astype(np.float32)
+
+
+def melscale_fbanks(n_freqs=257, f_min=0.0, f_max=8000.0, n_mels=64, sample_rate=16000):
+    """float32 restatement of torchaudio.functional.melscale_fbanks (htk, norm=None)."""
+    all_freqs = np.linspace(0, sample_rate // 2, n_freqs, dtype=np.float32)
+    m_min = 2595.0 * math.log10(1.0 + f_min / 700.0)
+    m_max = 2595.0 * math.log10(1.0 + f_max / 700.0)
+    m_pts = np.linspace(m_min, m_max, n_mels + 2, dtype=np.float32)
+    f_pts = (700.0 * (np.power(np.float32(10.0), m_pts / np.float32(2595.0)) - 1.0)).astype(np.float32)
+    f_diff = f_pts[1:] - f_pts[:-1]
+    slopes = f_pts[None, :] - all_freqs[:, None]
+    down = -slopes[:, :-2] / f_diff[:-1]
+    up = slopes[:, 2:] / f_diff[1:]
+    return np.maximum(0.0, np.minimum(down, up)).astype(np.float32)
+
+
+def make_state_dict(name="uit_xs", seed=0, scale=1.0, outputdim=537, target_length=102, dim=128, n_mels=64):
+    depth = DEPTH[name]
+    rng = np.random.default_rng(seed)
+    gt, gf, inner, hidden = target_length // 16, n_mels // 16, dim // 4, int(dim * 3.0)
+
+    def tn(*shape, std=0.02):
+        return (np.clip(rng.standard_normal(shape), -2.0, 2.0) * std * scale).astype(np.float32)
+
+    def nrm(*shape, std=1.0, mean=0.0):
+        return (mean + std * rng.standard_normal(shape)).astype(np.float32)
+
+    sd = {}
+    sd["cls_token"] = nrm(1, 1, dim, std=1e-6)
+    sd["token_pos_embed"] = nrm(1, dim, std=0.02)
+    sd["time_pos_embed"] = nrm(1, dim, 1, gt, std=0.02)
+    sd["freq_pos_embed"] = nrm(1, dim, gf, 1, std=0.02)
+    sd["front_end.0.spectrogram.window"] = hann_periodic(512)
+    sd["front_end.0.mel_scale.fb"] = melscale_fbanks(257, 0.0, 8000.0, n_mels, 16000)
+    sd["init_bn.1.weight"] = nrm(n_mels, std=0.2, mean=1.0)
+    sd["init_bn.1.bias"] = nrm(n_mels, std=0.1)
+    sd["init_bn.1.running_mean"] = nrm(n_mels, std=10.0, mean=-30.0)
+    sd["init_bn.1.running_var"] = (200.0 + 400.0 * rng.random(n_mels)).astype(np.float32)
+    sd["init_bn.1.num_batches_tracked"] = np.array(1000, dtype=np.int64)
+    bound = 1.0 / 16.0
+    sd["patch_embed.proj.weight"] = ((rng.random((dim, 1, 16, 16)) * 2 - 1) * bound * scale).astype(np.float32)
+    sd["patch_embed.proj.bias"] = ((rng.random(dim) * 2 - 1) * bound).astype(np.float32)
+    for b in range(depth):
+        p = f"blocks.{b}."
+        sd[p + "norm1.weight"] = nrm(dim, std=0.3, mean=1.0)
+        sd[p + "norm1.bias"] = nrm(dim, std=0.1)
+        sd[p + "attn.qkv.weight"] = tn(3 * inner, dim)
+        sd[p + "attn.qkv.bias"] = nrm(3 * inner, std=0.1)
+        sd[p + "attn.proj.weight"] = tn(dim, inner)
+        sd[p + "attn.proj.bias"] = nrm(dim, std=0.1)
+        sd[p + "norm2.weight"] = nrm(dim, std=0.3, mean=1.0)
+        sd[p + "norm2.bias"] = nrm(dim, std=0.1)
+        sd[p + "mlp.fc1.weight"] = tn(hidden, dim)
+        sd[p + "mlp.fc1.bias"] = nrm(hidden, std=0.1)
+        sd[p + "mlp.fc2.weight"] = tn(dim, hidden)
+        sd[p + "mlp.fc2.bias"] = nrm(dim, std=0.1)
+    sd["norm.weight"] = nrm(dim, std=0.3, mean=1.0)
+    sd["norm.bias"] = nrm(dim, std=0.1)
+    sd["outputlayer.0.weight"] = nrm(dim, std=0.3, mean=1.0)
+    sd["outputlayer.0.bias"] = nrm(dim, std=0.1)
+    sd["outputlayer.1.weight"] = tn(outputdim, dim)
+    sd["outputlayer.1.bias"] = nrm(outputdim, std=0.1)
+    return sd
+
+
+def synth_pcm_i16(B, T, seed=0):
+    """Bench/test input generator: uniform noise in [-0.5,0.5) as int16 PCM; every 8th clip is a
+    loud 1 kHz-ish tone burst, every 8th+1 clip is digital silence over its last quarter (exercises the floor)."""
+    rng = np.random.default_rng(1000 + seed)
+    x = (rng.random((B, T), dtype=np.float32) - 0.5)
+    t = np.arange(T, dtype=np.float32)
+    for b in range(B):
+        if b % 8 == 1:
+            x[b] = 0.9 * np.sin(2 * np.pi * (440.0 + 37.0 * b) * t / 16000.0)
+        if b % 8 == 2:
+            x[b, T - T // 4:] = 0.0
+        if b % 8 == 3:
+            x[b] *= 0.001
+    return np.clip(np.round(x * 32768.0), -32768, 32767).astype(np.int16)

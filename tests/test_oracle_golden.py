@@ -1,0 +1,102 @@
+"""Pins the CPU oracle (oracle/uit_oracle.c) against the fixtures produced by the reference's own
+models/uit.py on torch CPU (tests/golden/make_golden.py).  CPU only.
+
+Tolerances: the oracle is fp32 like the reference; differences are summation-order noise.
+  mel dB   : graded by depth below the clip's peak, 5e-4 .. 0.25 dB (fp32 FFT round-off floor, see
+             conftest.assert_mel_close)
+  tokens   : 2e-5 abs per stage (5e-3 for the pure-tone clip)
+  logits   : 1e-4 abs, probs 5e-5 abs   (the product gate vs the oracle is 1e-3)
+"""
+import numpy as np
+import pytest
+
+from oracle.oracle import Oracle
+from synth_weights import make_state_dict
+from conftest import assert_mel_close
+
+MODELS = ["uit_xxxs", "uit_xxs", "uit_xs"]
+
+
+def _oracle(name, seed, scale=1.0, **kw):
+    return Oracle(make_state_dict(name, int(seed), float(scale), **{k: v for k, v in kw.items() if k == "outputdim"}),
+                  **{k: v for k, v in kw.items() if k != "outputdim"})
+
+
+@pytest.mark.parametrize("name", MODELS)
+def test_synth_1s_all_stages(golden, name):
+    g = golden(f"synth1s_{name}")
+    o = _oracle(name, g["seed"])
+    r = o.forward(g["pcm"], want_stages=True)
+    assert r["mel_db"].shape == g["mel_db"].shape == (8, 64, 101)
+    assert_mel_close(r["mel_db"], g["mel_db"])
+    # the batch contains digital silence: the floor must be batch-global (amax - 120), SURVEY 8a row 3
+    assert g["mel_db"].min() == pytest.approx(g["mel_db"].max() - 120.0, abs=1e-4)
+    assert r["mel_db"].min() == pytest.approx(r["mel_db"].max() - 120.0, abs=1e-4)
+    ns = g["stages"].shape[0]
+    assert np.abs(r["stages"][0] - g["stages"][0]).max() < 2e-5          # noise clip
+    # clip 1 is a full-scale pure tone: nearly all of its bins sit on the FFT round-off floor (see
+    # assert_mel_close), which BN + patch-embed turn into ~1e-3 token differences; logits still agree to 1e-4
+    assert np.abs(r["stages"][1] - g["stages"][1]).max() < 5e-3
+    assert np.abs(r["logits"] - g["logits"]).max() < 1e-4
+    assert np.abs(r["probs"] - g["probs"]).max() < 5e-5
+
+
+def test_int16_and_float_inputs_agree(golden):
+    g = golden("synth1s_uit_xxxs")
+    o = _oracle("uit_xxxs", g["seed"])
+    a = o.forward(g["pcm"][:3])["probs"]
+    b = o.forward(g["pcm"][:3].astype(np.float32) / 32768.0)["probs"]
+    assert np.array_equal(a, b)
+
+
+def test_scaled_weights(golden):
+    g = golden("synth1s_uit_xs_scale3")
+    r = _oracle("uit_xs", g["seed"], g["scale"]).forward(g["pcm"])
+    assert np.abs(r["logits"] - g["logits"]).max() < 3e-4
+    assert np.abs(r["probs"] - g["probs"]).max() < 1e-4   # x3 weights amplify the pure-tone clip (index 1)
+
+
+@pytest.mark.parametrize("name", ["uit_xs", "uit_xxxs"])
+def test_reference_sample_clips(golden, name):
+    """BASELINE config #1 inputs: water_000 (16384 samples -> 103 frames -> 2 crops) and the GSC clip."""
+    g = golden(f"samples_{name}")
+    o = _oracle(name, g["seed"])
+    for key, ncrops in (("water_000", 2), ("water_003", 2), ("85b877b5_nohash_0", 1)):
+        pcm = g[f"{key}_pcm"][None]
+        assert o.num_crops(pcm.shape[1]) == ncrops
+        r = o.forward(pcm)
+        assert np.abs(r["logits"][0] - g[f"{key}_logits"]).max() < 1e-4
+        assert np.abs(r["probs"][0] - g[f"{key}_probs"]).max() < 5e-5
+    # evaluate.py:56-64 pad rule: 16000 -> 16160 samples (102 frames, single crop)
+    assert int(g["gsc_pad_diff"]) == 160
+    r = o.forward(g["gsc_padded_pcm"][None])
+    assert o.num_crops(16160) == 1
+    assert np.abs(r["probs"][0] - g["gsc_padded_probs"]).max() < 5e-5
+
+
+@pytest.mark.parametrize("avg", ["mean", "max"])
+def test_long_clip_multicrop(golden, avg):
+    """313 frames -> crops at 0,102,204 and the re-cropped tail (last 102 frames), models/uit.py:474-488."""
+    g = golden(f"long_{avg}_uit_xxxs")
+    o = _oracle("uit_xxxs", g["seed"], eval_avg=avg)
+    assert o.num_crops(g["pcm"].shape[1]) == 4
+    r = o.forward(g["pcm"])
+    assert_mel_close(r["mel_db"], g["mel_db"])
+    assert np.abs(r["logits"] - g["logits"]).max() < 1e-4
+    assert np.abs(r["probs"] - g["probs"]).max() < 5e-5
+
+
+def test_short_clip_fewer_time_patches(golden):
+    """8000 samples -> 51 frames -> 3 time patches -> 12 tokens, time_pos_embed[..., :3] (models/uit.py:382)."""
+    g = golden("short_uit_xxxs")
+    r = _oracle("uit_xxxs", g["seed"]).forward(g["pcm"], want_stages=True)
+    assert g["stages"].shape[-2] == 12 and r["stages"].shape[-2] == 12
+    assert np.abs(r["stages"][:1] - g["stages"]).max() < 2e-4
+    assert np.abs(r["probs"] - g["probs"]).max() < 5e-5
+
+
+def test_527_classes(golden):
+    g = golden("synth1s_uit_xxs_527")
+    r = _oracle("uit_xxs", g["seed"], outputdim=527).forward(g["pcm"])
+    assert r["probs"].shape == (3, 527)
+    assert np.abs(r["probs"] - g["probs"]).max() < 5e-5
