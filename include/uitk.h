@@ -1,0 +1,158 @@
+/*
+ * uitk.h -- C ABI of libuitk.so: MI355X-native batched inference for the UiT audio models
+ *           (log-mel front-end + UiT encoder + head), the hot path of RicherMans/UIT_Mobile.
+ *
+ * The reference has no FFI: its boundary for this path is the Python nn.Module API of models/uit.py
+ * (factories uit_xs/uit_xxs/uit_xxxs :581-635, UITBase.__init__ :253-363, load_state_dict :416-423,
+ * forward :452-493), called from inference.py:55 and evaluate.py:65.  The Python wrapper in
+ * uit_mobile_amd/models/uit.py keeps that API and calls these entry points through ctypes; nothing else
+ * does.  Each entry point names the reference interface it stands in for.
+ *
+ * Conventions: plain pointers and sizes, int return codes (0 = ok, no exceptions across the boundary),
+ * caller owns input/output device buffers, the model owns packed weights + workspace, every call is
+ * enqueue-only on the HIP stream passed in (no host synchronisation) once the workspace is reserved.
+ * One model handle per device; a handle is not re-entrant.  There is NO CPU implementation behind this
+ * ABI: without a HIP device uitk_create() fails with UITK_ERR_NO_DEVICE.
+ */
+#ifndef UITK_H
+#define UITK_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define UITK_OK 0
+#define UITK_ERR_INVALID_ARG (-1)   /* null pointer, bad size */
+#define UITK_ERR_UNSUPPORTED (-2)   /* configuration outside the uit_* family this library is built for */
+#define UITK_ERR_NO_DEVICE (-3)     /* no HIP device / HIP runtime error at create */
+#define UITK_ERR_HIP (-4)           /* HIP runtime error (see uitk_last_error) */
+#define UITK_ERR_TOO_SHORT (-5)     /* clip shorter than n_fft/2+1 samples (reflect pad) or than one patch */
+#define UITK_ERR_WORKSPACE (-6)     /* workspace too small and growth not allowed (stream capture) */
+
+typedef enum uitk_in_dtype {
+    UITK_IN_F32 = 0, /* float32 in [-1,1): what torchaudio.load / the collate hand the model (inference.py:52) */
+    UITK_IN_I16 = 1  /* int16 PCM as stored (dataset.py:44-46); the x(1/32768) is fused into the load       */
+} uitk_in_dtype;
+
+typedef enum uitk_precision {
+    UITK_PREC_F16 = 0,  /* fp16 MFMA operands, fp32 accumulate/residual/LN/softmax (default: meets 1e-3) */
+    UITK_PREC_BF16 = 1  /* bf16 MFMA operands, same structure (same MFMA rate, ~8x the operand rounding) */
+} uitk_precision;
+
+typedef enum uitk_eval_avg { UITK_AVG_MEAN = 0, UITK_AVG_MAX = 1 } uitk_eval_avg; /* models/uit.py:483-488 */
+
+/* Mirrors the UITBase.__init__ kwargs that matter in eval mode (models/uit.py:253-293, factories :581-635). */
+typedef struct uitk_config {
+    int32_t depth;         /* 12 / 6 / 4                                   uit.py:585,623,604 */
+    int32_t embed_dim;     /* 128                                           uit.py:584 */
+    int32_t num_heads;     /* 2                                             uit.py:586 */
+    int32_t mlp_hidden;    /* int(embed_dim*mlp_ratio) = 384                uit.py:237,587 */
+    int32_t outputdim;     /* 537 (527 also used)                           uit.py:642, evaluate.py:33 */
+    int32_t target_length; /* 102                                           uit.py:642 */
+    int32_t n_mels;        /* 64   uit.py:287 */
+    int32_t n_fft;         /* 512  uit.py:288 */
+    int32_t hop_size;      /* 160  uit.py:289 */
+    int32_t win_size;      /* 512  uit.py:290 */
+    int32_t patch_size;    /* 16 (== stride)  uit.py:583 */
+    int32_t center;        /* 1    uit.py:293 */
+    int32_t eval_avg;      /* uitk_eval_avg   uit.py:294 */
+    int32_t precision;     /* uitk_precision */
+    float top_db;          /* 120  uit.py:307 */
+} uitk_config;
+
+/* Per-block parameters, fp32 host pointers in the reference's state_dict layout (blocks.N.*). */
+typedef struct uitk_block_weights {
+    const float* norm1_w; const float* norm1_b; /* [128]      uit.py:223  (eps 1e-6, :337) */
+    const float* qkv_w;   const float* qkv_b;   /* [96,128],[96]   uit.py:103 */
+    const float* proj_w;  const float* proj_b;  /* [128,32],[128]  uit.py:105 */
+    const float* norm2_w; const float* norm2_b; /* [128]      uit.py:235 */
+    const float* fc1_w;   const float* fc1_b;   /* [384,128],[384] uit.py:192 */
+    const float* fc2_w;   const float* fc2_b;   /* [128,384],[128] uit.py:194 */
+} uitk_block_weights;
+
+/* Whole-model parameters, fp32 host pointers, reference state_dict names in comments. */
+typedef struct uitk_weights {
+    const float* window;     /* front_end.0.spectrogram.window [win_size]          */
+    const float* mel_fb;     /* front_end.0.mel_scale.fb [n_fft/2+1, n_mels]       */
+    const float* bn_weight;  /* init_bn.1.weight [n_mels]          uit.py:310-313 */
+    const float* bn_bias;    /* init_bn.1.bias                                     */
+    const float* bn_mean;    /* init_bn.1.running_mean                             */
+    const float* bn_var;     /* init_bn.1.running_var                              */
+    const float* pe_w;       /* patch_embed.proj.weight [128,1,16,16]  uit.py:63-66 */
+    const float* pe_b;       /* patch_embed.proj.bias [128]                        */
+    const float* time_pos;   /* time_pos_embed [1,128,1,target_length/16]  uit.py:333 */
+    const float* freq_pos;   /* freq_pos_embed [1,128,n_mels/16,1]         uit.py:335 */
+    const float* norm_w;     /* norm.weight [128]  (eps 1e-6)              uit.py:357 */
+    const float* norm_b;     /* norm.bias                                          */
+    const float* head_ln_w;  /* outputlayer.0.weight [128] (eps 1e-5)      uit.py:359 */
+    const float* head_ln_b;  /* outputlayer.0.bias                                 */
+    const float* head_w;     /* outputlayer.1.weight [outputdim,128]       uit.py:360 */
+    const float* head_b;     /* outputlayer.1.bias [outputdim]                     */
+    const uitk_block_weights* blocks; /* [depth]                                   */
+} uitk_weights;
+
+typedef struct uitk_model uitk_model;
+
+/* Build a model on the CURRENT HIP device: validates the config, packs the weights into the kernels'
+ * layouts (folded BN / LayerNorm affine / attention scale, MFMA fragment order) and uploads them.
+ * Stands in for: factory call + load_state_dict + .to(DEVICE).eval()  (inference.py:39-49, evaluate.py:34-37). */
+int uitk_create(const uitk_config* cfg, const uitk_weights* w, uitk_model** out);
+int uitk_destroy(uitk_model* m);
+
+/* Host-only: size of / fill the packed parameter image uitk_create uploads (no GPU needed; used by the
+ * layout tests).  *needed receives the byte size; out may be NULL to query. */
+int uitk_pack_weights(const uitk_config* cfg, const uitk_weights* w, void* out, size_t cap, size_t* needed);
+
+/* Frames and crops the reference makes for a T-sample clip: 1 + T/hop frames (center=True); more than
+ * target_length frames are split into ceil(frames/target_length) crops, a short tail being replaced by the
+ * last target_length frames (uit.py:468-481). */
+int uitk_num_frames(const uitk_model* m, int64_t T);
+int uitk_num_crops(const uitk_model* m, int64_t T);
+
+/* Pre-allocate the workspace for batches up to B clips of T samples (may synchronise; call outside timed /
+ * captured regions).  forward/frontend grow it on demand otherwise. */
+int uitk_reserve(uitk_model* m, int64_t B, int64_t T);
+
+/* The whole path: probs[B,outputdim] = model(pcm[B,T])   (UITBase.forward, uit.py:452-493, eval branch).
+ *   pcm     device pointer, [B,T] row-major, float32 or int16 (in_dtype)
+ *   probs   device pointer, [B,outputdim] float32 sigmoid outputs (mean/max over crops)
+ *   logits  optional device pointer, [B,ncrops,outputdim] float32 pre-sigmoid outputs of outputlayer[1]
+ *   stream  hipStream_t (NULL = default stream)
+ * The top_db floor is amax-over-this-call's-batch minus top_db, exactly as the reference computes it for the
+ * tensor of one forward call.  = uitk_frontend + uitk_encode. */
+int uitk_forward(uitk_model* m, const void* pcm, int in_dtype, int64_t B, int64_t T,
+                 float* probs, float* logits, void* stream);
+
+/* Stage 1: log-mel dB of every frame into the model's workspace + the batch amax.
+ * Stands in for self.front_end(x) minus the clamp (uit.py:298-308, 455). */
+int uitk_frontend(uitk_model* m, const void* pcm, int in_dtype, int64_t B, int64_t T, void* stream);
+
+/* Device pointer to the batch amax slots (UITK_AMAX_SLOTS floats; the floor uses their max).  A multi-GPU
+ * caller that wants the reference's batch-global floor across shards all-reduces (MAX) these in place
+ * between uitk_frontend and uitk_encode. */
+#define UITK_AMAX_SLOTS 64
+float* uitk_amax_ptr(uitk_model* m);
+
+/* Stage 2: top_db clamp + init_bn + patch-embed + blocks + head on the mel of the last uitk_frontend call
+ * (same B, T).  Stands in for uit.py:460-492. */
+int uitk_encode(uitk_model* m, int64_t B, int64_t T, float* probs, float* logits, void* stream);
+
+/* Copy the front-end output of the last uitk_frontend call, floor applied, in the reference's layout
+ * [B][n_mels][frames] (what self.front_end(x) returns).  For stage-level parity tests. */
+int uitk_mel_db(uitk_model* m, int64_t B, int64_t T, float* out, void* stream);
+
+/* Optional: device buffer [B*ncrops][depth+1][24][128] float32 receiving the residual stream after
+ * patch-embed(+pos) and after every block (token = f*6+t as in uit.py:388).  NULL disables (default). */
+int uitk_set_debug_tokens(uitk_model* m, float* dev_buf);
+
+/* Last error message of the calling thread ("" if none). */
+const char* uitk_last_error(void);
+const char* uitk_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* UITK_H */

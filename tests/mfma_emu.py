@@ -1,0 +1,261 @@
+"""numpy emulation of the encoder kernel's DATAFLOW on the packed parameter image (test helper, CPU only).
+
+Purpose: pin the host-side packing (csrc/pack.cpp: folds + MFMA fragment order) and the kernel's index algebra
+without a GPU.  It executes the same steps as csrc/encoder.hip on "wave registers" shaped [64 lanes, n] using the
+documented gfx950 MFMA lane maps (cdna_hip_programming.md section 3):
+    16x16x32: A[row = l&15][k = 8*(l>>4)+j], B[k = 8*(l>>4)+j][col = l&15], C/D[row = 4*(l>>4)+r][col = l&15]
+    16x16x16: the same with k = 4*(l>>4)+j.
+This is NOT a product path and is never compared against itself: tests compare it with the C oracle.
+"""
+import struct
+
+import numpy as np
+
+LANES = np.arange(64)
+C_ = LANES & 15
+G_ = LANES >> 4
+
+HDR_FMT = "<I4i3iQ15Q"
+HDR_FIELDS = ["magic", "precision", "depth", "outputdim", "mel_nnz", "_p0", "_p1", "_p2", "total_bytes",
+              "off_wstream", "off_bias", "off_bn_sc", "off_bn_sh", "off_pe_bias", "off_fin", "off_head_w",
+              "off_head_b", "off_window", "off_tw256", "off_tw512", "off_mel_lo", "off_mel_n", "off_mel_off",
+              "off_mel_w"]
+FRAG, STAGE = 1024, 16384
+PE_STAGES, BLOCK_STAGES, BIAS_FLOATS = 4, 14, 1024
+BIAS_QKV, BIAS_PROJ, BIAS_FC1, BIAS_FC2 = 0, 96, 224, 608
+
+
+def parse_header(img):
+    vals = struct.unpack_from(HDR_FMT, img, 0)
+    return dict(zip(HDR_FIELDS, vals))
+
+
+def to_f32(u16, prec):
+    u16 = np.asarray(u16, dtype=np.uint16)
+    if prec == 0:
+        return u16.view(np.float16).astype(np.float32)
+    return (u16.astype(np.uint32) << 16).view(np.float32)
+
+
+def round_op(x, prec):
+    x = np.asarray(x, dtype=np.float32)
+    if prec == 0:
+        return x.astype(np.float16).astype(np.float32)
+    u = x.view(np.uint32)
+    u = (u + 0x7FFF + ((u >> 16) & 1)) & 0xFFFF0000
+    return u.astype(np.uint32).view(np.float32)
+
+
+def mfma32(A, B, Cc):
+    Am = np.zeros((16, 32), np.float32)
+    Bm = np.zeros((32, 16), np.float32)
+    k = 8 * G_[:, None] + np.arange(8)[None]
+    Am[C_[:, None], k] = A
+    Bm[k, C_[:, None]] = B
+    D = (Am.astype(np.float64) @ Bm.astype(np.float64)).astype(np.float32)
+    return Cc + D[4 * G_[:, None] + np.arange(4)[None], C_[:, None]]
+
+
+def mfma16(A, B, Cc):
+    Am = np.zeros((16, 16), np.float32)
+    Bm = np.zeros((16, 16), np.float32)
+    k = 4 * G_[:, None] + np.arange(4)[None]
+    Am[C_[:, None], k] = A
+    Bm[k, C_[:, None]] = B
+    D = (Am.astype(np.float64) @ Bm.astype(np.float64)).astype(np.float32)
+    return Cc + D[4 * G_[:, None] + np.arange(4)[None], C_[:, None]]
+
+
+class EncoderEmu:
+    def __init__(self, img):
+        self.img = img
+        self.h = parse_header(img)
+        assert self.h["magic"] == 0x4B544955
+        self.prec = self.h["precision"]
+        self.depth = self.h["depth"]
+        self.C = self.h["outputdim"]
+
+    def _f32(self, off, n):
+        return np.frombuffer(self.img, np.float32, n, off)
+
+    def frag(self, stage, f):
+        off = self.h["off_wstream"] + stage * STAGE + f * FRAG
+        return to_f32(np.frombuffer(self.img, np.uint16, 512, off).reshape(64, 8), self.prec)
+
+    def head_frag(self, ot, s):
+        off = self.h["off_head_w"] + (ot * 4 + s) * FRAG
+        return to_f32(np.frombuffer(self.img, np.uint16, 512, off).reshape(64, 8), self.prec)
+
+    def pack8(self, lo, hi):
+        return round_op(np.concatenate([lo, hi], axis=1), self.prec)
+
+    def pack4(self, x):
+        return round_op(x, self.prec)
+
+    def layernorm_to_operand(self, R, eps):
+        X = [[None] * 3 for _ in range(4)]
+        for ct in range(3):
+            tot = sum(R[ft][ct].sum(1) for ft in range(8))                      # per lane
+            tot = tot.reshape(4, 16).sum(0)[C_]                                   # xsum over g
+            mean = tot / 128.0
+            var = sum(((R[ft][ct] - mean[:, None]) ** 2).sum(1) for ft in range(8)).reshape(4, 16).sum(0)[C_] / 128.0
+            rstd = 1.0 / np.sqrt(var + eps)
+            for s in range(4):
+                X[s][ct] = self.pack8((R[2 * s][ct] - mean[:, None]) * rstd[:, None],
+                                      (R[2 * s + 1][ct] - mean[:, None]) * rstd[:, None])
+        return X
+
+    def run_wave(self, mel2, floor_db, nt=6):
+        """mel2: two crops [2][frames>=16*nt][64] dB (no floor).  -> logits [2][C], stages [2][depth+1][24][128]"""
+        h, prec = self.h, self.prec
+        bn_sc, bn_sh = self._f32(h["off_bn_sc"], 64), self._f32(h["off_bn_sh"], 64)
+        pe_bias = self._f32(h["off_pe_bias"], 24 * 128).reshape(24, 128)
+        fin = self._f32(h["off_fin"], 4 * 128).reshape(4, 128)
+        col = [16 * ct + C_ for ct in range(3)]
+        clip = [(cc >= 24).astype(int) for cc in col]
+        tk = [col[ct] - 24 * clip[ct] for ct in range(3)]
+        pf = [t // 6 for t in tk]
+        pt = [t % 6 for t in tk]
+        j8 = np.arange(8)[None]
+        # patch-embed operand
+        XB = [[None] * 3 for _ in range(8)]
+        for ct in range(3):
+            f0 = 16 * pf[ct] + 8 * (G_ & 1)
+            for s in range(8):
+                t = 16 * pt[ct] + 2 * s + (G_ >> 1)
+                t = np.minimum(t, mel2.shape[1] - 1)
+                x = mel2[clip[ct][:, None], t[:, None], f0[:, None] + j8]
+                x = np.maximum(x, floor_db) * bn_sc[f0[:, None] + j8] + bn_sh[f0[:, None] + j8]
+                XB[s][ct] = round_op(x, prec)
+        r4 = np.arange(4)[None]
+        R = [[pe_bias[tk[ct][:, None], 16 * ft + 4 * G_[:, None] + r4].copy() for ct in range(3)] for ft in range(8)]
+        for i in range(PE_STAGES):
+            for f in range(16):
+                A = self.frag(i, f)
+                for ct in range(3):
+                    R[2 * i + f // 8][ct] = mfma32(A, XB[f % 8][ct], R[2 * i + f // 8][ct])
+        stages = np.zeros((2, self.depth + 1, 24, 128), np.float32)
+
+        def dump(st):
+            for ct in range(3):
+                for ft in range(8):
+                    stages[clip[ct][:, None], st, tk[ct][:, None], 16 * ft + 4 * G_[:, None] + r4] = R[ft][ct]
+        dump(0)
+        TJ, TI = [0, 1, 0, 1, 2, 1, 2], [0, 0, 1, 1, 1, 2, 2]
+        valid = []
+        for i in range(7):
+            j = 16 * TJ[i] + 4 * G_[:, None] + r4
+            q = 16 * TI[i] + C_[:, None]
+            valid.append(((j >= 24) == (q >= 24)) & (((j % 24) % 6) < nt))
+        for blk in range(self.depth):
+            tb = PE_STAGES + blk * BLOCK_STAGES
+            bias = self._f32(h["off_bias"] + blk * BIAS_FLOATS * 4, BIAS_FLOATS)
+            X = self.layernorm_to_operand(R, 1e-6)
+            QK = [[np.repeat(bias[BIAS_QKV + 16 * ft + 4 * G_[:, None] + r4], 1, 0).copy() for _ in range(3)] for ft in range(4)]
+            for f in range(16):
+                A = self.frag(tb, f)
+                for ct in range(3):
+                    QK[f // 4][ct] = mfma32(A, X[f % 4][ct], QK[f // 4][ct])
+            Qh = [[self.pack4(QK[hh][ct]) for ct in range(3)] for hh in range(2)]
+            Kh = [[self.pack4(QK[2 + hh][ct]) for ct in range(3)] for hh in range(2)]
+            V = [[np.repeat(bias[BIAS_QKV + 64 + 16 * hh + C_][:, None], 4, 1) for hh in range(2)] for _ in range(3)]
+            for f in range(8):
+                Bw = self.frag(tb + 1, f)
+                for ct in range(3):
+                    V[ct][f // 4] = mfma32(X[f % 4][ct], Bw, V[ct][f // 4])
+            Vh = [[self.pack4(V[ct][hh]) for hh in range(2)] for ct in range(3)]
+            O = [[None] * 3 for _ in range(2)]
+            for hh in range(2):
+                S = []
+                for i in range(7):
+                    s = mfma16(Kh[hh][TJ[i]], Qh[hh][TI[i]], np.zeros((64, 4), np.float32))
+                    S.append(np.where(valid[i], s, -np.inf))
+                mx = [np.full(64, -np.inf, np.float32) for _ in range(3)]
+                for i in range(7):
+                    mx[TI[i]] = np.maximum(mx[TI[i]], S[i].max(1))
+                mx = [m_.reshape(4, 16).max(0)[C_] for m_ in mx]
+                sm = [np.zeros(64, np.float32) for _ in range(3)]
+                Pm = []
+                for i in range(7):
+                    p = np.exp(S[i] - mx[TI[i]][:, None]).astype(np.float32)
+                    sm[TI[i]] = sm[TI[i]] + p.sum(1)
+                    Pm.append(self.pack4(p))
+                inv = [1.0 / s_.reshape(4, 16).sum(0)[C_] for s_ in sm]
+                acc = [np.zeros((64, 4), np.float32) for _ in range(3)]
+                for i in range(7):
+                    acc[TI[i]] = mfma16(Vh[TJ[i]][hh], Pm[i], acc[TI[i]])
+                for it in range(3):
+                    O[hh][it] = acc[it] * inv[it][:, None]
+            OX = [self.pack8(O[0][ct], O[1][ct]) for ct in range(3)]
+            for ft in range(8):
+                A = self.frag(tb + 1, 8 + ft)
+                bp = bias[BIAS_PROJ + 16 * ft + 4 * G_[:, None] + r4]
+                for ct in range(3):
+                    R[ft][ct] = mfma32(A, OX[ct], R[ft][ct] + bp)
+            X = self.layernorm_to_operand(R, 1e-6)
+            for ch in range(12):
+                t = tb + 2 + ch
+                Hh = [[bias[BIAS_FC1 + 32 * ch + 16 * j + 4 * G_[:, None] + r4].copy() for _ in range(3)] for j in range(2)]
+                for f in range(8):
+                    A = self.frag(t, f)
+                    for ct in range(3):
+                        Hh[f // 4][ct] = mfma32(A, X[f % 4][ct], Hh[f // 4][ct])
+                HX = [self.pack8(np.maximum(Hh[0][ct], 0), np.maximum(Hh[1][ct], 0)) for ct in range(3)]
+                for ft in range(8):
+                    A = self.frag(t, 8 + ft)
+                    for ct in range(3):
+                        R[ft][ct] = mfma32(A, HX[ct], R[ft][ct])
+            for ft in range(8):
+                b2 = bias[BIAS_FC2 + 16 * ft + 4 * G_[:, None] + r4]
+                for ct in range(3):
+                    R[ft][ct] = R[ft][ct] + b2
+            dump(blk + 1)
+        # final norm + masked mean pool (per clip) -- done directly on the dumped layout semantics
+        xn = []
+        for ct in range(3):
+            tot = sum(R[ft][ct].sum(1) for ft in range(8)).reshape(4, 16).sum(0)[C_]
+            mean = tot / 128.0
+            var = sum(((R[ft][ct] - mean[:, None]) ** 2).sum(1) for ft in range(8)).reshape(4, 16).sum(0)[C_] / 128.0
+            rstd = np.where(pt[ct] < nt, 1.0 / np.sqrt(var + 1e-6), 0.0)
+            xn.append([(R[ft][ct] - mean[:, None]) * rstd[:, None] for ft in range(8)])
+        lo = (C_ < 8)[:, None]
+        pooled = []
+        for ft in range(8):
+            Aa = np.where(lo, xn[0][ft] + xn[1][ft], xn[0][ft])
+            Bb = np.where(lo, xn[2][ft], xn[2][ft] + xn[1][ft])
+            keep, send = np.where(lo, Aa, Bb), np.where(lo, Bb, Aa)
+            v = keep + send[LANES ^ 8]
+            for o in (4, 2, 1):
+                v = v + v[LANES ^ o]
+            pooled.append(v)
+        inv_ntok = 1.0 / (4 * nt)
+        z = [pooled[ft] * inv_ntok * fin[0][16 * ft + 4 * G_[:, None] + r4] + fin[1][16 * ft + 4 * G_[:, None] + r4] for ft in range(8)]
+        tot = sum(zz.sum(1) for zz in z).reshape(4, 16).sum(0)[C_]
+        mean = tot / 128.0
+        var = sum(((zz - mean[:, None]) ** 2).sum(1) for zz in z).reshape(4, 16).sum(0)[C_] / 128.0
+        rstd = 1.0 / np.sqrt(var + 1e-5)
+        zbuf = np.zeros((16, 128), np.float32)
+        for ft in range(8):
+            zn = (z[ft] - mean[:, None]) * rstd[:, None] * fin[2][16 * ft + 4 * G_[:, None] + r4] + fin[3][16 * ft + 4 * G_[:, None] + r4]
+            zn = self.pack4(zn)
+            for ln in LANES[(C_ & 7) == 0]:
+                zbuf[int(C_[ln] >= 8), 16 * ft + 4 * G_[ln] + np.arange(4)] = zn[ln]
+        # head: clip slot = column
+        ntiles = (self.C + 15) // 16
+        head_b = self._f32(h["off_head_b"], ntiles * 16)
+        logits = np.zeros((2, self.C), np.float32)
+        Bz = []
+        for s in range(4):
+            lo4 = zbuf[C_[:, None], 32 * s + 4 * G_[:, None] + r4]
+            hi4 = zbuf[C_[:, None], 32 * s + 16 + 4 * G_[:, None] + r4]
+            Bz.append(np.concatenate([lo4, hi4], 1))
+        for ot in range(ntiles):
+            acc = head_b[16 * ot + 4 * G_[:, None] + r4].copy()
+            for s in range(4):
+                acc = mfma32(self.head_frag(ot, s), Bz[s], acc)
+            for ln in LANES[C_ < 2]:
+                for r in range(4):
+                    cls = 16 * ot + 4 * G_[ln] + r
+                    if cls < self.C:
+                        logits[C_[ln], cls] = acc[ln, r]
+        return logits, stages

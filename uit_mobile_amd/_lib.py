@@ -1,0 +1,86 @@
+"""ctypes binding of libuitk.so -- one function per entry point of include/uitk.h, nothing else."""
+import ctypes
+from ctypes import POINTER, Structure, c_char_p, c_float, c_int, c_int32, c_int64, c_size_t, c_void_p
+from pathlib import Path
+
+HERE = Path(__file__).resolve().parent
+LIB_PATH = HERE / "libuitk.so"
+
+UITK_OK = 0
+ERR_INVALID_ARG, ERR_UNSUPPORTED, ERR_NO_DEVICE, ERR_HIP, ERR_TOO_SHORT, ERR_WORKSPACE = -1, -2, -3, -4, -5, -6
+IN_F32, IN_I16 = 0, 1
+PREC_F16, PREC_BF16 = 0, 1
+AVG_MEAN, AVG_MAX = 0, 1
+AMAX_SLOTS = 64
+
+EXPORTS = ["uitk_create", "uitk_destroy", "uitk_pack_weights", "uitk_num_frames", "uitk_num_crops",
+           "uitk_reserve", "uitk_forward", "uitk_frontend", "uitk_amax_ptr", "uitk_encode", "uitk_mel_db",
+           "uitk_set_debug_tokens", "uitk_last_error", "uitk_version"]
+
+
+class Config(Structure):
+    _fields_ = [(n, c_int32) for n in ("depth", "embed_dim", "num_heads", "mlp_hidden", "outputdim",
+                                       "target_length", "n_mels", "n_fft", "hop_size", "win_size", "patch_size",
+                                       "center", "eval_avg", "precision")] + [("top_db", c_float)]
+
+
+_BLOCK_FIELDS = ["norm1_w", "norm1_b", "qkv_w", "qkv_b", "proj_w", "proj_b", "norm2_w", "norm2_b",
+                 "fc1_w", "fc1_b", "fc2_w", "fc2_b"]
+_GLOBAL_FIELDS = ["window", "mel_fb", "bn_weight", "bn_bias", "bn_mean", "bn_var", "pe_w", "pe_b", "time_pos",
+                  "freq_pos", "norm_w", "norm_b", "head_ln_w", "head_ln_b", "head_w", "head_b"]
+
+
+class BlockWeights(Structure):
+    _fields_ = [(n, c_void_p) for n in _BLOCK_FIELDS]
+
+
+class Weights(Structure):
+    _fields_ = [(n, c_void_p) for n in _GLOBAL_FIELDS] + [("blocks", POINTER(BlockWeights))]
+
+
+_lib = None
+
+
+def load():
+    """Load libuitk.so.  Fails loudly if it has not been built -- there is no fallback implementation."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not LIB_PATH.exists():
+        raise RuntimeError(f"{LIB_PATH} is missing: build it with `python -m uit_mobile_amd.build` "
+                           "(hipcc, gfx950). uit_mobile_amd has no CPU or PyTorch fallback path.")
+    L = ctypes.CDLL(str(LIB_PATH))
+    L.uitk_create.argtypes = [POINTER(Config), POINTER(Weights), POINTER(c_void_p)]
+    L.uitk_destroy.argtypes = [c_void_p]
+    L.uitk_pack_weights.argtypes = [POINTER(Config), POINTER(Weights), c_void_p, c_size_t, POINTER(c_size_t)]
+    L.uitk_num_frames.argtypes = [c_void_p, c_int64]
+    L.uitk_num_crops.argtypes = [c_void_p, c_int64]
+    L.uitk_reserve.argtypes = [c_void_p, c_int64, c_int64]
+    L.uitk_forward.argtypes = [c_void_p, c_void_p, c_int, c_int64, c_int64, c_void_p, c_void_p, c_void_p]
+    L.uitk_frontend.argtypes = [c_void_p, c_void_p, c_int, c_int64, c_int64, c_void_p]
+    L.uitk_amax_ptr.argtypes = [c_void_p]
+    L.uitk_amax_ptr.restype = c_void_p
+    L.uitk_encode.argtypes = [c_void_p, c_int64, c_int64, c_void_p, c_void_p, c_void_p]
+    L.uitk_mel_db.argtypes = [c_void_p, c_int64, c_int64, c_void_p, c_void_p]
+    L.uitk_set_debug_tokens.argtypes = [c_void_p, c_void_p]
+    L.uitk_last_error.restype = c_char_p
+    L.uitk_version.restype = c_char_p
+    for name in EXPORTS:
+        if getattr(L, name).restype is c_int:
+            pass
+    _lib = L
+    return L
+
+
+def last_error():
+    return load().uitk_last_error().decode()
+
+
+def check(rc, what):
+    """Map C return codes onto the exception types the reference's callers see (Errors row)."""
+    if rc == UITK_OK:
+        return
+    msg = f"{what}: {last_error()} (uitk rc={rc})"
+    if rc in (ERR_INVALID_ARG, ERR_UNSUPPORTED, ERR_TOO_SHORT):
+        raise ValueError(msg)
+    raise RuntimeError(msg)

@@ -1,0 +1,211 @@
+// api.cpp -- the C ABI of libuitk.so (include/uitk.h): model lifetime, workspace, stage launches.
+// Host code only; the kernels live in frontend.hip / encoder.hip.  There is no CPU compute path here.
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/uitk.h"
+#include "pack.h"
+#include "uitk_dev.h"
+
+using namespace uitk;
+
+static thread_local std::string g_err;
+static int fail(int code, const std::string& msg) { g_err = msg; return code; }
+#define HIP_TRY(expr)                                                                                   \
+    do {                                                                                                \
+        hipError_t _e = (expr);                                                                         \
+        if (_e != hipSuccess) return fail(UITK_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(_e)); \
+    } while (0)
+
+struct uitk_model {
+    uitk_config cfg;
+    ImageHeader hdr;
+    char* image = nullptr;        // device copy of the packed parameter image
+    float* mel = nullptr;         // [B][nF][64]
+    float* amax = nullptr;        // [AMAX_SLOTS]
+    float* rowprobs = nullptr;    // [B*ncrops][C] (multi-crop only)
+    size_t mel_cap = 0, rowprobs_cap = 0;
+    float* dbg = nullptr;
+    int n_cu = 256;
+    int device = 0;
+};
+
+extern "C" {
+
+const char* uitk_last_error(void) { return g_err.c_str(); }
+const char* uitk_version(void) { return "uitk 0.1 (gfx950)"; }
+
+int uitk_pack_weights(const uitk_config* cfg, const uitk_weights* w, void* out, size_t cap, size_t* needed) {
+    if (!cfg || !w || !needed) return fail(UITK_ERR_INVALID_ARG, "null argument");
+    const char* why = "";
+    if (int rc = validate_config(cfg, &why)) return fail(rc, why);
+    std::vector<char> img;
+    ImageHeader h;
+    if (int rc = pack_image(cfg, w, &img, &h)) return fail(rc, "pack failed");
+    *needed = img.size();
+    if (out) {
+        if (cap < img.size()) return fail(UITK_ERR_INVALID_ARG, "output buffer too small");
+        std::memcpy(out, img.data(), img.size());
+    }
+    return UITK_OK;
+}
+
+int uitk_create(const uitk_config* cfg, const uitk_weights* w, uitk_model** out) {
+    if (!cfg || !w || !out) return fail(UITK_ERR_INVALID_ARG, "null argument");
+    const char* why = "";
+    if (int rc = validate_config(cfg, &why)) return fail(rc, why);
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
+        return fail(UITK_ERR_NO_DEVICE, "no HIP device: libuitk has no CPU path");
+    uitk_model* m = new uitk_model();
+    m->cfg = *cfg;
+    std::vector<char> img;
+    if (int rc = pack_image(cfg, w, &img, &m->hdr)) { delete m; return fail(rc, "pack failed"); }
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&m->device) != hipSuccess || hipGetDeviceProperties(&prop, m->device) != hipSuccess) {
+        delete m; return fail(UITK_ERR_NO_DEVICE, "cannot query HIP device");
+    }
+    if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+        std::string arch = prop.gcnArchName; delete m;
+        return fail(UITK_ERR_NO_DEVICE, "libuitk is built for gfx950 only, found " + arch);
+    }
+    m->n_cu = prop.multiProcessorCount;
+    if (hipMalloc((void**)&m->image, img.size()) != hipSuccess || hipMalloc((void**)&m->amax, AMAX_SLOTS * 4) != hipSuccess) {
+        uitk_destroy(m); return fail(UITK_ERR_HIP, "hipMalloc failed for the parameter image");
+    }
+    if (hipMemcpy(m->image, img.data(), img.size(), hipMemcpyHostToDevice) != hipSuccess) {
+        uitk_destroy(m); return fail(UITK_ERR_HIP, "parameter upload failed");
+    }
+    *out = m;
+    return UITK_OK;
+}
+
+int uitk_destroy(uitk_model* m) {
+    if (!m) return UITK_OK;
+    if (m->image) (void)hipFree(m->image);
+    if (m->mel) (void)hipFree(m->mel);
+    if (m->amax) (void)hipFree(m->amax);
+    if (m->rowprobs) (void)hipFree(m->rowprobs);
+    delete m;
+    return UITK_OK;
+}
+
+int uitk_num_frames(const uitk_model* m, int64_t T) { return m ? (int)(1 + T / m->cfg.hop_size) : -1; }
+
+int uitk_num_crops(const uitk_model* m, int64_t T) {
+    if (!m) return -1;
+    const int nF = uitk_num_frames(m, T), tl = m->cfg.target_length;
+    return nF <= tl ? 1 : (nF + tl - 1) / tl;
+}
+
+static int check_shape(const uitk_model* m, int64_t B, int64_t T) {
+    if (!m) return fail(UITK_ERR_INVALID_ARG, "null model");
+    if (B < 1 || T < 1) return fail(UITK_ERR_INVALID_ARG, "B and T must be positive");
+    if (T <= m->cfg.n_fft / 2) return fail(UITK_ERR_TOO_SHORT, "clip must be longer than n_fft/2 samples (reflect padding)");
+    if (uitk_num_frames(m, T) < m->cfg.patch_size) return fail(UITK_ERR_TOO_SHORT, "clip shorter than one 16-frame patch");
+    if (T >= (int64_t)1 << 30) return fail(UITK_ERR_INVALID_ARG, "T too large");
+    return UITK_OK;
+}
+
+int uitk_reserve(uitk_model* m, int64_t B, int64_t T) {
+    if (int rc = check_shape(m, B, T)) return rc;
+    const size_t mel_bytes = (size_t)B * uitk_num_frames(m, T) * NMEL * 4;
+    const int nc = uitk_num_crops(m, T);
+    const size_t rp_bytes = nc > 1 ? (size_t)B * nc * m->cfg.outputdim * 4 : 0;
+    if (mel_bytes > m->mel_cap) {
+        HIP_TRY(hipDeviceSynchronize());
+        if (m->mel) (void)hipFree(m->mel);
+        m->mel = nullptr; m->mel_cap = 0;
+        HIP_TRY(hipMalloc((void**)&m->mel, mel_bytes));
+        m->mel_cap = mel_bytes;
+    }
+    if (rp_bytes > m->rowprobs_cap) {
+        HIP_TRY(hipDeviceSynchronize());
+        if (m->rowprobs) (void)hipFree(m->rowprobs);
+        m->rowprobs = nullptr; m->rowprobs_cap = 0;
+        HIP_TRY(hipMalloc((void**)&m->rowprobs, rp_bytes));
+        m->rowprobs_cap = rp_bytes;
+    }
+    return UITK_OK;
+}
+
+float* uitk_amax_ptr(uitk_model* m) { return m ? m->amax : nullptr; }
+
+int uitk_set_debug_tokens(uitk_model* m, float* dev_buf) {
+    if (!m) return fail(UITK_ERR_INVALID_ARG, "null model");
+    m->dbg = dev_buf;
+    return UITK_OK;
+}
+
+int uitk_frontend(uitk_model* m, const void* pcm, int in_dtype, int64_t B, int64_t T, void* stream) {
+    if (int rc = check_shape(m, B, T)) return rc;
+    if (!pcm) return fail(UITK_ERR_INVALID_ARG, "null pcm");
+    if (in_dtype != UITK_IN_F32 && in_dtype != UITK_IN_I16) return fail(UITK_ERR_INVALID_ARG, "unknown in_dtype");
+    if (int rc = uitk_reserve(m, B, T)) return rc;
+    hipStream_t s = (hipStream_t)stream;
+    const ImageHeader& h = m->hdr;
+    FrontendArgs a{};
+    a.pcm = pcm; a.B = B; a.T = T; a.nF = uitk_num_frames(m, T); a.hop = m->cfg.hop_size;
+    a.window = (const float*)(m->image + h.off_window);
+    a.tw256 = (const float2*)(m->image + h.off_tw256);
+    a.tw512 = (const float2*)(m->image + h.off_tw512);
+    a.mel_lo = (const int*)(m->image + h.off_mel_lo);
+    a.mel_n = (const int*)(m->image + h.off_mel_n);
+    a.mel_off = (const int*)(m->image + h.off_mel_off);
+    a.mel_w = (const float*)(m->image + h.off_mel_w);
+    a.mel_nnz = h.mel_nnz;
+    a.melw_lds_bytes = (h.mel_nnz * 4 + 15) / 16 * 16;
+    a.mel = m->mel; a.amax = m->amax;
+    HIP_TRY(hipMemsetAsync(m->amax, 0xFF, AMAX_SLOTS * 4, s));
+    HIP_TRY(launch_frontend(a, in_dtype == UITK_IN_I16, m->n_cu, s));
+    return UITK_OK;
+}
+
+int uitk_encode(uitk_model* m, int64_t B, int64_t T, float* probs, float* logits, void* stream) {
+    if (int rc = check_shape(m, B, T)) return rc;
+    if (!probs) return fail(UITK_ERR_INVALID_ARG, "null probs");
+    const int nF = uitk_num_frames(m, T), nc = uitk_num_crops(m, T), tl = m->cfg.target_length;
+    if ((size_t)B * nF * NMEL * 4 > m->mel_cap) return fail(UITK_ERR_WORKSPACE, "uitk_encode without a matching uitk_frontend");
+    if (B * nc >= (int64_t)1 << 31) return fail(UITK_ERR_INVALID_ARG, "batch too large");
+    hipStream_t s = (hipStream_t)stream;
+    const ImageHeader& h = m->hdr;
+    EncoderArgs a{};
+    a.mel = m->mel; a.amax = m->amax; a.top_db = m->cfg.top_db;
+    a.nF = nF; a.rows = (int)(B * nc); a.ncrops = nc; a.tl = tl;
+    a.nt = (nc > 1 ? tl : nF) / 16; if (a.nt > GT) a.nt = GT;
+    a.depth = m->cfg.depth; a.C = m->cfg.outputdim;
+    a.wstream = m->image + h.off_wstream;
+    a.bias = (const float*)(m->image + h.off_bias);
+    a.bn_sc = (const float*)(m->image + h.off_bn_sc);
+    a.bn_sh = (const float*)(m->image + h.off_bn_sh);
+    a.pe_bias = (const float*)(m->image + h.off_pe_bias);
+    a.fin = (const float*)(m->image + h.off_fin);
+    a.head_w = m->image + h.off_head_w;
+    a.head_b = (const float*)(m->image + h.off_head_b);
+    a.probs = nc > 1 ? m->rowprobs : probs;
+    a.logits = logits; a.dbg = m->dbg;
+    HIP_TRY(launch_encoder(a, m->cfg.precision, s));
+    if (nc > 1) HIP_TRY(launch_crop_reduce(m->rowprobs, probs, B, nc, a.C, m->cfg.eval_avg, s));
+    return UITK_OK;
+}
+
+int uitk_forward(uitk_model* m, const void* pcm, int in_dtype, int64_t B, int64_t T, float* probs, float* logits,
+                 void* stream) {
+    if (int rc = uitk_frontend(m, pcm, in_dtype, B, T, stream)) return rc;
+    return uitk_encode(m, B, T, probs, logits, stream);
+}
+
+int uitk_mel_db(uitk_model* m, int64_t B, int64_t T, float* out, void* stream) {
+    if (int rc = check_shape(m, B, T)) return rc;
+    if (!out) return fail(UITK_ERR_INVALID_ARG, "null out");
+    const int nF = uitk_num_frames(m, T);
+    if ((size_t)B * nF * NMEL * 4 > m->mel_cap) return fail(UITK_ERR_WORKSPACE, "uitk_mel_db without a matching uitk_frontend");
+    HIP_TRY(launch_mel_export(m->mel, m->amax, m->cfg.top_db, B, nF, out, (hipStream_t)stream));
+    return UITK_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,215 @@
+// pack.cpp -- host-only: turn reference-layout fp32 parameters into the kernels' packed image.
+//
+// No HIP calls here (uitk_pack_weights works without a GPU; the layout tests drive it on CPU).
+// Folding done at pack time (exact algebra, computed in double, rounded once to the operand type):
+//   * init_bn (eval BatchNorm2d, models/uit.py:310-313)      -> per-mel-bin scale/shift applied before conversion
+//   * conv bias + time_pos_embed + freq_pos_embed (:380-383)  -> bias table [24][128] = accumulator init
+//   * LayerNorm affine of norm1 / norm2 (:223, 235)           -> folded into qkv / fc1 weights and biases
+//   * attention scale (dim//heads)^-0.5 = 0.125 (:99-100,115) -> folded into the q rows of qkv
+// Fragment order: see uitk_dev.h and encoder.hip.  A "fragment" is the 1 KiB A/B operand of one
+// mfma_f32_16x16x32: lane l (c = l&15, g = l>>4), element j  <->  W[16*ft + c][ 32*s + 16*(j>>2) + 4*g + (j&3) ]
+// (the k-order a C/D tile pair has after in-register conversion, so activations never move between lanes).
+#include <cmath>
+#include <cstdint>
+#include <cstring>
+#include <functional>
+#include <vector>
+
+#include "../../include/uitk.h"
+#include "pack.h"
+#include "uitk_dev.h"
+
+namespace uitk {
+
+static uint16_t f32_to_f16(float f) {          // round-to-nearest-even, subnormals, inf/nan
+    uint32_t x; std::memcpy(&x, &f, 4);
+    const uint32_t sign = (x >> 16) & 0x8000u;
+    x &= 0x7fffffffu;
+    if (x >= 0x7f800000u) return (uint16_t)(sign | 0x7c00u | (x > 0x7f800000u ? 0x200u : 0u));
+    if (x >= 0x477ff000u) return (uint16_t)(sign | 0x7c00u);          // overflow -> inf (after rounding)
+    if (x < 0x33000001u) return (uint16_t)sign;                        // underflow -> 0 (< half the smallest subnormal)
+    int e = (int)(x >> 23) - 127;
+    uint32_t m = (x & 0x7fffffu) | 0x800000u;
+    int shift;
+    uint32_t base;
+    if (e < -14) { shift = 13 + (-14 - e); base = 0; }                 // subnormal
+    else { shift = 13; base = (uint32_t)(e + 15) << 10; m &= 0x7fffffu; }
+    uint32_t r = m >> shift;
+    const uint32_t rem = m & ((1u << shift) - 1), half = 1u << (shift - 1);
+    if (rem > half || (rem == half && (r & 1u))) ++r;
+    return (uint16_t)(sign | (base + r));
+}
+
+static uint16_t f32_to_bf16(float f) {
+    uint32_t x; std::memcpy(&x, &f, 4);
+    if ((x & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((x >> 16) | 0x40u);
+    x += 0x7fffu + ((x >> 16) & 1u);
+    return (uint16_t)(x >> 16);
+}
+
+static inline uint16_t cvt(double v, int prec) { return prec == UITK_PREC_BF16 ? f32_to_bf16((float)v) : f32_to_f16((float)v); }
+
+static size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+
+int validate_config(const uitk_config* c, const char** why) {
+    auto bad = [&](const char* m) { *why = m; return UITK_ERR_UNSUPPORTED; };
+    if (c->embed_dim != DIM) return bad("embed_dim must be 128 (uit_* family)");
+    if (c->num_heads != 2) return bad("num_heads must be 2");
+    if (c->mlp_hidden != HID) return bad("mlp hidden must be 384 (mlp_ratio 3.0)");
+    if (c->n_mels != NMEL) return bad("n_mels must be 64");
+    if (c->n_fft != 512 || c->win_size != 512) return bad("n_fft and win_size must be 512");
+    if (c->hop_size < 1 || c->hop_size > 512) return bad("hop_size out of range");
+    if (c->patch_size != 16) return bad("patch_size must be 16");
+    if (c->target_length / 16 != GT) return bad("target_length must give 6 time patches (96..111)");
+    if (c->center != 1) return bad("center must be True");
+    if (c->depth < 1 || c->depth > 64) return bad("depth out of range");
+    if (c->outputdim < 1 || c->outputdim > 65536) return bad("outputdim out of range");
+    if (c->eval_avg != UITK_AVG_MEAN && c->eval_avg != UITK_AVG_MAX) return bad("unknown eval_avg");
+    if (c->precision != UITK_PREC_F16 && c->precision != UITK_PREC_BF16) return bad("unknown precision");
+    return UITK_OK;
+}
+
+// one 1 KiB fragment from an accessor W(row, k) -> double
+static void pack_frag(uint16_t* dst, int prec, const std::function<double(int, int)>& W, int ft, int s) {
+    for (int l = 0; l < 64; ++l)
+        for (int j = 0; j < 8; ++j) {
+            const int row = 16 * ft + (l & 15);
+            const int k = 32 * s + 16 * (j >> 2) + 4 * (l >> 4) + (j & 3);
+            dst[l * 8 + j] = cvt(W(row, k), prec);
+        }
+}
+
+int pack_image(const uitk_config* c, const uitk_weights* w, std::vector<char>* out, ImageHeader* hdr_out) {
+    const int prec = c->precision, depth = c->depth, C = c->outputdim;
+    const int ntiles = (C + 15) / 16;
+    const int nb = c->n_fft / 2 + 1;
+    // ---- mel bands
+    std::vector<int> lo(NMEL), n(NMEL), off(NMEL);
+    std::vector<float> mw;
+    for (int m = 0; m < NMEL; ++m) {
+        int first = -1, last = -1;
+        for (int k = 0; k < nb; ++k)
+            if (w->mel_fb[k * NMEL + m] != 0.0f) { if (first < 0) first = k; last = k; }
+        lo[m] = first < 0 ? 0 : first;
+        n[m] = first < 0 ? 0 : last - first + 1;
+        off[m] = (int)mw.size();
+        for (int t = 0; t < n[m]; ++t) mw.push_back(w->mel_fb[(lo[m] + t) * NMEL + m]);
+    }
+    ImageHeader h{};
+    h.magic = IMAGE_MAGIC; h.precision = prec; h.depth = depth; h.outputdim = C; h.mel_nnz = (int)mw.size();
+    size_t o = align_up(sizeof(ImageHeader), 256);
+    auto take = [&](size_t bytes) { size_t r = o; o = align_up(o + bytes, 256); return r; };
+    h.off_wstream = take((size_t)(PE_STAGES + depth * BLOCK_STAGES) * STAGE_BYTES);
+    h.off_bias = take((size_t)depth * BIAS_FLOATS * 4);
+    h.off_bn_sc = take(NMEL * 4); h.off_bn_sh = take(NMEL * 4);
+    h.off_pe_bias = take(NTOK * DIM * 4);
+    h.off_fin = take(4 * DIM * 4);
+    h.off_head_w = take((size_t)ntiles * 4 * FRAG_BYTES);
+    h.off_head_b = take((size_t)ntiles * 16 * 4);
+    h.off_window = take(512 * 4);
+    h.off_tw256 = take(256 * 8);
+    h.off_tw512 = take(128 * 8);
+    h.off_mel_lo = take(NMEL * 4); h.off_mel_n = take(NMEL * 4); h.off_mel_off = take(NMEL * 4);
+    h.off_mel_w = take(mw.size() * 4 + 16);
+    h.total_bytes = o;
+    out->assign(o, 0);
+    char* img = out->data();
+    std::memcpy(img, &h, sizeof h);
+
+    // ---- front-end tables
+    std::memcpy(img + h.off_window, w->window, 512 * 4);
+    float* tw256 = (float*)(img + h.off_tw256);
+    for (int p = 0; p < 16; ++p)
+        for (int k1 = 0; k1 < 16; ++k1) {
+            const double a = 2.0 * M_PI * (double)(p * k1) / 256.0;
+            tw256[2 * (p * 16 + k1)] = (float)std::cos(a);
+            tw256[2 * (p * 16 + k1) + 1] = (float)-std::sin(a);
+        }
+    float* tw512 = (float*)(img + h.off_tw512);
+    for (int k = 0; k < 128; ++k) {
+        const double a = 2.0 * M_PI * (double)k / 512.0;
+        tw512[2 * k] = (float)std::cos(a); tw512[2 * k + 1] = (float)std::sin(a);
+    }
+    std::memcpy(img + h.off_mel_lo, lo.data(), NMEL * 4);
+    std::memcpy(img + h.off_mel_n, n.data(), NMEL * 4);
+    std::memcpy(img + h.off_mel_off, off.data(), NMEL * 4);
+    std::memcpy(img + h.off_mel_w, mw.data(), mw.size() * 4);
+
+    // ---- init_bn -> scale/shift
+    float* sc = (float*)(img + h.off_bn_sc); float* sh = (float*)(img + h.off_bn_sh);
+    for (int m = 0; m < NMEL; ++m) {
+        const double s = (double)w->bn_weight[m] / std::sqrt((double)w->bn_var[m] + 1e-5);
+        sc[m] = (float)s; sh[m] = (float)((double)w->bn_bias[m] - (double)w->bn_mean[m] * s);
+    }
+    // ---- conv bias + pos-embeds
+    float* peb = (float*)(img + h.off_pe_bias);
+    const int gt_model = c->target_length / 16;
+    for (int pf = 0; pf < GF; ++pf)
+        for (int pt = 0; pt < GT; ++pt)
+            for (int oc = 0; oc < DIM; ++oc)
+                peb[(pf * GT + pt) * DIM + oc] =
+                    (float)((double)w->pe_b[oc] + (double)w->time_pos[oc * gt_model + pt] + (double)w->freq_pos[oc * GF + pf]);
+    // ---- final norms
+    float* fin = (float*)(img + h.off_fin);
+    std::memcpy(fin + 0 * DIM, w->norm_w, DIM * 4); std::memcpy(fin + 1 * DIM, w->norm_b, DIM * 4);
+    std::memcpy(fin + 2 * DIM, w->head_ln_w, DIM * 4); std::memcpy(fin + 3 * DIM, w->head_ln_b, DIM * 4);
+
+    // ---- weight stream
+    uint16_t* ws = (uint16_t*)(img + h.off_wstream);
+    auto frag_ptr = [&](int stage, int f) { return ws + ((size_t)stage * STAGE_FRAGS + f) * (FRAG_BYTES / 2); };
+    // patch embed: k-slot (s,g,j) <-> (ti = 2s + (g>>1), fi = 8(g&1) + j); Conv2d weight [oc][0][fi][ti]
+    for (int i = 0; i < PE_STAGES; ++i)
+        for (int f = 0; f < STAGE_FRAGS; ++f) {
+            const int ft = 2 * i + f / 8, s = f % 8;
+            uint16_t* dst = frag_ptr(i, f);
+            for (int l = 0; l < 64; ++l)
+                for (int j = 0; j < 8; ++j) {
+                    const int g = l >> 4, ti = 2 * s + (g >> 1), fi = 8 * (g & 1) + j;
+                    dst[l * 8 + j] = cvt(w->pe_w[(16 * ft + (l & 15)) * 256 + fi * 16 + ti], prec);
+                }
+        }
+    float* bias = (float*)(img + h.off_bias);
+    for (int b = 0; b < depth; ++b) {
+        const uitk_block_weights& bw = w->blocks[b];
+        const int st = PE_STAGES + b * BLOCK_STAGES;
+        float* bb = bias + (size_t)b * BIAS_FLOATS;
+        const double scale = 1.0 / std::sqrt((double)(DIM / 2));         // head_dim = dim // num_heads
+        auto Wqkv = [&](int r, int k) { return (double)bw.qkv_w[r * DIM + k] * (double)bw.norm1_w[k] * (r < INNER ? scale : 1.0); };
+        auto Wproj = [&](int r, int k) { return (double)bw.proj_w[r * INNER + k]; };
+        auto Wfc1 = [&](int r, int k) { return (double)bw.fc1_w[r * DIM + k] * (double)bw.norm2_w[k]; };
+        auto Wfc2 = [&](int r, int k) { return (double)bw.fc2_w[r * HID + k]; };
+        for (int r = 0; r < 3 * INNER; ++r) {
+            double acc = bw.qkv_b[r];
+            for (int k = 0; k < DIM; ++k) acc += (double)bw.qkv_w[r * DIM + k] * (double)bw.norm1_b[k];
+            bb[BIAS_QKV + r] = (float)(acc * (r < INNER ? scale : 1.0));
+        }
+        for (int r = 0; r < DIM; ++r) bb[BIAS_PROJ + r] = bw.proj_b[r];
+        for (int r = 0; r < HID; ++r) {
+            double acc = bw.fc1_b[r];
+            for (int k = 0; k < DIM; ++k) acc += (double)bw.fc1_w[r * DIM + k] * (double)bw.norm2_b[k];
+            bb[BIAS_FC1 + r] = (float)acc;
+        }
+        for (int r = 0; r < DIM; ++r) bb[BIAS_FC2 + r] = bw.fc2_b[r];
+        // stage QK: ft = f/4 over qkv rows 0..63 (q h0, q h1, k h0, k h1), s = f%4
+        for (int f = 0; f < 16; ++f) pack_frag(frag_ptr(st, f), prec, Wqkv, f / 4, f % 4);
+        // stage VP: V rows 64..95 (tile 4 + h), then proj (K = 32: one k-step)
+        for (int f = 0; f < 8; ++f) pack_frag(frag_ptr(st + 1, f), prec, Wqkv, 4 + f / 4, f % 4);
+        for (int ft = 0; ft < 8; ++ft) pack_frag(frag_ptr(st + 1, 8 + ft), prec, Wproj, ft, 0);
+        // MLP chunks
+        for (int ch = 0; ch < 12; ++ch) {
+            for (int f = 0; f < 8; ++f) pack_frag(frag_ptr(st + 2 + ch, f), prec, Wfc1, 2 * ch + f / 4, f % 4);
+            for (int ft = 0; ft < 8; ++ft) pack_frag(frag_ptr(st + 2 + ch, 8 + ft), prec, Wfc2, ft, ch);
+        }
+    }
+    // ---- head
+    uint16_t* hw = (uint16_t*)(img + h.off_head_w);
+    auto Whead = [&](int r, int k) { return r < C ? (double)w->head_w[r * DIM + k] : 0.0; };
+    for (int ot = 0; ot < ntiles; ++ot)
+        for (int s = 0; s < 4; ++s) pack_frag(hw + ((size_t)ot * 4 + s) * (FRAG_BYTES / 2), prec, Whead, ot, s);
+    float* hb = (float*)(img + h.off_head_b);
+    for (int r = 0; r < C; ++r) hb[r] = w->head_b[r];
+    if (hdr_out) *hdr_out = h;
+    return UITK_OK;
+}
+
+}  // namespace uitk

@@ -1,0 +1,75 @@
+// uitk_dev.h -- kernel argument blocks and layout constants shared by the host code and the HIP kernels.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace uitk {
+
+constexpr int AMAX_SLOTS = 64;          // == UITK_AMAX_SLOTS
+
+// ---- fixed geometry of the uit_* family (models/uit.py:581-635 with target_length 96..111)
+constexpr int DIM = 128;                // embed_dim
+constexpr int NTOK = 24;                // 4 freq patches x 6 time patches, token = f*6 + t (uit.py:388)
+constexpr int GT = 6, GF = 4;
+constexpr int INNER = 32;               // BNeckAttention inner_dim = dim/4 (uit.py:101), 2 heads x 16
+constexpr int HID = 384;                // mlp hidden
+constexpr int NMEL = 64;
+
+// ---- weight stream: 16 KiB stages of sixteen 1 KiB MFMA A/B fragments (see pack.cpp / encoder.hip)
+constexpr int FRAG_BYTES = 1024;        // 64 lanes x 8 x 16-bit
+constexpr int STAGE_FRAGS = 16;
+constexpr int STAGE_BYTES = STAGE_FRAGS * FRAG_BYTES;
+constexpr int PE_STAGES = 4;            // patch-embed: 8 out tiles x 8 k-steps
+constexpr int BLOCK_STAGES = 14;        // QK, V+proj, 12 MLP chunks
+constexpr int BIAS_FLOATS = 1024;       // per block: qkv 96 | proj 128 | fc1 384 | fc2 128 (padded to 4 KiB)
+constexpr int BIAS_QKV = 0, BIAS_PROJ = 96, BIAS_FC1 = 224, BIAS_FC2 = 608;
+
+struct FrontendArgs {
+    const void* pcm;        // [B][T] f32 or i16
+    int64_t B, T;
+    int nF, hop;
+    const float* window;    // [512]
+    const float2* tw256;    // [16][16]  W256^(p*k1) = (cos, -sin)(2 pi p k1 / 256)
+    const float2* tw512;    // [128]     (cos, sin)(2 pi k / 512)
+    const int* mel_lo;      // [64] first bin of each mel band
+    const int* mel_n;       // [64] band length
+    const int* mel_off;     // [64] offset into mel_w
+    const float* mel_w;     // [mel_nnz] band weights
+    int mel_nnz;
+    int melw_lds_bytes;     // mel_nnz*4 rounded up to 16
+    float* mel;             // [B][nF][64] dB (no floor)
+    float* amax;            // [AMAX_SLOTS]
+};
+
+struct EncoderArgs {
+    const float* mel;       // [B][nF][64]
+    const float* amax;      // [AMAX_SLOTS]
+    float top_db;
+    int nF;                 // frames per clip
+    int rows;               // B * ncrops
+    int ncrops;
+    int tl;                 // target_length (crop stride)
+    int nt;                 // valid time patches per crop (1..6)
+    int depth;
+    int C;                  // outputdim
+    const char* wstream;    // PE_STAGES + depth*BLOCK_STAGES stages of STAGE_BYTES
+    const float* bias;      // [depth][BIAS_FLOATS]
+    const float* bn_sc;     // [64]  w / sqrt(var + 1e-5)
+    const float* bn_sh;     // [64]  b - mean * sc
+    const float* pe_bias;   // [24][128] conv bias + time_pos + freq_pos
+    const float* fin;       // [4][128] norm.w, norm.b, head_ln.w, head_ln.b
+    const char* head_w;     // [ceil(C/16)][4] fragments
+    const float* head_b;    // [ceil(C/16)*16]
+    float* probs;           // [rows][C]
+    float* logits;          // [rows][C] or null
+    float* dbg;             // [rows][depth+1][24][128] or null
+};
+
+hipError_t launch_frontend(const FrontendArgs& a, int in_i16, int n_cu, hipStream_t stream);
+hipError_t launch_mel_export(const float* mel, const float* amax, float top_db, int64_t B, int nF, float* out,
+                             hipStream_t stream);
+hipError_t launch_encoder(const EncoderArgs& a, int precision, hipStream_t stream);
+hipError_t launch_crop_reduce(const float* rowprobs, float* probs, int64_t B, int ncrops, int C, int eval_avg,
+                              hipStream_t stream);
+
+}  // namespace uitk

@@ -1,0 +1,384 @@
+"""Host-side mirror of the reference's `models/uit.py` model API, backed by libuitk.so (HIP, gfx950).
+
+What is kept from the reference interface (citations into /root/reference/models/uit.py):
+  * factories `uit_xs / uit_xxs / uit_xxxs(**kwargs)` (:581-635) and `PRETRAINED_CHECKPOINTS` (:639-655);
+  * `UITBase(**kwargs)` kwargs (:253-293) incl. `outputdim`, `target_length`, `eval_avg`, front-end knobs;
+  * the exact `state_dict()` key set / shapes, `load_state_dict(sd, strict=True)` with the positional-embedding
+    resize rule (:416-450), `.eval()`, `.to(device)`, attributes `target_length`, `hop_size`, `n_mels`,
+    `outputdim`, `patch_embed.grid_size` (read by evaluate.py:57-62, 255-259);
+  * `model(wave[B, T]) -> probs[B, outputdim]` (:452-493, eval branch: crops, mean/max over crops).
+
+What is different: the torch sub-modules below only HOLD parameters (so checkpoints load unchanged); all
+arithmetic of `forward` runs in two HIP kernels (csrc/frontend.hip, csrc/encoder.hip).  Training-mode branches
+(mixup, wav/spec transforms, patch-out) are not implemented; `forward` in training mode raises.  There is no CPU
+path: a non-HIP input raises RuntimeError.
+"""
+import ctypes
+import math
+from functools import partial
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from .. import _lib
+
+__all__ = ["UITBase", "uit_xs", "uit_xxs", "uit_xxxs", "PRETRAINED_CHECKPOINTS"]
+
+
+# ----------------------------------------------------------------------------- parameter holders
+def _melscale_fbanks(n_freqs, f_min, f_max, n_mels, sample_rate):
+    """torchaudio.functional.melscale_fbanks(norm=None, mel_scale='htk') -- the buffer MelScale registers."""
+    all_freqs = torch.linspace(0, sample_rate // 2, n_freqs)
+    m_min = 2595.0 * math.log10(1.0 + (f_min / 700.0))
+    m_max = 2595.0 * math.log10(1.0 + (f_max / 700.0))
+    m_pts = torch.linspace(m_min, m_max, n_mels + 2)
+    f_pts = 700.0 * (10 ** (m_pts / 2595.0) - 1.0)
+    f_diff = f_pts[1:] - f_pts[:-1]
+    slopes = f_pts.unsqueeze(0) - all_freqs.unsqueeze(1)
+    down = (-1.0 * slopes[:, :-2]) / f_diff[:-1]
+    up = slopes[:, 2:] / f_diff[1:]
+    return torch.max(torch.zeros(1), torch.min(down, up))
+
+
+class _Buffers(nn.Module):
+    def __init__(self, **bufs):
+        super().__init__()
+        for k, v in bufs.items():
+            self.register_buffer(k, v)
+
+
+class _MelSpectrogramParams(nn.Module):
+    """Holds `spectrogram.window` and `mel_scale.fb` under torchaudio's names (front_end.0.*)."""
+
+    def __init__(self, n_fft, win_length, f_min, f_max, n_mels, sample_rate):
+        super().__init__()
+        self.spectrogram = _Buffers(window=torch.hann_window(win_length))
+        self.mel_scale = _Buffers(fb=_melscale_fbanks(n_fft // 2 + 1, f_min, f_max, n_mels, sample_rate))
+
+
+class _PatchEmbedParams(nn.Module):
+    def __init__(self, input_size, patch_size, patch_stride, embed_dim):
+        super().__init__()
+        self.input_size = input_size
+        self.patch_size = (patch_size, patch_size)
+        self.grid_size = (input_size[0] // patch_stride, input_size[1] // patch_stride)
+        self.num_patches = self.grid_size[0] * self.grid_size[1]
+        self.proj = nn.Conv2d(1, embed_dim, kernel_size=patch_size, stride=patch_stride)
+
+
+class _AttnParams(nn.Module):
+    def __init__(self, dim, qkv_bias):
+        super().__init__()
+        self.qkv = nn.Linear(dim, (dim // 4) * 3, bias=qkv_bias)
+        self.proj = nn.Linear(dim // 4, dim)
+
+
+class _MlpParams(nn.Module):
+    def __init__(self, dim, hidden):
+        super().__init__()
+        self.fc1 = nn.Linear(dim, hidden)
+        self.fc2 = nn.Linear(hidden, dim)
+
+
+class _BlockParams(nn.Module):
+    def __init__(self, dim, hidden, qkv_bias):
+        super().__init__()
+        self.norm1 = nn.LayerNorm(dim, eps=1e-6)
+        self.attn = _AttnParams(dim, qkv_bias)
+        self.norm2 = nn.LayerNorm(dim, eps=1e-6)
+        self.mlp = _MlpParams(dim, hidden)
+
+
+class _Handle:
+    """Owns one uitk_model* (per device)."""
+
+    def __init__(self, ptr):
+        self.ptr = ptr
+
+    def __del__(self):
+        try:
+            if self.ptr:
+                _lib.load().uitk_destroy(self.ptr)
+        except Exception:
+            pass
+
+
+class _DevPtr:
+    """Zero-copy torch view of a raw device pointer (amax slots) via __cuda_array_interface__."""
+
+    def __init__(self, ptr, n):
+        self.__cuda_array_interface__ = {"shape": (n,), "typestr": "<f4", "data": (ptr, False), "version": 2}
+
+
+class UITBase(nn.Module):
+    def __init__(self, outputdim=527, patch_size=16, patch_stride=16, embed_dim=768, depth=12, num_heads=12,
+                 mlp_ratio=4., qkv_bias=True, drop_rate=0., attn_drop_rate=0., drop_path_rate=0., init_bn=True,
+                 norm_layer=None, act_layer=None, init_values=None, target_length=1012, pooling='token',
+                 wavtransforms=None, spectransforms=None, time_patch_out=None, freq_patch_out=None,
+                 block_type='Block', attention_type='Attention', eval_avg='mean', precision='f16', **kwargs):
+        super().__init__()
+        assert pooling in ('mean', 'token', 'dm')
+        self.outputdim = outputdim
+        self.pooling = pooling
+        self.embed_dim = embed_dim
+        self.patch_stride = patch_stride
+        self.patch_size = patch_size
+        self.n_mels = kwargs.get('n_mels', 64)
+        n_fft = kwargs.get('n_fft', 512)
+        self.hop_size = kwargs.get('hop_size', 160)
+        self.win_size = kwargs.get('win_size', 512)
+        f_min = kwargs.get('f_min', 0)
+        f_max = kwargs.get('f_max', 8000)
+        self.center = kwargs.get('center', True)
+        self.eval_avg = eval_avg
+        self.time_patch_out = time_patch_out
+        self.freq_patch_out = freq_patch_out
+        self.target_length = target_length
+        self.precision = precision
+        self.depth = depth
+        self.num_heads = num_heads
+        self.mlp_hidden = int(embed_dim * mlp_ratio)
+        self.n_fft = n_fft
+        # what the HIP kernels are built for: the uit_* family (uit.py:581-635)
+        unsupported = []
+        if pooling != 'mean': unsupported.append("pooling must be 'mean'")
+        if attention_type != 'BNeckAttention': unsupported.append("attention_type must be 'BNeckAttention'")
+        if act_layer is not None and act_layer is not nn.ReLU: unsupported.append("act_layer must be nn.ReLU")
+        if act_layer is None: unsupported.append("act_layer must be nn.ReLU (GELU variants are out of scope)")
+        if not init_bn: unsupported.append("init_bn must be True")
+        if init_values: unsupported.append("LayerScale (init_values) is not supported")
+        if patch_size != 16 or patch_stride != 16: unsupported.append("patch 16x16 stride 16 only")
+        if block_type != 'Block': unsupported.append("block_type must be 'Block'")
+        if not qkv_bias: unsupported.append("qkv_bias must be True")
+        if unsupported:
+            raise NotImplementedError("uit_mobile_amd implements the uit_xs/xxs/xxxs family only: " + "; ".join(unsupported))
+        if precision not in ('f16', 'bf16'):
+            raise ValueError(f"Unknown precision ({precision})")
+
+        self.front_end = nn.Sequential(
+            _MelSpectrogramParams(n_fft, self.win_size, f_min, f_max, self.n_mels, 16000), nn.Identity())
+        self.init_bn = nn.Sequential(nn.Identity(), nn.BatchNorm2d(self.n_mels, momentum=0.01), nn.Identity())
+        self.patch_embed = _PatchEmbedParams((self.n_mels, target_length), patch_size, patch_stride, embed_dim)
+        self.cls_token = nn.Parameter(torch.zeros(1, 1, embed_dim))
+        self.token_pos_embed = nn.Parameter(torch.randn(1, embed_dim) * .02)
+        self.time_pos_embed = nn.Parameter(torch.randn(1, embed_dim, 1, self.patch_embed.grid_size[1]) * .02)
+        self.freq_pos_embed = nn.Parameter(torch.randn(1, embed_dim, self.patch_embed.grid_size[0], 1) * .02)
+        self.blocks = nn.Sequential(*[_BlockParams(embed_dim, self.mlp_hidden, qkv_bias) for _ in range(depth)])
+        self.norm = nn.LayerNorm(embed_dim, eps=1e-6)
+        self.outputlayer = nn.Sequential(nn.LayerNorm(embed_dim), nn.Linear(embed_dim, outputdim))
+        self.apply(self.init_weights)
+        nn.init.normal_(self.cls_token, std=1e-6)
+        self._handles = {}          # device index -> (_Handle, version stamp)
+
+    def init_weights(self, module):
+        if isinstance(module, nn.Linear):
+            nn.init.trunc_normal_(module.weight, std=.02)
+            if module.bias is not None:
+                nn.init.zeros_(module.bias)
+        elif isinstance(module, nn.LayerNorm):
+            nn.init.constant_(module.bias, 0)
+            nn.init.constant_(module.weight, 1.0)
+
+    # ------------------------------------------------------------------ checkpoints (uit.py:416-450)
+    def load_state_dict(self, state_dict, strict=True):
+        if 'time_pos_embed' in state_dict and self.time_pos_embed.shape != state_dict['time_pos_embed'].shape:
+            state_dict = dict(state_dict)
+            self.change_pos_embedding(state_dict)
+        out = super().load_state_dict(state_dict, strict=strict)
+        self._handles.clear()
+        return out
+
+    def change_pos_embedding(self, state_dict):
+        tt, tf = self.time_pos_embed.shape[-1], self.freq_pos_embed.shape[-2]
+        pt, pf = state_dict['time_pos_embed'], state_dict['freq_pos_embed']
+        if tt <= pt.shape[-1]:
+            state_dict['time_pos_embed'] = pt[..., :tt]
+        else:
+            state_dict['time_pos_embed'] = torch.nn.functional.interpolate(pt, size=(1, tt), align_corners=False, mode='bilinear')
+        if tf <= pf.shape[-2]:
+            state_dict['freq_pos_embed'] = pf[:, :, :tf, :]
+        else:
+            state_dict['freq_pos_embed'] = torch.nn.functional.interpolate(pf, size=(tf, 1), align_corners=False, mode='bilinear')
+
+    # ------------------------------------------------------------------ C-ABI plumbing
+    def _stamp(self):
+        return sum(int(p._version) for p in list(self.parameters()) + list(self.buffers()))
+
+    def _config(self):
+        return _lib.Config(depth=self.depth, embed_dim=self.embed_dim, num_heads=self.num_heads,
+                           mlp_hidden=self.mlp_hidden, outputdim=self.outputdim, target_length=self.target_length,
+                           n_mels=self.n_mels, n_fft=self.n_fft, hop_size=self.hop_size, win_size=self.win_size,
+                           patch_size=self.patch_size, center=int(bool(self.center)),
+                           eval_avg={'mean': _lib.AVG_MEAN, 'max': _lib.AVG_MAX}.get(self.eval_avg, -1),
+                           precision={'f16': _lib.PREC_F16, 'bf16': _lib.PREC_BF16}[self.precision], top_db=120.0)
+
+    def _host_weights(self):
+        """-> (Weights struct, keep-alive list) with fp32 host pointers in reference layout."""
+        sd = self.state_dict()
+        keep = []
+
+        def ptr(key):
+            a = np.ascontiguousarray(sd[key].detach().to('cpu', torch.float32).numpy())
+            keep.append(a)
+            return a.ctypes.data
+
+        blocks = (_lib.BlockWeights * self.depth)()
+        names = {"norm1_w": "norm1.weight", "norm1_b": "norm1.bias", "qkv_w": "attn.qkv.weight", "qkv_b": "attn.qkv.bias",
+                 "proj_w": "attn.proj.weight", "proj_b": "attn.proj.bias", "norm2_w": "norm2.weight",
+                 "norm2_b": "norm2.bias", "fc1_w": "mlp.fc1.weight", "fc1_b": "mlp.fc1.bias",
+                 "fc2_w": "mlp.fc2.weight", "fc2_b": "mlp.fc2.bias"}
+        for b in range(self.depth):
+            for f, k in names.items():
+                setattr(blocks[b], f, ptr(f"blocks.{b}.{k}"))
+        keep.append(blocks)
+        w = _lib.Weights(window=ptr("front_end.0.spectrogram.window"), mel_fb=ptr("front_end.0.mel_scale.fb"),
+                         bn_weight=ptr("init_bn.1.weight"), bn_bias=ptr("init_bn.1.bias"),
+                         bn_mean=ptr("init_bn.1.running_mean"), bn_var=ptr("init_bn.1.running_var"),
+                         pe_w=ptr("patch_embed.proj.weight"), pe_b=ptr("patch_embed.proj.bias"),
+                         time_pos=ptr("time_pos_embed"), freq_pos=ptr("freq_pos_embed"),
+                         norm_w=ptr("norm.weight"), norm_b=ptr("norm.bias"),
+                         head_ln_w=ptr("outputlayer.0.weight"), head_ln_b=ptr("outputlayer.0.bias"),
+                         head_w=ptr("outputlayer.1.weight"), head_b=ptr("outputlayer.1.bias"), blocks=blocks)
+        return w, keep
+
+    def packed_image(self):
+        """Host-only: the packed parameter image uitk_create would upload (bytes).  No GPU needed."""
+        L = _lib.load()
+        cfg = self._config()
+        w, keep = self._host_weights()
+        need = ctypes.c_size_t()
+        _lib.check(L.uitk_pack_weights(ctypes.byref(cfg), ctypes.byref(w), None, 0, ctypes.byref(need)), "uitk_pack_weights")
+        buf = (ctypes.c_char * need.value)()
+        _lib.check(L.uitk_pack_weights(ctypes.byref(cfg), ctypes.byref(w), buf, need.value, ctypes.byref(need)), "uitk_pack_weights")
+        return bytes(buf)
+
+    def _handle(self, device):
+        if self.eval_avg not in ('mean', 'max'):
+            raise ValueError(f'Unknown Eval average function ({self.eval_avg})')      # uit.py:488
+        idx = device.index if device.index is not None else torch.cuda.current_device()
+        stamp = self._stamp()
+        h = self._handles.get(idx)
+        if h is not None and h[1] == stamp:
+            return h[0].ptr
+        L = _lib.load()
+        cfg = self._config()
+        w, keep = self._host_weights()
+        out = ctypes.c_void_p()
+        with torch.cuda.device(idx):
+            _lib.check(L.uitk_create(ctypes.byref(cfg), ctypes.byref(w), ctypes.byref(out)), "uitk_create")
+        self._handles[idx] = (_Handle(out.value), stamp)
+        return out.value
+
+    @staticmethod
+    def _prep_input(x):
+        if not isinstance(x, torch.Tensor):
+            raise TypeError("expected a torch.Tensor [B, T]")
+        if not x.is_cuda:
+            raise RuntimeError("uit_mobile_amd runs on a HIP device only (no CPU path): move the input with "
+                               ".to('cuda') as evaluate.py does via transfer_to_device")
+        if x.dim() == 1:
+            x = x.unsqueeze(0)
+        if x.dim() != 2:
+            raise ValueError("expected input of shape [B, T]")
+        if x.dtype == torch.int16:
+            return x.contiguous(), _lib.IN_I16
+        return x.to(torch.float32).contiguous(), _lib.IN_F32
+
+    def num_frames(self, T):
+        return 1 + T // self.hop_size
+
+    def num_crops(self, T):
+        nf = self.num_frames(T)
+        return 1 if nf <= self.target_length else -(-nf // self.target_length)
+
+    # ------------------------------------------------------------------ forward (uit.py:452-493, eval branch)
+    def forward(self, x, mixup=None, return_logits=False, amax_sync=None):
+        """probs[B, outputdim] = model(wave[B, T]).
+
+        return_logits: also return the pre-sigmoid outputs [B, ncrops, outputdim].
+        amax_sync: optional callable(tensor[64]) run between the two kernels on the batch-amax slots (used by the
+        data-parallel wrapper to MAX-all-reduce the top_db reference across shards)."""
+        if self.training:
+            raise RuntimeError("uit_mobile_amd implements inference only: call model.eval() first")
+        x, in_dtype = self._prep_input(x)
+        B, T = x.shape
+        L = _lib.load()
+        h = self._handle(x.device)
+        with torch.cuda.device(x.device):
+            stream = ctypes.c_void_p(torch.cuda.current_stream(x.device).cuda_stream)
+            probs = torch.empty((B, self.outputdim), device=x.device, dtype=torch.float32)
+            logits = torch.empty((B, self.num_crops(T), self.outputdim), device=x.device, dtype=torch.float32) if return_logits else None
+            lp = ctypes.c_void_p(logits.data_ptr()) if return_logits else None
+            if amax_sync is None:
+                _lib.check(L.uitk_forward(h, ctypes.c_void_p(x.data_ptr()), in_dtype, B, T,
+                                          ctypes.c_void_p(probs.data_ptr()), lp, stream), "uitk_forward")
+            else:
+                _lib.check(L.uitk_frontend(h, ctypes.c_void_p(x.data_ptr()), in_dtype, B, T, stream), "uitk_frontend")
+                amax_sync(self.amax_tensor(x.device))
+                _lib.check(L.uitk_encode(h, B, T, ctypes.c_void_p(probs.data_ptr()), lp, stream), "uitk_encode")
+        return (probs, logits) if return_logits else probs
+
+    def amax_tensor(self, device):
+        h = self._handle(device)
+        ptr = _lib.load().uitk_amax_ptr(h)
+        return torch.as_tensor(_DevPtr(ptr, _lib.AMAX_SLOTS), device=device)
+
+    # ------------------------------------------------------------------ stage outputs for parity tests
+    def melspec_db(self, x):
+        """What self.front_end(x) returns in the reference: dB mel [B, n_mels, frames], batch-global floor applied."""
+        x, in_dtype = self._prep_input(x)
+        B, T = x.shape
+        L = _lib.load()
+        h = self._handle(x.device)
+        with torch.cuda.device(x.device):
+            stream = ctypes.c_void_p(torch.cuda.current_stream(x.device).cuda_stream)
+            out = torch.empty((B, self.n_mels, self.num_frames(T)), device=x.device, dtype=torch.float32)
+            _lib.check(L.uitk_frontend(h, ctypes.c_void_p(x.data_ptr()), in_dtype, B, T, stream), "uitk_frontend")
+            _lib.check(L.uitk_mel_db(h, B, T, ctypes.c_void_p(out.data_ptr()), stream), "uitk_mel_db")
+        return out
+
+    def debug_tokens(self, x):
+        """(probs, tokens[B, ncrops, depth+1, 24, 128]): residual stream after patch-embed and after each block."""
+        x, _ = self._prep_input(x)
+        B, T = x.shape
+        L = _lib.load()
+        h = self._handle(x.device)
+        nc = self.num_crops(T)
+        buf = torch.zeros((B, nc, self.depth + 1, 24, self.embed_dim), device=x.device, dtype=torch.float32)
+        _lib.check(L.uitk_set_debug_tokens(h, ctypes.c_void_p(buf.data_ptr())), "uitk_set_debug_tokens")
+        try:
+            probs = self.forward(x)
+            torch.cuda.synchronize(x.device)
+        finally:
+            L.uitk_set_debug_tokens(h, None)
+        return probs, buf
+
+
+def _family(depth, **kwargs):
+    model_kwargs = dict(patch_size=16, embed_dim=128, depth=depth, num_heads=2, mlp_ratio=3.0, pooling='mean',
+                        init_bn=True, drop_path_rate=0.0, act_layer=nn.ReLU, attention_type='BNeckAttention')
+    model_kwargs = {**model_kwargs, **kwargs}
+    return UITBase(**model_kwargs)
+
+
+def uit_xs(**kwargs):      # uit.py:581-597
+    return _family(12, **kwargs)
+
+
+def uit_xxs(**kwargs):     # uit.py:619-635
+    return _family(6, **kwargs)
+
+
+def uit_xxxs(**kwargs):    # uit.py:600-616
+    return _family(4, **kwargs)
+
+
+PRETRAINED_CHECKPOINTS = {   # uit.py:639-655
+    'uit_xs': {'model': uit_xs, 'model_kwargs': dict(outputdim=537, target_length=102),
+               'chkpt': 'https://zenodo.org/record/7690036/files/uit_xs_mAP3409.pt?download=1'},
+    'uit_xxs': {'model': uit_xxs, 'model_kwargs': dict(outputdim=537, target_length=102),
+                'chkpt': 'https://zenodo.org/record/7690036/files/uit_xxs_mAP3221.pt?download=1'},
+    'uit_xxxs': {'model': uit_xxxs, 'model_kwargs': dict(outputdim=537, target_length=102),
+                 'chkpt': 'https://zenodo.org/record/7690036/files/uit_xxxs_mAP3097.pt?download=1'},
+}
