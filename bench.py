@@ -1,0 +1,197 @@
+#!/usr/bin/env python3
+"""bench.py -- throughput of the hot path (log-mel front-end + UiT-XS encoder + head) on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]            # N = 1
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W                     # N > 1, one rank per GPU over RCCL
+
+A "step" = one pass of the whole path over one batch of synthetic 16 kHz x 1 s clips already resident in HBM:
+uitk_frontend -> (N>1: 256-byte MAX all-reduce of the batch amax) -> uitk_encode -> (N>1: RCCL all-gather of the
+[B/N,537] outputs).  Workload = BASELINE.json configs[2]: UiT-XS, 8192 clips per GPU (weak scaling: 65536 at N=8 =
+configs[3]).  Prints ONE JSON line (rank 0).  The CPU baseline (oracle/torch_port.py, never the thing measured on
+the GPU) is timed on rank 0 at N=1 only, on a bounded sample.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parent
+for p in (str(ROOT), str(ROOT / "tests" / "golden")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+from synth_weights import make_state_dict  # noqa: E402
+from uit_mobile_amd import models  # noqa: E402
+from uit_mobile_amd.sharded import amax_allreduce, gather_outputs  # noqa: E402
+
+GEMM_FLOP = {"uit_xs": 68.66e6, "uit_xxs": 35.18e6, "uit_xxxs": 24.03e6}   # BASELINE.md section 3, per clip
+FRONTEND_VALU_FLOP = 4.56e6                                                 # dense-mel count, BASELINE.md section 3
+PEAK_MFMA_TFLOPS = 2500.0        # dense bf16/f16, MI355X_MICROARCH.md chip table
+PEAK_HBM_GBS = 8000.0
+PEAK_VALU_TFLOPS = 157.3
+
+
+def synth_batch(B, T, first_clip, device, i16):
+    """Device-resident synthetic PCM, a function of the GLOBAL clip index only (=> independent of the rank count).
+    Uniform noise in [-0.5,0.5); every 8th clip a loud tone, every 8th+2 silent over its last quarter, 8th+3 quiet."""
+    out = torch.empty((B, T), device=device, dtype=torch.int16)
+    t = torch.arange(T, device=device, dtype=torch.float32)
+    CH = 512
+    for lo in range(0, B, CH):
+        n = min(CH, B - lo)
+        g = torch.Generator(device=device)
+        g.manual_seed(977 + (first_clip + lo) // CH)
+        x = torch.rand((n, T), device=device, generator=g) - 0.5
+        idx = torch.arange(first_clip + lo, first_clip + lo + n, device=device)
+        tone = 0.9 * torch.sin(2 * np.pi * (440.0 + 37.0 * (idx % 64).float())[:, None] * t[None] / 16000.0)
+        x = torch.where((idx % 8 == 1)[:, None], tone, x)
+        x[:, T - T // 4:] = torch.where((idx % 8 == 2)[:, None], torch.zeros((), device=device), x[:, T - T // 4:])
+        x = torch.where((idx % 8 == 3)[:, None], x * 0.001, x)
+        out[lo:lo + n] = torch.clamp(torch.round(x * 32768.0), -32768, 32767).to(torch.int16)
+    return out if i16 else out.float() / 32768.0
+
+
+def cpu_baseline(model_name, sd, T, budget_s):
+    """The reference PyTorch CPU path (op-for-op port, oracle/torch_port.py) on this host's cores."""
+    from oracle.torch_port import TorchPort
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    tp = TorchPort(sd)
+    Bc = 256
+    wave = synth_batch(Bc, T, 0, "cpu", False)
+    tp.forward(wave[:32])                                   # warm-up
+    n, t0 = 0, time.perf_counter()
+    while True:
+        tp.forward(wave)
+        n += Bc
+        el = time.perf_counter() - t0
+        if el >= budget_s and n >= 2 * Bc:
+            break
+    return {"value": round(n / el, 1), "unit": "clips/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"{n} synthetic 1 s clips ({n // Bc} batches of {Bc}) through oracle/torch_port.py "
+                      f"(torch {torch.__version__} CPU fp32, same ATen ops as the reference), {el:.1f} s"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--model", default="uit_xs", choices=list(GEMM_FLOP))
+    ap.add_argument("--batch-per-gpu", type=int, default=8192)
+    ap.add_argument("--precision", default="f16", choices=["f16", "bf16"])
+    ap.add_argument("--pcm16", action="store_true", help="feed int16 PCM instead of float32 waves")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run for N>1")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a HIP device (there is no CPU path to benchmark)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    T, Bl = 16000, args.batch_per_gpu
+    sd = make_state_dict(args.model, 13)
+    m = getattr(models, args.model)(outputdim=537, target_length=102, precision=args.precision)
+    m.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()}, strict=True)
+    m = m.to(dev).eval()
+    x = synth_batch(Bl, T, rank * Bl, dev, args.pcm16)
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+    enc_ms, fe_ms = [], []
+
+    def sync_hook(slots):
+        ev[1].record()                                     # between the two kernels, on the launch stream
+        if world > 1:
+            amax_allreduce(slots)
+
+    def step(timed):
+        ev[0].record()
+        probs = m(x, amax_sync=sync_hook)
+        ev[2].record()
+        out = gather_outputs(probs)
+        return out
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    with torch.no_grad():
+        for _ in range(args.warmup):
+            out = step(False)
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            out = step(True)
+        barrier()
+        el = time.perf_counter() - t0
+        # per-kernel durations: a second, un-timed pass with per-step event reads (needs a sync per step)
+        for _ in range(min(args.steps, 20)):
+            step(False)
+            torch.cuda.synchronize()
+            fe_ms.append(ev[0].elapsed_time(ev[1]))
+            enc_ms.append(ev[1].elapsed_time(ev[2]))
+    assert out.shape == (world * Bl, 537) and bool(torch.isfinite(out).all())
+    t = torch.tensor([el], device=dev, dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    el = float(t.item())
+
+    if rank == 0:
+        ms = el / args.steps * 1e3
+        value = world * Bl * args.steps / el
+        enc = float(np.mean(enc_ms)) if world == 1 else float(np.mean(enc_ms))
+        fe = float(np.mean(fe_ms))
+        in_bytes = 2 if args.pcm16 else 4
+        achieved = Bl * GEMM_FLOP[args.model] / (enc * 1e-3) / 1e12
+        traffic = None
+        pmc = ROOT / "profiles" / "pmc_latest.json"
+        if pmc.exists():
+            try:
+                traffic = json.loads(pmc.read_text()).get("encoder_hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        line = {
+            "metric": "1s-clips/sec/node (mel+UiT-XS fwd)", "value": round(value, 1), "unit": "clips/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 4),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.precision,
+            "data": "synthetic",
+            "config": {"workload": f"{args.model} (UiT-XS family, seeded random-init weights), {Bl} synthetic "
+                                   f"16 kHz x 1 s clips per GPU ({'int16 PCM' if args.pcm16 else 'float32 wave'} "
+                                   f"resident in HBM), global batch {world * Bl}",
+                       "global_batch": world * Bl, "clip_samples": T,
+                       "parallelism": f"dp{world} (batch shards, RCCL amax MAX all-reduce + all-gather of [B,537])"},
+            "roofline": {"bound": "mfma", "kernel": "uit_encoder_kernel", "achieved": round(achieved, 2),
+                         "peak": PEAK_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / PEAK_MFMA_TFLOPS, 5),
+                         "traffic": traffic, "launch_ms": round(enc, 4),
+                         "algorithmic_flops_per_launch": Bl * GEMM_FLOP[args.model]},
+            "frontend": {"kernel": "mel_frontend_kernel", "launch_ms": round(fe, 4),
+                         "hbm_GBs": round(Bl * (T * in_bytes + 101 * 64 * 4) / (fe * 1e-3) / 1e9, 1),
+                         "hbm_frac": round(Bl * (T * in_bytes + 101 * 64 * 4) / (fe * 1e-3) / 1e9 / PEAK_HBM_GBS, 5),
+                         "valu_TFLOPs": round(Bl * FRONTEND_VALU_FLOP / (fe * 1e-3) / 1e12, 2),
+                         "valu_frac": round(Bl * FRONTEND_VALU_FLOP / (fe * 1e-3) / 1e12 / PEAK_VALU_TFLOPS, 5)},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(args.model, sd, T, args.cpu_seconds)
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -100,3 +100,19 @@ def test_527_classes(golden):
     r = _oracle("uit_xxs", g["seed"], outputdim=527).forward(g["pcm"])
     assert r["probs"].shape == (3, 527)
     assert np.abs(r["probs"] - g["probs"]).max() < 5e-5
+
+
+@pytest.mark.parametrize("name", ["uit_xxxs", "uit_xs"])
+def test_torch_port_matches_reference_fixtures(golden, name):
+    """oracle/torch_port.py (the op-for-op torch-CPU restatement used as bench.py's cpu_baseline)."""
+    import torch
+    from oracle.torch_port import TorchPort
+    g = golden(f"synth1s_{name}")
+    tp = TorchPort(make_state_dict(name, int(g["seed"])))
+    p, l = tp.forward(torch.from_numpy(g["pcm"].astype(np.float32) / 32768.0), return_logits=True)
+    assert np.abs(l.numpy() - g["logits"]).max() < 2e-5
+    assert np.abs(p.numpy() - g["probs"]).max() < 1e-5
+    g = golden("long_max_uit_xxxs")
+    tp = TorchPort(make_state_dict("uit_xxxs", int(g["seed"])), eval_avg="max")
+    p = tp.forward(torch.from_numpy(g["pcm"].astype(np.float32) / 32768.0))
+    assert np.abs(p.numpy() - g["probs"]).max() < 1e-5

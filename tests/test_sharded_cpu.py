@@ -1,0 +1,62 @@
+"""N>1 host logic on CPU: world_size-2 gloo processes drive the sharding wrapper (shard ranges, amax MAX
+all-reduce semantics incl. NaN = untouched slot, all-gather row order) around a stand-in model function.
+The HIP model itself cannot run here; what is under test is the distributed plumbing in uit_mobile_amd/sharded.py."""
+import os
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from uit_mobile_amd.sharded import ShardedUiT, amax_allreduce, gather_outputs, shard_range
+
+
+def test_shard_range():
+    assert [shard_range(8, r, 4) for r in range(4)] == [(0, 2), (2, 4), (4, 6), (6, 8)]
+    with pytest.raises(ValueError):
+        shard_range(10, 0, 4)
+
+
+def test_amax_allreduce_single_process_ignores_nan_slots():
+    s = torch.full((64,), float("nan"))
+    s[3], s[40] = -12.5, 7.25
+    amax_allreduce(s)
+    assert torch.all(s == 7.25)
+
+
+def _worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        B, C = 8, 5
+        full = torch.arange(B * 4, dtype=torch.float32).reshape(B, 4)
+        lo, hi = shard_range(B, rank, world)
+
+        def fake_model(x, amax_sync=None):
+            slots = torch.full((64,), float("nan"))
+            slots[rank] = float(x.max())                      # this shard's "amax"
+            amax_sync(slots)
+            # output depends on the (now global) amax, like the top_db floor does
+            return torch.cat([x, slots[:1].expand(x.shape[0], 1)], 1)
+
+        out = ShardedUiT(fake_model)(full[lo:hi])
+        expect = torch.cat([full, torch.full((B, 1), float(full.max()))], 1)
+        ok = out.shape == (B, C) and torch.equal(out, expect)
+        g = gather_outputs(torch.full((2, 3), float(rank)))
+        ok = ok and torch.equal(g, torch.tensor([[0.] * 3] * 2 + [[1.] * 3] * 2))
+        q.put((rank, bool(ok)))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_world_size_2_gloo():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + os.getpid() % 2000
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+    assert res == [(0, True), (1, True)]

@@ -1,0 +1,53 @@
+"""Data-parallel sharding of the hot path across the GPUs of one node (one process per GPU, RCCL over xGMI).
+
+The path is embarrassingly parallel over clips: rank r of R owns the contiguous rows
+[r*B/R, (r+1)*B/R) of the batch and a full replica of the (<= 3 MB) packed weights.  There are exactly two
+collectives, both on torch.distributed's "nccl" backend (= RCCL on ROCm):
+  * a 256-byte MAX all-reduce of the batch-amax slots between the two kernels, so the top_db floor is the one the
+    reference computes for the WHOLE batch (models/uit.py:307 via torchaudio's packed-channel reshape) and the
+    result does not depend on R;
+  * one all-gather of the [B/R, outputdim] fp32 outputs into [B, outputdim] on every rank (what evaluate.py's
+    metric accumulation consumes).
+Nothing else crosses GPUs; there is no collective inside either kernel.
+"""
+import torch
+import torch.distributed as dist
+
+
+def shard_range(B, rank, world):
+    """Contiguous, equal shards (the all-gather needs equal sizes): B must divide by world."""
+    if B % world:
+        raise ValueError(f"global batch {B} must be divisible by the number of ranks {world}")
+    per = B // world
+    return rank * per, (rank + 1) * per
+
+
+def amax_allreduce(slots, group=None):
+    """In-place: every slot <- max over all ranks and slots.  Untouched slots hold NaN (0xFFFFFFFF) and are ignored."""
+    m = torch.nan_to_num(slots, nan=float("-inf")).max().reshape(1)
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+        dist.all_reduce(m, op=dist.ReduceOp.MAX, group=group)
+    slots.copy_(m.expand_as(slots))          # stream-ordered, no host sync
+    return slots
+
+
+def gather_outputs(local, group=None):
+    """[B/R, C] on every rank -> [B, C] on every rank (rank order == row order)."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return local
+    world = dist.get_world_size(group)
+    out = torch.empty((world * local.shape[0],) + tuple(local.shape[1:]), device=local.device, dtype=local.dtype)
+    dist.all_gather_into_tensor(out, local.contiguous(), group=group)
+    return out
+
+
+class ShardedUiT:
+    """model: any callable `model(x, amax_sync=fn) -> probs` (uit_mobile_amd.models.UITBase on a HIP device)."""
+
+    def __init__(self, model, group=None, global_floor=True):
+        self.model, self.group, self.global_floor = model, group, global_floor
+
+    def __call__(self, local_x):
+        sync = (lambda slots: amax_allreduce(slots, self.group)) if self.global_floor else None
+        probs = self.model(local_x, amax_sync=sync)
+        return gather_outputs(probs, self.group)
