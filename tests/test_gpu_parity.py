@@ -153,7 +153,8 @@ def test_full_size_properties():
     assert np.isfinite(p).all() and (p > 0).all() and (p < 1).all()
     perm = np.random.default_rng(0).permutation(B)
     pp, _ = run(m, pcm[perm])
-    assert np.array_equal(pp, p[perm])
+    # a clip's slot inside its wave changes the fp32 summation order of the token mean-pool: ~1e-7, not bitwise
+    assert np.abs(pp - p[perm]).max() < 1e-5
     idx = np.arange(0, B, 257)                            # includes tone / silence / quiet clip classes
     sub = pcm[idx]
     # the subset's own amax equals the batch amax when it contains the loudest clip class (b % 8 == 1)
