@@ -149,16 +149,18 @@ def test_full_size_properties():
     B = 4096
     m, sd = build("uit_xxxs", 22)
     pcm = synth_pcm_i16(B, 16000, seed=5)
+    # clip 0 = full-scale 1 kHz square wave: the loudest clip by a margin, so any subset containing it has the
+    # batch's amax and therefore the batch's top_db floor
+    pcm[0] = np.where((np.arange(16000) // 8) % 2 == 0, 32767, -32768).astype(np.int16)
     p, l = run(m, pcm)
     assert np.isfinite(p).all() and (p > 0).all() and (p < 1).all()
     perm = np.random.default_rng(0).permutation(B)
     pp, _ = run(m, pcm[perm])
     # a clip's slot inside its wave changes the fp32 summation order of the token mean-pool: ~1e-7, not bitwise
     assert np.abs(pp - p[perm]).max() < 1e-5
-    idx = np.arange(0, B, 257)                            # includes tone / silence / quiet clip classes
+    idx = np.arange(0, B, 257)                            # includes clip 0 and tone / silence / quiet classes
     sub = pcm[idx]
-    # the subset's own amax equals the batch amax when it contains the loudest clip class (b % 8 == 1)
-    assert (idx % 8 == 1).any()
+    assert idx[0] == 0 and (idx % 8 == 2).any()
     ref = Oracle(sd).forward(sub)
     assert np.abs(p[idx] - ref["probs"]).max() < TOL
     assert np.abs(l[idx] - ref["logits"]).max() < TOL
