@@ -142,11 +142,13 @@ class EncoderEmu:
                     stages[clip[ct][:, None], st, tk[ct][:, None], 16 * ft + 4 * G_[:, None] + r4] = R[ft][ct]
         dump(0)
         TJ, TI = [0, 1, 0, 1, 2, 1, 2], [0, 0, 1, 1, 1, 2, 2]
-        valid = []
+        tvalid, pvalid = [], []
         for i in range(7):
             j = 16 * TJ[i] + 4 * G_[:, None] + r4
             q = 16 * TI[i] + C_[:, None]
-            valid.append(((j >= 24) == (q >= 24)) & (((j % 24) % 6) < nt))
+            same = (j >= 24) == (q >= 24)
+            tvalid.append(same[:, 0])                                  # uniform over r (kernel: tvalid[i])
+            pvalid.append(same & (((j % 24) % 6) < nt))                # kernel: pmask[i]
         for blk in range(self.depth):
             tb = PE_STAGES + blk * BLOCK_STAGES
             bias = self._f32(h["off_bias"] + blk * BIAS_FLOATS * 4, BIAS_FLOATS)
@@ -166,26 +168,26 @@ class EncoderEmu:
             Vh = [[self.pack4(V[ct][hh]) for hh in range(2)] for ct in range(3)]
             O = [[None] * 3 for _ in range(2)]
             for hh in range(2):
-                S = []
+                S, tm = [], []
                 for i in range(7):
-                    s = mfma16(Kh[hh][TJ[i]], Qh[hh][TI[i]], np.zeros((64, 4), np.float32))
-                    S.append(np.where(valid[i], s, -np.inf))
+                    s_ = mfma16(Kh[hh][TJ[i]], Qh[hh][TI[i]], np.zeros((64, 4), np.float32))    # log2-domain scores
+                    S.append(s_)
+                    tm.append(np.where(tvalid[i], s_.max(1), -np.inf))
                 mx = [np.full(64, -np.inf, np.float32) for _ in range(3)]
                 for i in range(7):
-                    mx[TI[i]] = np.maximum(mx[TI[i]], S[i].max(1))
+                    mx[TI[i]] = np.maximum(mx[TI[i]], tm[i])
                 mx = [m_.reshape(4, 16).max(0)[C_] for m_ in mx]
-                sm = [np.zeros(64, np.float32) for _ in range(3)]
-                Pm = []
-                for i in range(7):
-                    p = np.exp(S[i] - mx[TI[i]][:, None]).astype(np.float32)
-                    sm[TI[i]] = sm[TI[i]] + p.sum(1)
-                    Pm.append(self.pack4(p))
-                inv = [1.0 / s_.reshape(4, 16).sum(0)[C_] for s_ in sm]
                 acc = [np.zeros((64, 4), np.float32) for _ in range(3)]
+                Ls = [np.zeros((64, 4), np.float32) for _ in range(3)]
+                ones = np.ones((64, 4), np.float32)
                 for i in range(7):
-                    acc[TI[i]] = mfma16(Vh[TJ[i]][hh], Pm[i], acc[TI[i]])
+                    with np.errstate(over="ignore"):
+                        p = np.exp2(S[i] - mx[TI[i]][:, None]).astype(np.float32)
+                    Pm = np.where(pvalid[i], self.pack4(p), 0.0).astype(np.float32)
+                    acc[TI[i]] = mfma16(Vh[TJ[i]][hh], Pm, acc[TI[i]])
+                    Ls[TI[i]] = mfma16(ones, Pm, Ls[TI[i]])
                 for it in range(3):
-                    O[hh][it] = acc[it] * inv[it][:, None]
+                    O[hh][it] = acc[it] / Ls[it][:, :1]
             OX = [self.pack8(O[0][ct], O[1][ct]) for ct in range(3)]
             for ft in range(8):
                 A = self.frag(tb + 1, 8 + ft)

@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -31,6 +32,7 @@ struct uitk_model {
     size_t mel_cap = 0, rowprobs_cap = 0;
     float* dbg = nullptr;
     int n_cu = 256;
+    int enc_waves = 8;            // waves per encoder workgroup (8 = one WG per CU; 4 = two independent WGs per CU)
     int device = 0;
 };
 
@@ -74,6 +76,7 @@ int uitk_create(const uitk_config* cfg, const uitk_weights* w, uitk_model** out)
         return fail(UITK_ERR_NO_DEVICE, "libuitk is built for gfx950 only, found " + arch);
     }
     m->n_cu = prop.multiProcessorCount;
+    if (const char* e = std::getenv("UITK_ENC_WAVES")) m->enc_waves = std::atoi(e) == 4 ? 4 : 8;
     if (hipMalloc((void**)&m->image, img.size()) != hipSuccess || hipMalloc((void**)&m->amax, AMAX_SLOTS * 4) != hipSuccess) {
         uitk_destroy(m); return fail(UITK_ERR_HIP, "hipMalloc failed for the parameter image");
     }
@@ -188,7 +191,7 @@ int uitk_encode(uitk_model* m, int64_t B, int64_t T, float* probs, float* logits
     a.head_b = (const float*)(m->image + h.off_head_b);
     a.probs = nc > 1 ? m->rowprobs : probs;
     a.logits = logits; a.dbg = m->dbg;
-    HIP_TRY(launch_encoder(a, m->cfg.precision, s));
+    HIP_TRY(launch_encoder(a, m->cfg.precision, m->enc_waves, s));
     if (nc > 1) HIP_TRY(launch_crop_reduce(m->rowprobs, probs, B, nc, a.C, m->cfg.eval_avg, s));
     return UITK_OK;
 }

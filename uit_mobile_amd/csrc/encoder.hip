@@ -54,6 +54,13 @@ template <> struct Op<0> {   // fp16 operands
     static __device__ __forceinline__ f4 mfma16(v4 a, v4 b, f4 c) {
         return __builtin_amdgcn_mfma_f32_16x16x16f16(a, b, c, 0, 0, 0);
     }
+    // ReLU after conversion: relu(cvt(x)) == cvt(relu(x)); v_pk_max_f16 does two elements per instruction and
+    // avoids the canonicalising v_max the compiler puts in front of an f32 max on MFMA results.
+    static __device__ __forceinline__ v8 relu_pack8(f4 lo, f4 hi) {
+        const v8 z = {0, 0, 0, 0, 0, 0, 0, 0};
+        return __builtin_elementwise_max(pack8(lo, hi), z);
+    }
+    static __device__ __forceinline__ v4 ones4() { return v4{(_Float16)1.f, (_Float16)1.f, (_Float16)1.f, (_Float16)1.f}; }
 };
 template <> struct Op<1> {   // bf16 operands
     using v8 = b8; using v4 = b4;
@@ -70,14 +77,21 @@ template <> struct Op<1> {   // bf16 operands
     static __device__ __forceinline__ f4 mfma16(v4 a, v4 b, f4 c) {
         return __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(__builtin_bit_cast(s4, a), __builtin_bit_cast(s4, b), c, 0, 0, 0);
     }
+    static __device__ __forceinline__ float relu1(float x) {   // single v_max_f32, no canonicalise
+        float r; asm("v_max_f32 %0, 0, %1" : "=v"(r) : "v"(x)); return r;
+    }
+    static __device__ __forceinline__ v8 relu_pack8(f4 lo, f4 hi) {
+        return pack8(f4{relu1(lo[0]), relu1(lo[1]), relu1(lo[2]), relu1(lo[3])},
+                     f4{relu1(hi[0]), relu1(hi[1]), relu1(hi[2]), relu1(hi[3])});
+    }
+    static __device__ __forceinline__ v4 ones4() { return v4{(__bf16)1.f, (__bf16)1.f, (__bf16)1.f, (__bf16)1.f}; }
 };
 
-constexpr int ENC_WAVES = 8;
 constexpr int RING_SLOTS = 4;           // >= PREFETCH + 2 (see ring_step)
 constexpr int PREFETCH = 2;             // stages in flight ahead of the one being consumed
 constexpr int LDS_RING = RING_SLOTS * STAGE_BYTES;            // 64 KiB
 constexpr int LDS_BIAS = 2 * BIAS_FLOATS * 4;                 // 8 KiB (double-buffered per block)
-constexpr int LDS_ZBUF = 2 * ENC_WAVES * DIM * 2;             // 4 KiB: 16 pooled vectors, 16-bit
+constexpr int LDS_ZBUF = 16 * DIM * 2;                        // 4 KiB: up to 16 pooled vectors, 16-bit
 constexpr int ENC_LDS = LDS_RING + LDS_BIAS + LDS_ZBUF;
 
 #define GPTR(p) ((const __attribute__((address_space(1))) void*)(p))
@@ -88,6 +102,7 @@ constexpr int ENC_LDS = LDS_RING + LDS_BIAS + LDS_ZBUF;
 // (2) waits (counted vmcnt) until its share of stage t has landed, (3) s_barrier => the whole stage is visible.
 // WAR safety: the slot overwritten at step t held stage t+PREFETCH-RING_SLOTS <= t-2, and a wave can only be
 // at step t after all waves passed barrier(t-1), i.e. finished reading stage t-2.
+// The stream is padded with PREFETCH dummy stages (pack.cpp) so the issue and the vmcnt immediate never vary.
 template <int WAVES>
 __device__ __forceinline__ void ring_issue(const char* wstream, char* ring, int stage, int wave, int lane) {
     constexpr int PER_WAVE = STAGE_FRAGS / WAVES;
@@ -101,28 +116,20 @@ __device__ __forceinline__ void ring_issue(const char* wstream, char* ring, int 
 }
 
 template <int WAVES>
-__device__ __forceinline__ void ring_step(const char* wstream, char* ring, int t, int total, int wave, int lane) {
+__device__ __forceinline__ void ring_step(const char* wstream, char* ring, int t, int wave, int lane) {
     constexpr int PER_WAVE = STAGE_FRAGS / WAVES;
-    static_assert(PREFETCH == 2, "vmcnt immediates below assume PREFETCH == 2");
-    if (t + PREFETCH < total) ring_issue<WAVES>(wstream, ring, t + PREFETCH, wave, lane);
-    const int younger = total - 1 - t;          // stages issued after stage t (capped at PREFETCH)
-    if (younger >= 2) {
-        if constexpr (PER_WAVE == 2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-    } else if (younger == 1) {
-        if constexpr (PER_WAVE == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-    } else {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    }
+    static_assert(PREFETCH == 2 && (PER_WAVE == 2 || PER_WAVE == 4), "vmcnt immediates below");
+    ring_issue<WAVES>(wstream, ring, t + PREFETCH, wave, lane);
+    // all but the 2*PER_WAVE youngest LDS-DMAs (stages t+1, t+2) have landed => this wave's share of stage t
+    if constexpr (PER_WAVE == 2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
 }
 
 template <int WAVES>
 __device__ __forceinline__ void bias_issue(const float* bias, char* breg, int blk, int wave, int lane) {
-    // 4 KiB per block = WAVES waves x (512/WAVES*... ) -> each wave copies 4096/WAVES bytes with dword LDS-DMA
-    constexpr int PER_WAVE_BYTES = BIAS_FLOATS * 4 / WAVES;      // 512 (8 waves)
+    constexpr int PER_WAVE_BYTES = BIAS_FLOATS * 4 / WAVES;
     constexpr int N = PER_WAVE_BYTES / 256;                      // dword x 64 lanes = 256 B per instruction
     const char* src = (const char*)(bias + (size_t)blk * BIAS_FLOATS) + wave * PER_WAVE_BYTES;
     char* dst = breg + (blk & 1) * BIAS_FLOATS * 4 + wave * PER_WAVE_BYTES;
@@ -138,48 +145,54 @@ __device__ __forceinline__ typename Op<PREC>::v8 lds_frag(const char* slot, int 
 
 __device__ __forceinline__ f4 splat(float x) { return f4{x, x, x, x}; }
 __device__ __forceinline__ float hsum(f4 x) { return (x[0] + x[1]) + (x[2] + x[3]); }
-__device__ __forceinline__ float xsum(float v) {   // sum over the 4 lane groups g (lanes c, c+16, c+32, c+48)
-    v += __shfl_xor(v, 16);
-    v += __shfl_xor(v, 32);
-    return v;
+__device__ __forceinline__ float hmax(f4 x) { return fmaxf(fmaxf(x[0], x[1]), fmaxf(x[2], x[3])); }
+
+// Reductions over the 4 lane groups g (lanes c, c+16, c+32, c+48) with the gfx950 VALU swaps (no LDS crossbar):
+// v_permlane16_swap(v, v): {rows 0,0,2,2 | rows 1,1,3,3}; v_permlane32_swap(v, v): {lo,lo | hi,hi}.
+__device__ __forceinline__ float xsum(float v) {
+    auto a = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    v = __uint_as_float(a[0]) + __uint_as_float(a[1]);
+    auto b = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return __uint_as_float(b[0]) + __uint_as_float(b[1]);
 }
 __device__ __forceinline__ float xmax(float v) {
-    v = fmaxf(v, __shfl_xor(v, 16));
-    v = fmaxf(v, __shfl_xor(v, 32));
-    return v;
+    auto a = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    v = fmaxf(__uint_as_float(a[0]), __uint_as_float(a[1]));
+    auto b = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return fmaxf(__uint_as_float(b[0]), __uint_as_float(b[1]));
 }
 
-// LayerNorm statistics + normalisation of the residual stream (affine folded into the next linear by pack.cpp).
-// R[ft][ct] holds features 16ft+4g+r of token column 16ct+c.
+// LayerNorm statistics (two-pass, fp32) of one token column held as R[ft][ct], ft = 0..7.
+__device__ __forceinline__ void ln_stats(const f4 (&R)[8][3], int ct, float eps, float& mean, float& rstd) {
+    f4 acc = R[0][ct];
+#pragma unroll
+    for (int ft = 1; ft < 8; ++ft) acc = acc + R[ft][ct];
+    mean = xsum(hsum(acc)) * (1.0f / DIM);
+    f4 q = splat(0.f);
+#pragma unroll
+    for (int ft = 0; ft < 8; ++ft) { const f4 d = R[ft][ct] - splat(mean); q = q + d * d; }
+    rstd = __builtin_amdgcn_rsqf(xsum(hsum(q)) * (1.0f / DIM) + eps);
+}
+
+// LN + conversion to the MFMA operand of the next linear (its affine is folded into that linear by pack.cpp).
 template <int PREC>
 __device__ __forceinline__ void layernorm_to_operand(const f4 (&R)[8][3], float eps, typename Op<PREC>::v8 (&X)[4][3]) {
 #pragma unroll
     for (int ct = 0; ct < 3; ++ct) {
-        float s = 0.f;
+        float mean, rstd;
+        ln_stats(R, ct, eps, mean, rstd);
+        const f4 nm = splat(-mean * rstd), rs = splat(rstd);
 #pragma unroll
-        for (int ft = 0; ft < 8; ++ft) s += hsum(R[ft][ct]);
-        const float mean = xsum(s) * (1.0f / DIM);
-        float v = 0.f;
-#pragma unroll
-        for (int ft = 0; ft < 8; ++ft) {
-            f4 d = R[ft][ct] - splat(mean);
-            v += hsum(d * d);
-        }
-        const float rstd = __frsqrt_rn(xsum(v) * (1.0f / DIM) + eps);
-#pragma unroll
-        for (int s4i = 0; s4i < 4; ++s4i) {
-            f4 lo = (R[2 * s4i][ct] - splat(mean)) * splat(rstd);
-            f4 hi = (R[2 * s4i + 1][ct] - splat(mean)) * splat(rstd);
-            X[s4i][ct] = Op<PREC>::pack8(lo, hi);
-        }
+        for (int s = 0; s < 4; ++s) X[s][ct] = Op<PREC>::pack8(R[2 * s][ct] * rs + nm, R[2 * s + 1][ct] * rs + nm);
     }
 }
 
 template <int PREC, int WAVES>
-__global__ __launch_bounds__(WAVES * 64) void uit_encoder_kernel(EncoderArgs a) {
+__global__ __launch_bounds__(WAVES * 64, 2) void uit_encoder_kernel(EncoderArgs a) {
     using OP = Op<PREC>;
     using v8 = typename OP::v8;
     using v4 = typename OP::v4;
+    typedef unsigned u2 __attribute__((ext_vector_type(2)));
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* ring = smem;
     char* breg = smem + LDS_RING;
@@ -188,16 +201,16 @@ __global__ __launch_bounds__(WAVES * 64) void uit_encoder_kernel(EncoderArgs a) 
     const int tid = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lane = tid & 63, c = lane & 15, g = lane >> 4;
-    const int total = PE_STAGES + a.depth * BLOCK_STAGES;
 
-    // ---- kick the weight stream
+    // ---- kick the weight stream: block-0 biases + the whole patch-embed weight set (4 stages = the whole ring)
     if (a.depth > 0) bias_issue<WAVES>(a.bias, breg, 0, wave, lane);
-    ring_issue<WAVES>(a.wstream, ring, 0, wave, lane);
-    ring_issue<WAVES>(a.wstream, ring, 1, wave, lane);
+#pragma unroll
+    for (int i = 0; i < PE_STAGES; ++i) ring_issue<WAVES>(a.wstream, ring, i, wave, lane);
 
     // ---- rows (clip-crops) of this wave, token maps
     const int r0 = (blockIdx.x * WAVES + wave) * 2;
     int64_t mel_base[2];
+    int fr_limit[2];
 #pragma unroll
     for (int k = 0; k < 2; ++k) {
         int row = r0 + k; if (row > a.rows - 1) row = a.rows - 1;
@@ -205,6 +218,7 @@ __global__ __launch_bounds__(WAVES * 64) void uit_encoder_kernel(EncoderArgs a) 
         int start = 0;
         if (a.ncrops > 1) { start = cr * a.tl; if (start > a.nF - a.tl) start = a.nF - a.tl; }
         mel_base[k] = ((int64_t)b * a.nF + start) * NMEL;
+        fr_limit[k] = a.nF - 1 - start;                    // last valid frame offset from the crop start
     }
     int clip_[3], tk_[3], pf_[3], pt_[3];
 #pragma unroll
@@ -219,48 +233,53 @@ __global__ __launch_bounds__(WAVES * 64) void uit_encoder_kernel(EncoderArgs a) 
     for (int i = 0; i < AMAX_SLOTS; ++i) amx = fmaxf(amx, a.amax[i]);     // NaN (untouched) slots are ignored
     const float floor_db = amx - a.top_db;
 
-    // ---- patch-embed B operand: clamp + init_bn + convert.  k-slot (s,g,j) <-> (ti = 2s + (g>>1), fi = 8(g&1) + j)
-    v8 XB[8][3];
-#pragma unroll
-    for (int ct = 0; ct < 3; ++ct) {
+    // ---- patch embed.  All 64 weight fragments (ft = f/8, s = f%8) are LDS-resident; one token tile at a time
+    // keeps the live set at 8 operand + 8 accumulator tiles.  k-slot (s,g,j) <-> (ti = 2s+(g>>1), fi = 8(g&1)+j).
+    f4 R[8][3];
+    auto pe_tile = [&](int ct, bool first) {
         const int f0 = 16 * pf_[ct] + 8 * (g & 1);
         const f4 sc0 = *(const f4*)(a.bn_sc + f0), sc1 = *(const f4*)(a.bn_sc + f0 + 4);
         const f4 sh0 = *(const f4*)(a.bn_sh + f0), sh1 = *(const f4*)(a.bn_sh + f0 + 4);
         const int64_t base = clip_[ct] ? mel_base[1] : mel_base[0];
-        const int fr_limit = a.nF - 1 - (int)((base / NMEL) % a.nF);      // last valid frame offset from crop start
+        const int lim = clip_[ct] ? fr_limit[1] : fr_limit[0];
+        f4 x0[8], x1[8];
 #pragma unroll
         for (int s = 0; s < 8; ++s) {
             int t = 16 * pt_[ct] + 2 * s + (g >> 1);
-            if (t > fr_limit) t = fr_limit;                               // masked tokens of short clips: stay in bounds
+            if (t > lim) t = lim;                                         // masked tokens of short clips: stay in bounds
             const float* src = a.mel + base + (int64_t)t * NMEL + f0;
-            f4 x0 = *(const f4*)src, x1 = *(const f4*)(src + 4);
-            x0 = __builtin_elementwise_max(x0, splat(floor_db)) * sc0 + sh0;
-            x1 = __builtin_elementwise_max(x1, splat(floor_db)) * sc1 + sh1;
-            XB[s][ct] = OP::pack8(x0, x1);
+            x0[s] = *(const f4*)src; x1[s] = *(const f4*)(src + 4);
         }
-    }
-    // ---- residual stream, initialised with conv bias + pos-embeds
-    f4 R[8][3];
 #pragma unroll
-    for (int ft = 0; ft < 8; ++ft)
+        for (int ft = 0; ft < 8; ++ft) R[ft][ct] = *(const f4*)(a.pe_bias + tk_[ct] * DIM + 16 * ft + 4 * g);
+        v8 XB[8];
 #pragma unroll
-        for (int ct = 0; ct < 3; ++ct) R[ft][ct] = *(const f4*)(a.pe_bias + tk_[ct] * DIM + 16 * ft + 4 * g);
-
-    // ---- patch embed: 4 stages, stage i holds fragments (ft = 2i + f/8, s = f%8)
-#pragma unroll
-    for (int i = 0; i < PE_STAGES; ++i) {
-        ring_step<WAVES>(a.wstream, ring, i, total, wave, lane);
-        const char* slot = ring + (i & (RING_SLOTS - 1)) * STAGE_BYTES;
-#pragma unroll
-        for (int f = 0; f < STAGE_FRAGS; ++f) {
-            const v8 A = lds_frag<PREC>(slot, f, lane);
-#pragma unroll
-            for (int ct = 0; ct < 3; ++ct) R[2 * i + f / 8][ct] = OP::mfma32(A, XB[f % 8][ct], R[2 * i + f / 8][ct]);
+        for (int s = 0; s < 8; ++s)                                       // top_db clamp + init_bn + convert
+            XB[s] = OP::pack8(__builtin_elementwise_max(x0[s], splat(floor_db)) * sc0 + sh0,
+                              __builtin_elementwise_max(x1[s], splat(floor_db)) * sc1 + sh1);
+        if (first) {                                                      // PE weights landed + visible
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
         }
-    }
+#pragma unroll
+        for (int ft = 0; ft < 8; ++ft) {
+            v8 A[8];
+#pragma unroll
+            for (int s = 0; s < 8; ++s) A[s] = lds_frag<PREC>(ring, ft * 8 + s, lane);
+#pragma unroll
+            for (int s = 0; s < 8; ++s) R[ft][ct] = OP::mfma32(A[s], XB[s], R[ft][ct]);
+        }
+    };
+    pe_tile(0, true);
+    pe_tile(1, false);
+    pe_tile(2, false);
+    __builtin_amdgcn_s_barrier();                                         // every wave is done with the PE weights
+    asm volatile("" ::: "memory");
+    ring_issue<WAVES>(a.wstream, ring, PE_STAGES, wave, lane);
+    ring_issue<WAVES>(a.wstream, ring, PE_STAGES + 1, wave, lane);
 
     auto dbg_store = [&](int stage) {
-        if (a.dbg == nullptr) return;
 #pragma unroll
         for (int ct = 0; ct < 3; ++ct) {
             const int row = r0 + clip_[ct];
@@ -271,21 +290,30 @@ __global__ __launch_bounds__(WAVES * 64) void uit_encoder_kernel(EncoderArgs a) 
             }
         }
     };
-    dbg_store(0);
+    if (a.dbg != nullptr) dbg_store(0);
 
-    // ---- attention validity mask (constant over blocks): tile list (jt,it)
+    // ---- attention masks (constant over blocks).  Score tiles (jt,it): S^T[j = 16jt+4g+r][i = 16it+c].
+    //   tvalid[i]: this lane's 4 keys of tile i belong to the query's clip (uniform over r: 24 = 16 + 8 and the
+    //              key index is 4g+r) -> used for the row max;
+    //   pmask[i] : per-element AND mask on the packed probabilities (clip membership AND key time-patch < nt).
     constexpr int TJ[7] = {0, 1, 0, 1, 2, 1, 2};
     constexpr int TI[7] = {0, 0, 1, 1, 1, 2, 2};
-    unsigned vmask = 0;
+    bool tvalid[7];
+    u2 pmask[7];
 #pragma unroll
-    for (int i = 0; i < 7; ++i)
+    for (int i = 0; i < 7; ++i) {
+        const int qc = (16 * TI[i] + c) >= NTOK ? 1 : 0;
+        const int jc = (16 * TJ[i] + 4 * g) >= NTOK ? 1 : 0;
+        tvalid[i] = jc == qc;
+        unsigned m[4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            const int j = 16 * TJ[i] + 4 * g + r, q = 16 * TI[i] + c;
-            const int jc = j >= NTOK ? 1 : 0, qc = q >= NTOK ? 1 : 0;
+            const int j = 16 * TJ[i] + 4 * g + r;
             const int jt = (j - NTOK * jc) % GT;
-            if (jc == qc && jt < a.nt) vmask |= 1u << (4 * i + r);
+            m[r] = (jc == qc && jt < a.nt) ? 0xFFFFu : 0u;
         }
+        pmask[i] = u2{m[0] | (m[1] << 16), m[2] | (m[3] << 16)};
+    }
 
     // ---- transformer blocks
 #pragma unroll 1
@@ -296,104 +324,97 @@ __global__ __launch_bounds__(WAVES * 64) void uit_encoder_kernel(EncoderArgs a) 
         layernorm_to_operand<PREC>(R, 1e-6f, X);
 
         // ===== stage QK: fragments (ft = f/4 in {q h0, q h1, k h0, k h1}, s = f%4)
-        ring_step<WAVES>(a.wstream, ring, tb, total, wave, lane);
+        ring_step<WAVES>(a.wstream, ring, tb, wave, lane);
         if (blk + 1 < a.depth) bias_issue<WAVES>(a.bias, breg, blk + 1, wave, lane);
         v4 Qh[2][3], Kh[2][3];
         {
             const char* slot = ring + (tb & (RING_SLOTS - 1)) * STAGE_BYTES;
-            f4 QK[4][3];
+            v8 A[16];
+#pragma unroll
+            for (int f = 0; f < 8; ++f) A[f] = lds_frag<PREC>(slot, f, lane);
 #pragma unroll
             for (int ft = 0; ft < 4; ++ft) {
+                if (ft == 1) {
+#pragma unroll
+                    for (int f = 8; f < 16; ++f) A[f] = lds_frag<PREC>(slot, f, lane);
+                }
                 const f4 bq = *(const f4*)(bias + BIAS_QKV + 16 * ft + 4 * g);
 #pragma unroll
-                for (int ct = 0; ct < 3; ++ct) QK[ft][ct] = bq;
+                for (int ct = 0; ct < 3; ++ct) {
+                    f4 acc = bq;
+#pragma unroll
+                    for (int s = 0; s < 4; ++s) acc = OP::mfma32(A[ft * 4 + s], X[s][ct], acc);
+                    if (ft < 2) Qh[ft][ct] = OP::pack4(acc); else Kh[ft - 2][ct] = OP::pack4(acc);
+                }
             }
-#pragma unroll
-            for (int f = 0; f < 16; ++f) {
-                const v8 A = lds_frag<PREC>(slot, f, lane);
-#pragma unroll
-                for (int ct = 0; ct < 3; ++ct) QK[f / 4][ct] = OP::mfma32(A, X[f % 4][ct], QK[f / 4][ct]);
-            }
-#pragma unroll
-            for (int h = 0; h < 2; ++h)
-#pragma unroll
-                for (int ct = 0; ct < 3; ++ct) { Qh[h][ct] = OP::pack4(QK[h][ct]); Kh[h][ct] = OP::pack4(QK[2 + h][ct]); }
         }
 
         // ===== stage VP: fragments 0..7 = V (h = f/4, s = f%4) used as the B operand; 8..15 = proj (ft = f-8)
-        ring_step<WAVES>(a.wstream, ring, tb + 1, total, wave, lane);
+        ring_step<WAVES>(a.wstream, ring, tb + 1, wave, lane);
         {
             const char* slot = ring + ((tb + 1) & (RING_SLOTS - 1)) * STAGE_BYTES;
             v4 Vh[3][2];                       // V[token 16ct+4g+r][d = c] -> A operand of P.V (rows d, k = token)
             {
-                f4 V[3][2];
+                v8 Bw[8];
+#pragma unroll
+                for (int f = 0; f < 8; ++f) Bw[f] = lds_frag<PREC>(slot, f, lane);
 #pragma unroll
                 for (int h = 0; h < 2; ++h) {
-                    const float bv = bias[BIAS_QKV + 64 + 16 * h + c];
+                    const f4 bv = splat(bias[BIAS_QKV + 64 + 16 * h + c]);
 #pragma unroll
-                    for (int ct = 0; ct < 3; ++ct) V[ct][h] = splat(bv);
+                    for (int ct = 0; ct < 3; ++ct) {
+                        f4 acc = bv;
+#pragma unroll
+                        for (int s = 0; s < 4; ++s) acc = OP::mfma32(X[s][ct], Bw[h * 4 + s], acc);
+                        Vh[ct][h] = OP::pack4(acc);
+                    }
                 }
-#pragma unroll
-                for (int f = 0; f < 8; ++f) {
-                    const v8 Bw = lds_frag<PREC>(slot, f, lane);
-#pragma unroll
-                    for (int ct = 0; ct < 3; ++ct) V[ct][f / 4] = OP::mfma32(X[f % 4][ct], Bw, V[ct][f / 4]);
-                }
-#pragma unroll
-                for (int ct = 0; ct < 3; ++ct)
-#pragma unroll
-                    for (int h = 0; h < 2; ++h) Vh[ct][h] = OP::pack4(V[ct][h]);
             }
             f4 O[2][3];
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
-                // S^T[j = 16jt+4g+r][i = 16it+c] = sum_d K[j][d] Q[i][d]   (scale folded into Wq)
+                // S^T = K.Q^T in the log2 domain (0.125*log2(e) folded into Wq/bq by pack.cpp)
                 f4 S[7];
+                float tm[7];
 #pragma unroll
                 for (int i = 0; i < 7; ++i) {
                     S[i] = OP::mfma16(Kh[h][TJ[i]], Qh[h][TI[i]], splat(0.f));
-#pragma unroll
-                    for (int r = 0; r < 4; ++r)
-                        if (!((vmask >> (4 * i + r)) & 1u)) S[i][r] = -INFINITY;
+                    tm[i] = tvalid[i] ? hmax(S[i]) : -INFINITY;
                 }
-                // softmax over j per query column: tiles {0,1} -> it 0, {2,3,4} -> it 1, {5,6} -> it 2
-                float mx[3], inv[3];
-                mx[0] = fmaxf(fmaxf(fmaxf(S[0][0], S[0][1]), fmaxf(S[0][2], S[0][3])), fmaxf(fmaxf(S[1][0], S[1][1]), fmaxf(S[1][2], S[1][3])));
-                mx[1] = fmaxf(fmaxf(fmaxf(fmaxf(S[2][0], S[2][1]), fmaxf(S[2][2], S[2][3])), fmaxf(fmaxf(S[3][0], S[3][1]), fmaxf(S[3][2], S[3][3]))),
-                              fmaxf(fmaxf(S[4][0], S[4][1]), fmaxf(S[4][2], S[4][3])));
-                mx[2] = fmaxf(fmaxf(fmaxf(S[5][0], S[5][1]), fmaxf(S[5][2], S[5][3])), fmaxf(fmaxf(S[6][0], S[6][1]), fmaxf(S[6][2], S[6][3])));
+                float mx[3];
+                mx[0] = xmax(fmaxf(tm[0], tm[1]));
+                mx[1] = xmax(fmaxf(fmaxf(tm[2], tm[3]), tm[4]));
+                mx[2] = xmax(fmaxf(tm[5], tm[6]));
+                // P = 2^(S - max), converted, masked on the packed bits; row sums by a ones-row MFMA (sums exactly the
+                // rounded probabilities that multiply V; every output row holds the column sum => no cross-lane step)
+                f4 Lsum[3];
 #pragma unroll
-                for (int it = 0; it < 3; ++it) mx[it] = xmax(mx[it]);
-                v4 Pm[7];
-                float sm[3] = {0.f, 0.f, 0.f};
+                for (int it = 0; it < 3; ++it) { O[h][it] = splat(0.f); Lsum[it] = splat(0.f); }
 #pragma unroll
                 for (int i = 0; i < 7; ++i) {
                     f4 p;
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) p[r] = __expf(S[i][r] - mx[TI[i]]);
-                    sm[TI[i]] += hsum(p);
-                    Pm[i] = OP::pack4(p);
+                    for (int r = 0; r < 4; ++r) p[r] = __builtin_amdgcn_exp2f(S[i][r] - mx[TI[i]]);
+                    const u2 bits = __builtin_bit_cast(u2, OP::pack4(p)) & pmask[i];
+                    const v4 Pm = __builtin_bit_cast(v4, bits);
+                    O[h][TI[i]] = OP::mfma16(Vh[TJ[i]][h], Pm, O[h][TI[i]]);
+                    Lsum[TI[i]] = OP::mfma16(OP::ones4(), Pm, Lsum[TI[i]]);
                 }
 #pragma unroll
-                for (int it = 0; it < 3; ++it) inv[it] = __frcp_rn(xsum(sm[it]));
-                // O^T[d = 4g+r][i] = sum_j V[j][d] P^T[j][i]
-#pragma unroll
-                for (int it = 0; it < 3; ++it) O[h][it] = splat(0.f);
-#pragma unroll
-                for (int i = 0; i < 7; ++i) O[h][TI[i]] = OP::mfma16(Vh[TJ[i]][h], Pm[i], O[h][TI[i]]);
-#pragma unroll
-                for (int it = 0; it < 3; ++it) O[h][it] = O[h][it] * splat(inv[it]);
+                for (int it = 0; it < 3; ++it) O[h][it] = O[h][it] * splat(__builtin_amdgcn_rcpf(Lsum[it][0]));
             }
-            // proj: K = 32 = (head, d); slots j<4 head 0, j>=4 head 1 (same universal k-order as pack_A)
+            // proj: K = 32 = (head, d); slots j<4 head 0, j>=4 head 1 (same universal k-order as pack_frag)
+            v8 A[8];
+#pragma unroll
+            for (int ft = 0; ft < 8; ++ft) A[ft] = lds_frag<PREC>(slot, 8 + ft, lane);
             v8 OX[3];
 #pragma unroll
             for (int ct = 0; ct < 3; ++ct) OX[ct] = OP::pack8(O[0][ct], O[1][ct]);
 #pragma unroll
             for (int ft = 0; ft < 8; ++ft) {
-                const v8 A = lds_frag<PREC>(slot, 8 + ft, lane);
                 const f4 bp = *(const f4*)(bias + BIAS_PROJ + 16 * ft + 4 * g);
 #pragma unroll
-                for (int ct = 0; ct < 3; ++ct) R[ft][ct] = OP::mfma32(A, OX[ct], R[ft][ct] + bp);
+                for (int ct = 0; ct < 3; ++ct) R[ft][ct] = OP::mfma32(A[ft], OX[ct], R[ft][ct] + bp);
             }
         }
 
@@ -402,31 +423,37 @@ __global__ __launch_bounds__(WAVES * 64) void uit_encoder_kernel(EncoderArgs a) 
 #pragma unroll 1
         for (int ch = 0; ch < 12; ++ch) {
             const int t = tb + 2 + ch;
-            ring_step<WAVES>(a.wstream, ring, t, total, wave, lane);
+            ring_step<WAVES>(a.wstream, ring, t, wave, lane);
             const char* slot = ring + (t & (RING_SLOTS - 1)) * STAGE_BYTES;
-            f4 Hh[2][3];
+            v8 A[8], A2[8];
 #pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                const f4 b1 = *(const f4*)(bias + BIAS_FC1 + 32 * ch + 16 * j + 4 * g);
+            for (int f = 0; f < 8; ++f) A[f] = lds_frag<PREC>(slot, f, lane);
+            const f4 b10 = *(const f4*)(bias + BIAS_FC1 + 32 * ch + 4 * g);
+            const f4 b11 = *(const f4*)(bias + BIAS_FC1 + 32 * ch + 16 + 4 * g);
+            f4 H0[3], H1[3];
 #pragma unroll
-                for (int ct = 0; ct < 3; ++ct) Hh[j][ct] = b1;
+            for (int ct = 0; ct < 3; ++ct) {
+                H0[ct] = b10;
+#pragma unroll
+                for (int s = 0; s < 4; ++s) H0[ct] = OP::mfma32(A[s], X[s][ct], H0[ct]);
             }
 #pragma unroll
-            for (int f = 0; f < 8; ++f) {
-                const v8 A = lds_frag<PREC>(slot, f, lane);
+            for (int f = 0; f < 4; ++f) A2[f] = lds_frag<PREC>(slot, 8 + f, lane);
 #pragma unroll
-                for (int ct = 0; ct < 3; ++ct) Hh[f / 4][ct] = OP::mfma32(A, X[f % 4][ct], Hh[f / 4][ct]);
+            for (int ct = 0; ct < 3; ++ct) {
+                H1[ct] = b11;
+#pragma unroll
+                for (int s = 0; s < 4; ++s) H1[ct] = OP::mfma32(A[4 + s], X[s][ct], H1[ct]);
             }
+#pragma unroll
+            for (int f = 4; f < 8; ++f) A2[f] = lds_frag<PREC>(slot, 8 + f, lane);
             v8 HX[3];
 #pragma unroll
-            for (int ct = 0; ct < 3; ++ct)
-                HX[ct] = OP::pack8(__builtin_elementwise_max(Hh[0][ct], splat(0.f)), __builtin_elementwise_max(Hh[1][ct], splat(0.f)));
+            for (int ct = 0; ct < 3; ++ct) HX[ct] = OP::relu_pack8(H0[ct], H1[ct]);
 #pragma unroll
-            for (int ft = 0; ft < 8; ++ft) {
-                const v8 A = lds_frag<PREC>(slot, 8 + ft, lane);
+            for (int ft = 0; ft < 8; ++ft)
 #pragma unroll
-                for (int ct = 0; ct < 3; ++ct) R[ft][ct] = OP::mfma32(A, HX[ct], R[ft][ct]);
-            }
+                for (int ct = 0; ct < 3; ++ct) R[ft][ct] = OP::mfma32(A2[ft], HX[ct], R[ft][ct]);
         }
 #pragma unroll
         for (int ft = 0; ft < 8; ++ft) {
@@ -439,6 +466,7 @@ __global__ __launch_bounds__(WAVES * 64) void uit_encoder_kernel(EncoderArgs a) 
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // drain the dummy tail stages before the LDS can be re-used
 
     // ---- final norm (eps 1e-6) -> masked mean over tokens -> head LayerNorm (eps 1e-5)
     f4 pooled[8];
@@ -446,14 +474,7 @@ __global__ __launch_bounds__(WAVES * 64) void uit_encoder_kernel(EncoderArgs a) 
         float mean[3], rstd[3];
 #pragma unroll
         for (int ct = 0; ct < 3; ++ct) {
-            float s = 0.f;
-#pragma unroll
-            for (int ft = 0; ft < 8; ++ft) s += hsum(R[ft][ct]);
-            mean[ct] = xsum(s) * (1.0f / DIM);
-            float v = 0.f;
-#pragma unroll
-            for (int ft = 0; ft < 8; ++ft) { f4 d = R[ft][ct] - splat(mean[ct]); v += hsum(d * d); }
-            rstd[ct] = __frsqrt_rn(xsum(v) * (1.0f / DIM) + 1e-6f);
+            ln_stats(R, ct, 1e-6f, mean[ct], rstd[ct]);
             if (pt_[ct] >= a.nt) rstd[ct] = 0.f;          // masked token contributes 0 to the pool
         }
         const bool lo = c < 8;
@@ -479,19 +500,19 @@ __global__ __launch_bounds__(WAVES * 64) void uit_encoder_kernel(EncoderArgs a) 
     }
     {
         const float inv_ntok = 1.0f / (float)(GF * a.nt);
-        float s = 0.f;
+        f4 acc = splat(0.f);
 #pragma unroll
         for (int ft = 0; ft < 8; ++ft) {
             const f4 gw = *(const f4*)(a.fin + 0 * DIM + 16 * ft + 4 * g);
             const f4 gb = *(const f4*)(a.fin + 1 * DIM + 16 * ft + 4 * g);
             pooled[ft] = pooled[ft] * splat(inv_ntok) * gw + gb;
-            s += hsum(pooled[ft]);
+            acc = acc + pooled[ft];
         }
-        const float mean = xsum(s) * (1.0f / DIM);
-        float v = 0.f;
+        const float mean = xsum(hsum(acc)) * (1.0f / DIM);
+        f4 q = splat(0.f);
 #pragma unroll
-        for (int ft = 0; ft < 8; ++ft) { f4 d = pooled[ft] - splat(mean); v += hsum(d * d); }
-        const float rstd = __frsqrt_rn(xsum(v) * (1.0f / DIM) + 1e-5f);
+        for (int ft = 0; ft < 8; ++ft) { const f4 d = pooled[ft] - splat(mean); q = q + d * d; }
+        const float rstd = __builtin_amdgcn_rsqf(xsum(hsum(q)) * (1.0f / DIM) + 1e-5f);
         const int slot_clip = 2 * wave + (c >= 8 ? 1 : 0);
 #pragma unroll
         for (int ft = 0; ft < 8; ++ft) {
@@ -505,11 +526,12 @@ __global__ __launch_bounds__(WAVES * 64) void uit_encoder_kernel(EncoderArgs a) 
 
     // ---- classifier head once per workgroup: logits^T[class][clip slot] = Whead . z^T
     {
+        const int cz = c < 2 * WAVES ? c : 0;             // columns beyond the workgroup's clips: any valid data
         v8 Bz[4];
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
-            const v4 lo = *(const v4*)(zbuf + (c * DIM + 32 * s + 4 * g) * 2);
-            const v4 hi = *(const v4*)(zbuf + (c * DIM + 32 * s + 16 + 4 * g) * 2);
+            const v4 lo = *(const v4*)(zbuf + (cz * DIM + 32 * s + 4 * g) * 2);
+            const v4 hi = *(const v4*)(zbuf + (cz * DIM + 32 * s + 16 + 4 * g) * 2);
             Bz[s] = v8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
         }
         const int ntiles = (a.C + 15) / 16;
@@ -527,7 +549,7 @@ __global__ __launch_bounds__(WAVES * 64) void uit_encoder_kernel(EncoderArgs a) 
                     const int cls = 16 * ot + 4 * g + r;
                     if (cls < a.C) {
                         if (a.logits) a.logits[(int64_t)rowg * a.C + cls] = acc[r];
-                        a.probs[(int64_t)rowg * a.C + cls] = __frcp_rn(1.0f + __expf(-acc[r]));
+                        a.probs[(int64_t)rowg * a.C + cls] = __builtin_amdgcn_rcpf(1.0f + __expf(-acc[r]));
                     }
                 }
             }
@@ -550,19 +572,23 @@ __global__ void crop_reduce_kernel(const float* __restrict__ rp, float* __restri
     }
 }
 
-hipError_t launch_encoder(const EncoderArgs& a, int precision, hipStream_t stream) {
-    const int grid = (a.rows + 2 * ENC_WAVES - 1) / (2 * ENC_WAVES);
+template <int PREC, int WAVES>
+static hipError_t launch_enc(const EncoderArgs& a, hipStream_t stream) {
     static bool attr_done = false;
     if (!attr_done) {
-        hipFuncSetAttribute((const void*)uit_encoder_kernel<0, ENC_WAVES>, hipFuncAttributeMaxDynamicSharedMemorySize, ENC_LDS);
-        hipFuncSetAttribute((const void*)uit_encoder_kernel<1, ENC_WAVES>, hipFuncAttributeMaxDynamicSharedMemorySize, ENC_LDS);
+        hipError_t e = hipFuncSetAttribute((const void*)uit_encoder_kernel<PREC, WAVES>,
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, ENC_LDS);
+        if (e != hipSuccess) return e;
         attr_done = true;
     }
-    if (precision == 0)
-        hipLaunchKernelGGL((uit_encoder_kernel<0, ENC_WAVES>), dim3(grid), dim3(ENC_WAVES * 64), ENC_LDS, stream, a);
-    else
-        hipLaunchKernelGGL((uit_encoder_kernel<1, ENC_WAVES>), dim3(grid), dim3(ENC_WAVES * 64), ENC_LDS, stream, a);
+    const int grid = (a.rows + 2 * WAVES - 1) / (2 * WAVES);
+    hipLaunchKernelGGL((uit_encoder_kernel<PREC, WAVES>), dim3(grid), dim3(WAVES * 64), ENC_LDS, stream, a);
     return hipGetLastError();
+}
+
+hipError_t launch_encoder(const EncoderArgs& a, int precision, int waves, hipStream_t stream) {
+    if (waves == 4) return precision == 0 ? launch_enc<0, 4>(a, stream) : launch_enc<1, 4>(a, stream);
+    return precision == 0 ? launch_enc<0, 8>(a, stream) : launch_enc<1, 8>(a, stream);
 }
 
 hipError_t launch_crop_reduce(const float* rowprobs, float* probs, int64_t B, int ncrops, int C, int eval_avg,

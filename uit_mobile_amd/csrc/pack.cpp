@@ -5,7 +5,8 @@
 //   * init_bn (eval BatchNorm2d, models/uit.py:310-313)      -> per-mel-bin scale/shift applied before conversion
 //   * conv bias + time_pos_embed + freq_pos_embed (:380-383)  -> bias table [24][128] = accumulator init
 //   * LayerNorm affine of norm1 / norm2 (:223, 235)           -> folded into qkv / fc1 weights and biases
-//   * attention scale (dim//heads)^-0.5 = 0.125 (:99-100,115) -> folded into the q rows of qkv
+//   * attention scale (dim//heads)^-0.5 = 0.125 (:99-100,115), times log2(e) (softmax computed with exp2)
+//                                                             -> folded into the q rows of qkv
 // Fragment order: see uitk_dev.h and encoder.hip.  A "fragment" is the 1 KiB A/B operand of one
 // mfma_f32_16x16x32: lane l (c = l&15, g = l>>4), element j  <->  W[16*ft + c][ 32*s + 16*(j>>2) + 4*g + (j&3) ]
 // (the k-order a C/D tile pair has after in-register conversion, so activations never move between lanes).
@@ -99,7 +100,7 @@ int pack_image(const uitk_config* c, const uitk_weights* w, std::vector<char>* o
     h.magic = IMAGE_MAGIC; h.precision = prec; h.depth = depth; h.outputdim = C; h.mel_nnz = (int)mw.size();
     size_t o = align_up(sizeof(ImageHeader), 256);
     auto take = [&](size_t bytes) { size_t r = o; o = align_up(o + bytes, 256); return r; };
-    h.off_wstream = take((size_t)(PE_STAGES + depth * BLOCK_STAGES) * STAGE_BYTES);
+    h.off_wstream = take((size_t)(PE_STAGES + depth * BLOCK_STAGES + TAIL_STAGES) * STAGE_BYTES);
     h.off_bias = take((size_t)depth * BIAS_FLOATS * 4);
     h.off_bn_sc = take(NMEL * 4); h.off_bn_sh = take(NMEL * 4);
     h.off_pe_bias = take(NTOK * DIM * 4);
@@ -173,7 +174,8 @@ int pack_image(const uitk_config* c, const uitk_weights* w, std::vector<char>* o
         const uitk_block_weights& bw = w->blocks[b];
         const int st = PE_STAGES + b * BLOCK_STAGES;
         float* bb = bias + (size_t)b * BIAS_FLOATS;
-        const double scale = 1.0 / std::sqrt((double)(DIM / 2));         // head_dim = dim // num_heads
+        // head_dim = dim // num_heads (uit.py:99-100); log2(e) rides along so the kernel's softmax is exp2
+        const double scale = 1.0 / std::sqrt((double)(DIM / 2)) * 1.4426950408889634074;
         auto Wqkv = [&](int r, int k) { return (double)bw.qkv_w[r * DIM + k] * (double)bw.norm1_w[k] * (r < INNER ? scale : 1.0); };
         auto Wproj = [&](int r, int k) { return (double)bw.proj_w[r * INNER + k]; };
         auto Wfc1 = [&](int r, int k) { return (double)bw.fc1_w[r * DIM + k] * (double)bw.norm2_w[k]; };

@@ -21,6 +21,7 @@ constexpr int STAGE_FRAGS = 16;
 constexpr int STAGE_BYTES = STAGE_FRAGS * FRAG_BYTES;
 constexpr int PE_STAGES = 4;            // patch-embed: 8 out tiles x 8 k-steps
 constexpr int BLOCK_STAGES = 14;        // QK, V+proj, 12 MLP chunks
+constexpr int TAIL_STAGES = 2;          // zero stages after the last block: the ring prefetch never branches
 constexpr int BIAS_FLOATS = 1024;       // per block: qkv 96 | proj 128 | fc1 384 | fc2 128 (padded to 4 KiB)
 constexpr int BIAS_QKV = 0, BIAS_PROJ = 96, BIAS_FC1 = 224, BIAS_FC2 = 608;
 
@@ -52,7 +53,7 @@ struct EncoderArgs {
     int nt;                 // valid time patches per crop (1..6)
     int depth;
     int C;                  // outputdim
-    const char* wstream;    // PE_STAGES + depth*BLOCK_STAGES stages of STAGE_BYTES
+    const char* wstream;    // PE_STAGES + depth*BLOCK_STAGES + TAIL_STAGES stages of STAGE_BYTES
     const float* bias;      // [depth][BIAS_FLOATS]
     const float* bn_sc;     // [64]  w / sqrt(var + 1e-5)
     const float* bn_sh;     // [64]  b - mean * sc
@@ -68,7 +69,7 @@ struct EncoderArgs {
 hipError_t launch_frontend(const FrontendArgs& a, int in_i16, int n_cu, hipStream_t stream);
 hipError_t launch_mel_export(const float* mel, const float* amax, float top_db, int64_t B, int nF, float* out,
                              hipStream_t stream);
-hipError_t launch_encoder(const EncoderArgs& a, int precision, hipStream_t stream);
+hipError_t launch_encoder(const EncoderArgs& a, int precision, int waves, hipStream_t stream);
 hipError_t launch_crop_reduce(const float* rowprobs, float* probs, int64_t B, int ncrops, int C, int eval_avg,
                               hipStream_t stream);
 
