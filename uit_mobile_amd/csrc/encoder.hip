@@ -77,12 +77,12 @@ template <> struct Op<1> {   // bf16 operands
     static __device__ __forceinline__ f4 mfma16(v4 a, v4 b, f4 c) {
         return __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(__builtin_bit_cast(s4, a), __builtin_bit_cast(s4, b), c, 0, 0, 0);
     }
-    static __device__ __forceinline__ float relu1(float x) {   // single v_max_f32, no canonicalise
-        float r; asm("v_max_f32 %0, 0, %1" : "=v"(r) : "v"(x)); return r;
-    }
+    // ReLU on the converted bits: a negative bf16 is a negative int16, so a packed signed max with 0 clears it
+    // (v_pk_max_i16, two elements per instruction, no inline asm => the compiler handles the MFMA hazards).
     static __device__ __forceinline__ v8 relu_pack8(f4 lo, f4 hi) {
-        return pack8(f4{relu1(lo[0]), relu1(lo[1]), relu1(lo[2]), relu1(lo[3])},
-                     f4{relu1(hi[0]), relu1(hi[1]), relu1(hi[2]), relu1(hi[3])});
+        typedef short s8 __attribute__((ext_vector_type(8)));
+        const s8 z = {0, 0, 0, 0, 0, 0, 0, 0};
+        return __builtin_bit_cast(v8, __builtin_elementwise_max(__builtin_bit_cast(s8, pack8(lo, hi)), z));
     }
     static __device__ __forceinline__ v4 ones4() { return v4{(__bf16)1.f, (__bf16)1.f, (__bf16)1.f, (__bf16)1.f}; }
 };
