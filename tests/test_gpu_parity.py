@@ -156,8 +156,9 @@ def test_full_size_properties():
     assert np.isfinite(p).all() and (p > 0).all() and (p < 1).all()
     perm = np.random.default_rng(0).permutation(B)
     pp, _ = run(m, pcm[perm])
-    # a clip's slot inside its wave changes the fp32 summation order of the token mean-pool: ~1e-7, not bitwise
-    assert np.abs(pp - p[perm]).max() < 1e-5
+    # a clip's slot inside its wave changes the fp32 summation order of the token mean-pool (~1e-7); the pooled
+    # vector is then rounded to fp16 for the head GEMM, where a flipped rounding shows as ~2e-5: not bitwise
+    assert np.abs(pp - p[perm]).max() < 1e-4
     idx = np.arange(0, B, 257)                            # includes clip 0 and tone / silence / quiet classes
     sub = pcm[idx]
     assert idx[0] == 0 and (idx % 8 == 2).any()

@@ -21,8 +21,13 @@ sd = {k: torch.from_numpy(np.asarray(v)) for k, v in make_state_dict(name, 13).i
 x = synth_batch(B, 16000, 0, dev, False)
 xi = synth_batch(B, 16000, 0, dev, True)
 variants = {}
-for tag, waves, prec in (("w8/f16", "8", "f16"), ("w4/f16", "4", "f16"), ("w8/bf16", "8", "bf16")):
+VARS = [("w8/f16", "8", "f16", "0", "0"), ("w8/sched", "8", "f16", "1", "0"), ("w4/f16", "4", "f16", "0", "0"),
+        ("w4/sched", "4", "f16", "1", "0"), ("w4/stag20k", "4", "f16", "0", "20000"), ("w4/stag40k", "4", "f16", "0", "40000"),
+        ("w4/sch+st", "4", "f16", "1", "20000"), ("w8/bf16", "8", "bf16", "0", "0")]
+for tag, waves, prec, sched, stag in VARS:
     os.environ["UITK_ENC_WAVES"] = waves
+    os.environ["UITK_ENC_SCHED"] = sched
+    os.environ["UITK_ENC_STAGGER"] = stag
     m = getattr(models, name)(outputdim=537, target_length=102, precision=prec)
     m.load_state_dict(sd, strict=True)
     m = m.to(dev).eval()

@@ -187,7 +187,7 @@ __device__ __forceinline__ void layernorm_to_operand(const f4 (&R)[8][3], float 
     }
 }
 
-template <int PREC, int WAVES>
+template <int PREC, int WAVES, bool SCHED>
 __global__ __launch_bounds__(WAVES * 64, 2) void uit_encoder_kernel(EncoderArgs a) {
     using OP = Op<PREC>;
     using v8 = typename OP::v8;
@@ -201,6 +201,13 @@ __global__ __launch_bounds__(WAVES * 64, 2) void uit_encoder_kernel(EncoderArgs 
     const int tid = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lane = tid & 63, c = lane & 15, g = lane >> 4;
+
+    // ---- optional stagger: delay every second resident workgroup generation so that the two workgroups sharing a
+    // CU run out of phase (one in its MFMA-bound MLP while the other is in its VALU-bound LN/softmax)
+    if (a.stagger > 0 && ((blockIdx.x / a.stagger_group) & 1)) {
+        const uint64_t t0 = __builtin_amdgcn_s_memtime();
+        while (__builtin_amdgcn_s_memtime() - t0 < (uint64_t)a.stagger) __builtin_amdgcn_s_sleep(32);
+    }
 
     // ---- kick the weight stream: block-0 biases + the whole patch-embed weight set (4 stages = the whole ring)
     if (a.depth > 0) bias_issue<WAVES>(a.bias, breg, 0, wave, lane);
@@ -454,6 +461,22 @@ __global__ __launch_bounds__(WAVES * 64, 2) void uit_encoder_kernel(EncoderArgs 
             for (int ft = 0; ft < 8; ++ft)
 #pragma unroll
                 for (int ct = 0; ct < 3; ++ct) R[ft][ct] = OP::mfma32(A2[ft], HX[ct], R[ft][ct]);
+            if constexpr (SCHED) {
+                // issue order: keep 4 fragment reads in flight ahead of the MFMAs that consume them
+                __builtin_amdgcn_sched_group_barrier(0x100, 6, 0);          // 2 bias + 4 fragment ds_reads
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);      // 3 MFMA (one fragment x 3 token tiles)
+                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);      // next fragment read
+                }
+                __builtin_amdgcn_sched_group_barrier(0x002, 24, 0);         // convert + ReLU
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                }
+                __builtin_amdgcn_sched_group_barrier(0x008, 12, 0);
+            }
         }
 #pragma unroll
         for (int ft = 0; ft < 8; ++ft) {
@@ -572,23 +595,27 @@ __global__ void crop_reduce_kernel(const float* __restrict__ rp, float* __restri
     }
 }
 
-template <int PREC, int WAVES>
+template <int PREC, int WAVES, bool SCHED>
 static hipError_t launch_enc(const EncoderArgs& a, hipStream_t stream) {
     static bool attr_done = false;
     if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute((const void*)uit_encoder_kernel<PREC, WAVES>,
+        hipError_t e = hipFuncSetAttribute((const void*)uit_encoder_kernel<PREC, WAVES, SCHED>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, ENC_LDS);
         if (e != hipSuccess) return e;
         attr_done = true;
     }
     const int grid = (a.rows + 2 * WAVES - 1) / (2 * WAVES);
-    hipLaunchKernelGGL((uit_encoder_kernel<PREC, WAVES>), dim3(grid), dim3(WAVES * 64), ENC_LDS, stream, a);
+    hipLaunchKernelGGL((uit_encoder_kernel<PREC, WAVES, SCHED>), dim3(grid), dim3(WAVES * 64), ENC_LDS, stream, a);
     return hipGetLastError();
 }
 
-hipError_t launch_encoder(const EncoderArgs& a, int precision, int waves, hipStream_t stream) {
-    if (waves == 4) return precision == 0 ? launch_enc<0, 4>(a, stream) : launch_enc<1, 4>(a, stream);
-    return precision == 0 ? launch_enc<0, 8>(a, stream) : launch_enc<1, 8>(a, stream);
+hipError_t launch_encoder(const EncoderArgs& a, int precision, int waves, int sched, hipStream_t stream) {
+    if (sched) {
+        if (waves == 4) return precision == 0 ? launch_enc<0, 4, true>(a, stream) : launch_enc<1, 4, true>(a, stream);
+        return precision == 0 ? launch_enc<0, 8, true>(a, stream) : launch_enc<1, 8, true>(a, stream);
+    }
+    if (waves == 4) return precision == 0 ? launch_enc<0, 4, false>(a, stream) : launch_enc<1, 4, false>(a, stream);
+    return precision == 0 ? launch_enc<0, 8, false>(a, stream) : launch_enc<1, 8, false>(a, stream);
 }
 
 hipError_t launch_crop_reduce(const float* rowprobs, float* probs, int64_t B, int ncrops, int C, int eval_avg,

@@ -64,12 +64,14 @@ struct EncoderArgs {
     float* probs;           // [rows][C]
     float* logits;          // [rows][C] or null
     float* dbg;             // [rows][depth+1][24][128] or null
+    int stagger;            // 0 = off, else shader cycles to delay every other workgroup generation
+    int stagger_group;      // workgroups per generation (= CU count)
 };
 
 hipError_t launch_frontend(const FrontendArgs& a, int in_i16, int n_cu, hipStream_t stream);
 hipError_t launch_mel_export(const float* mel, const float* amax, float top_db, int64_t B, int nF, float* out,
                              hipStream_t stream);
-hipError_t launch_encoder(const EncoderArgs& a, int precision, int waves, hipStream_t stream);
+hipError_t launch_encoder(const EncoderArgs& a, int precision, int waves, int sched, hipStream_t stream);
 hipError_t launch_crop_reduce(const float* rowprobs, float* probs, int64_t B, int ncrops, int C, int eval_avg,
                               hipStream_t stream);
 
