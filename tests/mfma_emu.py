@@ -15,11 +15,11 @@ LANES = np.arange(64)
 C_ = LANES & 15
 G_ = LANES >> 4
 
-HDR_FMT = "<I4i3iQ15Q"
-HDR_FIELDS = ["magic", "precision", "depth", "outputdim", "mel_nnz", "_p0", "_p1", "_p2", "total_bytes",
+HDR_FMT = "<I4i12i3iQ12Q"
+HDR_FIELDS = (["magic", "precision", "depth", "outputdim", "mel_steps"] + [f"mel_tile_{n}{j}" for n in ("klo", "steps", "base")
+              for j in range(4)] + ["_p0", "_p1", "_p2", "total_bytes",
               "off_wstream", "off_bias", "off_bn_sc", "off_bn_sh", "off_pe_bias", "off_fin", "off_head_w",
-              "off_head_b", "off_window", "off_tw256", "off_tw512", "off_mel_lo", "off_mel_n", "off_mel_off",
-              "off_mel_w"]
+              "off_head_b", "off_window", "off_tw256", "off_tw512", "off_mel_b"])
 FRAG, STAGE = 1024, 16384
 PE_STAGES, BLOCK_STAGES, BIAS_FLOATS = 4, 14, 1024
 BIAS_QKV, BIAS_PROJ, BIAS_FC1, BIAS_FC2 = 0, 96, 224, 608

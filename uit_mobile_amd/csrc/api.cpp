@@ -159,12 +159,10 @@ int uitk_frontend(uitk_model* m, const void* pcm, int in_dtype, int64_t B, int64
     a.window = (const float*)(m->image + h.off_window);
     a.tw256 = (const float2*)(m->image + h.off_tw256);
     a.tw512 = (const float2*)(m->image + h.off_tw512);
-    a.mel_lo = (const int*)(m->image + h.off_mel_lo);
-    a.mel_n = (const int*)(m->image + h.off_mel_n);
-    a.mel_off = (const int*)(m->image + h.off_mel_off);
-    a.mel_w = (const float*)(m->image + h.off_mel_w);
-    a.mel_nnz = h.mel_nnz;
-    a.melw_lds_bytes = (h.mel_nnz * 4 + 15) / 16 * 16;
+    a.mel_b = (const float*)(m->image + h.off_mel_b);
+    for (int j = 0; j < 4; ++j) {
+        a.mel_tile_klo[j] = h.mel_tile_klo[j]; a.mel_tile_steps[j] = h.mel_tile_steps[j]; a.mel_tile_base[j] = h.mel_tile_base[j];
+    }
     a.mel = m->mel; a.amax = m->amax;
     HIP_TRY(hipMemsetAsync(m->amax, 0xFF, AMAX_SLOTS * 4, s));
     HIP_TRY(launch_frontend(a, in_dtype == UITK_IN_I16, m->n_cu, s));

@@ -84,20 +84,21 @@ int pack_image(const uitk_config* c, const uitk_weights* w, std::vector<char>* o
     const int prec = c->precision, depth = c->depth, C = c->outputdim;
     const int ntiles = (C + 15) / 16;
     const int nb = c->n_fft / 2 + 1;
-    // ---- mel bands
-    std::vector<int> lo(NMEL), n(NMEL), off(NMEL);
-    std::vector<float> mw;
-    for (int m = 0; m < NMEL; ++m) {
+    // ---- mel filterbank as banded MFMA B operands: per 16-mel tile the bin range [klo, klo + 4*steps)
+    int tile_klo[4], tile_steps[4], tile_base[4], total_steps = 0;
+    for (int j = 0; j < 4; ++j) {
         int first = -1, last = -1;
         for (int k = 0; k < nb; ++k)
-            if (w->mel_fb[k * NMEL + m] != 0.0f) { if (first < 0) first = k; last = k; }
-        lo[m] = first < 0 ? 0 : first;
-        n[m] = first < 0 ? 0 : last - first + 1;
-        off[m] = (int)mw.size();
-        for (int t = 0; t < n[m]; ++t) mw.push_back(w->mel_fb[(lo[m] + t) * NMEL + m]);
+            for (int m = 16 * j; m < 16 * j + 16; ++m)
+                if (w->mel_fb[k * NMEL + m] != 0.0f) { if (first < 0) first = k; last = k; }
+        tile_klo[j] = first < 0 ? 0 : (first & ~3);
+        tile_steps[j] = first < 0 ? 0 : (last - tile_klo[j]) / 4 + 1;
+        tile_base[j] = total_steps;
+        total_steps += tile_steps[j];
     }
     ImageHeader h{};
-    h.magic = IMAGE_MAGIC; h.precision = prec; h.depth = depth; h.outputdim = C; h.mel_nnz = (int)mw.size();
+    h.magic = IMAGE_MAGIC; h.precision = prec; h.depth = depth; h.outputdim = C; h.mel_steps = total_steps;
+    for (int j = 0; j < 4; ++j) { h.mel_tile_klo[j] = tile_klo[j]; h.mel_tile_steps[j] = tile_steps[j]; h.mel_tile_base[j] = tile_base[j]; }
     size_t o = align_up(sizeof(ImageHeader), 256);
     auto take = [&](size_t bytes) { size_t r = o; o = align_up(o + bytes, 256); return r; };
     h.off_wstream = take((size_t)(PE_STAGES + depth * BLOCK_STAGES + TAIL_STAGES) * STAGE_BYTES);
@@ -110,8 +111,7 @@ int pack_image(const uitk_config* c, const uitk_weights* w, std::vector<char>* o
     h.off_window = take(512 * 4);
     h.off_tw256 = take(256 * 8);
     h.off_tw512 = take(128 * 8);
-    h.off_mel_lo = take(NMEL * 4); h.off_mel_n = take(NMEL * 4); h.off_mel_off = take(NMEL * 4);
-    h.off_mel_w = take(mw.size() * 4 + 16);
+    h.off_mel_b = take((size_t)total_steps * 64 * 4 + 16);
     h.total_bytes = o;
     out->assign(o, 0);
     char* img = out->data();
@@ -131,10 +131,13 @@ int pack_image(const uitk_config* c, const uitk_weights* w, std::vector<char>* o
         const double a = 2.0 * M_PI * (double)k / 512.0;
         tw512[2 * k] = (float)std::cos(a); tw512[2 * k + 1] = (float)std::sin(a);
     }
-    std::memcpy(img + h.off_mel_lo, lo.data(), NMEL * 4);
-    std::memcpy(img + h.off_mel_n, n.data(), NMEL * 4);
-    std::memcpy(img + h.off_mel_off, off.data(), NMEL * 4);
-    std::memcpy(img + h.off_mel_w, mw.data(), mw.size() * 4);
+    float* mb = (float*)(img + h.off_mel_b);
+    for (int j = 0; j < 4; ++j)
+        for (int st = 0; st < tile_steps[j]; ++st)
+            for (int l = 0; l < 64; ++l) {
+                const int k = tile_klo[j] + 4 * st + (l >> 4), m = 16 * j + (l & 15);
+                mb[(size_t)(tile_base[j] + st) * 64 + l] = k < nb ? w->mel_fb[k * NMEL + m] : 0.0f;
+            }
 
     // ---- init_bn -> scale/shift
     float* sc = (float*)(img + h.off_bn_sc); float* sh = (float*)(img + h.off_bn_sh);

@@ -13,11 +13,12 @@ constexpr uint32_t IMAGE_MAGIC = 0x4b544955u;   // "UITK"
 // All offsets are bytes from the start of the image, 256-byte aligned.
 struct ImageHeader {
     uint32_t magic;
-    int32_t precision, depth, outputdim, mel_nnz;
+    int32_t precision, depth, outputdim, mel_steps;
+    int32_t mel_tile_klo[4], mel_tile_steps[4], mel_tile_base[4];
     int32_t _pad[3];
     uint64_t total_bytes;
     uint64_t off_wstream, off_bias, off_bn_sc, off_bn_sh, off_pe_bias, off_fin, off_head_w, off_head_b;
-    uint64_t off_window, off_tw256, off_tw512, off_mel_lo, off_mel_n, off_mel_off, off_mel_w;
+    uint64_t off_window, off_tw256, off_tw512, off_mel_b;
 };
 
 int validate_config(const uitk_config* c, const char** why);

@@ -32,12 +32,10 @@ struct FrontendArgs {
     const float* window;    // [512]
     const float2* tw256;    // [16][16]  W256^(p*k1) = (cos, -sin)(2 pi p k1 / 256)
     const float2* tw512;    // [128]     (cos, sin)(2 pi k / 512)
-    const int* mel_lo;      // [64] first bin of each mel band
-    const int* mel_n;       // [64] band length
-    const int* mel_off;     // [64] offset into mel_w
-    const float* mel_w;     // [mel_nnz] band weights
-    int mel_nnz;
-    int melw_lds_bytes;     // mel_nnz*4 rounded up to 16
+    const float* mel_b;     // banded filterbank as MFMA B operands: [sum of steps][64 lanes]
+    int mel_tile_klo[4];    // first bin (multiple of 4) of each 16-mel tile's band
+    int mel_tile_steps[4];  // k-steps (of 4 bins) per tile
+    int mel_tile_base[4];   // first step of each tile in mel_b
     float* mel;             // [B][nF][64] dB (no floor)
     float* amax;            // [AMAX_SLOTS]
 };
