@@ -180,3 +180,36 @@ def test_errors_map_to_exceptions():
     m.eval_avg = "mean"
     with pytest.raises(RuntimeError):
         m(torch.zeros(1, 16000, device="cuda"))
+
+
+def test_inference_cli_counterpart_config1(golden, tmp_path, capsys):
+    """BASELINE config #1 plumbing: `inference.py -m <ckpt> water_000.wav` through the counterpart CLI (own WAV reader,
+    {'model','config'} checkpoint format of inference.py:42-48, label lookup, 'Keyword:' prefix)."""
+    from uit_mobile_amd import inference
+    from uit_mobile_amd.wav import write_wav_pcm16
+    g = golden("samples_uit_xs")
+    sd = {k: torch.from_numpy(np.asarray(v)) for k, v in make_state_dict("uit_xs", int(g["seed"])).items()}
+    torch.save({"model": sd, "config": {"model": "uit_xs", "num_classes": 537, "model_args": {"target_length": 102}}},
+               tmp_path / "ckpt.pt")
+    write_wav_pcm16(tmp_path / "water_000.wav", g["water_000_pcm"])
+    inference.main([str(tmp_path / "water_000.wav"), "-m", str(tmp_path / "ckpt.pt"), "-k", "5"])
+    out = capsys.readouterr().out.strip().splitlines()
+    labels = inference.load_label_map()
+    want = g["water_000_probs"]
+    top = np.argsort(-want)[:5]
+    assert out[0].startswith("=====") and len(out) == 6
+    for line, idx in zip(out[1:], top):
+        name = labels[int(idx)] if idx <= 526 else f"Keyword: {labels[int(idx)]}"
+        assert line.startswith(name[:30])
+        assert abs(float(line.split()[-1]) - want[idx]) < 1.1e-3
+
+
+def test_evaluator_batch_step_pad_rule(golden, tmp_path):
+    from uit_mobile_amd.evaluate import Evaluator
+    g = golden("samples_uit_xs")
+    sd = {k: torch.from_numpy(np.asarray(v)) for k, v in make_state_dict("uit_xs", int(g["seed"])).items()}
+    torch.save(sd, tmp_path / "bare.pt")                   # bare state_dict format (inference.py:37-40)
+    ev = Evaluator(str(tmp_path / "bare.pt"))
+    pcm = torch.from_numpy(g["85b877b5_nohash_0_pcm"].astype(np.float32) / 32768.0)[None]
+    out, _ = ev._inference((pcm, torch.zeros(1, 537), torch.tensor([16000]), ["x"]), pad=True)
+    assert np.abs(out.cpu().numpy()[0] - g["gsc_padded_probs"]).max() < TOL

@@ -1,0 +1,113 @@
+"""CPU: host-side mirror of the reference interface -- state_dict keys/shapes, checkpoint formats, pos-embed resize,
+crop planning, pad rule, WAV reader, label lookup, C-ABI exports, loud failure without a device."""
+import ctypes
+from pathlib import Path
+
+import numpy as np
+import pytest
+import torch
+
+from synth_weights import make_state_dict
+from uit_mobile_amd import _lib, models
+from uit_mobile_amd.evaluate import pad_to_target, sequential_pad
+from uit_mobile_amd.inference import load_label_map, topk_lines
+from uit_mobile_amd.wav import read_wav_pcm16, write_wav_pcm16
+
+ROOT = Path(__file__).resolve().parents[1]
+
+
+def test_library_exports_every_declared_symbol():
+    L = _lib.load()
+    header = (ROOT / "include" / "uitk.h").read_text()
+    import re
+    declared = set(re.findall(r"\b(uitk_[a-z_0-9]+)\s*\(", header))
+    assert declared == set(_lib.EXPORTS), declared ^ set(_lib.EXPORTS)
+    for name in declared:
+        assert getattr(L, name) is not None
+    assert L.uitk_version().startswith(b"uitk")
+
+
+def test_create_fails_loudly_without_device():
+    if torch.cuda.is_available():
+        pytest.skip("a HIP device is present")
+    m = models.uit_xxxs(outputdim=537, target_length=102).eval()
+    cfg = m._config()
+    w, keep = m._host_weights()
+    out = ctypes.c_void_p()
+    rc = _lib.load().uitk_create(ctypes.byref(cfg), ctypes.byref(w), ctypes.byref(out))
+    assert rc == _lib.ERR_NO_DEVICE and "no CPU path" in _lib.last_error()
+    with pytest.raises(RuntimeError):
+        m(torch.zeros(1, 16000))
+
+
+@pytest.mark.parametrize("name,depth", [("uit_xs", 12), ("uit_xxs", 6), ("uit_xxxs", 4)])
+def test_state_dict_matches_reference_layout(name, depth):
+    m = getattr(models, name)(outputdim=537, target_length=102)
+    sd = make_state_dict(name, 0)                  # loaded with strict=True into the REAL reference in make_golden.py
+    mine = m.state_dict()
+    assert set(mine) == set(sd)
+    for k in sd:
+        assert tuple(mine[k].shape) == tuple(np.asarray(sd[k]).shape), k
+    assert m.depth == depth and m.target_length == 102 and m.hop_size == 160 and m.n_mels == 64
+    assert m.patch_embed.grid_size == (4, 6) and m.outputdim == 537
+    assert set(models.PRETRAINED_CHECKPOINTS) == {"uit_xs", "uit_xxs", "uit_xxxs"}
+    assert models.PRETRAINED_CHECKPOINTS[name]["model_kwargs"] == dict(outputdim=537, target_length=102)
+
+
+def test_strict_load_and_pos_embed_resize():
+    m = models.uit_xxxs(outputdim=537, target_length=102)
+    sd = {k: torch.from_numpy(np.asarray(v)) for k, v in make_state_dict("uit_xxxs", 1).items()}
+    bad = dict(sd); bad.pop("norm.weight")
+    with pytest.raises(RuntimeError):
+        m.load_state_dict(bad, strict=True)
+    long = {k: torch.from_numpy(np.asarray(v)) for k, v in make_state_dict("uit_xxxs", 1, target_length=160).items()}
+    assert long["time_pos_embed"].shape[-1] == 10
+    m.load_state_dict(long, strict=True)           # truncated to 6 (models/uit.py:432-434)
+    assert torch.equal(m.time_pos_embed, long["time_pos_embed"][..., :6])
+    short = dict(sd); short["time_pos_embed"] = sd["time_pos_embed"][..., :3]
+    m.load_state_dict(short, strict=True)          # bilinear interpolation 3 -> 6 (models/uit.py:436-440)
+    ref = torch.nn.functional.interpolate(short["time_pos_embed"], size=(1, 6), align_corners=False, mode="bilinear")
+    assert torch.allclose(m.time_pos_embed, ref)
+
+
+def test_unsupported_variants_raise():
+    with pytest.raises(NotImplementedError):
+        models.UITBase(embed_dim=128, depth=4, num_heads=2, mlp_ratio=3.0, pooling="token",
+                       attention_type="BNeckAttention", act_layer=torch.nn.ReLU)
+    m = models.uit_xs(embed_dim=256)                # geometry outside the kernels' family -> C ABI rejects it
+    with pytest.raises(ValueError):
+        m.packed_image()
+
+
+def test_crop_planning_matches_reference_rule():
+    m = models.uit_xs(outputdim=537, target_length=102)
+    assert [m.num_frames(t) for t in (16000, 16160, 16384, 160000)] == [101, 102, 103, 1001]
+    assert [m.num_crops(t) for t in (16000, 16160, 16384, 50000, 160000)] == [1, 1, 2, 4, 10]
+
+
+def test_pad_rule_and_collate():
+    m = models.uit_xs(outputdim=537, target_length=102)
+    x = torch.zeros(2, 16000)
+    assert pad_to_target(x, m).shape[-1] == 16160          # evaluate.py:56-64
+    assert pad_to_target(torch.zeros(2, 16160), m).shape[-1] == 16160
+    b, lengths = sequential_pad([torch.ones(5, dtype=torch.int16), torch.ones(3, dtype=torch.int16)])
+    assert b.dtype == torch.int16 and b.tolist() == [[1, 1, 1, 1, 1], [1, 1, 1, 0, 0]] and lengths.tolist() == [5, 3]
+
+
+def test_wav_reader_roundtrip(tmp_path):
+    pcm = (np.arange(1000) * 31 % 65536 - 32768).astype(np.int16)
+    write_wav_pcm16(tmp_path / "a.wav", pcm)
+    got, sr = read_wav_pcm16(tmp_path / "a.wav")
+    assert sr == 16000 and np.array_equal(got, pcm)
+    (tmp_path / "bad.wav").write_bytes(b"nope")
+    with pytest.raises(ValueError):
+        read_wav_pcm16(tmp_path / "bad.wav")
+
+
+def test_label_lookup_and_topk_format():
+    lm = load_label_map()
+    assert len(lm) == 537 and lm[0] == "Speech" and lm[532] == "on"
+    p = torch.zeros(537); p[532] = 0.9999; p[0] = 1.0; p[500] = 0.0001
+    lines = topk_lines(p, lm, 3)
+    assert lines[0].startswith("Speech") and lines[0].endswith("1.0000")
+    assert lines[1].startswith("Keyword: on") and lines[1].endswith("0.9999")

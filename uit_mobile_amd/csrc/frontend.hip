@@ -69,6 +69,7 @@ constexpr int FE_WAVE_LDS = 4 * FE_ZROW * 8;             // 8704 B per wave: E[4
 constexpr int FE_PROW = 290;                             // power-tile row stride (floats): == 2 mod 32, >= 260
 constexpr int FE_P_LDS = 2 * 16 * FE_PROW * 4;           // double-buffered P[16][290]
 constexpr int FE_LDS = FE_WAVES * FE_WAVE_LDS + FE_P_LDS;
+constexpr int FE_BREG = 40;                              // filterbank k-steps per mel tile held in VGPRs (HTK: <= 40)
 
 template <bool I16>
 __device__ __forceinline__ float load_sample(const void* pcm, int64_t row_off, int T, int s) {
@@ -108,6 +109,18 @@ __global__ __launch_bounds__(FE_WAVES * 64, 2) void mel_frontend_kernel(Frontend
     int it = 0;
     for (int64_t pass = blockIdx.x; pass < npass; pass += gridDim.x, ++it) {
         float* P = Pbase + (it & 1) * 16 * FE_PROW;
+        // this wave's 16-mel tile for this pass; its B operands (filterbank band, zero-padded to 8-step chunks by
+        // pack.cpp) are fetched NOW so their L2 latency hides under the FFT phase
+        const int j = (wave + it) & 3;
+        const int klo = a.mel_tile_klo[j], nst = a.mel_tile_steps[j];
+        const float* Bt = a.mel_b + (size_t)a.mel_tile_base[j] * 64 + lane;
+        float bw[FE_BREG];
+#pragma unroll
+        for (int c = 0; c < FE_BREG / 8; ++c)
+            if (8 * c < nst) {
+#pragma unroll
+                for (int s = 0; s < 8; ++s) bw[8 * c + s] = Bt[64 * (8 * c + s)];
+            }
         // -------------------------------------------------------------------------------- FFT phase
         {
             int64_t fid = pass * 16 + 4 * wave + q;
@@ -180,17 +193,19 @@ __global__ __launch_bounds__(FE_WAVES * 64, 2) void mel_frontend_kernel(Frontend
         __syncthreads();                                 // P complete (and everyone is done with the other buffer)
         // -------------------------------------------------------------------------------- mel phase (matrix pipe)
         {
-            const int j = (wave + it) & 3;               // this wave's 16-mel tile for this pass
-            const int klo = a.mel_tile_klo[j], nst = a.mel_tile_steps[j];
-            const float* Bt = a.mel_b + (size_t)a.mel_tile_base[j] * 64 + lane;
             const float* Ar = P + p * FE_PROW + klo + q; // A[row = frame p][k = q]  (lane&15 = row, lane>>4 = k)
             f4v acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
-            int s = 0;
-            for (; s + 1 < nst; s += 2) {
+#pragma unroll
+            for (int c = 0; c < FE_BREG / 8; ++c)
+                if (8 * c < nst) {
+#pragma unroll
+                    for (int s = 0; s < 8; s += 2) {
+                        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(Ar[4 * (8 * c + s)], bw[8 * c + s], acc0, 0, 0, 0);
+                        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(Ar[4 * (8 * c + s + 1)], bw[8 * c + s + 1], acc1, 0, 0, 0);
+                    }
+                }
+            for (int s = FE_BREG; s < nst; ++s)          // filterbanks wider than FE_BREG steps per tile (not HTK)
                 acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(Ar[4 * s], Bt[64 * s], acc0, 0, 0, 0);
-                acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(Ar[4 * s + 4], Bt[64 * s + 64], acc1, 0, 0, 0);
-            }
-            if (s < nst) acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(Ar[4 * s], Bt[64 * s], acc0, 0, 0, 0);
             const f4v acc = acc0 + acc1;                 // D[frame 4q + r][mel 16j + p]
 #pragma unroll
             for (int r = 0; r < 4; ++r) {

@@ -94,7 +94,7 @@ int pack_image(const uitk_config* c, const uitk_weights* w, std::vector<char>* o
         tile_klo[j] = first < 0 ? 0 : (first & ~3);
         tile_steps[j] = first < 0 ? 0 : (last - tile_klo[j]) / 4 + 1;
         tile_base[j] = total_steps;
-        total_steps += tile_steps[j];
+        total_steps += (tile_steps[j] + 7) / 8 * 8;            // table zero-padded to whole 8-step chunks
     }
     ImageHeader h{};
     h.magic = IMAGE_MAGIC; h.precision = prec; h.depth = depth; h.outputdim = C; h.mel_steps = total_steps;

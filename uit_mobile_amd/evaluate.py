@@ -1,0 +1,74 @@
+"""Counterpart of the hot-path callers in the reference's evaluate.py: the batch step `Evaluator._inference`
+(evaluate.py:53-66) with its pad rule, `test_sample` (:247-263) and a plain batch loop standing in for the ignite
+engine (:153).  Metric post-processing (sklearn / ignite, evaluate.py:94-101, 212-229) is CPU-side scoring and out
+of scope; `run` returns the stacked model outputs so any scorer can consume them.
+"""
+import numpy as np
+import torch
+
+from .inference import build_model
+from .wav import read_wav_pcm16
+
+DEVICE = torch.device("cuda" if torch.cuda.is_available() else "cpu")      # run.py:27
+
+
+def transfer_to_device(batch, device=DEVICE):                               # run.py:30-32
+    return (x.to(device, non_blocking=True) if isinstance(x, torch.Tensor) else x for x in batch)
+
+
+def pad_to_target(data, model):
+    """evaluate.py:56-64: right-zero-pad so that the clip has target_length-1 hops."""
+    if hasattr(model, "target_length"):
+        t_len = model.target_length - 1
+        input_nframes = data.shape[-1] / model.hop_size
+        if input_nframes < t_len:
+            diff = int((t_len - input_nframes) * model.hop_size)
+            data = torch.nn.functional.pad(data, (0, diff), mode="constant")
+    return data
+
+
+def sequential_pad(waves, padding_value=0.0):
+    """dataset.py:183-204 collate: zero right-pad variable-length clips to the batch maximum; returns (batch, lengths).
+    int16 clips stay int16 (the x(1/32768) of dataset.py:44-46 is fused into the kernel's load)."""
+    lengths = [int(w.shape[-1]) for w in waves]
+    dtype = torch.int16 if all(torch.as_tensor(w).dtype == torch.int16 for w in waves) else torch.float32
+    out = torch.full((len(waves), max(lengths)), padding_value, dtype=dtype)
+    for i, w in enumerate(waves):
+        w = torch.as_tensor(w)
+        out[i, : lengths[i]] = w if dtype == torch.int16 else w.to(torch.float32) / (32768.0 if w.dtype == torch.int16 else 1.0)
+    return out, torch.as_tensor(lengths)
+
+
+class Evaluator:
+    def __init__(self, experiment_path, device=DEVICE, precision="f16"):
+        self.model = build_model(experiment_path, device=device, precision=precision)
+        self.device = device
+
+    def _inference(self, batch, pad=False):
+        """batch = (data, targets, lengths, filenames) as produced by the reference's collate."""
+        with torch.no_grad():
+            data, targets, lengths, filenames = transfer_to_device(batch, self.device)
+            if pad:
+                data = pad_to_target(data, self.model)
+            clip_out = self.model(data)
+            return clip_out, targets
+
+    def run(self, dataloader, pad=False, num_labels=None):
+        """Plain batch loop (the ignite engine of evaluate.py:153 without the metrics)."""
+        outs, tgts = [], []
+        for batch in dataloader:
+            y, t = self._inference(batch, pad=pad)
+            outs.append(y[..., :num_labels] if num_labels else y)          # evaluate.py:92 slices to 527
+            tgts.append(t)
+        return torch.cat(outs), tgts
+
+    def test_sample(self, sample):
+        pcm, sr = read_wav_pcm16(sample)
+        wav = torch.from_numpy(np.ascontiguousarray(pcm)).unsqueeze(0)
+        wav = pad_to_target(wav, self.model)
+        pred = self.model(wav.to(self.device))[0].cpu()
+        lines = []
+        for val, idx in zip(*pred.topk(5)):
+            lines.append(f"[{int(idx):=3}] : {float(val) * 100:.2f}")
+        print("\n".join(lines))
+        return pred
