@@ -140,13 +140,21 @@ float* uitk_amax_ptr(uitk_model* m);
  * (same B, T).  Stands in for uit.py:460-492. */
 int uitk_encode(uitk_model* m, int64_t B, int64_t T, float* probs, float* logits, void* stream);
 
-/* Copy the front-end output of the last uitk_frontend call, floor applied, in the reference's layout
- * [B][n_mels][frames] (what self.front_end(x) returns).  For stage-level parity tests. */
-int uitk_mel_db(uitk_model* m, int64_t B, int64_t T, float* out, void* stream);
+/* Diagnostic / stage-parity entry: run the front-end on pcm and return what self.front_end(x) returns in the
+ * reference: dB mel, batch-global floor applied, layout [B][n_mels][frames].  (The production path keeps the mel
+ * in the encoder's patch-major operand layout; this call re-runs the front-end kernel in a frame-major mode and
+ * overwrites the amax slots.) */
+int uitk_mel_db(uitk_model* m, const void* pcm, int in_dtype, int64_t B, int64_t T, float* out, void* stream);
 
 /* Optional: device buffer [B*ncrops][depth+1][24][128] float32 receiving the residual stream after
  * patch-embed(+pos) and after every block (token = f*6+t as in uit.py:388).  NULL disables (default). */
 int uitk_set_debug_tokens(uitk_model* m, float* dev_buf);
+
+/* Diagnostics: device buffers receiving per-phase shader-cycle sums per wave -- encoder [waves][12] uint64 (LN1,
+ * ring wait QK, QK, ring wait VP, attention+proj, LN2, ring waits MLP, MLP, setup, convert, patch embed, pool+head),
+ * front-end [waves][8].  A non-NULL buffer selects a separate instrumented kernel build (slower; never use it to
+ * time the product).  NULL (default) = normal kernels. */
+int uitk_set_timing_buffers(uitk_model* m, unsigned long long* enc_buf, unsigned long long* fe_buf);
 
 /* Last error message of the calling thread ("" if none). */
 const char* uitk_last_error(void);

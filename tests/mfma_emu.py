@@ -120,13 +120,14 @@ class EncoderEmu:
         # patch-embed operand
         XB = [[None] * 3 for _ in range(8)]
         for ct in range(3):
-            f0 = 16 * pf[ct] + 8 * (G_ & 1)
             for s in range(8):
-                t = 16 * pt[ct] + 2 * s + (G_ >> 1)
+                # k-slot (s,g,j) <-> mel-in-patch fi = 2s + (g>>1), frame-in-patch ti = 8(g&1) + j
+                fbin = 16 * pf[ct] + 2 * s + (G_ >> 1)
+                t = 16 * pt[ct][:, None] + 8 * (G_ & 1)[:, None] + j8
                 t = np.minimum(t, mel2.shape[1] - 1)
-                x = mel2[clip[ct][:, None], t[:, None], f0[:, None] + j8]
-                x = np.maximum(x, floor_db) * bn_sc[f0[:, None] + j8] + bn_sh[f0[:, None] + j8]
-                XB[s][ct] = round_op(x, prec)
+                x = mel2[clip[ct][:, None], t, fbin[:, None]]
+                x = np.maximum(x, floor_db) * bn_sc[fbin][:, None] + bn_sh[fbin][:, None]
+                XB[s][ct] = round_op(x, prec) * (pt[ct] < nt)[:, None]
         r4 = np.arange(4)[None]
         R = [[pe_bias[tk[ct][:, None], 16 * ft + 4 * G_[:, None] + r4].copy() for ct in range(3)] for ft in range(8)]
         for i in range(PE_STAGES):

@@ -21,9 +21,10 @@ sd = {k: torch.from_numpy(np.asarray(v)) for k, v in make_state_dict(name, 13).i
 x = synth_batch(B, 16000, 0, dev, False)
 xi = synth_batch(B, 16000, 0, dev, True)
 variants = {}
-VARS = [("w8/f16", "8", "f16", "0", "0"), ("w8/sched", "8", "f16", "1", "0"), ("w4/f16", "4", "f16", "0", "0"),
-        ("w4/sched", "4", "f16", "1", "0"), ("w4/stag20k", "4", "f16", "0", "20000"), ("w4/stag40k", "4", "f16", "0", "40000"),
-        ("w4/sch+st", "4", "f16", "1", "20000"), ("w8/bf16", "8", "bf16", "0", "0")]
+VARS = [("w8/f16", "8", "f16", "0", "0"), ("w4/f16", "4", "f16", "0", "0")]
+for d in (4000, 8000, 12000, 16000, 24000):
+    VARS.append((f"w4/slot{d//1000}k", "4", "f16", "0", str(d)))
+os.environ["UITK_ENC_STAGGER_MODE"] = "2"
 for tag, waves, prec, sched, stag in VARS:
     os.environ["UITK_ENC_WAVES"] = waves
     os.environ["UITK_ENC_SCHED"] = sched

@@ -1,0 +1,39 @@
+"""GPU diagnostic: where do an encoder block's cycles go?  (instrumented kernel build, s_memtime stamps)"""
+import ctypes, os, sys
+from pathlib import Path
+import numpy as np, torch
+ROOT = Path(__file__).resolve().parents[1]
+sys.path[:0] = [str(ROOT), str(ROOT / "tests" / "golden")]
+from synth_weights import make_state_dict
+from uit_mobile_amd import models, _lib
+from bench import synth_batch
+dev = torch.device("cuda", 0)
+sd = {k: torch.from_numpy(np.asarray(v)) for k, v in make_state_dict("uit_xs", 13).items()}
+x = synth_batch(8192, 16000, 0, dev, False)
+names = ["LN1", "wait QK", "QK", "wait VP", "attn+proj", "LN2", "wait MLP(12)", "MLP(12)"]
+names2 = ["setup", "PE tile0", "PE tiles1,2", "pool+head"]
+for waves, B in (("8", 8192),):
+    os.environ["UITK_ENC_WAVES"] = waves
+    m = models.uit_xs(outputdim=537, target_length=102).to(dev); m.load_state_dict(sd); m.eval()
+    xb = x[:B]
+    m(xb); torch.cuda.synchronize()
+    nw = B // 2
+    buf = torch.zeros((nw, 12), dtype=torch.int64, device=dev)
+    h = m._handle(dev)
+    fbuf = torch.zeros((4096, 8), dtype=torch.int64, device=dev)
+    _lib.check(_lib.load().uitk_set_timing_buffers(h, ctypes.c_void_p(buf.data_ptr()), ctypes.c_void_p(fbuf.data_ptr())), "timing")
+    m(xb); torch.cuda.synchronize()
+    _lib.load().uitk_set_timing_buffers(h, None, None)
+    raw = buf.cpu().numpy().astype(np.float64)
+    med = np.median(raw[:, :8] / 12.0, 0)
+    fixed = np.median(raw[:, 8:], 0)
+    print(f"waves/WG {waves} B {B}: per-block cycles (median over {nw} waves), block total {med.sum():.0f}; "
+          f"12 blocks {12 * med.sum():.0f}; fixed {fixed.sum():.0f}")
+    print("   " + "  ".join(f"{n}={v:.0f}" for n, v in zip(names, med)))
+    print("   " + "  ".join(f"{n}={v:.0f}" for n, v in zip(names2, fixed)))
+    fr = fbuf.cpu().numpy().astype(np.float64)
+    fr = fr[fr.sum(1) > 0]
+    npass = B * 7 / 512.0
+    fn = ["samples+window", "FFT1+tw+Ewrite", "Eread+FFT2+Zwrite", "Zread+split+P", "barrier", "mel MFMA", "tail", "log+store"]
+    print(f"   frontend per-pass cycles (median over {len(fr)} waves, {npass:.1f} passes/WG): "
+          + "  ".join(f"{n}={v:.0f}" for n, v in zip(fn, np.median(fr, 0) / npass)) + f"  total/pass {np.median(fr.sum(1)) / npass:.0f}")

@@ -26,14 +26,18 @@ struct uitk_model {
     uitk_config cfg;
     ImageHeader hdr;
     char* image = nullptr;        // device copy of the packed parameter image
-    float* mel = nullptr;         // [B][nF][64]
+    float* mel = nullptr;         // patch-major 16-bit operands [B*ncrops][24][16][16]
+    float* mel_frames = nullptr;  // [B][nF][64], only for uitk_mel_db
+    size_t mel_frames_cap = 0;
     float* amax = nullptr;        // [AMAX_SLOTS]
     float* rowprobs = nullptr;    // [B*ncrops][C] (multi-crop only)
     size_t mel_cap = 0, rowprobs_cap = 0;
     float* dbg = nullptr;
+    unsigned long long* timing = nullptr;
+    unsigned long long* timing_fe = nullptr;
     int n_cu = 256;
     int enc_waves = 8;            // waves per encoder workgroup (8 = one WG per CU; 4 = two independent WGs per CU)
-    int enc_sched = 0, enc_stagger = 0;   // tuning knobs (UITK_ENC_SCHED, UITK_ENC_STAGGER)
+    int enc_sched = 0, enc_stagger = 0, enc_stagger_mode = 1;   // tuning knobs (UITK_ENC_SCHED, UITK_ENC_STAGGER)
     int device = 0;
 };
 
@@ -80,6 +84,7 @@ int uitk_create(const uitk_config* cfg, const uitk_weights* w, uitk_model** out)
     if (const char* e = std::getenv("UITK_ENC_WAVES")) m->enc_waves = std::atoi(e) == 4 ? 4 : 8;
     if (const char* e = std::getenv("UITK_ENC_SCHED")) m->enc_sched = std::atoi(e) != 0;
     if (const char* e = std::getenv("UITK_ENC_STAGGER")) m->enc_stagger = std::atoi(e);
+    if (const char* e = std::getenv("UITK_ENC_STAGGER_MODE")) m->enc_stagger_mode = std::atoi(e);
     if (hipMalloc((void**)&m->image, img.size()) != hipSuccess || hipMalloc((void**)&m->amax, AMAX_SLOTS * 4) != hipSuccess) {
         uitk_destroy(m); return fail(UITK_ERR_HIP, "hipMalloc failed for the parameter image");
     }
@@ -94,6 +99,7 @@ int uitk_destroy(uitk_model* m) {
     if (!m) return UITK_OK;
     if (m->image) (void)hipFree(m->image);
     if (m->mel) (void)hipFree(m->mel);
+    if (m->mel_frames) (void)hipFree(m->mel_frames);
     if (m->amax) (void)hipFree(m->amax);
     if (m->rowprobs) (void)hipFree(m->rowprobs);
     delete m;
@@ -114,13 +120,14 @@ static int check_shape(const uitk_model* m, int64_t B, int64_t T) {
     if (T <= m->cfg.n_fft / 2) return fail(UITK_ERR_TOO_SHORT, "clip must be longer than n_fft/2 samples (reflect padding)");
     if (uitk_num_frames(m, T) < m->cfg.patch_size) return fail(UITK_ERR_TOO_SHORT, "clip shorter than one 16-frame patch");
     if (T >= (int64_t)1 << 30) return fail(UITK_ERR_INVALID_ARG, "T too large");
+    if (B * (int64_t)uitk_num_frames(m, T) >= (int64_t)1 << 31) return fail(UITK_ERR_INVALID_ARG, "B * frames must be below 2^31 per call");
     return UITK_OK;
 }
 
 int uitk_reserve(uitk_model* m, int64_t B, int64_t T) {
     if (int rc = check_shape(m, B, T)) return rc;
-    const size_t mel_bytes = (size_t)B * uitk_num_frames(m, T) * NMEL * 4;
     const int nc = uitk_num_crops(m, T);
+    const size_t mel_bytes = (size_t)B * nc * NTOK * 256 * 2;
     const size_t rp_bytes = nc > 1 ? (size_t)B * nc * m->cfg.outputdim * 4 : 0;
     if (mel_bytes > m->mel_cap) {
         HIP_TRY(hipDeviceSynchronize());
@@ -147,12 +154,20 @@ int uitk_set_debug_tokens(uitk_model* m, float* dev_buf) {
     return UITK_OK;
 }
 
-int uitk_frontend(uitk_model* m, const void* pcm, int in_dtype, int64_t B, int64_t T, void* stream) {
-    if (int rc = check_shape(m, B, T)) return rc;
-    if (!pcm) return fail(UITK_ERR_INVALID_ARG, "null pcm");
-    if (in_dtype != UITK_IN_F32 && in_dtype != UITK_IN_I16) return fail(UITK_ERR_INVALID_ARG, "unknown in_dtype");
-    if (int rc = uitk_reserve(m, B, T)) return rc;
-    hipStream_t s = (hipStream_t)stream;
+int uitk_set_timing_buffers(uitk_model* m, unsigned long long* enc_buf, unsigned long long* fe_buf) {
+    if (!m) return fail(UITK_ERR_INVALID_ARG, "null model");
+    m->timing = enc_buf; m->timing_fe = fe_buf;
+    return UITK_OK;
+}
+
+static int crop_nt(const uitk_model* m, int64_t T) {
+    const int nF = uitk_num_frames(m, T), nc = uitk_num_crops(m, T);
+    int nt = (nc > 1 ? m->cfg.target_length : nF) / 16;
+    return nt > GT ? GT : nt;
+}
+
+static int run_frontend(uitk_model* m, const void* pcm, int in_dtype, int64_t B, int64_t T, float* mel_out, int patch,
+                        hipStream_t s) {
     const ImageHeader& h = m->hdr;
     FrontendArgs a{};
     a.pcm = pcm; a.B = B; a.T = T; a.nF = uitk_num_frames(m, T); a.hop = m->cfg.hop_size;
@@ -163,24 +178,37 @@ int uitk_frontend(uitk_model* m, const void* pcm, int in_dtype, int64_t B, int64
     for (int j = 0; j < 4; ++j) {
         a.mel_tile_klo[j] = h.mel_tile_klo[j]; a.mel_tile_steps[j] = h.mel_tile_steps[j]; a.mel_tile_base[j] = h.mel_tile_base[j];
     }
-    a.mel = m->mel; a.amax = m->amax;
+    a.mel = mel_out; a.amax = m->amax;
+    a.bn_sc = (const float*)(m->image + h.off_bn_sc); a.bn_sh = (const float*)(m->image + h.off_bn_sh);
+    a.op_bf16 = m->cfg.precision == UITK_PREC_BF16;
+    a.timing = m->timing_fe;
+    a.ncrops = uitk_num_crops(m, T); a.tl = m->cfg.target_length; a.nt = crop_nt(m, T);
     HIP_TRY(hipMemsetAsync(m->amax, 0xFF, AMAX_SLOTS * 4, s));
-    HIP_TRY(launch_frontend(a, in_dtype == UITK_IN_I16, m->n_cu, s));
+    HIP_TRY(launch_frontend(a, in_dtype == UITK_IN_I16, patch, m->n_cu, s));
     return UITK_OK;
+}
+
+int uitk_frontend(uitk_model* m, const void* pcm, int in_dtype, int64_t B, int64_t T, void* stream) {
+    if (int rc = check_shape(m, B, T)) return rc;
+    if (!pcm) return fail(UITK_ERR_INVALID_ARG, "null pcm");
+    if (in_dtype != UITK_IN_F32 && in_dtype != UITK_IN_I16) return fail(UITK_ERR_INVALID_ARG, "unknown in_dtype");
+    if (int rc = uitk_reserve(m, B, T)) return rc;
+    return run_frontend(m, pcm, in_dtype, B, T, m->mel, 1, (hipStream_t)stream);
 }
 
 int uitk_encode(uitk_model* m, int64_t B, int64_t T, float* probs, float* logits, void* stream) {
     if (int rc = check_shape(m, B, T)) return rc;
     if (!probs) return fail(UITK_ERR_INVALID_ARG, "null probs");
     const int nF = uitk_num_frames(m, T), nc = uitk_num_crops(m, T), tl = m->cfg.target_length;
-    if ((size_t)B * nF * NMEL * 4 > m->mel_cap) return fail(UITK_ERR_WORKSPACE, "uitk_encode without a matching uitk_frontend");
+    if ((size_t)B * nc * NTOK * 256 * 2 > m->mel_cap) return fail(UITK_ERR_WORKSPACE, "uitk_encode without a matching uitk_frontend");
+    (void)nF; (void)tl;
     if (B * nc >= (int64_t)1 << 31) return fail(UITK_ERR_INVALID_ARG, "batch too large");
     hipStream_t s = (hipStream_t)stream;
     const ImageHeader& h = m->hdr;
     EncoderArgs a{};
-    a.mel = m->mel; a.amax = m->amax; a.top_db = m->cfg.top_db;
-    a.nF = nF; a.rows = (int)(B * nc); a.ncrops = nc; a.tl = tl;
-    a.nt = (nc > 1 ? tl : nF) / 16; if (a.nt > GT) a.nt = GT;
+    a.mel = (const unsigned short*)m->mel; a.amax = m->amax; a.top_db = m->cfg.top_db;
+    a.rows = (int)(B * nc);
+    a.nt = crop_nt(m, T);
     a.depth = m->cfg.depth; a.C = m->cfg.outputdim;
     a.wstream = m->image + h.off_wstream;
     a.bias = (const float*)(m->image + h.off_bias);
@@ -192,7 +220,8 @@ int uitk_encode(uitk_model* m, int64_t B, int64_t T, float* probs, float* logits
     a.head_b = (const float*)(m->image + h.off_head_b);
     a.probs = nc > 1 ? m->rowprobs : probs;
     a.logits = logits; a.dbg = m->dbg;
-    a.stagger = m->enc_stagger; a.stagger_group = m->n_cu;
+    a.timing = m->timing;
+    a.stagger = m->enc_stagger; a.stagger_group = m->n_cu; a.stagger_mode = m->enc_stagger_mode;
     HIP_TRY(launch_encoder(a, m->cfg.precision, m->enc_waves, m->enc_sched, s));
     if (nc > 1) HIP_TRY(launch_crop_reduce(m->rowprobs, probs, B, nc, a.C, m->cfg.eval_avg, s));
     return UITK_OK;
@@ -204,12 +233,21 @@ int uitk_forward(uitk_model* m, const void* pcm, int in_dtype, int64_t B, int64_
     return uitk_encode(m, B, T, probs, logits, stream);
 }
 
-int uitk_mel_db(uitk_model* m, int64_t B, int64_t T, float* out, void* stream) {
+int uitk_mel_db(uitk_model* m, const void* pcm, int in_dtype, int64_t B, int64_t T, float* out, void* stream) {
     if (int rc = check_shape(m, B, T)) return rc;
-    if (!out) return fail(UITK_ERR_INVALID_ARG, "null out");
+    if (!pcm || !out) return fail(UITK_ERR_INVALID_ARG, "null pointer");
+    if (in_dtype != UITK_IN_F32 && in_dtype != UITK_IN_I16) return fail(UITK_ERR_INVALID_ARG, "unknown in_dtype");
     const int nF = uitk_num_frames(m, T);
-    if ((size_t)B * nF * NMEL * 4 > m->mel_cap) return fail(UITK_ERR_WORKSPACE, "uitk_mel_db without a matching uitk_frontend");
-    HIP_TRY(launch_mel_export(m->mel, m->amax, m->cfg.top_db, B, nF, out, (hipStream_t)stream));
+    const size_t need = (size_t)B * nF * NMEL * 4;
+    if (need > m->mel_frames_cap) {
+        HIP_TRY(hipDeviceSynchronize());
+        if (m->mel_frames) (void)hipFree(m->mel_frames);
+        m->mel_frames = nullptr; m->mel_frames_cap = 0;
+        HIP_TRY(hipMalloc((void**)&m->mel_frames, need));
+        m->mel_frames_cap = need;
+    }
+    if (int rc = run_frontend(m, pcm, in_dtype, B, T, m->mel_frames, 0, (hipStream_t)stream)) return rc;
+    HIP_TRY(launch_mel_export(m->mel_frames, m->amax, m->cfg.top_db, B, nF, out, (hipStream_t)stream));
     return UITK_OK;
 }
 

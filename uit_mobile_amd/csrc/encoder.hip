@@ -61,6 +61,10 @@ template <> struct Op<0> {   // fp16 operands
         return __builtin_elementwise_max(pack8(lo, hi), z);
     }
     static __device__ __forceinline__ v4 ones4() { return v4{(_Float16)1.f, (_Float16)1.f, (_Float16)1.f, (_Float16)1.f}; }
+    static __device__ __forceinline__ v8 max8(v8 y, v8 t) { return __builtin_elementwise_max(y, t); }
+    static __device__ __forceinline__ v8 min8(v8 y, v8 t) { return __builtin_elementwise_min(y, t); }
+    static __device__ __forceinline__ v8 from_f32x8(f4 lo, f4 hi) { return pack8(lo, hi); }
+    static __device__ __forceinline__ v8 zero8() { return v8{0, 0, 0, 0, 0, 0, 0, 0}; }
 };
 template <> struct Op<1> {   // bf16 operands
     using v8 = b8; using v4 = b4;
@@ -85,6 +89,20 @@ template <> struct Op<1> {   // bf16 operands
         return __builtin_bit_cast(v8, __builtin_elementwise_max(__builtin_bit_cast(s8, pack8(lo, hi)), z));
     }
     static __device__ __forceinline__ v4 ones4() { return v4{(__bf16)1.f, (__bf16)1.f, (__bf16)1.f, (__bf16)1.f}; }
+    static __device__ __forceinline__ v8 max8(v8 y, v8 t) {
+        v8 r;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) r[i] = (float)y[i] > (float)t[i] ? y[i] : t[i];
+        return r;
+    }
+    static __device__ __forceinline__ v8 min8(v8 y, v8 t) {
+        v8 r;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) r[i] = (float)y[i] < (float)t[i] ? y[i] : t[i];
+        return r;
+    }
+    static __device__ __forceinline__ v8 from_f32x8(f4 lo, f4 hi) { return pack8(lo, hi); }
+    static __device__ __forceinline__ v8 zero8() { return v8{(__bf16)0.f, (__bf16)0.f, (__bf16)0.f, (__bf16)0.f, (__bf16)0.f, (__bf16)0.f, (__bf16)0.f, (__bf16)0.f}; }
 };
 
 constexpr int RING_SLOTS = 4;           // >= PREFETCH + 2 (see ring_step)
@@ -162,6 +180,16 @@ __device__ __forceinline__ float xmax(float v) {
     return fmaxf(__uint_as_float(b[0]), __uint_as_float(b[1]));
 }
 
+// x + (x moved by a DPP row operation within each 16-lane row): quad_perm / row_half_mirror / row_mirror (pure VALU)
+template <int CTRL>
+__device__ __forceinline__ float dpp_add(float v) {
+    return v + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, true));
+}
+template <int CTRL>
+__device__ __forceinline__ float dpp_mov(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, true));
+}
+
 // LayerNorm statistics (two-pass, fp32) of one token column held as R[ft][ct], ft = 0..7.
 __device__ __forceinline__ void ln_stats(const f4 (&R)[8][3], int ct, float eps, float& mean, float& rstd) {
     f4 acc = R[0][ct];
@@ -187,7 +215,17 @@ __device__ __forceinline__ void layernorm_to_operand(const f4 (&R)[8][3], float 
     }
 }
 
-template <int PREC, int WAVES, bool SCHED>
+// In-kernel stamps (diagnostic build only, TIMING = true): one asm statement = s_memtime + lgkmcnt(0), fenced.
+__device__ __forceinline__ unsigned long long stamp() {
+    unsigned long long t;
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) :: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    return t;
+}
+#define TSTAMP(slot) do { if constexpr (TIMING) { const unsigned long long _t = stamp(); tacc[slot] += _t - tlast; tlast = _t; } } while (0)
+
+template <int PREC, int WAVES, bool SCHED, bool TIMING>
 __global__ __launch_bounds__(WAVES * 64, 2) void uit_encoder_kernel(EncoderArgs a) {
     using OP = Op<PREC>;
     using v8 = typename OP::v8;
@@ -202,13 +240,28 @@ __global__ __launch_bounds__(WAVES * 64, 2) void uit_encoder_kernel(EncoderArgs 
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lane = tid & 63, c = lane & 15, g = lane >> 4;
 
-    // ---- optional stagger: delay every second resident workgroup generation so that the two workgroups sharing a
-    // CU run out of phase (one in its MFMA-bound MLP while the other is in its VALU-bound LN/softmax)
-    if (a.stagger > 0 && ((blockIdx.x / a.stagger_group) & 1)) {
-        const uint64_t t0 = __builtin_amdgcn_s_memtime();
-        while (__builtin_amdgcn_s_memtime() - t0 < (uint64_t)a.stagger) __builtin_amdgcn_s_sleep(32);
+    // ---- optional stagger: delay one of the two workgroups sharing a CU so that they run out of phase (one in its
+    // MFMA-bound MLP while the other is in its VALU-bound LN/softmax).  Mode 1 keys on the workgroup generation,
+    // mode 2 on the hardware wave slot of wave 0 (HW_REG_HW_ID[3:0]); a pure speed knob, results do not depend on it.
+    if (a.stagger > 0) {
+        bool delay;
+        if (a.stagger_mode == 2) {
+            unsigned* flag = (unsigned*)(smem + LDS_RING + LDS_BIAS);
+            if (tid == 0) *flag = __builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 4) & 1u;   // WAVE_ID parity
+            __syncthreads();
+            delay = *flag != 0;
+            __syncthreads();
+        } else {
+            delay = ((blockIdx.x / a.stagger_group) & 1) != 0;
+        }
+        if (delay) {
+            const uint64_t t0 = __builtin_amdgcn_s_memtime();
+            while (__builtin_amdgcn_s_memtime() - t0 < (uint64_t)a.stagger) __builtin_amdgcn_s_sleep(16);
+        }
     }
 
+    unsigned long long tacc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, tlast = 0;
+    if constexpr (TIMING) tlast = stamp();
     // ---- kick the weight stream: block-0 biases + the whole patch-embed weight set (4 stages = the whole ring)
     if (a.depth > 0) bias_issue<WAVES>(a.bias, breg, 0, wave, lane);
 #pragma unroll
@@ -216,17 +269,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void uit_encoder_kernel(EncoderArgs 
 
     // ---- rows (clip-crops) of this wave, token maps
     const int r0 = (blockIdx.x * WAVES + wave) * 2;
-    int64_t mel_base[2];
-    int fr_limit[2];
-#pragma unroll
-    for (int k = 0; k < 2; ++k) {
-        int row = r0 + k; if (row > a.rows - 1) row = a.rows - 1;
-        const int b = row / a.ncrops, cr = row - b * a.ncrops;
-        int start = 0;
-        if (a.ncrops > 1) { start = cr * a.tl; if (start > a.nF - a.tl) start = a.nF - a.tl; }
-        mel_base[k] = ((int64_t)b * a.nF + start) * NMEL;
-        fr_limit[k] = a.nF - 1 - start;                    // last valid frame offset from the crop start
-    }
+    const int row_lo = r0 < a.rows ? r0 : a.rows - 1, row_hi = r0 + 1 < a.rows ? r0 + 1 : a.rows - 1;
     int clip_[3], tk_[3], pf_[3], pt_[3];
 #pragma unroll
     for (int ct = 0; ct < 3; ++ct) {
@@ -236,51 +279,61 @@ __global__ __launch_bounds__(WAVES * 64, 2) void uit_encoder_kernel(EncoderArgs 
         pf_[ct] = tk_[ct] / GT;
         pt_[ct] = tk_[ct] - GT * pf_[ct];
     }
-    float amx = -INFINITY;
-    for (int i = 0; i < AMAX_SLOTS; ++i) amx = fmaxf(amx, a.amax[i]);     // NaN (untouched) slots are ignored
+    // ---- issue ALL patch loads now (3 token tiles x 8 k-steps x 16 B per lane).  The front-end wrote each token's
+    // 256 operands contiguously in k-slot order ((s,g,j) <-> mel 2s+(g>>1), frame 8(g&1)+j = offset 32s+8g+j),
+    // already init_bn-normalised and converted, so a wave-instruction reads sixteen 64-byte runs and one HBM round
+    // trip covers the whole patch embed.
+    v8 XB[3][8];
+#pragma unroll
+    for (int ct = 0; ct < 3; ++ct) {
+        const unsigned short* src = a.mel + ((int64_t)(clip_[ct] ? row_hi : row_lo) * NTOK + tk_[ct]) * 256 + 8 * g;
+#pragma unroll
+        for (int s = 0; s < 8; ++s) XB[ct][s] = *(const v8*)(src + 32 * s);
+    }
+    float amx = a.amax[lane];                                             // 64 slots, one per lane; NaN = untouched slot
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) amx = fmaxf(amx, __shfl_xor(amx, o));
     const float floor_db = amx - a.top_db;
+    TSTAMP(8);                                                            // setup
 
-    // ---- patch embed.  All 64 weight fragments (ft = f/8, s = f%8) are LDS-resident; one token tile at a time
-    // keeps the live set at 8 operand + 8 accumulator tiles.  k-slot (s,g,j) <-> (ti = 2s+(g>>1), fi = 8(g&1)+j).
-    f4 R[8][3];
-    auto pe_tile = [&](int ct, bool first) {
-        const int f0 = 16 * pf_[ct] + 8 * (g & 1);
-        const f4 sc0 = *(const f4*)(a.bn_sc + f0), sc1 = *(const f4*)(a.bn_sc + f0 + 4);
-        const f4 sh0 = *(const f4*)(a.bn_sh + f0), sh1 = *(const f4*)(a.bn_sh + f0 + 4);
-        const int64_t base = clip_[ct] ? mel_base[1] : mel_base[0];
-        const int lim = clip_[ct] ? fr_limit[1] : fr_limit[0];
-        f4 x0[8], x1[8];
+    // ---- top_db clamp on the normalised operands: y = max(y, sc*floor + sh) for sc >= 0, min(...) for sc < 0
+    // (exactly round(init_bn(max(dB, floor))): the affine map and the rounding are monotone).  All 8 operands of a
+    // lane's k-step share one mel bin 16pf + 2s + (g>>1).  Masked tokens of short clips -> 0.
+#pragma unroll
+    for (int ct = 0; ct < 3; ++ct) {
+        const bool live = pt_[ct] < a.nt;
 #pragma unroll
         for (int s = 0; s < 8; ++s) {
-            int t = 16 * pt_[ct] + 2 * s + (g >> 1);
-            if (t > lim) t = lim;                                         // masked tokens of short clips: stay in bounds
-            const float* src = a.mel + base + (int64_t)t * NMEL + f0;
-            x0[s] = *(const f4*)src; x1[s] = *(const f4*)(src + 4);
+            const int fbin = 16 * pf_[ct] + 2 * s + (g >> 1);
+            const float sc = a.bn_sc[fbin], th = floor_db * sc + a.bn_sh[fbin];
+            const v8 t8 = OP::from_f32x8(splat(th), splat(th));
+            const v8 y = sc >= 0.f ? OP::max8(XB[ct][s], t8) : OP::min8(XB[ct][s], t8);
+            XB[ct][s] = live ? y : OP::zero8();
         }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                      // patch-embed weights landed ...
+    __builtin_amdgcn_s_barrier();                                         // ... for every wave
+    asm volatile("" ::: "memory");
+    TSTAMP(9);                                                            // convert + weight landing
+
+    // ---- patch embed: 64 LDS-resident fragments (ft = f/8, s = f%8) x 3 token tiles; accumulators start from the
+    // conv bias + positional embeddings table
+    f4 R[8][3];
+#pragma unroll
+    for (int ct = 0; ct < 3; ++ct)
 #pragma unroll
         for (int ft = 0; ft < 8; ++ft) R[ft][ct] = *(const f4*)(a.pe_bias + tk_[ct] * DIM + 16 * ft + 4 * g);
-        v8 XB[8];
 #pragma unroll
-        for (int s = 0; s < 8; ++s)                                       // top_db clamp + init_bn + convert
-            XB[s] = OP::pack8(__builtin_elementwise_max(x0[s], splat(floor_db)) * sc0 + sh0,
-                              __builtin_elementwise_max(x1[s], splat(floor_db)) * sc1 + sh1);
-        if (first) {                                                      // PE weights landed + visible
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();
-            asm volatile("" ::: "memory");
-        }
+    for (int ft = 0; ft < 8; ++ft) {
+        v8 A[8];
 #pragma unroll
-        for (int ft = 0; ft < 8; ++ft) {
-            v8 A[8];
+        for (int s = 0; s < 8; ++s) A[s] = lds_frag<PREC>(ring, ft * 8 + s, lane);
 #pragma unroll
-            for (int s = 0; s < 8; ++s) A[s] = lds_frag<PREC>(ring, ft * 8 + s, lane);
+        for (int s = 0; s < 8; ++s)
 #pragma unroll
-            for (int s = 0; s < 8; ++s) R[ft][ct] = OP::mfma32(A[s], XB[s], R[ft][ct]);
-        }
-    };
-    pe_tile(0, true);
-    pe_tile(1, false);
-    pe_tile(2, false);
+            for (int ct = 0; ct < 3; ++ct) R[ft][ct] = OP::mfma32(A[s], XB[ct][s], R[ft][ct]);
+    }
+    TSTAMP(10);                                                           // patch-embed MFMAs
     __builtin_amdgcn_s_barrier();                                         // every wave is done with the PE weights
     asm volatile("" ::: "memory");
     ring_issue<WAVES>(a.wstream, ring, PE_STAGES, wave, lane);
@@ -329,9 +382,11 @@ __global__ __launch_bounds__(WAVES * 64, 2) void uit_encoder_kernel(EncoderArgs 
         const float* bias = (const float*)(breg + (blk & 1) * BIAS_FLOATS * 4);
         v8 X[4][3];
         layernorm_to_operand<PREC>(R, 1e-6f, X);
+        TSTAMP(0);                                                     // LN1
 
         // ===== stage QK: fragments (ft = f/4 in {q h0, q h1, k h0, k h1}, s = f%4)
         ring_step<WAVES>(a.wstream, ring, tb, wave, lane);
+        TSTAMP(1);                                                     // ring wait QK
         if (blk + 1 < a.depth) bias_issue<WAVES>(a.bias, breg, blk + 1, wave, lane);
         v4 Qh[2][3], Kh[2][3];
         {
@@ -356,8 +411,10 @@ __global__ __launch_bounds__(WAVES * 64, 2) void uit_encoder_kernel(EncoderArgs 
             }
         }
 
+        TSTAMP(2);                                                     // QK compute
         // ===== stage VP: fragments 0..7 = V (h = f/4, s = f%4) used as the B operand; 8..15 = proj (ft = f-8)
         ring_step<WAVES>(a.wstream, ring, tb + 1, wave, lane);
+        TSTAMP(3);                                                     // ring wait VP
         {
             const char* slot = ring + ((tb + 1) & (RING_SLOTS - 1)) * STAGE_BYTES;
             v4 Vh[3][2];                       // V[token 16ct+4g+r][d = c] -> A operand of P.V (rows d, k = token)
@@ -425,18 +482,19 @@ __global__ __launch_bounds__(WAVES * 64, 2) void uit_encoder_kernel(EncoderArgs 
             }
         }
 
+        TSTAMP(4);                                                     // V + attention + proj
         // ===== MLP: 12 stages; stage ch = fc1 rows 32ch..32ch+31 (frags j*4+s) and fc2 k-step ch (frags 8+ft)
         layernorm_to_operand<PREC>(R, 1e-6f, X);
-#pragma unroll 1
-        for (int ch = 0; ch < 12; ++ch) {
-            const int t = tb + 2 + ch;
-            ring_step<WAVES>(a.wstream, ring, t, wave, lane);
-            const char* slot = ring + (t & (RING_SLOTS - 1)) * STAGE_BYTES;
-            v8 A[8], A2[8];
-#pragma unroll
-            for (int f = 0; f < 8; ++f) A[f] = lds_frag<PREC>(slot, f, lane);
+        TSTAMP(5);                                                     // LN2
+        // Software-pipelined over the 12 stages: at stage ch the fc1 fragment reads are issued first, then the fc2
+        // MFMAs of chunk ch-1 run from registers (A2/HX carried across the barrier) and cover the LDS latency; the
+        // fc2 fragment reads of chunk ch fly under its fc1 MFMAs.
+        v8 A2[8], HX[3];
+        auto fc1_chunk = [&](const char* slot, int ch, const v8 (&A)[8]) {
             const f4 b10 = *(const f4*)(bias + BIAS_FC1 + 32 * ch + 4 * g);
             const f4 b11 = *(const f4*)(bias + BIAS_FC1 + 32 * ch + 16 + 4 * g);
+#pragma unroll
+            for (int f = 0; f < 8; ++f) A2[f] = lds_frag<PREC>(slot, 8 + f, lane);       // fc2 fragments of this chunk
             f4 H0[3], H1[3];
 #pragma unroll
             for (int ct = 0; ct < 3; ++ct) {
@@ -445,39 +503,45 @@ __global__ __launch_bounds__(WAVES * 64, 2) void uit_encoder_kernel(EncoderArgs 
                 for (int s = 0; s < 4; ++s) H0[ct] = OP::mfma32(A[s], X[s][ct], H0[ct]);
             }
 #pragma unroll
-            for (int f = 0; f < 4; ++f) A2[f] = lds_frag<PREC>(slot, 8 + f, lane);
-#pragma unroll
             for (int ct = 0; ct < 3; ++ct) {
                 H1[ct] = b11;
 #pragma unroll
                 for (int s = 0; s < 4; ++s) H1[ct] = OP::mfma32(A[4 + s], X[s][ct], H1[ct]);
             }
 #pragma unroll
-            for (int f = 4; f < 8; ++f) A2[f] = lds_frag<PREC>(slot, 8 + f, lane);
-            v8 HX[3];
-#pragma unroll
             for (int ct = 0; ct < 3; ++ct) HX[ct] = OP::relu_pack8(H0[ct], H1[ct]);
+        };
+        {   // chunk 0 (peeled: defines A2 / HX before the steady-state loop)
+            ring_step<WAVES>(a.wstream, ring, tb + 2, wave, lane);
+            TSTAMP(6);
+            const char* slot = ring + ((tb + 2) & (RING_SLOTS - 1)) * STAGE_BYTES;
+            v8 A[8];
 #pragma unroll
-            for (int ft = 0; ft < 8; ++ft)
+            for (int f = 0; f < 8; ++f) A[f] = lds_frag<PREC>(slot, f, lane);
+            fc1_chunk(slot, 0, A);
+            TSTAMP(7);
+        }
+#pragma unroll 1
+        for (int ch = 1; ch < 12; ++ch) {
+            const int t = tb + 2 + ch;
+            ring_step<WAVES>(a.wstream, ring, t, wave, lane);
+            TSTAMP(6);                                                 // ring wait MLP (sum of 12)
+            const char* slot = ring + (t & (RING_SLOTS - 1)) * STAGE_BYTES;
+            v8 A[8];
+#pragma unroll
+            for (int f = 0; f < 8; ++f) A[f] = lds_frag<PREC>(slot, f, lane);          // fc1 fragments: in flight ...
+#pragma unroll
+            for (int ft = 0; ft < 8; ++ft)                                              // ... under chunk ch-1's fc2
 #pragma unroll
                 for (int ct = 0; ct < 3; ++ct) R[ft][ct] = OP::mfma32(A2[ft], HX[ct], R[ft][ct]);
-            if constexpr (SCHED) {
-                // issue order: keep 4 fragment reads in flight ahead of the MFMAs that consume them
-                __builtin_amdgcn_sched_group_barrier(0x100, 6, 0);          // 2 bias + 4 fragment ds_reads
-#pragma unroll
-                for (int i = 0; i < 8; ++i) {
-                    __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);      // 3 MFMA (one fragment x 3 token tiles)
-                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);      // next fragment read
-                }
-                __builtin_amdgcn_sched_group_barrier(0x002, 24, 0);         // convert + ReLU
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);
-                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-                }
-                __builtin_amdgcn_sched_group_barrier(0x008, 12, 0);
-            }
+            if constexpr (SCHED) __builtin_amdgcn_sched_barrier(0);
+            fc1_chunk(slot, ch, A);
+            TSTAMP(7);                                                 // MLP chunk compute (sum of 12)
         }
+#pragma unroll
+        for (int ft = 0; ft < 8; ++ft)
+#pragma unroll
+            for (int ct = 0; ct < 3; ++ct) R[ft][ct] = OP::mfma32(A2[ft], HX[ct], R[ft][ct]);
 #pragma unroll
         for (int ft = 0; ft < 8; ++ft) {
             const f4 b2 = *(const f4*)(bias + BIAS_FC2 + 16 * ft + 4 * g);
@@ -490,6 +554,15 @@ __global__ __launch_bounds__(WAVES * 64, 2) void uit_encoder_kernel(EncoderArgs 
         }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // drain the dummy tail stages before the LDS can be re-used
+    unsigned long long t_blocks_end = 0;
+    if constexpr (TIMING) t_blocks_end = stamp();
+    // classifier weights of this wave's first output tile: fetched now, consumed after pooling
+    const int ntiles = (a.C + 15) / 16;
+    v8 Hn[4];
+    if (wave < ntiles) {
+#pragma unroll
+        for (int s = 0; s < 4; ++s) Hn[s] = *(const v8*)(a.head_w + (size_t)(wave * 4 + s) * FRAG_BYTES + lane * 16);
+    }
 
     // ---- final norm (eps 1e-6) -> masked mean over tokens -> head LayerNorm (eps 1e-5)
     f4 pooled[8];
@@ -512,10 +585,10 @@ __global__ __launch_bounds__(WAVES * 64, 2) void uit_encoder_kernel(EncoderArgs 
             f4 v;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                float t = keep[r] + __shfl_xor(send[r], 8);
-                t += __shfl_xor(t, 4);
-                t += __shfl_xor(t, 2);
-                t += __shfl_xor(t, 1);
+                float t = keep[r] + dpp_mov<0x140>(send[r]);          // row_mirror: lane i <- lane 15-i (other half)
+                t = dpp_add<0x141>(t);                                // row_half_mirror: i <- 7-i
+                t = dpp_add<0x4E>(t);                                 // quad_perm [2,3,0,1]: i <- i^2
+                t = dpp_add<0xB1>(t);                                 // quad_perm [1,0,3,2]: i <- i^1
                 v[r] = t;
             }
             pooled[ft] = v;                               // lanes c<8: clip 0, lanes c>=8: clip 1
@@ -557,15 +630,18 @@ __global__ __launch_bounds__(WAVES * 64, 2) void uit_encoder_kernel(EncoderArgs 
             const v4 hi = *(const v4*)(zbuf + (cz * DIM + 32 * s + 16 + 4 * g) * 2);
             Bz[s] = v8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
         }
-        const int ntiles = (a.C + 15) / 16;
         const int rowg = blockIdx.x * WAVES * 2 + c;
         for (int ot = wave; ot < ntiles; ot += WAVES) {
+            v8 Hc[4];
+#pragma unroll
+            for (int s = 0; s < 4; ++s) Hc[s] = Hn[s];
+            if (ot + WAVES < ntiles) {                      // prefetch the next tile's fragments under this tile's MFMAs
+#pragma unroll
+                for (int s = 0; s < 4; ++s) Hn[s] = *(const v8*)(a.head_w + (size_t)((ot + WAVES) * 4 + s) * FRAG_BYTES + lane * 16);
+            }
             f4 acc = *(const f4*)(a.head_b + 16 * ot + 4 * g);
 #pragma unroll
-            for (int s = 0; s < 4; ++s) {
-                const v8 A = *(const v8*)(a.head_w + (size_t)(ot * 4 + s) * FRAG_BYTES + lane * 16);
-                acc = OP::mfma32(A, Bz[s], acc);
-            }
+            for (int s = 0; s < 4; ++s) acc = OP::mfma32(Hc[s], Bz[s], acc);
             if (c < 2 * WAVES && rowg < a.rows) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
@@ -576,6 +652,14 @@ __global__ __launch_bounds__(WAVES * 64, 2) void uit_encoder_kernel(EncoderArgs 
                     }
                 }
             }
+        }
+    }
+    if constexpr (TIMING) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        tacc[11] = stamp() - t_blocks_end;                                // pooling + head + stores
+        if (a.timing != nullptr && lane == 0) {
+#pragma unroll
+            for (int i = 0; i < 12; ++i) a.timing[((size_t)blockIdx.x * WAVES + wave) * 12 + i] = tacc[i];
         }
     }
 }
@@ -595,21 +679,23 @@ __global__ void crop_reduce_kernel(const float* __restrict__ rp, float* __restri
     }
 }
 
-template <int PREC, int WAVES, bool SCHED>
+template <int PREC, int WAVES, bool SCHED, bool TIMING = false>
 static hipError_t launch_enc(const EncoderArgs& a, hipStream_t stream) {
     static bool attr_done = false;
     if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute((const void*)uit_encoder_kernel<PREC, WAVES, SCHED>,
+        hipError_t e = hipFuncSetAttribute((const void*)uit_encoder_kernel<PREC, WAVES, SCHED, TIMING>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, ENC_LDS);
         if (e != hipSuccess) return e;
         attr_done = true;
     }
     const int grid = (a.rows + 2 * WAVES - 1) / (2 * WAVES);
-    hipLaunchKernelGGL((uit_encoder_kernel<PREC, WAVES, SCHED>), dim3(grid), dim3(WAVES * 64), ENC_LDS, stream, a);
+    hipLaunchKernelGGL((uit_encoder_kernel<PREC, WAVES, SCHED, TIMING>), dim3(grid), dim3(WAVES * 64), ENC_LDS, stream, a);
     return hipGetLastError();
 }
 
 hipError_t launch_encoder(const EncoderArgs& a, int precision, int waves, int sched, hipStream_t stream) {
+    if (a.timing != nullptr)                              // diagnostic build with in-kernel stamps (f16 only)
+        return waves == 4 ? launch_enc<0, 4, false, true>(a, stream) : launch_enc<0, 8, false, true>(a, stream);
     if (sched) {
         if (waves == 4) return precision == 0 ? launch_enc<0, 4, true>(a, stream) : launch_enc<1, 4, true>(a, stream);
         return precision == 0 ? launch_enc<0, 8, true>(a, stream) : launch_enc<1, 8, true>(a, stream);

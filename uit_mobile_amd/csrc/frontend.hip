@@ -6,21 +6,26 @@
 // |X|^2 + mel filterbank + 10*log10(max(.,1e-10)) and the batch amax; the top_db clamp itself
 // (max(x, amax-120)) needs the amax of the WHOLE call, so it is applied by the consumer (encoder prologue).
 //
-// Mapping (wave64; a workgroup = 4 waves walks "passes" of 16 consecutive frames of the flattened [B*nF] list):
+// Mapping (wave64; a workgroup = 4 waves walks "passes" = (clip, 16-frame column); a clip's last pass is partial
+// and its fully dead quads skip the FFT):
 //   FFT phase, per wave, 4 frames x 16 lanes:
 //     * the 512 real samples of a frame are packed as 256 complex z[m] = x[2m] + i x[2m+1]; the 256-point complex
 //       FFT is a 16x16 Cooley-Tukey: lane p holds z[16*m1 + p] (m1 = 0..15), does a 16-point FFT in registers,
 //       multiplies by W256^(p*k1), transposes through a conflict-free padded LDS tile (row stride 17 complex),
 //       does the second 16-point FFT, and the real-FFT split X[k] = ((Z[k]+conj Z[256-k]) - i w^k (Z[k]-conj
 //       Z[256-k]))/2 pairs bins k and 256-k through LDS.  Complex values are float2 => v_pk_* math, b64 LDS ops.
-//     * window and both twiddle sets are per-lane constants held in VGPRs for the whole (persistent) kernel.
+//     * window and both twiddle sets live in LDS tables (b64 reads, conflict-free); the NEXT pass's samples are
+//       prefetched into VGPRs at the start of each pass, so their HBM latency hides under the FFT math.
 //     * |X|^2 of the 4 frames goes to a workgroup-shared power tile P[16 frames][290] (double-buffered).
 //   mel phase, after ONE workgroup barrier per pass:
 //     * mel[16 frames][64] = P[16][257] . fb[257][64] on the matrix pipe with the EXACT-fp32 MFMA
 //       v_mfma_f32_16x16x4_f32 (bitwise an fp32 fma chain, MI355X guide section 3).  The HTK filterbank is banded:
 //       each 16-mel tile only needs its own bin range, 70 k-steps of 4 in total instead of 4 x 65.  Each wave owns
 //       one mel tile per pass; the assignment rotates with the pass so the four (unequal) tiles balance.
-//     * 10*log10(max(.,1e-10)), store mel[B][nF][64] (frame-major: the encoder's patch gather reads 32-byte runs),
+//     * 10*log10(max(.,1e-10)) -> init_bn -> 16-bit operand, stored PATCH-MAJOR [clip-crop][24 tokens][16 mels][16 frames]
+//       (one 512-byte store per wave for single-crop clips) = exactly the k-slot order
+//       of the encoder's patch-embed MFMA operand (its gather becomes full 128-byte lines; the crop logic of
+//       models/uit.py:468-481 is resolved here: a frame lands in its regular crop and/or the re-cropped tail),
 //       wave-reduced amax -> one atomic per wave at kernel end.
 //   HBM traffic: the PCM is read once (frames overlap 3.2x, absorbed by L1/L2), output 256 B per frame.
 #include <hip/hip_runtime.h>
@@ -68,7 +73,8 @@ constexpr int FE_ZROW = 272;                             // per-frame stride (co
 constexpr int FE_WAVE_LDS = 4 * FE_ZROW * 8;             // 8704 B per wave: E[4][16][17] (8704 B) / Z[4][272]
 constexpr int FE_PROW = 290;                             // power-tile row stride (floats): == 2 mod 32, >= 260
 constexpr int FE_P_LDS = 2 * 16 * FE_PROW * 4;           // double-buffered P[16][290]
-constexpr int FE_LDS = FE_WAVES * FE_WAVE_LDS + FE_P_LDS;
+constexpr int FE_TAB_LDS = (256 + 256 + 128) * 8;        // window pairs, W256^(p*k1) as [k1][p], (cos,sin)(2 pi k/512)
+constexpr int FE_LDS = FE_WAVES * FE_WAVE_LDS + FE_P_LDS + FE_TAB_LDS;
 constexpr int FE_BREG = 40;                              // filterbank k-steps per mel tile held in VGPRs (HTK: <= 40)
 
 template <bool I16>
@@ -79,7 +85,22 @@ __device__ __forceinline__ float load_sample(const void* pcm, int64_t row_off, i
     return ((const float*)pcm)[row_off + s];
 }
 
-template <bool I16>
+// 16-bit operand conversions (round-to-nearest-even, identical to the encoder's v_cvt_pk_*)
+__device__ __forceinline__ unsigned short to_op16(float x, int bf16) {
+    if (bf16) { __bf16 h = (__bf16)x; return __builtin_bit_cast(unsigned short, h); }
+    _Float16 h = (_Float16)x; return __builtin_bit_cast(unsigned short, h);
+}
+
+__device__ __forceinline__ unsigned long long fe_stamp() {
+    unsigned long long t;
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) :: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    return t;
+}
+#define FSTAMP(slot) do { if constexpr (TIMING) { const unsigned long long _t = fe_stamp(); tacc[slot] += _t - tlast; tlast = _t; } } while (0)
+
+template <bool I16, bool PATCH, bool TIMING>
 __global__ __launch_bounds__(FE_WAVES * 64, 2) void mel_frontend_kernel(FrontendArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
@@ -88,29 +109,81 @@ __global__ __launch_bounds__(FE_WAVES * 64, 2) void mel_frontend_kernel(Frontend
     c32* E = (c32*)(smem + wave * FE_WAVE_LDS);          // [4][16][17] transpose tile, then Z[4][272]
     float* Pbase = (float*)(smem + FE_WAVES * FE_WAVE_LDS);
     for (int i = tid; i < 2 * 16 * FE_PROW; i += FE_WAVES * 64) Pbase[i] = 0.f;   // pad columns must stay finite
+    // constant tables in LDS (b64 reads, conflict-free across p, broadcast across the 4 frames of a wave)
+    c32* Wwin = (c32*)(smem + FE_WAVES * FE_WAVE_LDS + FE_P_LDS);       // window[(2m, 2m+1)], m = 16 m1 + p
+    c32* Wtw = Wwin + 256;                                               // W256^(p*k1) at [k1][p]
+    c32* Wpw = Wtw + 256;                                                // (cos, sin)(2 pi k / 512), k < 128
+    {
+        const int i = tid;                                               // 256 threads
+        Wwin[i] = *(const c32*)(a.window + 2 * i);
+        const float2 t = a.tw256[(i & 15) * 16 + (i >> 4)];              // source is [p][k1]
+        Wtw[i] = c32{t.x, t.y};
+        if (i < 128) { const float2 u = a.tw512[i]; Wpw[i] = c32{u.x, u.y}; }
+    }
     __syncthreads();
 
-    // per-lane constants (VGPR-resident for the whole kernel)
-    c32 win[16];
-#pragma unroll
-    for (int m1 = 0; m1 < 16; ++m1) win[m1] = *(const c32*)(a.window + 32 * m1 + 2 * p);
-    c32 tw[16];                                          // W256^(p*k1)
-#pragma unroll
-    for (int k1 = 0; k1 < 16; ++k1) { const float2 t = a.tw256[p * 16 + k1]; tw[k1] = c32{t.x, t.y}; }
-    c32 pw[8];                                           // (cos, sin)(2 pi k / 512), k = p + 16 j
-#pragma unroll
-    for (int j = 0; j < 8; ++j) { const float2 t = a.tw512[p + 16 * j]; pw[j] = c32{t.x, t.y}; }
-
-    const int64_t total = a.B * (int64_t)a.nF;
-    const int64_t npass = (total + 15) >> 4;
+    // passes are aligned to clips: pass = (clip b, column k) covers frames 16k..16k+15 of clip b (clipped to nF), so
+    // for single-crop clips a pass is exactly one patch column and a wave's mel tile is one whole 16x16 patch
+    const int ppc = (a.nF + 15) >> 4;                    // passes per clip
+    const int64_t npass = a.B * (int64_t)ppc;
     const int T = (int)a.T;
     const bool pair_ok = (T & 1) == 0;                   // pair loads need every row to start pair-aligned
     float lmax = -INFINITY;
     int it = 0;
+    float bnsc[4] = {0.f, 0.f, 0.f, 0.f}, bnsh[4] = {0.f, 0.f, 0.f, 0.f};      // init_bn scale/shift of mel 16j + p
+    if (PATCH) {
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) { bnsc[jj] = a.bn_sc[16 * jj + p]; bnsh[jj] = a.bn_sh[16 * jj + p]; }
+    }
+    // raw (unwindowed) sample pairs of this lane's frame for a pass: z[m1] = (x[32 m1 + 2p], x[32 m1 + 2p + 1])
+    auto load_pass = [&](int64_t pass, c32 (&raw)[16]) {
+        const int b = (int)(pass / ppc);
+        const int fbase = 16 * (int)(pass - (int64_t)b * ppc);
+        if (fbase + 4 * wave >= a.nF) return;                             // fully dead quad (uniform per wave)
+        int f = fbase + 4 * wave + q;
+        if (f >= a.nF) f = a.nF - 1;                                      // dead frames inside a live quad: any valid frame
+        const int64_t row_off = (int64_t)b * a.T;
+        const int s0 = f * a.hop - 256 + 2 * p;
+        if (pair_ok && s0 >= 0 && s0 + 32 * 15 + 1 < T) {                 // interior frame: no reflection, pair loads
+            if (I16) {
+                const int16_t* src = (const int16_t*)a.pcm + row_off + s0;
+#pragma unroll
+                for (int m1 = 0; m1 < 16; ++m1) {
+                    const short2 s2 = *(const short2*)(src + 32 * m1);
+                    raw[m1] = c32{(float)s2.x, (float)s2.y} * (1.0f / 32768.0f);
+                }
+            } else {
+                const float* src = (const float*)a.pcm + row_off + s0;
+#pragma unroll
+                for (int m1 = 0; m1 < 16; ++m1) raw[m1] = *(const c32*)(src + 32 * m1);
+            }
+        } else {
+#pragma unroll
+            for (int m1 = 0; m1 < 16; ++m1)
+                raw[m1] = c32{load_sample<I16>(a.pcm, row_off, T, s0 + 32 * m1),
+                              load_sample<I16>(a.pcm, row_off, T, s0 + 32 * m1 + 1)};
+        }
+    };
+    unsigned long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tlast = 0;
+    if constexpr (TIMING) tlast = fe_stamp();
+    c32 nxt[16];
+#pragma unroll
+    for (int m1 = 0; m1 < 16; ++m1) nxt[m1] = c32{0.f, 0.f};
+    if ((int64_t)blockIdx.x < npass) load_pass(blockIdx.x, nxt);
     for (int64_t pass = blockIdx.x; pass < npass; pass += gridDim.x, ++it) {
         float* P = Pbase + (it & 1) * 16 * FE_PROW;
+        const int b = (int)(pass / ppc);                 // uniform: one 64-bit division per pass on the scalar side
+        const int k0 = (int)(pass - (int64_t)b * ppc);
+        const int fbase = 16 * k0;                       // first frame of the pass
+        // -------------------------------------------------------------------------------- FFT phase
+            const bool quad_live = fbase + 4 * wave < a.nF;               // uniform per wave: skip fully dead quads
+            c32 v[16];
+#pragma unroll
+            for (int m1 = 0; m1 < 16; ++m1) v[m1] = nxt[m1] * Wwin[16 * m1 + p];
+            if (pass + gridDim.x < npass) load_pass(pass + gridDim.x, nxt);      // prefetch: lands under this pass's math
         // this wave's 16-mel tile for this pass; its B operands (filterbank band, zero-padded to 8-step chunks by
-        // pack.cpp) are fetched NOW so their L2 latency hides under the FFT phase
+        // pack.cpp) are fetched now -- AFTER the prefetched samples were consumed, so that the wait for those does not
+        // also wait for these -- and their L2 latency hides under the FFT phase
         const int j = (wave + it) & 3;
         const int klo = a.mel_tile_klo[j], nst = a.mel_tile_steps[j];
         const float* Bt = a.mel_b + (size_t)a.mel_tile_base[j] * 64 + lane;
@@ -121,40 +194,16 @@ __global__ __launch_bounds__(FE_WAVES * 64, 2) void mel_frontend_kernel(Frontend
 #pragma unroll
                 for (int s = 0; s < 8; ++s) bw[8 * c + s] = Bt[64 * (8 * c + s)];
             }
-        // -------------------------------------------------------------------------------- FFT phase
-        {
-            int64_t fid = pass * 16 + 4 * wave + q;
-            if (fid >= total) fid = total - 1;
-            const int64_t b = fid / a.nF;
-            const int f = (int)(fid - b * a.nF);
-            const int64_t row_off = b * a.T;
-            const int s0 = f * a.hop - 256 + 2 * p;
-            c32 v[16];
-            if (pair_ok && s0 >= 0 && s0 + 32 * 15 + 1 < T) {            // interior frame: no reflection, pair loads
-                if (I16) {
-                    const int16_t* src = (const int16_t*)a.pcm + row_off + s0;
-#pragma unroll
-                    for (int m1 = 0; m1 < 16; ++m1) {
-                        const short2 s2 = *(const short2*)(src + 32 * m1);
-                        v[m1] = c32{(float)s2.x, (float)s2.y} * (1.0f / 32768.0f) * win[m1];
-                    }
-                } else {
-                    const float* src = (const float*)a.pcm + row_off + s0;
-#pragma unroll
-                    for (int m1 = 0; m1 < 16; ++m1) v[m1] = *(const c32*)(src + 32 * m1) * win[m1];
-                }
-            } else {
-#pragma unroll
-                for (int m1 = 0; m1 < 16; ++m1)
-                    v[m1] = c32{load_sample<I16>(a.pcm, row_off, T, s0 + 32 * m1),
-                                load_sample<I16>(a.pcm, row_off, T, s0 + 32 * m1 + 1)} * win[m1];
-            }
+            {
+            FSTAMP(0);                                                    // B-operand issue + window (sample wait)
+            if (quad_live) {
             fft16(v);                                    // over m1 -> k1 (at FPOS), for m2 = p
 #pragma unroll
             for (int k1 = 0; k1 < 16; ++k1) {            // twiddle + transpose write E[q][k1][m2 = p]
-                const c32 y = k1 == 0 ? v[FPOS(0)] : cmul(v[FPOS(k1)], tw[k1]);
+                const c32 y = k1 == 0 ? v[FPOS(0)] : cmul(v[FPOS(k1)], Wtw[16 * k1 + p]);
                 E[(q * 16 + k1) * FE_ROW + p] = y;
             }
+            FSTAMP(1);                                                    // FFT-1 + twiddle + transpose write
             __builtin_amdgcn_wave_barrier();
             asm volatile("" ::: "memory");
 #pragma unroll
@@ -167,6 +216,7 @@ __global__ __launch_bounds__(FE_WAVES * 64, 2) void mel_frontend_kernel(Frontend
             for (int k2 = 0; k2 < 16; ++k2) Z[q * FE_ZROW + 16 * k2 + p] = v[FPOS(k2)];
             __builtin_amdgcn_wave_barrier();
             asm volatile("" ::: "memory");
+            FSTAMP(2);                                                    // transpose read + FFT-2 + Z write
             c32 za[8], zb[8];
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
@@ -182,15 +232,19 @@ __global__ __launch_bounds__(FE_WAVES * 64, 2) void mel_frontend_kernel(Frontend
                 const int k = p + 16 * j;
                 const float Ar = za[j].x + zb[j].x, Ai = za[j].y - zb[j].y;
                 const float Br = za[j].x - zb[j].x, Bi = za[j].y + zb[j].y;
-                const float c = pw[j].x, s = pw[j].y;
+                const c32 cs = Wpw[k];
+                const float c = cs.x, s = cs.y;
                 const float Tr = c * Bi - s * Br, Ti = -s * Bi - c * Br;
                 const float xr = Ar + Tr, xi = Ai + Ti, yr = Ar - Tr, yi = Ti - Ai;
                 prow[k] = 0.25f * (xr * xr + xi * xi);
                 prow[256 - k] = 0.25f * (yr * yr + yi * yi);     // k = 0 writes bin 256 (Nyquist)
             }
             if (p == 0) prow[128] = z128.x * z128.x + z128.y * z128.y;
+            }
         }
-        __syncthreads();                                 // P complete (and everyone is done with the other buffer)
+        FSTAMP(3);                                                        // Z read + split + power write
+        __syncthreads();
+        FSTAMP(4);                                                        // barrier wait                                 // P complete (and everyone is done with the other buffer)
         // -------------------------------------------------------------------------------- mel phase (matrix pipe)
         {
             const float* Ar = P + p * FE_PROW + klo + q; // A[row = frame p][k = q]  (lane&15 = row, lane>>4 = k)
@@ -207,12 +261,61 @@ __global__ __launch_bounds__(FE_WAVES * 64, 2) void mel_frontend_kernel(Frontend
             for (int s = FE_BREG; s < nst; ++s)          // filterbanks wider than FE_BREG steps per tile (not HTK)
                 acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(Ar[4 * s], Bt[64 * s], acc0, 0, 0, 0);
             const f4v acc = acc0 + acc1;                 // D[frame 4q + r][mel 16j + p]
+            float bn_sc = 0.f, bn_sh = 0.f;
+            if (PATCH) {
+                bn_sc = j == 0 ? bnsc[0] : j == 1 ? bnsc[1] : j == 2 ? bnsc[2] : bnsc[3];
+                bn_sh = j == 0 ? bnsh[0] : j == 1 ? bnsh[1] : j == 2 ? bnsh[2] : bnsh[3];
+            }
+            FSTAMP(5);                                                    // mel MFMAs
+            float db[4];
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const int64_t fid = pass * 16 + 4 * q + r;
-                const float db = 10.0f * __log10f(fmaxf(acc[r], 1e-10f));
-                if (fid < total) { a.mel[fid * 64 + 16 * j + p] = db; lmax = fmaxf(lmax, db); }
+                db[r] = 10.0f * __log10f(fmaxf(acc[r], 1e-10f));
+                if (fbase + 4 * q + r < a.nF) lmax = fmaxf(lmax, db[r]);          // every frame counts for the top_db amax
             }
+            if (!PATCH) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (fbase + 4 * q + r < a.nF) a.mel[((int64_t)b * a.nF + fbase + 4 * q + r) * 64 + 16 * j + p] = db[r];
+            } else {
+                // 16-bit operands of the encoder's patch embed: init_bn applied here (y = sc*dB + sh, uit.py:310-313);
+                // the top_db clamp commutes with this monotone map and with rounding, so the encoder applies it on y.
+                // Layout [clip-crop][token pf*6+pt][mel-in-patch][frame-in-patch].
+                unsigned short y[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) y[r] = to_op16(db[r] * bn_sc + bn_sh, a.op_bf16);
+                unsigned short* out = (unsigned short*)a.mel;
+                if (a.ncrops == 1) {
+                    // the wave holds one whole patch (pf = j, pt = k0): lane = (mel p, frames 4q..4q+3) -> 8 contiguous
+                    // bytes per lane, 512 contiguous bytes per wave: ONE store instruction
+                    if (k0 < a.nt) {
+                        typedef unsigned short us4 __attribute__((ext_vector_type(4)));
+                        *(us4*)(out + (((int64_t)b * 24 + j * 6 + k0) * 16 + p) * 16 + 4 * q) = us4{y[0], y[1], y[2], y[3]};
+                    }
+                } else {
+                    // long clips: crops start every target_length frames, not patch aligned -> per-element stores; a frame
+                    // belongs to its regular crop and/or the re-cropped tail (models/uit.py:474-480)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int f = fbase + 4 * q + r;
+                        if (f >= a.nF) continue;
+                        const int cr0 = f / a.tl, t0 = f - cr0 * a.tl;
+                        if (cr0 < a.ncrops - 1 && t0 < 96)
+                            out[((((int64_t)b * a.ncrops + cr0) * 24 + j * 6 + (t0 >> 4)) * 16 + p) * 16 + (t0 & 15)] = y[r];
+                        const int t1 = f - (a.nF - a.tl);
+                        if (t1 >= 0 && t1 < 96)
+                            out[((((int64_t)b * a.ncrops + a.ncrops - 1) * 24 + j * 6 + (t1 >> 4)) * 16 + p) * 16 + (t1 & 15)] = y[r];
+                    }
+                }
+            }
+            FSTAMP(7);                                                    // log + bn + stores
+        }
+    }
+    FSTAMP(6);                                                            // (accumulates log + stores of all passes? no: tail only)
+    if constexpr (TIMING) {
+        if (a.timing != nullptr && lane == 0) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) a.timing[((size_t)blockIdx.x * FE_WAVES + wave) * 8 + i] = tacc[i];
         }
     }
     // batch amax: wave reduce, then one atomic per wave into one of UITK_AMAX_SLOTS slots.  Slots are
@@ -241,21 +344,25 @@ __global__ void mel_export_kernel(const float* __restrict__ mel, const float* __
     }
 }
 
-hipError_t launch_frontend(const FrontendArgs& a, int in_i16, int n_cu, hipStream_t stream) {
+template <bool I16, bool PATCH, bool TIMING = false>
+static hipError_t launch_fe(const FrontendArgs& a, int grid, hipStream_t stream) {
     static bool attr_done = false;
     if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute((const void*)mel_frontend_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, FE_LDS);
-        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)mel_frontend_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, FE_LDS);
+        hipError_t e = hipFuncSetAttribute((const void*)mel_frontend_kernel<I16, PATCH, TIMING>, hipFuncAttributeMaxDynamicSharedMemorySize, FE_LDS);
         if (e != hipSuccess) return e;
         attr_done = true;
     }
-    const int64_t total = a.B * (int64_t)a.nF;
-    const int64_t npass = (total + 15) / 16;
+    hipLaunchKernelGGL((mel_frontend_kernel<I16, PATCH, TIMING>), dim3(grid), dim3(FE_WAVES * 64), FE_LDS, stream, a);
+    return hipGetLastError();
+}
+
+hipError_t launch_frontend(const FrontendArgs& a, int in_i16, int patch_layout, int n_cu, hipStream_t stream) {
+    const int64_t npass = a.B * (int64_t)((a.nF + 15) / 16);
     int grid = (int)(npass < (int64_t)n_cu * 2 ? npass : (int64_t)n_cu * 2);      // 2 resident workgroups per CU
     if (grid < 1) grid = 1;
-    if (in_i16) hipLaunchKernelGGL(mel_frontend_kernel<true>, dim3(grid), dim3(FE_WAVES * 64), FE_LDS, stream, a);
-    else hipLaunchKernelGGL(mel_frontend_kernel<false>, dim3(grid), dim3(FE_WAVES * 64), FE_LDS, stream, a);
-    return hipGetLastError();
+    if (a.timing != nullptr && patch_layout && !in_i16) return launch_fe<false, true, true>(a, grid, stream);
+    if (patch_layout) return in_i16 ? launch_fe<true, true>(a, grid, stream) : launch_fe<false, true>(a, grid, stream);
+    return in_i16 ? launch_fe<true, false>(a, grid, stream) : launch_fe<false, false>(a, grid, stream);
 }
 
 hipError_t launch_mel_export(const float* mel, const float* amax, float top_db, int64_t B, int nF, float* out,

@@ -161,14 +161,15 @@ int pack_image(const uitk_config* c, const uitk_weights* w, std::vector<char>* o
     // ---- weight stream
     uint16_t* ws = (uint16_t*)(img + h.off_wstream);
     auto frag_ptr = [&](int stage, int f) { return ws + ((size_t)stage * STAGE_FRAGS + f) * (FRAG_BYTES / 2); };
-    // patch embed: k-slot (s,g,j) <-> (ti = 2s + (g>>1), fi = 8(g&1) + j); Conv2d weight [oc][0][fi][ti]
+    // patch embed: k-slot (s,g,j) <-> (mel-in-patch fi = 2s + (g>>1), frame-in-patch ti = 8(g&1) + j), i.e. operand
+    // offset fi*16 + ti = 32s + 8g + j in the front-end's [mel][frame] patch; Conv2d weight [oc][0][fi][ti]
     for (int i = 0; i < PE_STAGES; ++i)
         for (int f = 0; f < STAGE_FRAGS; ++f) {
             const int ft = 2 * i + f / 8, s = f % 8;
             uint16_t* dst = frag_ptr(i, f);
             for (int l = 0; l < 64; ++l)
                 for (int j = 0; j < 8; ++j) {
-                    const int g = l >> 4, ti = 2 * s + (g >> 1), fi = 8 * (g & 1) + j;
+                    const int g = l >> 4, fi = 2 * s + (g >> 1), ti = 8 * (g & 1) + j;
                     dst[l * 8 + j] = cvt(w->pe_w[(16 * ft + (l & 15)) * 256 + fi * 16 + ti], prec);
                 }
         }

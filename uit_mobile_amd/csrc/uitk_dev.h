@@ -36,18 +36,22 @@ struct FrontendArgs {
     int mel_tile_klo[4];    // first bin (multiple of 4) of each 16-mel tile's band
     int mel_tile_steps[4];  // k-steps (of 4 bins) per tile
     int mel_tile_base[4];   // first step of each tile in mel_b
-    float* mel;             // [B][nF][64] dB (no floor)
+    float* mel;             // PATCH layout: 16-bit MFMA operands [B*ncrops][24 tokens][16 frames][16 mels] holding
+                            // init_bn(dB) WITHOUT the top_db clamp (the encoder clamps); FRAMES layout (uitk_mel_db
+                            // only): fp32 dB [B][nF][64]
+    const float* bn_sc;     // [64] init_bn scale / shift (PATCH layout only)
+    const float* bn_sh;
+    int op_bf16;            // operand type of the PATCH layout: 0 = fp16, 1 = bf16
+    unsigned long long* timing;  // diagnostics: [waves][8] phase cycle sums (null = normal build)
+    int ncrops, tl, nt;     // crop plan (models/uit.py:468-481): crops per clip, target_length, valid time patches
     float* amax;            // [AMAX_SLOTS]
 };
 
 struct EncoderArgs {
-    const float* mel;       // [B][nF][64]
+    const unsigned short* mel;  // [rows][24][16][16] patch-major 16-bit operands: init_bn(dB), unclamped
     const float* amax;      // [AMAX_SLOTS]
     float top_db;
-    int nF;                 // frames per clip
     int rows;               // B * ncrops
-    int ncrops;
-    int tl;                 // target_length (crop stride)
     int nt;                 // valid time patches per crop (1..6)
     int depth;
     int C;                  // outputdim
@@ -62,11 +66,13 @@ struct EncoderArgs {
     float* probs;           // [rows][C]
     float* logits;          // [rows][C] or null
     float* dbg;             // [rows][depth+1][24][128] or null
+    unsigned long long* timing;  // diagnostics: [waves][12] phase cycle sums (null = off, normal build)
     int stagger;            // 0 = off, else shader cycles to delay every other workgroup generation
     int stagger_group;      // workgroups per generation (= CU count)
+    int stagger_mode;       // 1 = by workgroup generation, 2 = by hardware wave slot
 };
 
-hipError_t launch_frontend(const FrontendArgs& a, int in_i16, int n_cu, hipStream_t stream);
+hipError_t launch_frontend(const FrontendArgs& a, int in_i16, int patch_layout, int n_cu, hipStream_t stream);
 hipError_t launch_mel_export(const float* mel, const float* amax, float top_db, int64_t B, int nF, float* out,
                              hipStream_t stream);
 hipError_t launch_encoder(const EncoderArgs& a, int precision, int waves, int sched, hipStream_t stream);

@@ -334,8 +334,8 @@ class UITBase(nn.Module):
         with torch.cuda.device(x.device):
             stream = ctypes.c_void_p(torch.cuda.current_stream(x.device).cuda_stream)
             out = torch.empty((B, self.n_mels, self.num_frames(T)), device=x.device, dtype=torch.float32)
-            _lib.check(L.uitk_frontend(h, ctypes.c_void_p(x.data_ptr()), in_dtype, B, T, stream), "uitk_frontend")
-            _lib.check(L.uitk_mel_db(h, B, T, ctypes.c_void_p(out.data_ptr()), stream), "uitk_mel_db")
+            _lib.check(L.uitk_mel_db(h, ctypes.c_void_p(x.data_ptr()), in_dtype, B, T,
+                                     ctypes.c_void_p(out.data_ptr()), stream), "uitk_mel_db")
         return out
 
     def debug_tokens(self, x):
