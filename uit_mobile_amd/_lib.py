@@ -3,8 +3,11 @@ import ctypes
 from ctypes import POINTER, Structure, c_char_p, c_float, c_int, c_int32, c_int64, c_size_t, c_void_p
 from pathlib import Path
 
+import os
+
 HERE = Path(__file__).resolve().parent
-LIB_PATH = HERE / "libuitk.so"
+# UITK_LIB_PATH: development only (A/B timing of two builds of this same library on one GPU box)
+LIB_PATH = Path(os.environ["UITK_LIB_PATH"]) if os.environ.get("UITK_LIB_PATH") else HERE / "libuitk.so"
 
 UITK_OK = 0
 ERR_INVALID_ARG, ERR_UNSUPPORTED, ERR_NO_DEVICE, ERR_HIP, ERR_TOO_SHORT, ERR_WORKSPACE = -1, -2, -3, -4, -5, -6
