@@ -14,8 +14,8 @@
 //       multiplies by W256^(p*k1), transposes through a conflict-free padded LDS tile (row stride 17 complex),
 //       does the second 16-point FFT, and the real-FFT split X[k] = ((Z[k]+conj Z[256-k]) - i w^k (Z[k]-conj
 //       Z[256-k]))/2 pairs bins k and 256-k through LDS.  Complex values are float2 => v_pk_* math, b64 LDS ops.
-//     * window and both twiddle sets live in LDS tables (b64 reads, conflict-free); the NEXT pass's samples are
-//       prefetched into VGPRs at the start of each pass, so their HBM latency hides under the FFT math.
+//     * window and both twiddle sets are per-lane VGPR constants (an LDS-table variant and a next-pass sample
+//       prefetch exist behind FE_LDS_TABLES / FE_PREFETCH; both measured slower on MI355X).
 //     * |X|^2 of the 4 frames goes to a workgroup-shared power tile P[16 frames][290] (double-buffered).
 //   mel phase, after ONE workgroup barrier per pass:
 //     * mel[16 frames][64] = P[16][257] . fb[257][64] on the matrix pipe with the EXACT-fp32 MFMA
@@ -67,13 +67,19 @@ __device__ __forceinline__ void fft16(c32 (&v)[16]) {
     for (int k1 = 0; k1 < 4; ++k1) dft4(v[4 * k1 + 0], v[4 * k1 + 1], v[4 * k1 + 2], v[4 * k1 + 3]);
 }
 
+#ifndef FE_LDS_TABLES
+#define FE_LDS_TABLES 0      // 1: window/twiddles in LDS tables; 0: per-lane VGPR constants (measured faster: 0.49 vs 0.54 ms)
+#endif
+#ifndef FE_PREFETCH
+#define FE_PREFETCH 0        // 1: prefetch the next pass's samples during the current pass (measured slower: +0.02 ms)
+#endif
 constexpr int FE_WAVES = 4;
 constexpr int FE_ROW = 17;                               // padded row stride (complex) of the transpose tile
 constexpr int FE_ZROW = 272;                             // per-frame stride (complex) of the natural-order Z tile
 constexpr int FE_WAVE_LDS = 4 * FE_ZROW * 8;             // 8704 B per wave: E[4][16][17] (8704 B) / Z[4][272]
 constexpr int FE_PROW = 290;                             // power-tile row stride (floats): == 2 mod 32, >= 260
 constexpr int FE_P_LDS = 2 * 16 * FE_PROW * 4;           // double-buffered P[16][290]
-constexpr int FE_TAB_LDS = (256 + 256 + 128) * 8;        // window pairs, W256^(p*k1) as [k1][p], (cos,sin)(2 pi k/512)
+constexpr int FE_TAB_LDS = FE_LDS_TABLES ? (256 + 256 + 128) * 8 : 0;   // window pairs, W256^(p*k1) as [k1][p], (cos,sin)(2 pi k/512)
 constexpr int FE_LDS = FE_WAVES * FE_WAVE_LDS + FE_P_LDS + FE_TAB_LDS;
 constexpr int FE_BREG = 40;                              // filterbank k-steps per mel tile held in VGPRs (HTK: <= 40)
 
@@ -109,6 +115,7 @@ __global__ __launch_bounds__(FE_WAVES * 64, 2) void mel_frontend_kernel(Frontend
     c32* E = (c32*)(smem + wave * FE_WAVE_LDS);          // [4][16][17] transpose tile, then Z[4][272]
     float* Pbase = (float*)(smem + FE_WAVES * FE_WAVE_LDS);
     for (int i = tid; i < 2 * 16 * FE_PROW; i += FE_WAVES * 64) Pbase[i] = 0.f;   // pad columns must stay finite
+#if FE_LDS_TABLES
     // constant tables in LDS (b64 reads, conflict-free across p, broadcast across the 4 frames of a wave)
     c32* Wwin = (c32*)(smem + FE_WAVES * FE_WAVE_LDS + FE_P_LDS);       // window[(2m, 2m+1)], m = 16 m1 + p
     c32* Wtw = Wwin + 256;                                               // W256^(p*k1) at [k1][p]
@@ -121,11 +128,35 @@ __global__ __launch_bounds__(FE_WAVES * 64, 2) void mel_frontend_kernel(Frontend
         if (i < 128) { const float2 u = a.tw512[i]; Wpw[i] = c32{u.x, u.y}; }
     }
     __syncthreads();
+#define WIN(m1) Wwin[16 * (m1) + p]
+#define TW(k1) Wtw[16 * (k1) + p]
+#define PW(j) Wpw[p + 16 * (j)]
+#else
+    __syncthreads();
+    c32 win_[16], tw_[16], pw_[8];                                       // per-lane VGPR constants
+#pragma unroll
+    for (int m1 = 0; m1 < 16; ++m1) win_[m1] = *(const c32*)(a.window + 32 * m1 + 2 * p);
+#pragma unroll
+    for (int k1 = 0; k1 < 16; ++k1) { const float2 t = a.tw256[p * 16 + k1]; tw_[k1] = c32{t.x, t.y}; }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { const float2 t = a.tw512[p + 16 * j]; pw_[j] = c32{t.x, t.y}; }
+#define WIN(m1) win_[m1]
+#define TW(k1) tw_[k1]
+#define PW(j) pw_[j]
+#endif
 
-    // passes are aligned to clips: pass = (clip b, column k) covers frames 16k..16k+15 of clip b (clipped to nF), so
-    // for single-crop clips a pass is exactly one patch column and a wave's mel tile is one whole 16x16 patch
-    const int ppc = (a.nF + 15) >> 4;                    // passes per clip
-    const int64_t npass = a.B * (int64_t)ppc;
+    // "full" passes are (clip b, column k): frames 16k..16k+15; the nF % 16 leftover frames of a clip are bundled,
+    // per_tail clips at a time, into "tail" passes (for 1 s clips: 6 full passes per clip + one tail pass per 3 clips)
+    const int full = a.nF >> 4, rem = a.nF & 15;
+    const int per_tail = rem ? 16 / rem : 1;
+    const int64_t nfull = a.B * (int64_t)full;
+    const int64_t npass = nfull + (rem ? (a.B + per_tail - 1) / per_tail : 0);
+    // per-lane (clip offset, frame) of the 16 slots of a tail pass: slot = 4*wave+q in the FFT phase, 4q+r in the mel phase
+    const int tslot = 4 * wave + q;
+    const int t_cl = rem ? tslot / rem : 0, t_fr = rem ? tslot - t_cl * rem : 0;
+    int m_cl[4], m_fr[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { m_cl[r] = rem ? (4 * q + r) / rem : 0; m_fr[r] = rem ? (4 * q + r) - m_cl[r] * rem : 0; }
     const int T = (int)a.T;
     const bool pair_ok = (T & 1) == 0;                   // pair loads need every row to start pair-aligned
     float lmax = -INFINITY;
@@ -137,11 +168,16 @@ __global__ __launch_bounds__(FE_WAVES * 64, 2) void mel_frontend_kernel(Frontend
     }
     // raw (unwindowed) sample pairs of this lane's frame for a pass: z[m1] = (x[32 m1 + 2p], x[32 m1 + 2p + 1])
     auto load_pass = [&](int64_t pass, c32 (&raw)[16]) {
-        const int b = (int)(pass / ppc);
-        const int fbase = 16 * (int)(pass - (int64_t)b * ppc);
-        if (fbase + 4 * wave >= a.nF) return;                             // fully dead quad (uniform per wave)
-        int f = fbase + 4 * wave + q;
-        if (f >= a.nF) f = a.nF - 1;                                      // dead frames inside a live quad: any valid frame
+        int b, f;
+        if (pass < nfull) {
+            b = (int)(pass / full);
+            f = 16 * (int)(pass - (int64_t)b * full) + 4 * wave + q;
+        } else {
+            const int64_t cb = (pass - nfull) * per_tail;
+            if (4 * wave >= per_tail * rem) return;                       // fully dead quad of a tail pass (uniform)
+            b = (int)cb + t_cl; f = 16 * full + t_fr;
+            if (t_cl >= per_tail || b >= a.B) { b = (int)cb; f = 16 * full; }    // dead slot: any valid frame
+        }
         const int64_t row_off = (int64_t)b * a.T;
         const int s0 = f * a.hop - 256 + 2 * p;
         if (pair_ok && s0 >= 0 && s0 + 32 * 15 + 1 < T) {                 // interior frame: no reflection, pair loads
@@ -169,18 +205,26 @@ __global__ __launch_bounds__(FE_WAVES * 64, 2) void mel_frontend_kernel(Frontend
     c32 nxt[16];
 #pragma unroll
     for (int m1 = 0; m1 < 16; ++m1) nxt[m1] = c32{0.f, 0.f};
+#if FE_PREFETCH
     if ((int64_t)blockIdx.x < npass) load_pass(blockIdx.x, nxt);
+#endif
     for (int64_t pass = blockIdx.x; pass < npass; pass += gridDim.x, ++it) {
         float* P = Pbase + (it & 1) * 16 * FE_PROW;
-        const int b = (int)(pass / ppc);                 // uniform: one 64-bit division per pass on the scalar side
-        const int k0 = (int)(pass - (int64_t)b * ppc);
-        const int fbase = 16 * k0;                       // first frame of the pass
+        const bool is_tail = pass >= nfull;              // uniform
+        const int b = is_tail ? (int)((pass - nfull) * per_tail) : (int)(pass / full);   // (first) clip of the pass
+        const int k0 = is_tail ? full : (int)(pass - (int64_t)b * full);
+        const int fbase = 16 * k0;                       // first frame of a full pass
         // -------------------------------------------------------------------------------- FFT phase
-            const bool quad_live = fbase + 4 * wave < a.nF;               // uniform per wave: skip fully dead quads
+            const bool quad_live = !is_tail || 4 * wave < per_tail * rem;    // uniform per wave: skip fully dead quads
             c32 v[16];
+#if !FE_PREFETCH
+            load_pass(pass, nxt);
+#endif
 #pragma unroll
-            for (int m1 = 0; m1 < 16; ++m1) v[m1] = nxt[m1] * Wwin[16 * m1 + p];
+            for (int m1 = 0; m1 < 16; ++m1) v[m1] = nxt[m1] * WIN(m1);
+#if FE_PREFETCH
             if (pass + gridDim.x < npass) load_pass(pass + gridDim.x, nxt);      // prefetch: lands under this pass's math
+#endif
         // this wave's 16-mel tile for this pass; its B operands (filterbank band, zero-padded to 8-step chunks by
         // pack.cpp) are fetched now -- AFTER the prefetched samples were consumed, so that the wait for those does not
         // also wait for these -- and their L2 latency hides under the FFT phase
@@ -200,7 +244,7 @@ __global__ __launch_bounds__(FE_WAVES * 64, 2) void mel_frontend_kernel(Frontend
             fft16(v);                                    // over m1 -> k1 (at FPOS), for m2 = p
 #pragma unroll
             for (int k1 = 0; k1 < 16; ++k1) {            // twiddle + transpose write E[q][k1][m2 = p]
-                const c32 y = k1 == 0 ? v[FPOS(0)] : cmul(v[FPOS(k1)], Wtw[16 * k1 + p]);
+                const c32 y = k1 == 0 ? v[FPOS(0)] : cmul(v[FPOS(k1)], TW(k1));
                 E[(q * 16 + k1) * FE_ROW + p] = y;
             }
             FSTAMP(1);                                                    // FFT-1 + twiddle + transpose write
@@ -232,7 +276,7 @@ __global__ __launch_bounds__(FE_WAVES * 64, 2) void mel_frontend_kernel(Frontend
                 const int k = p + 16 * j;
                 const float Ar = za[j].x + zb[j].x, Ai = za[j].y - zb[j].y;
                 const float Br = za[j].x - zb[j].x, Bi = za[j].y + zb[j].y;
-                const c32 cs = Wpw[k];
+                const c32 cs = PW(j);
                 const float c = cs.x, s = cs.y;
                 const float Tr = c * Bi - s * Br, Ti = -s * Bi - c * Br;
                 const float xr = Ar + Tr, xi = Ai + Ti, yr = Ar - Tr, yi = Ti - Ai;
@@ -268,15 +312,18 @@ __global__ __launch_bounds__(FE_WAVES * 64, 2) void mel_frontend_kernel(Frontend
             }
             FSTAMP(5);                                                    // mel MFMAs
             float db[4];
+            int fb[4], ff[4];                            // clip / frame of this lane's 4 rows; fb < 0 = dead slot
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 db[r] = 10.0f * __log10f(fmaxf(acc[r], 1e-10f));
-                if (fbase + 4 * q + r < a.nF) lmax = fmaxf(lmax, db[r]);          // every frame counts for the top_db amax
+                if (!is_tail) { fb[r] = b; ff[r] = fbase + 4 * q + r; }
+                else { fb[r] = (m_cl[r] < per_tail && b + m_cl[r] < a.B) ? b + m_cl[r] : -1; ff[r] = 16 * full + m_fr[r]; }
+                if (fb[r] >= 0) lmax = fmaxf(lmax, db[r]);                            // every frame counts for the top_db amax
             }
             if (!PATCH) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r)
-                    if (fbase + 4 * q + r < a.nF) a.mel[((int64_t)b * a.nF + fbase + 4 * q + r) * 64 + 16 * j + p] = db[r];
+                    if (fb[r] >= 0) a.mel[((int64_t)fb[r] * a.nF + ff[r]) * 64 + 16 * j + p] = db[r];
             } else {
                 // 16-bit operands of the encoder's patch embed: init_bn applied here (y = sc*dB + sh, uit.py:310-313);
                 // the top_db clamp commutes with this monotone map and with rounding, so the encoder applies it on y.
@@ -288,7 +335,7 @@ __global__ __launch_bounds__(FE_WAVES * 64, 2) void mel_frontend_kernel(Frontend
                 if (a.ncrops == 1) {
                     // the wave holds one whole patch (pf = j, pt = k0): lane = (mel p, frames 4q..4q+3) -> 8 contiguous
                     // bytes per lane, 512 contiguous bytes per wave: ONE store instruction
-                    if (k0 < a.nt) {
+                    if (!is_tail && k0 < a.nt) {
                         typedef unsigned short us4 __attribute__((ext_vector_type(4)));
                         *(us4*)(out + (((int64_t)b * 24 + j * 6 + k0) * 16 + p) * 16 + 4 * q) = us4{y[0], y[1], y[2], y[3]};
                     }
@@ -297,8 +344,9 @@ __global__ __launch_bounds__(FE_WAVES * 64, 2) void mel_frontend_kernel(Frontend
                     // belongs to its regular crop and/or the re-cropped tail (models/uit.py:474-480)
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        const int f = fbase + 4 * q + r;
-                        if (f >= a.nF) continue;
+                        const int f = ff[r];
+                        const int64_t b = fb[r];
+                        if (b < 0) continue;
                         const int cr0 = f / a.tl, t0 = f - cr0 * a.tl;
                         if (cr0 < a.ncrops - 1 && t0 < 96)
                             out[((((int64_t)b * a.ncrops + cr0) * 24 + j * 6 + (t0 >> 4)) * 16 + p) * 16 + (t0 & 15)] = y[r];
@@ -357,7 +405,8 @@ static hipError_t launch_fe(const FrontendArgs& a, int grid, hipStream_t stream)
 }
 
 hipError_t launch_frontend(const FrontendArgs& a, int in_i16, int patch_layout, int n_cu, hipStream_t stream) {
-    const int64_t npass = a.B * (int64_t)((a.nF + 15) / 16);
+    const int rem = a.nF & 15;
+    const int64_t npass = a.B * (int64_t)(a.nF >> 4) + (rem ? (a.B + 16 / rem - 1) / (16 / rem) : 0);
     int grid = (int)(npass < (int64_t)n_cu * 2 ? npass : (int64_t)n_cu * 2);      // 2 resident workgroups per CU
     if (grid < 1) grid = 1;
     if (a.timing != nullptr && patch_layout && !in_i16) return launch_fe<false, true, true>(a, grid, stream);
