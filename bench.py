@@ -196,8 +196,9 @@ def main():
                          "traffic": traffic, "launch_ms": round(enc, 4),
                          "algorithmic_flops_per_launch": Bl * GEMM_FLOP[args.model]},
             "frontend": {"kernel": "mel_frontend_kernel", "launch_ms": round(fe, 4),
-                         "hbm_GBs": round(Bl * (T * in_bytes + 101 * 64 * 4) / (fe * 1e-3) / 1e9, 1),
-                         "hbm_frac": round(Bl * (T * in_bytes + 101 * 64 * 4) / (fe * 1e-3) / 1e9 / PEAK_HBM_GBS, 5),
+                         # algorithmic bytes: PCM in + 24 patches x 256 16-bit operands out per clip
+                         "hbm_GBs": round(Bl * (T * in_bytes + 24 * 256 * 2) / (fe * 1e-3) / 1e9, 1),
+                         "hbm_frac": round(Bl * (T * in_bytes + 24 * 256 * 2) / (fe * 1e-3) / 1e9 / PEAK_HBM_GBS, 5),
                          "valu_TFLOPs": round(Bl * FRONTEND_VALU_FLOP / (fe * 1e-3) / 1e12, 2),
                          "valu_frac": round(Bl * FRONTEND_VALU_FLOP / (fe * 1e-3) / 1e12 / PEAK_VALU_TFLOPS, 5)},
         }
