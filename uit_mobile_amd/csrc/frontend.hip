@@ -17,7 +17,8 @@
 //     * window and both twiddle sets are per-lane VGPR constants (an LDS-table variant and a next-pass sample
 //       prefetch exist behind FE_LDS_TABLES / FE_PREFETCH; both measured slower on MI355X).
 //     * |X|^2 of the 4 frames goes to a workgroup-shared power tile P[16 frames][290] (double-buffered).
-//   mel phase, after ONE workgroup barrier per pass:
+//   mel phase, ONE workgroup barrier per pass, software-pipelined one pass BEHIND the FFT phase (the next pass's
+//   sample loads are issued first and their HBM latency hides under it):
 //     * mel[16 frames][64] = P[16][257] . fb[257][64] on the matrix pipe with the EXACT-fp32 MFMA
 //       v_mfma_f32_16x16x4_f32 (bitwise an fp32 fma chain, MI355X guide section 3).  The HTK filterbank is banded:
 //       each 16-mel tile only needs its own bin range, 70 k-steps of 4 in total instead of 4 x 65.  Each wave owns
@@ -202,52 +203,120 @@ __global__ __launch_bounds__(FE_WAVES * 64, 2) void mel_frontend_kernel(Frontend
     };
     unsigned long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tlast = 0;
     if constexpr (TIMING) tlast = fe_stamp();
-    c32 nxt[16];
-#pragma unroll
-    for (int m1 = 0; m1 < 16; ++m1) nxt[m1] = c32{0.f, 0.f};
-#if FE_PREFETCH
-    if ((int64_t)blockIdx.x < npass) load_pass(blockIdx.x, nxt);
-#endif
-    for (int64_t pass = blockIdx.x; pass < npass; pass += gridDim.x, ++it) {
-        float* P = Pbase + (it & 1) * 16 * FE_PROW;
-        const bool is_tail = pass >= nfull;              // uniform
-        const int b = is_tail ? (int)((pass - nfull) * per_tail) : (int)(pass / full);   // (first) clip of the pass
-        const int k0 = is_tail ? full : (int)(pass - (int64_t)b * full);
-        const int fbase = 16 * k0;                       // first frame of a full pass
-        // -------------------------------------------------------------------------------- FFT phase
-            const bool quad_live = !is_tail || 4 * wave < per_tail * rem;    // uniform per wave: skip fully dead quads
-            c32 v[16];
-#if !FE_PREFETCH
-            load_pass(pass, nxt);
-#endif
-#pragma unroll
-            for (int m1 = 0; m1 < 16; ++m1) v[m1] = nxt[m1] * WIN(m1);
-#if FE_PREFETCH
-            if (pass + gridDim.x < npass) load_pass(pass + gridDim.x, nxt);      // prefetch: lands under this pass's math
-#endif
-        // this wave's 16-mel tile for this pass; its B operands (filterbank band, zero-padded to 8-step chunks by
-        // pack.cpp) are fetched now -- AFTER the prefetched samples were consumed, so that the wait for those does not
-        // also wait for these -- and their L2 latency hides under the FFT phase
-        const int j = (wave + it) & 3;
-        const int klo = a.mel_tile_klo[j], nst = a.mel_tile_steps[j];
+
+    // B operands (filterbank band of one 16-mel tile, zero-padded to 8-step chunks by pack.cpp) live in VGPRs
+    float bw[FE_BREG];
+    auto load_bw = [&](int j) {
+        const int nst = a.mel_tile_steps[j];
         const float* Bt = a.mel_b + (size_t)a.mel_tile_base[j] * 64 + lane;
-        float bw[FE_BREG];
 #pragma unroll
         for (int c = 0; c < FE_BREG / 8; ++c)
             if (8 * c < nst) {
 #pragma unroll
                 for (int s = 0; s < 8; ++s) bw[8 * c + s] = Bt[64 * (8 * c + s)];
             }
-            {
-            FSTAMP(0);                                                    // B-operand issue + window (sample wait)
-            if (quad_live) {
+    };
+
+    // ---- mel phase of one pass (matrix pipe): runs ONE PASS BEHIND the FFT phase, right after the next pass's sample
+    // loads were issued, so their HBM latency hides under these MFMAs, the log and the stores
+    auto mel_phase = [&](int itp, int64_t passp) {
+        const float* P = Pbase + (itp & 1) * 16 * FE_PROW;
+        const bool is_tail = passp >= nfull;             // uniform
+        const int b = is_tail ? (int)((passp - nfull) * per_tail) : (int)(passp / full);   // (first) clip of the pass
+        const int k0 = is_tail ? full : (int)(passp - (int64_t)b * full);
+        const int fbase = 16 * k0;                       // first frame of a full pass
+        const int j = (wave + itp) & 3;                  // this wave's 16-mel tile for that pass (rotates: tiles are unequal)
+        const int klo = a.mel_tile_klo[j], nst = a.mel_tile_steps[j];
+        const float* Bt = a.mel_b + (size_t)a.mel_tile_base[j] * 64 + lane;
+        const float* Ar = P + p * FE_PROW + klo + q;     // A[row = frame p][k = q]  (lane&15 = row, lane>>4 = k)
+        f4v acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int c = 0; c < FE_BREG / 8; ++c)
+            if (8 * c < nst) {
+#pragma unroll
+                for (int s = 0; s < 8; s += 2) {
+                    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(Ar[4 * (8 * c + s)], bw[8 * c + s], acc0, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(Ar[4 * (8 * c + s + 1)], bw[8 * c + s + 1], acc1, 0, 0, 0);
+                }
+            }
+        for (int s = FE_BREG; s < nst; ++s)              // filterbanks wider than FE_BREG steps per tile (not HTK)
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(Ar[4 * s], Bt[64 * s], acc0, 0, 0, 0);
+        const f4v acc = acc0 + acc1;                     // D[frame 4q + r][mel 16j + p]
+        float bn_sc = 0.f, bn_sh = 0.f;
+        if (PATCH) {
+            bn_sc = j == 0 ? bnsc[0] : j == 1 ? bnsc[1] : j == 2 ? bnsc[2] : bnsc[3];
+            bn_sh = j == 0 ? bnsh[0] : j == 1 ? bnsh[1] : j == 2 ? bnsh[2] : bnsh[3];
+        }
+        FSTAMP(5);                                       // mel MFMAs
+        float db[4];
+        int fb[4], ff[4];                                // clip / frame of this lane's 4 rows; fb < 0 = dead slot
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            db[r] = 10.0f * __log10f(fmaxf(acc[r], 1e-10f));
+            if (!is_tail) { fb[r] = b; ff[r] = fbase + 4 * q + r; }
+            else { fb[r] = (m_cl[r] < per_tail && b + m_cl[r] < a.B) ? b + m_cl[r] : -1; ff[r] = 16 * full + m_fr[r]; }
+            if (fb[r] >= 0) lmax = fmaxf(lmax, db[r]);                                // every frame counts for the top_db amax
+        }
+        if (!PATCH) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                if (fb[r] >= 0) a.mel[((int64_t)fb[r] * a.nF + ff[r]) * 64 + 16 * j + p] = db[r];
+        } else {
+            // 16-bit operands of the encoder's patch embed: init_bn applied here (y = sc*dB + sh, uit.py:310-313);
+            // the top_db clamp commutes with this monotone map and with rounding, so the encoder applies it on y.
+            // Layout [clip-crop][token pf*6+pt][mel-in-patch][frame-in-patch].
+            unsigned short y[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) y[r] = to_op16(db[r] * bn_sc + bn_sh, a.op_bf16);
+            unsigned short* out = (unsigned short*)a.mel;
+            if (a.ncrops == 1) {
+                // the wave holds one whole patch (pf = j, pt = k0): lane = (mel p, frames 4q..4q+3) -> 8 contiguous
+                // bytes per lane, 512 contiguous bytes per wave: ONE store instruction
+                if (!is_tail && k0 < a.nt) {
+                    typedef unsigned short us4 __attribute__((ext_vector_type(4)));
+                    *(us4*)(out + (((int64_t)b * 24 + j * 6 + k0) * 16 + p) * 16 + 4 * q) = us4{y[0], y[1], y[2], y[3]};
+                }
+            } else {
+                // long clips: crops start every target_length frames, not patch aligned -> per-element stores; a frame
+                // belongs to its regular crop and/or the re-cropped tail (models/uit.py:474-480)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int f = ff[r];
+                    const int64_t bb = fb[r];
+                    if (bb < 0) continue;
+                    const int cr0 = f / a.tl, t0 = f - cr0 * a.tl;
+                    if (cr0 < a.ncrops - 1 && t0 < 96)
+                        out[(((bb * a.ncrops + cr0) * 24 + j * 6 + (t0 >> 4)) * 16 + p) * 16 + (t0 & 15)] = y[r];
+                    const int t1 = f - (a.nF - a.tl);
+                    if (t1 >= 0 && t1 < 96)
+                        out[(((bb * a.ncrops + a.ncrops - 1) * 24 + j * 6 + (t1 >> 4)) * 16 + p) * 16 + (t1 & 15)] = y[r];
+                }
+            }
+        }
+        FSTAMP(7);                                       // log + bn + stores
+    };
+
+    int64_t prev = -1;
+    for (int64_t pass = blockIdx.x; pass < npass; pass += gridDim.x, ++it) {
+        float* P = Pbase + (it & 1) * 16 * FE_PROW;
+        const bool is_tail = pass >= nfull;              // uniform
+        const bool quad_live = !is_tail || 4 * wave < per_tail * rem;        // uniform per wave: skip fully dead quads
+        c32 v[16];
+        load_pass(pass, v);                              // issue this pass's sample loads ...
+        if (it > 0) mel_phase(it - 1, prev);             // ... and cover their latency with the previous pass's mel phase
+        load_bw((wave + it) & 3);                        // B operands of THIS pass's mel phase: land under the FFT below
+        FSTAMP(0);
+        // -------------------------------------------------------------------------------- FFT phase
+        if (quad_live) {
+#pragma unroll
+            for (int m1 = 0; m1 < 16; ++m1) v[m1] = v[m1] * WIN(m1);
             fft16(v);                                    // over m1 -> k1 (at FPOS), for m2 = p
 #pragma unroll
             for (int k1 = 0; k1 < 16; ++k1) {            // twiddle + transpose write E[q][k1][m2 = p]
                 const c32 y = k1 == 0 ? v[FPOS(0)] : cmul(v[FPOS(k1)], TW(k1));
                 E[(q * 16 + k1) * FE_ROW + p] = y;
             }
-            FSTAMP(1);                                                    // FFT-1 + twiddle + transpose write
+            FSTAMP(1);                                   // window + FFT-1 + twiddle + transpose write
             __builtin_amdgcn_wave_barrier();
             asm volatile("" ::: "memory");
 #pragma unroll
@@ -260,7 +329,7 @@ __global__ __launch_bounds__(FE_WAVES * 64, 2) void mel_frontend_kernel(Frontend
             for (int k2 = 0; k2 < 16; ++k2) Z[q * FE_ZROW + 16 * k2 + p] = v[FPOS(k2)];
             __builtin_amdgcn_wave_barrier();
             asm volatile("" ::: "memory");
-            FSTAMP(2);                                                    // transpose read + FFT-2 + Z write
+            FSTAMP(2);                                   // transpose read + FFT-2 + Z write
             c32 za[8], zb[8];
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
@@ -284,81 +353,13 @@ __global__ __launch_bounds__(FE_WAVES * 64, 2) void mel_frontend_kernel(Frontend
                 prow[256 - k] = 0.25f * (yr * yr + yi * yi);     // k = 0 writes bin 256 (Nyquist)
             }
             if (p == 0) prow[128] = z128.x * z128.x + z128.y * z128.y;
-            }
         }
-        FSTAMP(3);                                                        // Z read + split + power write
-        __syncthreads();
-        FSTAMP(4);                                                        // barrier wait                                 // P complete (and everyone is done with the other buffer)
-        // -------------------------------------------------------------------------------- mel phase (matrix pipe)
-        {
-            const float* Ar = P + p * FE_PROW + klo + q; // A[row = frame p][k = q]  (lane&15 = row, lane>>4 = k)
-            f4v acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int c = 0; c < FE_BREG / 8; ++c)
-                if (8 * c < nst) {
-#pragma unroll
-                    for (int s = 0; s < 8; s += 2) {
-                        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(Ar[4 * (8 * c + s)], bw[8 * c + s], acc0, 0, 0, 0);
-                        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(Ar[4 * (8 * c + s + 1)], bw[8 * c + s + 1], acc1, 0, 0, 0);
-                    }
-                }
-            for (int s = FE_BREG; s < nst; ++s)          // filterbanks wider than FE_BREG steps per tile (not HTK)
-                acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(Ar[4 * s], Bt[64 * s], acc0, 0, 0, 0);
-            const f4v acc = acc0 + acc1;                 // D[frame 4q + r][mel 16j + p]
-            float bn_sc = 0.f, bn_sh = 0.f;
-            if (PATCH) {
-                bn_sc = j == 0 ? bnsc[0] : j == 1 ? bnsc[1] : j == 2 ? bnsc[2] : bnsc[3];
-                bn_sh = j == 0 ? bnsh[0] : j == 1 ? bnsh[1] : j == 2 ? bnsh[2] : bnsh[3];
-            }
-            FSTAMP(5);                                                    // mel MFMAs
-            float db[4];
-            int fb[4], ff[4];                            // clip / frame of this lane's 4 rows; fb < 0 = dead slot
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                db[r] = 10.0f * __log10f(fmaxf(acc[r], 1e-10f));
-                if (!is_tail) { fb[r] = b; ff[r] = fbase + 4 * q + r; }
-                else { fb[r] = (m_cl[r] < per_tail && b + m_cl[r] < a.B) ? b + m_cl[r] : -1; ff[r] = 16 * full + m_fr[r]; }
-                if (fb[r] >= 0) lmax = fmaxf(lmax, db[r]);                            // every frame counts for the top_db amax
-            }
-            if (!PATCH) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r)
-                    if (fb[r] >= 0) a.mel[((int64_t)fb[r] * a.nF + ff[r]) * 64 + 16 * j + p] = db[r];
-            } else {
-                // 16-bit operands of the encoder's patch embed: init_bn applied here (y = sc*dB + sh, uit.py:310-313);
-                // the top_db clamp commutes with this monotone map and with rounding, so the encoder applies it on y.
-                // Layout [clip-crop][token pf*6+pt][mel-in-patch][frame-in-patch].
-                unsigned short y[4];
-#pragma unroll
-                for (int r = 0; r < 4; ++r) y[r] = to_op16(db[r] * bn_sc + bn_sh, a.op_bf16);
-                unsigned short* out = (unsigned short*)a.mel;
-                if (a.ncrops == 1) {
-                    // the wave holds one whole patch (pf = j, pt = k0): lane = (mel p, frames 4q..4q+3) -> 8 contiguous
-                    // bytes per lane, 512 contiguous bytes per wave: ONE store instruction
-                    if (!is_tail && k0 < a.nt) {
-                        typedef unsigned short us4 __attribute__((ext_vector_type(4)));
-                        *(us4*)(out + (((int64_t)b * 24 + j * 6 + k0) * 16 + p) * 16 + 4 * q) = us4{y[0], y[1], y[2], y[3]};
-                    }
-                } else {
-                    // long clips: crops start every target_length frames, not patch aligned -> per-element stores; a frame
-                    // belongs to its regular crop and/or the re-cropped tail (models/uit.py:474-480)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const int f = ff[r];
-                        const int64_t b = fb[r];
-                        if (b < 0) continue;
-                        const int cr0 = f / a.tl, t0 = f - cr0 * a.tl;
-                        if (cr0 < a.ncrops - 1 && t0 < 96)
-                            out[((((int64_t)b * a.ncrops + cr0) * 24 + j * 6 + (t0 >> 4)) * 16 + p) * 16 + (t0 & 15)] = y[r];
-                        const int t1 = f - (a.nF - a.tl);
-                        if (t1 >= 0 && t1 < 96)
-                            out[((((int64_t)b * a.ncrops + a.ncrops - 1) * 24 + j * 6 + (t1 >> 4)) * 16 + p) * 16 + (t1 & 15)] = y[r];
-                    }
-                }
-            }
-            FSTAMP(7);                                                    // log + bn + stores
-        }
+        FSTAMP(3);                                       // Z read + split + power write
+        __syncthreads();                                 // P[it&1] complete; everyone is done reading P[(it-1)&1]
+        FSTAMP(4);                                       // barrier wait
+        prev = pass;
     }
+    if (it > 0) mel_phase(it - 1, prev);
     FSTAMP(6);                                                            // (accumulates log + stores of all passes? no: tail only)
     if constexpr (TIMING) {
         if (a.timing != nullptr && lane == 0) {
