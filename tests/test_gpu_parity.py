@@ -7,6 +7,8 @@ the probabilities the reference returns and the pre-sigmoid logits, for the defa
 fp32 accumulate).  The bf16-operand mode has ~8x the operand rounding and is held to 1e-3 on probabilities and
 1e-2 on logits (measured 3e-3); it is not the parity default.
 """
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -213,3 +215,58 @@ def test_evaluator_batch_step_pad_rule(golden, tmp_path):
     pcm = torch.from_numpy(g["85b877b5_nohash_0_pcm"].astype(np.float32) / 32768.0)[None]
     out, _ = ev._inference((pcm, torch.zeros(1, 537), torch.tensor([16000]), ["x"]), pad=True)
     assert np.abs(out.cpu().numpy()[0] - g["gsc_padded_probs"]).max() < TOL
+
+
+def test_sharded_wrapper_single_rank_matches_plain_forward():
+    """world_size 1: the amax hook runs between the two kernels (in-place on the device slots) and must not change
+    the result; the gather is the identity."""
+    from uit_mobile_amd.sharded import ShardedUiT
+    m, sd = build("uit_xxxs", 31)
+    pcm = synth_pcm_i16(24, 16000, seed=12)
+    x = torch.from_numpy(pcm).cuda()
+    plain = m(x)
+    sharded = ShardedUiT(m)(x)
+    torch.cuda.synchronize()
+    assert torch.equal(plain, sharded)
+    slots = m.amax_tensor(x.device)
+    assert slots.shape == (64,) and torch.isfinite(slots).all() and float(slots.max()) == float(slots.min())
+
+
+def _rccl_worker(rank, world, port, q):
+    import os
+    import torch.distributed as dist
+    from uit_mobile_amd.sharded import ShardedUiT, shard_range
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    torch.cuda.set_device(rank)
+    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", rank))
+    try:
+        m, sd = build("uit_xxxs", 32)
+        m = m.to(f"cuda:{rank}")
+        pcm = synth_pcm_i16(16, 16000, seed=13)               # clip 1 is the loud tone, clip 2 has a silent tail
+        lo, hi = shard_range(16, rank, world)
+        out = ShardedUiT(m)(torch.from_numpy(pcm[lo:hi]).cuda())
+        torch.cuda.synchronize()
+        q.put((rank, out.cpu().numpy()))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs 2 GPUs (RCCL)")
+def test_two_rank_rccl_matches_single_rank_oracle():
+    """R-invariance: batch shards + MAX all-reduce of the amax + all-gather == the single-call result (the silent
+    tail of clip 2 sits on the top_db floor set by the loud clip 1, which lives on the other rank)."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_rccl_worker, args=(r, 2, 29400 + os.getpid() % 500, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=300) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+    _, sd = build("uit_xxxs", 32)
+    ref = Oracle(sd).forward(synth_pcm_i16(16, 16000, seed=13))
+    for r in range(2):
+        assert res[r].shape == (16, 537)
+        assert np.abs(res[r] - ref["probs"]).max() < TOL
+    assert np.array_equal(res[0], res[1])
