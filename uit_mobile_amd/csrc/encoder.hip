@@ -290,6 +290,12 @@ __global__ __launch_bounds__(WAVES * 64, 2) void uit_encoder_kernel(EncoderArgs 
 #pragma unroll
         for (int s = 0; s < 8; ++s) XB[ct][s] = *(const v8*)(src + 32 * s);
     }
+    // accumulator init (conv bias + positional embeddings) rides the same memory round trip
+    f4 R[8][3];
+#pragma unroll
+    for (int ct = 0; ct < 3; ++ct)
+#pragma unroll
+        for (int ft = 0; ft < 8; ++ft) R[ft][ct] = *(const f4*)(a.pe_bias + tk_[ct] * DIM + 16 * ft + 4 * g);
     float amx = a.amax[lane];                                             // 64 slots, one per lane; NaN = untouched slot
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) amx = fmaxf(amx, __shfl_xor(amx, o));
@@ -318,11 +324,6 @@ __global__ __launch_bounds__(WAVES * 64, 2) void uit_encoder_kernel(EncoderArgs 
 
     // ---- patch embed: 64 LDS-resident fragments (ft = f/8, s = f%8) x 3 token tiles; accumulators start from the
     // conv bias + positional embeddings table
-    f4 R[8][3];
-#pragma unroll
-    for (int ct = 0; ct < 3; ++ct)
-#pragma unroll
-        for (int ft = 0; ft < 8; ++ft) R[ft][ct] = *(const f4*)(a.pe_bias + tk_[ct] * DIM + 16 * ft + 4 * g);
 #pragma unroll
     for (int ft = 0; ft < 8; ++ft) {
         v8 A[8];
@@ -558,11 +559,14 @@ __global__ __launch_bounds__(WAVES * 64, 2) void uit_encoder_kernel(EncoderArgs 
     if constexpr (TIMING) t_blocks_end = stamp();
     // classifier weights of this wave's first output tile: fetched now, consumed after pooling
     const int ntiles = (a.C + 15) / 16;
-    v8 Hn[4];
-    if (wave < ntiles) {
+    constexpr int HEAD_PRE = 5;                           // tiles per wave held in VGPRs (5 x 8 waves covers C <= 640)
+    v8 Hpre[HEAD_PRE][4];
 #pragma unroll
-        for (int s = 0; s < 4; ++s) Hn[s] = *(const v8*)(a.head_w + (size_t)(wave * 4 + s) * FRAG_BYTES + lane * 16);
-    }
+    for (int i = 0; i < HEAD_PRE; ++i)
+        if (wave + i * WAVES < ntiles) {
+#pragma unroll
+            for (int s = 0; s < 4; ++s) Hpre[i][s] = *(const v8*)(a.head_w + (size_t)((wave + i * WAVES) * 4 + s) * FRAG_BYTES + lane * 16);
+        }
 
     // ---- final norm (eps 1e-6) -> masked mean over tokens -> head LayerNorm (eps 1e-5)
     f4 pooled[8];
@@ -631,14 +635,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void uit_encoder_kernel(EncoderArgs 
             Bz[s] = v8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
         }
         const int rowg = blockIdx.x * WAVES * 2 + c;
-        for (int ot = wave; ot < ntiles; ot += WAVES) {
-            v8 Hc[4];
-#pragma unroll
-            for (int s = 0; s < 4; ++s) Hc[s] = Hn[s];
-            if (ot + WAVES < ntiles) {                      // prefetch the next tile's fragments under this tile's MFMAs
-#pragma unroll
-                for (int s = 0; s < 4; ++s) Hn[s] = *(const v8*)(a.head_w + (size_t)((ot + WAVES) * 4 + s) * FRAG_BYTES + lane * 16);
-            }
+        auto head_tile = [&](int ot, const v8 (&Hc)[4]) {
             f4 acc = *(const f4*)(a.head_b + 16 * ot + 4 * g);
 #pragma unroll
             for (int s = 0; s < 4; ++s) acc = OP::mfma32(Hc[s], Bz[s], acc);
@@ -652,6 +649,15 @@ __global__ __launch_bounds__(WAVES * 64, 2) void uit_encoder_kernel(EncoderArgs 
                     }
                 }
             }
+        };
+#pragma unroll
+        for (int i = 0; i < HEAD_PRE; ++i)
+            if (wave + i * WAVES < ntiles) head_tile(wave + i * WAVES, Hpre[i]);
+        for (int ot = wave + HEAD_PRE * WAVES; ot < ntiles; ot += WAVES) {       // very wide heads: plain loop
+            v8 Hc[4];
+#pragma unroll
+            for (int s = 0; s < 4; ++s) Hc[s] = *(const v8*)(a.head_w + (size_t)(ot * 4 + s) * FRAG_BYTES + lane * 16);
+            head_tile(ot, Hc);
         }
     }
     if constexpr (TIMING) {
