@@ -103,6 +103,8 @@ def main():
     ap.add_argument("--pcm16", action="store_true", help="feed int16 PCM instead of float32 waves")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--from-host", action="store_true",
+                    help="additionally report the PCIe-inclusive rate (pinned int16 host buffers -> HostClipStreamer)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -202,6 +204,21 @@ def main():
                          "valu_TFLOPs": round(Bl * FRONTEND_VALU_FLOP / (fe * 1e-3) / 1e12, 2),
                          "valu_frac": round(Bl * FRONTEND_VALU_FLOP / (fe * 1e-3) / 1e12 / PEAK_VALU_TFLOPS, 5)},
         }
+        if world == 1 and args.from_host:
+            from uit_mobile_amd.streaming import HostClipStreamer
+            st = HostClipStreamer(m, Bl, T)
+            hb = [synth_batch(Bl, T, 0, "cpu", True).pin_memory()] * 12     # the producer fills pinned buffers
+            with torch.no_grad():
+                for _ in st.run(hb[:2]):
+                    pass
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for _ in st.run(hb):
+                    pass
+                torch.cuda.synchronize()
+            line["from_host_int16"] = {"value": round(len(hb) * Bl / (time.perf_counter() - t0), 1), "unit": "clips/s",
+                                       "note": "PCIe-inclusive: pinned int16 host buffers, async H2D overlapped with compute "
+                                               "(uit_mobile_amd/streaming.py); never the headline value"}
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(args.model, sd, T, args.cpu_seconds)
         print(json.dumps(line), flush=True)

@@ -270,3 +270,16 @@ def test_two_rank_rccl_matches_single_rank_oracle():
         assert res[r].shape == (16, 537)
         assert np.abs(res[r] - ref["probs"]).max() < TOL
     assert np.array_equal(res[0], res[1])
+
+
+def test_host_clip_streamer_matches_direct_calls():
+    """8f row 1: pinned int16 staging + async H2D overlapped with compute gives the same outputs, in order."""
+    from uit_mobile_amd.streaming import HostClipStreamer
+    m, sd = build("uit_xxxs", 33)
+    batches = [torch.from_numpy(synth_pcm_i16(n, 16000, seed=40 + i)) for i, n in enumerate((32, 32, 17, 32))]
+    st = HostClipStreamer(m, 32, 16000)
+    outs = [o.clone() for o in st.run(batches)]
+    torch.cuda.synchronize()
+    assert [o.shape[0] for o in outs] == [32, 32, 17, 32]
+    for b, o in zip(batches, outs):
+        assert torch.equal(o, m(b.cuda()))
