@@ -111,3 +111,33 @@ def test_label_lookup_and_topk_format():
     lines = topk_lines(p, lm, 3)
     assert lines[0].startswith("Speech") and lines[0].endswith("1.0000")
     assert lines[1].startswith("Keyword: on") and lines[1].endswith("0.9999")
+
+
+def _kws_loop_restatement(y_pred, y, threshold):
+    """Loop restatement of the reference's _output_transform_xiaoai (evaluate.py:212-229) -- the checker."""
+    y_pred = y_pred.clone()
+    mask = torch.ones_like(y_pred)
+    mask[:, :527] = (y_pred[:, :527] == y_pred[:, :527].max(dim=1, keepdim=True)[0]).to(torch.int32)
+    y_pred = y_pred * mask
+    _, yy = y.max(dim=-1)
+    for i, scores in enumerate(y_pred):
+        idx = scores[0:527].max(dim=-1)[1]
+        if yy[i] < 527:
+            yy[i] = idx
+        for score in scores[527:]:
+            if score >= threshold:
+                y_pred[i][idx] = 0.0
+    return y_pred, yy
+
+
+def test_kws_output_transform_matches_reference_loop():
+    from uit_mobile_amd.evaluate import output_transform_kws
+    g = torch.Generator().manual_seed(0)
+    y_pred = torch.rand(64, 537, generator=g)
+    y_pred[::3, 527:] *= 0.1                                  # rows without a firing keyword
+    y = torch.zeros(64, 537)
+    y[torch.arange(64), torch.randint(0, 537, (64,), generator=g)] = 1.0
+    for thr in (0.2, 0.5):
+        a, ya = output_transform_kws(y_pred, y, thr)
+        b, yb = _kws_loop_restatement(y_pred, y, thr)
+        assert torch.equal(a, b) and torch.equal(ya, yb)

@@ -39,6 +39,23 @@ def sequential_pad(waves, padding_value=0.0):
     return out, torch.as_tensor(lengths)
 
 
+def output_transform_kws(y_pred, y, threshold=0.2, num_fillers=527):
+    """Vectorised, device-side version of `_output_transform_xiaoai` (evaluate.py:212-229): keep only the maximal
+    AudioSet ("filler") score, map filler targets to it, and zero it whenever any keyword score reaches the threshold
+    (so Accuracy@threshold picks the keyword).  The reference does this with a Python loop over samples on the host.
+    y_pred [B, C] probabilities, y [B, C] one/multi-hot targets  ->  (y_pred', y_index)."""
+    fill = y_pred[:, :num_fillers]
+    fmax, fidx = fill.max(dim=1, keepdim=True)
+    out = y_pred.clone()
+    out[:, :num_fillers] = fill * (fill == fmax).to(fill.dtype)
+    tgt = y.max(dim=-1)[1]
+    tgt = torch.where(tgt < num_fillers, fidx.squeeze(1), tgt)
+    fire = (y_pred[:, num_fillers:] >= threshold).any(dim=1)
+    rows = torch.nonzero(fire, as_tuple=True)[0]
+    out[rows, fidx.squeeze(1)[rows]] = 0.0
+    return out, tgt
+
+
 class Evaluator:
     def __init__(self, experiment_path, device=DEVICE, precision="f16"):
         self.model = build_model(experiment_path, device=device, precision=precision)
