@@ -37,7 +37,7 @@ struct uitk_model {
     unsigned long long* timing_fe = nullptr;
     int n_cu = 256;
     int enc_waves = 8;            // waves per encoder workgroup (8 = one WG per CU; 4 = two independent WGs per CU)
-    int enc_sched = 0, enc_stagger = 0, enc_stagger_mode = 1;   // tuning knobs (UITK_ENC_SCHED, UITK_ENC_STAGGER)
+    int enc_sched = 0, enc_stagger = 0, enc_stagger_mode = 1, enc_ablate = 0;   // tuning knobs (UITK_ENC_SCHED, UITK_ENC_STAGGER)
     int device = 0;
 };
 
@@ -85,6 +85,7 @@ int uitk_create(const uitk_config* cfg, const uitk_weights* w, uitk_model** out)
     if (const char* e = std::getenv("UITK_ENC_SCHED")) m->enc_sched = std::atoi(e) != 0;
     if (const char* e = std::getenv("UITK_ENC_STAGGER")) m->enc_stagger = std::atoi(e);
     if (const char* e = std::getenv("UITK_ENC_STAGGER_MODE")) m->enc_stagger_mode = std::atoi(e);
+    if (const char* e = std::getenv("UITK_ENC_ABLATE")) m->enc_ablate = std::atoi(e);
     if (hipMalloc((void**)&m->image, img.size()) != hipSuccess || hipMalloc((void**)&m->amax, AMAX_SLOTS * 4) != hipSuccess) {
         uitk_destroy(m); return fail(UITK_ERR_HIP, "hipMalloc failed for the parameter image");
     }
@@ -220,7 +221,7 @@ int uitk_encode(uitk_model* m, int64_t B, int64_t T, float* probs, float* logits
     a.head_b = (const float*)(m->image + h.off_head_b);
     a.probs = nc > 1 ? m->rowprobs : probs;
     a.logits = logits; a.dbg = m->dbg;
-    a.timing = m->timing;
+    a.timing = m->timing; a.ablate = m->enc_ablate;
     a.stagger = m->enc_stagger; a.stagger_group = m->n_cu; a.stagger_mode = m->enc_stagger_mode;
     HIP_TRY(launch_encoder(a, m->cfg.precision, m->enc_waves, m->enc_sched, s));
     if (nc > 1) HIP_TRY(launch_crop_reduce(m->rowprobs, probs, B, nc, a.C, m->cfg.eval_avg, s));

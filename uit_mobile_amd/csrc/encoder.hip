@@ -225,7 +225,9 @@ __device__ __forceinline__ unsigned long long stamp() {
 }
 #define TSTAMP(slot) do { if constexpr (TIMING) { const unsigned long long _t = stamp(); tacc[slot] += _t - tlast; tlast = _t; } } while (0)
 
-template <int PREC, int WAVES, bool SCHED, bool TIMING>
+// ABL: timing experiments only (wrong outputs): 1 skip attention, 2 skip LayerNorms, 4 MLP without ring steps
+// (no DMA, no barrier), 8 MLP without LDS fragment reads, 16 MLP without ReLU/convert, 32 MLP without bias reads.  The product kernel is ABL = 0.
+template <int PREC, int WAVES, bool SCHED, bool TIMING, int ABL = 0>
 __global__ __launch_bounds__(WAVES * 64, 2) void uit_encoder_kernel(EncoderArgs a) {
     using OP = Op<PREC>;
     using v8 = typename OP::v8;
@@ -382,7 +384,8 @@ __global__ __launch_bounds__(WAVES * 64, 2) void uit_encoder_kernel(EncoderArgs 
         const int tb = PE_STAGES + blk * BLOCK_STAGES;
         const float* bias = (const float*)(breg + (blk & 1) * BIAS_FLOATS * 4);
         v8 X[4][3];
-        layernorm_to_operand<PREC>(R, 1e-6f, X);
+        if constexpr (!(ABL & 2)) layernorm_to_operand<PREC>(R, 1e-6f, X);
+        else { for (int s = 0; s < 4; ++s) for (int ct = 0; ct < 3; ++ct) X[s][ct] = OP::pack8(R[s][ct], R[s + 4][ct]); }
         TSTAMP(0);                                                     // LN1
 
         // ===== stage QK: fragments (ft = f/4 in {q h0, q h1, k h0, k h1}, s = f%4)
@@ -390,7 +393,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void uit_encoder_kernel(EncoderArgs 
         TSTAMP(1);                                                     // ring wait QK
         if (blk + 1 < a.depth) bias_issue<WAVES>(a.bias, breg, blk + 1, wave, lane);
         v4 Qh[2][3], Kh[2][3];
-        {
+        if constexpr (!(ABL & 1)) {
             const char* slot = ring + (tb & (RING_SLOTS - 1)) * STAGE_BYTES;
             v8 A[16];
 #pragma unroll
@@ -416,7 +419,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void uit_encoder_kernel(EncoderArgs 
         // ===== stage VP: fragments 0..7 = V (h = f/4, s = f%4) used as the B operand; 8..15 = proj (ft = f-8)
         ring_step<WAVES>(a.wstream, ring, tb + 1, wave, lane);
         TSTAMP(3);                                                     // ring wait VP
-        {
+        if constexpr (!(ABL & 1)) {
             const char* slot = ring + ((tb + 1) & (RING_SLOTS - 1)) * STAGE_BYTES;
             v4 Vh[3][2];                       // V[token 16ct+4g+r][d = c] -> A operand of P.V (rows d, k = token)
             {
@@ -485,17 +488,18 @@ __global__ __launch_bounds__(WAVES * 64, 2) void uit_encoder_kernel(EncoderArgs 
 
         TSTAMP(4);                                                     // V + attention + proj
         // ===== MLP: 12 stages; stage ch = fc1 rows 32ch..32ch+31 (frags j*4+s) and fc2 k-step ch (frags 8+ft)
-        layernorm_to_operand<PREC>(R, 1e-6f, X);
+        if constexpr (!(ABL & 2)) layernorm_to_operand<PREC>(R, 1e-6f, X);
         TSTAMP(5);                                                     // LN2
         // Software-pipelined over the 12 stages: at stage ch the fc1 fragment reads are issued first, then the fc2
         // MFMAs of chunk ch-1 run from registers (A2/HX carried across the barrier) and cover the LDS latency; the
         // fc2 fragment reads of chunk ch fly under its fc1 MFMAs.
         v8 A2[8], HX[3];
         auto fc1_chunk = [&](const char* slot, int ch, const v8 (&A)[8]) {
-            const f4 b10 = *(const f4*)(bias + BIAS_FC1 + 32 * ch + 4 * g);
-            const f4 b11 = *(const f4*)(bias + BIAS_FC1 + 32 * ch + 16 + 4 * g);
+            f4 b10, b11;
+            if constexpr (ABL & 32) { b10 = splat(0.f); b11 = splat(0.f); }
+            else { b10 = *(const f4*)(bias + BIAS_FC1 + 32 * ch + 4 * g); b11 = *(const f4*)(bias + BIAS_FC1 + 32 * ch + 16 + 4 * g); }
 #pragma unroll
-            for (int f = 0; f < 8; ++f) A2[f] = lds_frag<PREC>(slot, 8 + f, lane);       // fc2 fragments of this chunk
+            for (int f = 0; f < 8; ++f) { if constexpr (!(ABL & 8)) A2[f] = lds_frag<PREC>(slot, 8 + f, lane); else A2[f] = A[f]; }   // fc2 fragments of this chunk
             f4 H0[3], H1[3];
 #pragma unroll
             for (int ct = 0; ct < 3; ++ct) {
@@ -510,10 +514,13 @@ __global__ __launch_bounds__(WAVES * 64, 2) void uit_encoder_kernel(EncoderArgs 
                 for (int s = 0; s < 4; ++s) H1[ct] = OP::mfma32(A[4 + s], X[s][ct], H1[ct]);
             }
 #pragma unroll
-            for (int ct = 0; ct < 3; ++ct) HX[ct] = OP::relu_pack8(H0[ct], H1[ct]);
+            for (int ct = 0; ct < 3; ++ct) {
+                if constexpr (ABL & 16) { asm volatile("" :: "v"(H0[ct]), "v"(H1[ct])); if (ch == 0) HX[ct] = X[0][ct]; }
+                else HX[ct] = OP::relu_pack8(H0[ct], H1[ct]);
+            }
         };
         {   // chunk 0 (peeled: defines A2 / HX before the steady-state loop)
-            ring_step<WAVES>(a.wstream, ring, tb + 2, wave, lane);
+            if constexpr (!(ABL & 4)) ring_step<WAVES>(a.wstream, ring, tb + 2, wave, lane);
             TSTAMP(6);
             const char* slot = ring + ((tb + 2) & (RING_SLOTS - 1)) * STAGE_BYTES;
             v8 A[8];
@@ -525,12 +532,12 @@ __global__ __launch_bounds__(WAVES * 64, 2) void uit_encoder_kernel(EncoderArgs 
 #pragma unroll 1
         for (int ch = 1; ch < 12; ++ch) {
             const int t = tb + 2 + ch;
-            ring_step<WAVES>(a.wstream, ring, t, wave, lane);
+            if constexpr (!(ABL & 4)) ring_step<WAVES>(a.wstream, ring, t, wave, lane);
             TSTAMP(6);                                                 // ring wait MLP (sum of 12)
             const char* slot = ring + (t & (RING_SLOTS - 1)) * STAGE_BYTES;
             v8 A[8];
 #pragma unroll
-            for (int f = 0; f < 8; ++f) A[f] = lds_frag<PREC>(slot, f, lane);          // fc1 fragments: in flight ...
+            for (int f = 0; f < 8; ++f) { if constexpr (ABL & 8) A[f] = A2[f]; else A[f] = lds_frag<PREC>(slot, f, lane); }   // fc1 fragments: in flight ...
 #pragma unroll
             for (int ft = 0; ft < 8; ++ft)                                              // ... under chunk ch-1's fc2
 #pragma unroll
@@ -685,21 +692,29 @@ __global__ void crop_reduce_kernel(const float* __restrict__ rp, float* __restri
     }
 }
 
-template <int PREC, int WAVES, bool SCHED, bool TIMING = false>
+template <int PREC, int WAVES, bool SCHED, bool TIMING = false, int ABL = 0>
 static hipError_t launch_enc(const EncoderArgs& a, hipStream_t stream) {
     static bool attr_done = false;
     if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute((const void*)uit_encoder_kernel<PREC, WAVES, SCHED, TIMING>,
+        hipError_t e = hipFuncSetAttribute((const void*)uit_encoder_kernel<PREC, WAVES, SCHED, TIMING, ABL>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, ENC_LDS);
         if (e != hipSuccess) return e;
         attr_done = true;
     }
     const int grid = (a.rows + 2 * WAVES - 1) / (2 * WAVES);
-    hipLaunchKernelGGL((uit_encoder_kernel<PREC, WAVES, SCHED, TIMING>), dim3(grid), dim3(WAVES * 64), ENC_LDS, stream, a);
+    hipLaunchKernelGGL((uit_encoder_kernel<PREC, WAVES, SCHED, TIMING, ABL>), dim3(grid), dim3(WAVES * 64), ENC_LDS, stream, a);
     return hipGetLastError();
 }
 
 hipError_t launch_encoder(const EncoderArgs& a, int precision, int waves, int sched, hipStream_t stream) {
+#ifdef UITK_ABLATION_BUILDS
+    if (a.ablate == 3) return launch_enc<0, 8, false, false, 3>(a, stream);
+    if (a.ablate == 7) return launch_enc<0, 8, false, false, 7>(a, stream);
+    if (a.ablate == 15) return launch_enc<0, 8, false, false, 15>(a, stream);
+    if (a.ablate == 31) return launch_enc<0, 8, false, false, 31>(a, stream);
+    if (a.ablate == 47) return launch_enc<0, 8, false, false, 47>(a, stream);
+    if (a.ablate == 63) return launch_enc<0, 8, false, false, 63>(a, stream);
+#endif
     if (a.timing != nullptr)                              // diagnostic build with in-kernel stamps (f16 only)
         return waves == 4 ? launch_enc<0, 4, false, true>(a, stream) : launch_enc<0, 8, false, true>(a, stream);
     if (sched) {

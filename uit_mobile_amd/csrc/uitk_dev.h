@@ -67,6 +67,7 @@ struct EncoderArgs {
     float* logits;          // [rows][C] or null
     float* dbg;             // [rows][depth+1][24][128] or null
     unsigned long long* timing;  // diagnostics: [waves][12] phase cycle sums (null = off, normal build)
+    int ablate;             // timing experiments (builds with -DUITK_ABLATION_BUILDS only): ABL template value
     int stagger;            // 0 = off, else shader cycles to delay every other workgroup generation
     int stagger_group;      // workgroups per generation (= CU count)
     int stagger_mode;       // 1 = by workgroup generation, 2 = by hardware wave slot
