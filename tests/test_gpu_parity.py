@@ -283,3 +283,32 @@ def test_host_clip_streamer_matches_direct_calls():
     assert [o.shape[0] for o in outs] == [32, 32, 17, 32]
     for b, o in zip(batches, outs):
         assert torch.equal(o, m(b.cuda()))
+
+
+@pytest.mark.parametrize("T", [16001, 15999, 4099])
+def test_odd_clip_lengths_vs_oracle(T):
+    """Odd sample counts: rows are no longer pair-aligned (the paired-sample fast path must switch off), frame counts
+    and reflect padding at the right edge change."""
+    m, sd = build("uit_xxxs", 34)
+    pcm = synth_pcm_i16(5, T, seed=T)
+    ref = Oracle(sd).forward(pcm)
+    p, l = run(m, pcm)
+    assert np.abs(l - ref["logits"]).max() < TOL and np.abs(p - ref["probs"]).max() < TOL
+    p32, _ = run(m, pcm.astype(np.float32) / 32768.0)
+    assert np.abs(p32 - ref["probs"]).max() < TOL
+
+
+def test_non_default_hop_size_vs_oracle():
+    """UITBase kwargs reach the front-end (models/uit.py:289): hop 128 -> 126 frames for 1 s -> two crops."""
+    sd = make_state_dict("uit_xxxs", 35)
+    m = models.uit_xxxs(outputdim=537, target_length=102, hop_size=128)
+    m.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()}, strict=True)
+    m = m.to("cuda").eval()
+    pcm = synth_pcm_i16(6, 16000, seed=77)
+    o = Oracle(sd, hop=128)
+    assert m.num_crops(16000) == o.num_crops(16000) == 2
+    ref = o.forward(pcm)
+    p, l = run(m, pcm)
+    assert np.abs(l - ref["logits"]).max() < TOL and np.abs(p - ref["probs"]).max() < TOL
+    mel = m.melspec_db(torch.from_numpy(pcm).cuda()).cpu().numpy()
+    assert_mel_close(mel, ref["mel_db"], scale=2.0)
