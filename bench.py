@@ -7,7 +7,7 @@
 
 A "step" = one pass of the whole path over one batch of synthetic 16 kHz x 1 s clips already resident in HBM:
 uitk_frontend -> (N>1: 256-byte MAX all-reduce of the batch amax) -> uitk_encode -> (N>1: RCCL all-gather of the
-[B/N,537] outputs).  Workload = BASELINE.json configs[2]: UiT-XS, 8192 clips per GPU (weak scaling: 65536 at N=8 =
+[B/N,537] outputs, asynchronous: it overlaps the next step's kernels; all gathers complete inside the timed region).  Workload = BASELINE.json configs[2]: UiT-XS, 8192 clips per GPU (weak scaling: 65536 at N=8 =
 configs[3]).  Prints ONE JSON line (rank 0).  The CPU baseline (oracle/torch_port.py, never the thing measured on
 the GPU) is timed on rank 0 at N=1 only, on a bounded sample.
 """
@@ -29,7 +29,7 @@ import torch.distributed as dist  # noqa: E402
 
 from synth_weights import make_state_dict  # noqa: E402
 from uit_mobile_amd import models  # noqa: E402
-from uit_mobile_amd.sharded import amax_allreduce, gather_outputs  # noqa: E402
+from uit_mobile_amd.sharded import amax_allreduce, gather_outputs_async  # noqa: E402
 
 GEMM_FLOP = {"uit_xs": 68.66e6, "uit_xxs": 35.18e6, "uit_xxxs": 24.03e6}   # BASELINE.md section 3, per clip
 FRONTEND_VALU_FLOP = 4.56e6                                                 # dense-mel count, BASELINE.md section 3
@@ -131,6 +131,8 @@ def main():
     n_ev = args.warmup + args.steps
     evs = [[torch.cuda.Event(enable_timing=True) for _ in range(3)] for _ in range(n_ev)]
     cur = [0]
+    import collections
+    pending = collections.deque()
 
     def sync_hook(slots):
         evs[cur[0]][1].record()
@@ -142,8 +144,16 @@ def main():
         e[0].record()
         probs = m(x, amax_sync=sync_hook)
         e[2].record()
-        out = gather_outputs(probs)
+        # asynchronous RCCL all-gather: step n's gather overlaps step n+1's kernels; at most 2 in flight
+        pending.append(gather_outputs_async(probs))
+        out = pending.popleft().wait() if len(pending) > 2 else None
         cur[0] += 1
+        return out
+
+    def drain():
+        out = None
+        while pending:
+            out = pending.popleft().wait()
         return out
 
     def barrier():
@@ -153,12 +163,14 @@ def main():
 
     with torch.no_grad():
         for _ in range(args.warmup):
-            out = step(False)
+            step(False)
+        drain()
         barrier()
         t0 = time.perf_counter()
         for _ in range(args.steps):
-            out = step(True)
-        barrier()
+            step(True)
+        out = drain()                                      # every gather of the timed steps has completed ...
+        barrier()                                          # ... on every rank, inside the timed region
         el = time.perf_counter() - t0
     # per-kernel durations of the K timed steps, read after the closing synchronize
     fe_ms = [e[0].elapsed_time(e[1]) for e in evs[args.warmup:]]

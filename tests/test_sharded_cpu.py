@@ -8,7 +8,7 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
-from uit_mobile_amd.sharded import ShardedUiT, amax_allreduce, gather_outputs, shard_range
+from uit_mobile_amd.sharded import ShardedUiT, amax_allreduce, gather_outputs, gather_outputs_async, shard_range
 
 
 def test_shard_range():
@@ -44,6 +44,12 @@ def _worker(rank, world, port, q):
         ok = out.shape == (B, C) and torch.equal(out, expect)
         g = gather_outputs(torch.full((2, 3), float(rank)))
         ok = ok and torch.equal(g, torch.tensor([[0.] * 3] * 2 + [[1.] * 3] * 2))
+        # asynchronous gathers: several in flight, waited out of band (what bench.py does to overlap with compute)
+        hs = [gather_outputs_async(torch.full((2, 2), float(10 * i + rank))) for i in range(3)]
+        hs.append(ShardedUiT(fake_model)(full[lo:hi], async_gather=True))
+        for i, h in enumerate(hs[:3]):
+            ok = ok and torch.equal(h.wait(), torch.tensor([[10. * i] * 2] * 2 + [[10. * i + 1] * 2] * 2))
+        ok = ok and torch.equal(hs[3].wait(), expect)
         q.put((rank, bool(ok)))
     finally:
         dist.destroy_process_group()

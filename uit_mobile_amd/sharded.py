@@ -41,13 +41,41 @@ def gather_outputs(local, group=None):
     return out
 
 
+class GatherHandle:
+    """Result of an asynchronous all-gather: `.wait()` makes the current stream wait for it and returns [B, C]."""
+
+    def __init__(self, work, out, keep):
+        self.work, self.out, self._keep = work, out, keep      # `keep` pins the send buffer until completion
+
+    def wait(self):
+        if self.work is not None:
+            self.work.wait()
+            self.work = None
+        return self.out
+
+
+def gather_outputs_async(local, group=None):
+    """Like gather_outputs, but returns immediately with a GatherHandle: the collective runs on RCCL's own stream, so
+    the kernels of the NEXT batch (enqueued on the caller's stream) overlap with it.  At 8 ranks x 8192 clips the
+    gather moves 141 MB per step -- about half a compute step if it were serialised."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return GatherHandle(None, local, None)
+    world = dist.get_world_size(group)
+    local = local.contiguous()
+    out = torch.empty((world * local.shape[0],) + tuple(local.shape[1:]), device=local.device, dtype=local.dtype)
+    work = dist.all_gather_into_tensor(out, local, group=group, async_op=True)
+    return GatherHandle(work, out, local)
+
+
 class ShardedUiT:
     """model: any callable `model(x, amax_sync=fn) -> probs` (uit_mobile_amd.models.UITBase on a HIP device)."""
 
     def __init__(self, model, group=None, global_floor=True):
         self.model, self.group, self.global_floor = model, group, global_floor
 
-    def __call__(self, local_x):
+    def __call__(self, local_x, async_gather=False):
         sync = (lambda slots: amax_allreduce(slots, self.group)) if self.global_floor else None
         probs = self.model(local_x, amax_sync=sync)
+        if async_gather:
+            return gather_outputs_async(probs, self.group)      # -> GatherHandle, overlap with the next batch
         return gather_outputs(probs, self.group)
