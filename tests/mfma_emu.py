@@ -82,8 +82,8 @@ class EncoderEmu:
         off = self.h["off_wstream"] + stage * STAGE + f * FRAG
         return to_f32(np.frombuffer(self.img, np.uint16, 512, off).reshape(64, 8), self.prec)
 
-    def head_frag(self, ot, s):
-        off = self.h["off_head_w"] + (ot * 4 + s) * FRAG
+    def head_frag(self, ot, s, term=0):
+        off = self.h["off_head_w"] + ((ot * 4 + s) * 2 + term) * FRAG
         return to_f32(np.frombuffer(self.img, np.uint16, 512, off).reshape(64, 8), self.prec)
 
     def pack8(self, lo, hi):
@@ -238,24 +238,30 @@ class EncoderEmu:
         var = sum(((zz - mean[:, None]) ** 2).sum(1) for zz in z).reshape(4, 16).sum(0)[C_] / 128.0
         rstd = 1.0 / np.sqrt(var + 1e-5)
         zbuf = np.zeros((16, 128), np.float32)
+        zbuf_lo = np.zeros((16, 128), np.float32)
         for ft in range(8):
             zn = (z[ft] - mean[:, None]) * rstd[:, None] * fin[2][16 * ft + 4 * G_[:, None] + r4] + fin[3][16 * ft + 4 * G_[:, None] + r4]
-            zn = self.pack4(zn)
+            zh = self.pack4(zn)
+            zl = self.pack4(zn - zh)
             for ln in LANES[(C_ & 7) == 0]:
-                zbuf[int(C_[ln] >= 8), 16 * ft + 4 * G_[ln] + np.arange(4)] = zn[ln]
-        # head: clip slot = column
+                zbuf[int(C_[ln] >= 8), 16 * ft + 4 * G_[ln] + np.arange(4)] = zh[ln]
+                zbuf_lo[int(C_[ln] >= 8), 16 * ft + 4 * G_[ln] + np.arange(4)] = zl[ln]
+        # head on split operands: (Wh + Wl).(zh + zl) ~ Wh.zh + Wh.zl + Wl.zh; clip slot = column
         ntiles = (self.C + 15) // 16
         head_b = self._f32(h["off_head_b"], ntiles * 16)
         logits = np.zeros((2, self.C), np.float32)
-        Bz = []
+        Bz, Bzl = [], []
         for s in range(4):
-            lo4 = zbuf[C_[:, None], 32 * s + 4 * G_[:, None] + r4]
-            hi4 = zbuf[C_[:, None], 32 * s + 16 + 4 * G_[:, None] + r4]
-            Bz.append(np.concatenate([lo4, hi4], 1))
+            for buf, dst in ((zbuf, Bz), (zbuf_lo, Bzl)):
+                lo4 = buf[C_[:, None], 32 * s + 4 * G_[:, None] + r4]
+                hi4 = buf[C_[:, None], 32 * s + 16 + 4 * G_[:, None] + r4]
+                dst.append(np.concatenate([lo4, hi4], 1))
         for ot in range(ntiles):
             acc = head_b[16 * ot + 4 * G_[:, None] + r4].copy()
             for s in range(4):
-                acc = mfma32(self.head_frag(ot, s), Bz[s], acc)
+                acc = mfma32(self.head_frag(ot, s, 1), Bz[s], acc)
+                acc = mfma32(self.head_frag(ot, s, 0), Bzl[s], acc)
+                acc = mfma32(self.head_frag(ot, s, 0), Bz[s], acc)
             for ln in LANES[C_ < 2]:
                 for r in range(4):
                     cls = 16 * ot + 4 * G_[ln] + r

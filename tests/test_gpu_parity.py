@@ -4,8 +4,8 @@ CPU oracle on seeded inputs.
 
 Tolerance (BASELINE.json north_star): outputs within 1e-3 abs of the reference PyTorch CPU path -- asserted on both
 the probabilities the reference returns and the pre-sigmoid logits, for the default precision (fp16 MFMA operands,
-fp32 accumulate).  The bf16-operand mode has ~8x the operand rounding and is held to 1e-3 on probabilities and
-1e-2 on logits (measured 3e-3); it is not the parity default.
+fp32 accumulate; the classifier head runs on split hi+lo operands).  The bf16-operand mode has ~8x the operand rounding
+and is held to 1e-3 on probabilities and 3e-3 on logits (measured 1.2e-3); it is not the parity default.
 """
 import os
 
@@ -113,24 +113,26 @@ def test_golden_527_classes_and_pos_resize(golden):
 
 
 def test_scaled_weights_precision_modes(golden):
-    """x3 weights (trained-like magnitudes): logits span +-2.5.  fp16 operands: probs within 1e-3 (logits 3e-3);
-    bf16 operands are the measured-fast mode: probs within 5e-3."""
+    """x3 weights (trained-like magnitudes): logits span +-2.5.  fp16 operands with the split-operand classifier head
+    stay within 1e-3 on logits AND probabilities (measured 7.1e-4 / 1.6e-4); bf16 operands are the measured-fast mode:
+    probabilities within 2e-3 (measured 1.2e-3), logits within 8e-3 (measured 4.8e-3)."""
     g = golden("synth1s_uit_xs_scale3")
     m, _ = build("uit_xs", g["seed"], g["scale"])
     p, l = run(m, g["pcm"])
     assert np.abs(p - g["probs"]).max() < TOL
-    assert np.abs(l - g["logits"]).max() < 3e-3
+    assert np.abs(l - g["logits"]).max() < TOL
     m, _ = build("uit_xs", g["seed"], g["scale"], prec="bf16")
     p, l = run(m, g["pcm"])
-    assert np.abs(p - g["probs"]).max() < 5e-3
+    assert np.abs(p - g["probs"]).max() < 2e-3
+    assert np.abs(l - g["logits"]).max() < 8e-3
 
 
 def test_bf16_mode_init_scale(golden):
     g = golden("synth1s_uit_xs")
     m, _ = build("uit_xs", g["seed"], prec="bf16")
     p, l = run(m, g["pcm"])
-    assert np.abs(p - g["probs"]).max() < 2e-3
-    assert np.abs(l - g["logits"]).max() < 1e-2
+    assert np.abs(p - g["probs"]).max() < TOL          # measured 3.1e-4
+    assert np.abs(l - g["logits"]).max() < 3e-3        # measured 1.2e-3
 
 
 @pytest.mark.parametrize("B", [1, 2, 3, 15, 16, 17, 33])

@@ -61,6 +61,7 @@ template <> struct Op<0> {   // fp16 operands
         return __builtin_elementwise_max(pack8(lo, hi), z);
     }
     static __device__ __forceinline__ v4 ones4() { return v4{(_Float16)1.f, (_Float16)1.f, (_Float16)1.f, (_Float16)1.f}; }
+    static __device__ __forceinline__ f4 unpack4(v4 x) { return f4{(float)x[0], (float)x[1], (float)x[2], (float)x[3]}; }
     static __device__ __forceinline__ v8 max8(v8 y, v8 t) { return __builtin_elementwise_max(y, t); }
     static __device__ __forceinline__ v8 min8(v8 y, v8 t) { return __builtin_elementwise_min(y, t); }
     static __device__ __forceinline__ v8 from_f32x8(f4 lo, f4 hi) { return pack8(lo, hi); }
@@ -89,6 +90,7 @@ template <> struct Op<1> {   // bf16 operands
         return __builtin_bit_cast(v8, __builtin_elementwise_max(__builtin_bit_cast(s8, pack8(lo, hi)), z));
     }
     static __device__ __forceinline__ v4 ones4() { return v4{(__bf16)1.f, (__bf16)1.f, (__bf16)1.f, (__bf16)1.f}; }
+    static __device__ __forceinline__ f4 unpack4(v4 x) { return f4{(float)x[0], (float)x[1], (float)x[2], (float)x[3]}; }
     static __device__ __forceinline__ v8 max8(v8 y, v8 t) {
         v8 r;
 #pragma unroll
@@ -109,7 +111,7 @@ constexpr int RING_SLOTS = 4;           // >= PREFETCH + 2 (see ring_step)
 constexpr int PREFETCH = 2;             // stages in flight ahead of the one being consumed
 constexpr int LDS_RING = RING_SLOTS * STAGE_BYTES;            // 64 KiB
 constexpr int LDS_BIAS = 2 * BIAS_FLOATS * 4;                 // 8 KiB (double-buffered per block)
-constexpr int LDS_ZBUF = 16 * DIM * 2;                        // 4 KiB: up to 16 pooled vectors, 16-bit
+constexpr int LDS_ZBUF = 2 * 16 * DIM * 2;                    // 8 KiB: up to 16 pooled vectors, 16-bit hi + lo terms
 constexpr int ENC_LDS = LDS_RING + LDS_BIAS + LDS_ZBUF;
 
 #define GPTR(p) ((const __attribute__((address_space(1))) void*)(p))
@@ -572,7 +574,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void uit_encoder_kernel(EncoderArgs 
     for (int i = 0; i < HEAD_PRE; ++i)
         if (wave + i * WAVES < ntiles) {
 #pragma unroll
-            for (int s = 0; s < 4; ++s) Hpre[i][s] = *(const v8*)(a.head_w + (size_t)((wave + i * WAVES) * 4 + s) * FRAG_BYTES + lane * 16);
+            for (int s = 0; s < 4; ++s) Hpre[i][s] = *(const v8*)(a.head_w + (size_t)((wave + i * WAVES) * 4 + s) * 2 * FRAG_BYTES + lane * 16);
         }
 
     // ---- final norm (eps 1e-6) -> masked mean over tokens -> head LayerNorm (eps 1e-5)
@@ -626,7 +628,11 @@ __global__ __launch_bounds__(WAVES * 64, 2) void uit_encoder_kernel(EncoderArgs 
             const f4 gw = *(const f4*)(a.fin + 2 * DIM + 16 * ft + 4 * g);
             const f4 gb = *(const f4*)(a.fin + 3 * DIM + 16 * ft + 4 * g);
             const f4 z = (pooled[ft] - splat(mean)) * splat(rstd) * gw + gb;
-            if ((c & 7) == 0) *(v4*)(zbuf + (slot_clip * DIM + 16 * ft + 4 * g) * 2) = OP::pack4(z);
+            if ((c & 7) == 0) {                           // split operand: z = hi + lo (two 16-bit terms)
+                const v4 zh = OP::pack4(z);
+                *(v4*)(zbuf + (slot_clip * DIM + 16 * ft + 4 * g) * 2) = zh;
+                *(v4*)(zbuf + 16 * DIM * 2 + (slot_clip * DIM + 16 * ft + 4 * g) * 2) = OP::pack4(z - OP::unpack4(zh));
+            }
         }
     }
     __syncthreads();
@@ -634,18 +640,27 @@ __global__ __launch_bounds__(WAVES * 64, 2) void uit_encoder_kernel(EncoderArgs 
     // ---- classifier head once per workgroup: logits^T[class][clip slot] = Whead . z^T
     {
         const int cz = c < 2 * WAVES ? c : 0;             // columns beyond the workgroup's clips: any valid data
-        v8 Bz[4];
+        v8 Bz[4], Bzl[4];
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
             const v4 lo = *(const v4*)(zbuf + (cz * DIM + 32 * s + 4 * g) * 2);
             const v4 hi = *(const v4*)(zbuf + (cz * DIM + 32 * s + 16 + 4 * g) * 2);
             Bz[s] = v8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+            const v4 llo = *(const v4*)(zbuf + 16 * DIM * 2 + (cz * DIM + 32 * s + 4 * g) * 2);
+            const v4 lhi = *(const v4*)(zbuf + 16 * DIM * 2 + (cz * DIM + 32 * s + 16 + 4 * g) * 2);
+            Bzl[s] = v8{llo[0], llo[1], llo[2], llo[3], lhi[0], lhi[1], lhi[2], lhi[3]};
         }
         const int rowg = blockIdx.x * WAVES * 2 + c;
+        // logits = (Wh + Wl).(zh + zl) ~ Wh.zh + Wh.zl + Wl.zh : three MFMAs per k-step, fp32 accumulate
         auto head_tile = [&](int ot, const v8 (&Hc)[4]) {
             f4 acc = *(const f4*)(a.head_b + 16 * ot + 4 * g);
 #pragma unroll
-            for (int s = 0; s < 4; ++s) acc = OP::mfma32(Hc[s], Bz[s], acc);
+            for (int s = 0; s < 4; ++s) {
+                const v8 Hl = *(const v8*)(a.head_w + ((size_t)(ot * 4 + s) * 2 + 1) * FRAG_BYTES + lane * 16);
+                acc = OP::mfma32(Hl, Bz[s], acc);
+                acc = OP::mfma32(Hc[s], Bzl[s], acc);
+                acc = OP::mfma32(Hc[s], Bz[s], acc);
+            }
             if (c < 2 * WAVES && rowg < a.rows) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
@@ -663,7 +678,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void uit_encoder_kernel(EncoderArgs 
         for (int ot = wave + HEAD_PRE * WAVES; ot < ntiles; ot += WAVES) {       // very wide heads: plain loop
             v8 Hc[4];
 #pragma unroll
-            for (int s = 0; s < 4; ++s) Hc[s] = *(const v8*)(a.head_w + (size_t)(ot * 4 + s) * FRAG_BYTES + lane * 16);
+            for (int s = 0; s < 4; ++s) Hc[s] = *(const v8*)(a.head_w + (size_t)(ot * 4 + s) * 2 * FRAG_BYTES + lane * 16);
             head_tile(ot, Hc);
         }
     }

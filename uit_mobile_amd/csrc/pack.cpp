@@ -106,7 +106,7 @@ int pack_image(const uitk_config* c, const uitk_weights* w, std::vector<char>* o
     h.off_bn_sc = take(NMEL * 4); h.off_bn_sh = take(NMEL * 4);
     h.off_pe_bias = take(NTOK * DIM * 4);
     h.off_fin = take(4 * DIM * 4);
-    h.off_head_w = take((size_t)ntiles * 4 * FRAG_BYTES);
+    h.off_head_w = take((size_t)ntiles * 4 * 2 * FRAG_BYTES);         // hi + lo term per fragment
     h.off_head_b = take((size_t)ntiles * 16 * 4);
     h.off_window = take(512 * 4);
     h.off_tw256 = take(256 * 8);
@@ -210,8 +210,20 @@ int pack_image(const uitk_config* c, const uitk_weights* w, std::vector<char>* o
     // ---- head
     uint16_t* hw = (uint16_t*)(img + h.off_head_w);
     auto Whead = [&](int r, int k) { return r < C ? (double)w->head_w[r * DIM + k] : 0.0; };
+    // The classifier is the most rounding-sensitive GEMM of the path (it alone caused ~3/4 of the fp16 logit error),
+    // and it is tiny: it runs on split operands, W = hi + lo (two 16-bit terms), layout [ot][s][hi|lo].
+    auto op_to_double = [&](uint16_t u) -> double {
+        if (prec == UITK_PREC_BF16) { uint32_t x = (uint32_t)u << 16; float f; std::memcpy(&f, &x, 4); return f; }
+        const uint32_t sign = (u >> 15) & 1u, e = (u >> 10) & 31u, m = u & 1023u;
+        double v = e == 0 ? std::ldexp((double)m, -24) : std::ldexp((double)(m | 1024u), (int)e - 25);
+        return sign ? -v : v;
+    };
+    auto Whead_lo = [&](int r, int k) { const double w = Whead(r, k); return w - op_to_double(cvt(w, prec)); };
     for (int ot = 0; ot < ntiles; ++ot)
-        for (int s = 0; s < 4; ++s) pack_frag(hw + ((size_t)ot * 4 + s) * (FRAG_BYTES / 2), prec, Whead, ot, s);
+        for (int s = 0; s < 4; ++s) {
+            pack_frag(hw + ((size_t)(ot * 4 + s) * 2 + 0) * (FRAG_BYTES / 2), prec, Whead, ot, s);
+            pack_frag(hw + ((size_t)(ot * 4 + s) * 2 + 1) * (FRAG_BYTES / 2), prec, Whead_lo, ot, s);
+        }
     float* hb = (float*)(img + h.off_head_b);
     for (int r = 0; r < C; ++r) hb[r] = w->head_b[r];
     if (hdr_out) *hdr_out = h;
