@@ -141,3 +141,16 @@ def test_kws_output_transform_matches_reference_loop():
         a, ya = output_transform_kws(y_pred, y, thr)
         b, yb = _kws_loop_restatement(y_pred, y, thr)
         assert torch.equal(a, b) and torch.equal(ya, yb)
+
+
+def test_load_pretrained_filters_by_shape_and_resizes_pos_embed():
+    from uit_mobile_amd.evaluate import load_pretrained
+    m = models.uit_xxxs(outputdim=527, target_length=102)          # evaluate.py default num_classes = 527
+    ck = {k: torch.from_numpy(np.asarray(v)) for k, v in make_state_dict("uit_xxxs", 5, outputdim=537, target_length=160).items()}
+    before = m.outputlayer[1].weight.clone()
+    load_pretrained(m, {"model": ck})
+    assert torch.equal(m.outputlayer[1].weight, before)            # [537,128] does not fit [527,128]: skipped
+    assert torch.equal(m.blocks[2].mlp.fc1.weight, ck["blocks.2.mlp.fc1.weight"])
+    assert torch.equal(m.time_pos_embed, ck["time_pos_embed"][..., :6])   # 10 -> 6 entries
+    with pytest.raises(AssertionError):
+        load_pretrained(m, {"unrelated": torch.zeros(1)})

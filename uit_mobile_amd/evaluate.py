@@ -39,6 +39,23 @@ def sequential_pad(waves, padding_value=0.0):
     return out, torch.as_tensor(lengths)
 
 
+def load_pretrained(model, trained_model):
+    """Counterpart of utils.load_pretrained (utils.py:184-205, called at evaluate.py:37): keep only the checkpoint
+    entries whose key AND shape match the model, always take the positional embeddings (the model's load_state_dict
+    resizes them, uit.py:416-450), then load strictly."""
+    if 'model' in trained_model:
+        trained_model = trained_model['model']
+    model_dict = model.state_dict()
+    pretrained = {k: v for k, v in trained_model.items() if k in model_dict and model_dict[k].shape == v.shape}
+    assert len(pretrained) > 0, "Couldnt load pretrained model"
+    if 'time_pos_embed' in trained_model:
+        pretrained['time_pos_embed'] = trained_model['time_pos_embed']
+        pretrained['freq_pos_embed'] = trained_model['freq_pos_embed']
+    model_dict.update(pretrained)
+    model.load_state_dict(model_dict, strict=True)
+    return model
+
+
 def output_transform_kws(y_pred, y, threshold=0.2, num_fillers=527):
     """Vectorised, device-side version of `_output_transform_xiaoai` (evaluate.py:212-229): keep only the maximal
     AudioSet ("filler") score, map filler targets to it, and zero it whenever any keyword score reaches the threshold
