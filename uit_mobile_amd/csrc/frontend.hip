@@ -95,6 +95,7 @@ __device__ __forceinline__ float load_sample(const void* pcm, int64_t row_off, i
 // 16-bit operand conversions (round-to-nearest-even, identical to the encoder's v_cvt_pk_*)
 __device__ __forceinline__ unsigned short to_op16(float x, int bf16) {
     if (bf16) { __bf16 h = (__bf16)x; return __builtin_bit_cast(unsigned short, h); }
+    x = __builtin_amdgcn_fmed3f(x, -65504.0f, 65504.0f);    // degenerate init_bn statistics must not overflow fp16 to inf
     _Float16 h = (_Float16)x; return __builtin_bit_cast(unsigned short, h);
 }
 
