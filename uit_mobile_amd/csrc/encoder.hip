@@ -164,6 +164,14 @@ __device__ __forceinline__ typename Op<PREC>::v8 lds_frag(const char* slot, int 
 }
 
 __device__ __forceinline__ f4 splat(float x) { return f4{x, x, x, x}; }
+// a + b as four scalar v_add_f32: beside MFMAs a v_pk_add_f32 pair costs more issue time than the scalar adds it replaces
+__device__ __forceinline__ f4 add4s(f4 a, f4 b) {
+#ifdef UITK_PK_BIAS
+    return a + b;
+#else
+    return f4{a[0] + b[0], a[1] + b[1], a[2] + b[2], a[3] + b[3]};
+#endif
+}
 __device__ __forceinline__ float hsum(f4 x) { return (x[0] + x[1]) + (x[2] + x[3]); }
 __device__ __forceinline__ float hmax(f4 x) { return fmaxf(fmaxf(x[0], x[1]), fmaxf(x[2], x[3])); }
 
@@ -192,8 +200,11 @@ __device__ __forceinline__ float dpp_mov(float v) {
     return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, true));
 }
 
-// LayerNorm statistics (two-pass, fp32) of one token column held as R[ft][ct], ft = 0..7.
+// LayerNorm statistics (fp32) of one token column held as R[ft][ct], ft = 0..7.  One pass: var = E[x^2] - mean^2; the
+// cancellation error is ~6e-8 * E[x^2], harmless while |mean| is not orders of magnitude above the deviation (residual
+// streams are not); it saves the 32 subtractions per column tile of the two-pass form (UITK_LN_TWO_PASS restores it).
 __device__ __forceinline__ void ln_stats(const f4 (&R)[8][3], int ct, float eps, float& mean, float& rstd) {
+#ifdef UITK_LN_TWO_PASS
     f4 acc = R[0][ct];
 #pragma unroll
     for (int ft = 1; ft < 8; ++ft) acc = acc + R[ft][ct];
@@ -202,6 +213,14 @@ __device__ __forceinline__ void ln_stats(const f4 (&R)[8][3], int ct, float eps,
 #pragma unroll
     for (int ft = 0; ft < 8; ++ft) { const f4 d = R[ft][ct] - splat(mean); q = q + d * d; }
     rstd = __builtin_amdgcn_rsqf(xsum(hsum(q)) * (1.0f / DIM) + eps);
+#else
+    f4 acc = R[0][ct], q = R[0][ct] * R[0][ct];
+#pragma unroll
+    for (int ft = 1; ft < 8; ++ft) { acc = acc + R[ft][ct]; q = __builtin_elementwise_fma(R[ft][ct], R[ft][ct], q); }
+    mean = xsum(hsum(acc)) * (1.0f / DIM);
+    const float ex2 = xsum(hsum(q)) * (1.0f / DIM);
+    rstd = __builtin_amdgcn_rsqf(fmaxf(__builtin_fmaf(-mean, mean, ex2), 0.f) + eps);
+#endif
 }
 
 // LN + conversion to the MFMA operand of the next linear (its affine is folded into that linear by pack.cpp).
@@ -484,7 +503,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void uit_encoder_kernel(EncoderArgs 
             for (int ft = 0; ft < 8; ++ft) {
                 const f4 bp = *(const f4*)(bias + BIAS_PROJ + 16 * ft + 4 * g);
 #pragma unroll
-                for (int ct = 0; ct < 3; ++ct) R[ft][ct] = OP::mfma32(A[ft], OX[ct], R[ft][ct] + bp);
+                for (int ct = 0; ct < 3; ++ct) R[ft][ct] = OP::mfma32(A[ft], OX[ct], add4s(R[ft][ct], bp));
             }
         }
 
@@ -556,7 +575,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void uit_encoder_kernel(EncoderArgs 
         for (int ft = 0; ft < 8; ++ft) {
             const f4 b2 = *(const f4*)(bias + BIAS_FC2 + 16 * ft + 4 * g);
 #pragma unroll
-            for (int ct = 0; ct < 3; ++ct) R[ft][ct] = R[ft][ct] + b2;
+            for (int ct = 0; ct < 3; ++ct) R[ft][ct] = add4s(R[ft][ct], b2);
         }
         if (a.dbg != nullptr) {
             dbg_store(blk + 1);
