@@ -156,6 +156,21 @@ int uitk_set_debug_tokens(uitk_model* m, float* dev_buf);
  * time the product).  NULL (default) = normal kernels. */
 int uitk_set_timing_buffers(uitk_model* m, unsigned long long* enc_buf, unsigned long long* fe_buf);
 
+/* ---- Step after the path: post-processing of the probability rows on the device, so that only
+ * k winners (or class indices) cross PCIe instead of [B, outputdim].  Stateless: no model handle.  C <= 1024.
+ *
+ * uitk_topk: values[B,k], indices[B,k] = probs[b].topk(k), descending, ties by lower index.
+ * Stands in for output.topk(args.topk) (inference.py:57) and pred.topk (evaluate.py:263). */
+int uitk_topk(const float* probs, int64_t B, int32_t C, int32_t k, float* values, int32_t* indices, void* stream);
+
+/* uitk_kws_transform: Accuracy@threshold output transform of the keyword-spotting evaluation, in place on
+ * y_pred[B,C]: keep only the maximal score among the first num_fillers (AudioSet) classes, and clear it too when any
+ * keyword class (>= num_fillers) reaches the threshold; y_index[B] = argmax of the target row y[B,C] with filler targets
+ * mapped to the predicted filler (y / y_index may both be NULL).
+ * Stands in for the per-sample Python loop _output_transform_xiaoai (evaluate.py:212-229). */
+int uitk_kws_transform(float* y_pred, const float* y, int64_t B, int32_t C, int32_t num_fillers, float threshold,
+                       int64_t* y_index, void* stream);
+
 /* Last error message of the calling thread ("" if none). */
 const char* uitk_last_error(void);
 const char* uitk_version(void);

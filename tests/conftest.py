@@ -38,3 +38,22 @@ def assert_mel_close(got, want, scale=1.0):
         m = (depth >= lo) & (depth < hi)
         if m.any():
             assert d[m].max() < tol * scale, f"dB diff {d[m].max()} for bins {lo}..{hi} dB below peak"
+
+
+def kws_loop_restatement(y_pred, y, threshold, num_fillers=527):
+    """Loop restatement of the reference's _output_transform_xiaoai (evaluate.py:212-229) on host tensors -- the checker
+    for uit_mobile_amd.evaluate.output_transform_kws and the uitk_kws_transform kernel (test infrastructure)."""
+    import torch
+    y_pred = y_pred.clone()
+    mask = torch.ones_like(y_pred)
+    mask[:, :num_fillers] = (y_pred[:, :num_fillers] == y_pred[:, :num_fillers].max(dim=1, keepdim=True)[0]).to(torch.int32)
+    y_pred = y_pred * mask
+    _, yy = y.max(dim=-1)
+    for i, scores in enumerate(y_pred):
+        idx = scores[0:num_fillers].max(dim=-1)[1]
+        if yy[i] < num_fillers:
+            yy[i] = idx
+        for score in scores[num_fillers:]:
+            if score >= threshold:
+                y_pred[i][idx] = 0.0
+    return y_pred, yy

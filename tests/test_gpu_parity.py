@@ -314,3 +314,46 @@ def test_non_default_hop_size_vs_oracle():
     assert np.abs(l - ref["logits"]).max() < TOL and np.abs(p - ref["probs"]).max() < TOL
     mel = m.melspec_db(torch.from_numpy(pcm).cuda()).cpu().numpy()
     assert_mel_close(mel, ref["mel_db"], scale=2.0)
+
+
+def test_device_topk_matches_host_topk():
+    """uitk_topk (inference.py:57 `output.topk(k)` on the device): values bit-equal, indices equal; ties -> lower index."""
+    from uit_mobile_amd.postprocess import topk
+    g = torch.Generator().manual_seed(3)
+    for B, C, k in ((1, 537, 3), (37, 537, 5), (8, 527, 10), (5, 64, 64), (3, 1000, 7), (4097, 537, 1)):
+        p = torch.rand(B, C, generator=g)
+        vals, idx = topk(p.cuda(), k)
+        wv, wi = p.topk(k)
+        assert vals.dtype == torch.float32 and idx.dtype == torch.int64
+        assert torch.equal(vals.cpu(), wv) and torch.equal(idx.cpu(), wi)
+    p = torch.zeros(2, 537)
+    p[0, [400, 7, 300]] = 0.5                                  # three-way tie
+    p[1, :] = 0.25
+    vals, idx = topk(p.cuda(), 4)
+    assert idx.cpu().tolist() == [[7, 300, 400, 0], [0, 1, 2, 3]]
+    assert vals.cpu().tolist() == [[0.5, 0.5, 0.5, 0.0], [0.25] * 4]
+    v1, i1 = topk(torch.rand(537, generator=g).cuda(), 3)      # 1-D row, as inference.py passes it
+    assert v1.shape == (3,) and i1.shape == (3,)
+    with pytest.raises(ValueError):
+        topk(p.cuda(), 538)                                    # k > C: torch raises too
+    with pytest.raises(RuntimeError):
+        topk(p, 3)                                             # host tensor: no CPU path
+
+
+def test_device_kws_transform_matches_reference_loop():
+    """uitk_kws_transform vs the loop restatement of _output_transform_xiaoai (evaluate.py:212-229): bit-exact."""
+    from conftest import kws_loop_restatement
+    from uit_mobile_amd.evaluate import output_transform_kws
+    g = torch.Generator().manual_seed(0)
+    for B, C in ((64, 537), (3, 527), (1000, 537), (5, 600)):
+        y_pred = torch.rand(B, C, generator=g)
+        y_pred[::3, 527:] *= 0.1                               # rows without a firing keyword
+        y_pred[1, :527] = 0.0                                  # all-equal fillers
+        if B > 4:
+            y_pred[4, [10, 200]] = 0.999                       # tied maximal fillers: both kept, the first one cleared
+        y = torch.zeros(B, C)
+        y[torch.arange(B), torch.randint(0, C, (B,), generator=g)] = 1.0
+        for thr in (0.2, 0.5):
+            a, ya = output_transform_kws(y_pred.cuda(), y.cuda(), thr)
+            b, yb = kws_loop_restatement(y_pred, y, thr)
+            assert torch.equal(a.cpu(), b) and torch.equal(ya.cpu(), yb)

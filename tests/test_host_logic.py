@@ -113,21 +113,7 @@ def test_label_lookup_and_topk_format():
     assert lines[1].startswith("Keyword: on") and lines[1].endswith("0.9999")
 
 
-def _kws_loop_restatement(y_pred, y, threshold):
-    """Loop restatement of the reference's _output_transform_xiaoai (evaluate.py:212-229) -- the checker."""
-    y_pred = y_pred.clone()
-    mask = torch.ones_like(y_pred)
-    mask[:, :527] = (y_pred[:, :527] == y_pred[:, :527].max(dim=1, keepdim=True)[0]).to(torch.int32)
-    y_pred = y_pred * mask
-    _, yy = y.max(dim=-1)
-    for i, scores in enumerate(y_pred):
-        idx = scores[0:527].max(dim=-1)[1]
-        if yy[i] < 527:
-            yy[i] = idx
-        for score in scores[527:]:
-            if score >= threshold:
-                y_pred[i][idx] = 0.0
-    return y_pred, yy
+from conftest import kws_loop_restatement as _kws_loop_restatement  # noqa: E402
 
 
 def test_kws_output_transform_matches_reference_loop():

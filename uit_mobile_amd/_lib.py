@@ -18,7 +18,8 @@ AMAX_SLOTS = 64
 
 EXPORTS = ["uitk_create", "uitk_destroy", "uitk_pack_weights", "uitk_num_frames", "uitk_num_crops",
            "uitk_reserve", "uitk_forward", "uitk_frontend", "uitk_amax_ptr", "uitk_encode", "uitk_mel_db",
-           "uitk_set_debug_tokens", "uitk_set_timing_buffers", "uitk_last_error", "uitk_version"]
+           "uitk_set_debug_tokens", "uitk_set_timing_buffers", "uitk_topk", "uitk_kws_transform", "uitk_last_error",
+           "uitk_version"]
 
 
 class Config(Structure):
@@ -67,6 +68,8 @@ def load():
     L.uitk_mel_db.argtypes = [c_void_p, c_void_p, c_int, c_int64, c_int64, c_void_p, c_void_p]
     L.uitk_set_debug_tokens.argtypes = [c_void_p, c_void_p]
     L.uitk_set_timing_buffers.argtypes = [c_void_p, c_void_p, c_void_p]
+    L.uitk_topk.argtypes = [c_void_p, c_int64, c_int32, c_int32, c_void_p, c_void_p, c_void_p]
+    L.uitk_kws_transform.argtypes = [c_void_p, c_void_p, c_int64, c_int32, c_int32, c_float, c_void_p, c_void_p]
     L.uitk_last_error.restype = c_char_p
     L.uitk_version.restype = c_char_p
     for name in EXPORTS:

@@ -252,4 +252,22 @@ int uitk_mel_db(uitk_model* m, const void* pcm, int in_dtype, int64_t B, int64_t
     return UITK_OK;
 }
 
+int uitk_topk(const float* probs, int64_t B, int32_t C, int32_t k, float* values, int32_t* indices, void* stream) {
+    if (!probs || !values || !indices) return fail(UITK_ERR_INVALID_ARG, "null pointer");
+    if (B < 0 || C < 1 || C > 1024) return fail(UITK_ERR_INVALID_ARG, "topk: need 1 <= C <= 1024");
+    if (k < 1 || k > C) return fail(UITK_ERR_INVALID_ARG, "topk: selected index k out of range");     // torch.topk's RuntimeError
+    if (B == 0) return UITK_OK;
+    HIP_TRY(launch_topk(probs, B, C, k, values, indices, (hipStream_t)stream));
+    return UITK_OK;
+}
+
+int uitk_kws_transform(float* y_pred, const float* y, int64_t B, int32_t C, int32_t num_fillers, float threshold,
+                       int64_t* y_index, void* stream) {
+    if (!y_pred || ((y == nullptr) != (y_index == nullptr))) return fail(UITK_ERR_INVALID_ARG, "null pointer");
+    if (B < 0 || C < 1 || C > 1024 || num_fillers < 1) return fail(UITK_ERR_INVALID_ARG, "kws_transform: need 1 <= C <= 1024, num_fillers >= 1");
+    if (B == 0) return UITK_OK;
+    HIP_TRY(launch_kws_transform(y_pred, y, B, C, num_fillers < C ? num_fillers : C, threshold, y_index, (hipStream_t)stream));
+    return UITK_OK;
+}
+
 }  // extern "C"

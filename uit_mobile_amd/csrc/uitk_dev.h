@@ -79,5 +79,9 @@ hipError_t launch_mel_export(const float* mel, const float* amax, float top_db, 
 hipError_t launch_encoder(const EncoderArgs& a, int precision, int waves, int sched, hipStream_t stream);
 hipError_t launch_crop_reduce(const float* rowprobs, float* probs, int64_t B, int ncrops, int C, int eval_avg,
                               hipStream_t stream);
+// epilogue.hip: device-side post-processing of the probability rows (C <= 1024, k <= C)
+hipError_t launch_topk(const float* probs, int64_t B, int C, int k, float* values, int32_t* indices, hipStream_t stream);
+hipError_t launch_kws_transform(float* y_pred, const float* y, int64_t B, int C, int F, float threshold, int64_t* y_index,
+                                hipStream_t stream);
 
 }  // namespace uitk

@@ -57,10 +57,15 @@ def load_pretrained(model, trained_model):
 
 
 def output_transform_kws(y_pred, y, threshold=0.2, num_fillers=527):
-    """Vectorised, device-side version of `_output_transform_xiaoai` (evaluate.py:212-229): keep only the maximal
+    """`_output_transform_xiaoai` (evaluate.py:212-229) without its per-sample Python loop: keep only the maximal
     AudioSet ("filler") score, map filler targets to it, and zero it whenever any keyword score reaches the threshold
-    (so Accuracy@threshold picks the keyword).  The reference does this with a Python loop over samples on the host.
-    y_pred [B, C] probabilities, y [B, C] one/multi-hot targets  ->  (y_pred', y_index)."""
+    (so Accuracy@threshold picks the keyword).  y_pred [B, C] probabilities, y [B, C] one/multi-hot targets ->
+    (y_pred', y_index).  Model outputs live on the GPU: CUDA tensors go through the HIP kernel
+    (`postprocess.kws_transform`); host tensors (the reference's own setting for this host-side metric hook) take the
+    vectorised torch form below."""
+    if y_pred.is_cuda:
+        from .postprocess import kws_transform
+        return kws_transform(y_pred, y, threshold, num_fillers)
     fill = y_pred[:, :num_fillers]
     fmax, fidx = fill.max(dim=1, keepdim=True)
     out = y_pred.clone()
@@ -100,9 +105,11 @@ class Evaluator:
         pcm, sr = read_wav_pcm16(sample)
         wav = torch.from_numpy(np.ascontiguousarray(pcm)).unsqueeze(0)
         wav = pad_to_target(wav, self.model)
-        pred = self.model(wav.to(self.device))[0].cpu()
+        pred = self.model(wav.to(self.device))[0]
+        from .postprocess import topk
+        vals, idxs = topk(pred, 5)                                   # evaluate.py:263, reduced on the device
         lines = []
-        for val, idx in zip(*pred.topk(5)):
+        for val, idx in zip(vals.tolist(), idxs.tolist()):
             lines.append(f"[{int(idx):=3}] : {float(val) * 100:.2f}")
         print("\n".join(lines))
-        return pred
+        return pred.cpu()

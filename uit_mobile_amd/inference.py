@@ -51,8 +51,15 @@ def build_model(model_arg, device="cuda", precision="f16"):
 
 
 def topk_lines(probs, label_maps, k):
+    """The printed lines of inference.py:57-62 for one probability row.  A GPU row is reduced on the device
+    (postprocess.topk: only k scores cross PCIe); a host row (tests, goldens) uses torch's host topk."""
     lines = []
-    vals, idxs = torch.as_tensor(probs).topk(k)
+    probs = torch.as_tensor(probs)
+    if probs.is_cuda:
+        from .postprocess import topk
+        vals, idxs = topk(probs, k)
+    else:
+        vals, idxs = probs.topk(k)
     for prob, label in zip(vals.tolist(), idxs.tolist()):
         name = label_maps[label]
         if label > 526:
@@ -77,7 +84,7 @@ def main(argv=None):
         if pcm.ndim > 1:
             pcm = pcm[:, 0]
         with torch.no_grad():
-            output = model(torch.from_numpy(np.ascontiguousarray(pcm)).unsqueeze(0).cuda()).squeeze(0).cpu()
+            output = model(torch.from_numpy(np.ascontiguousarray(pcm)).unsqueeze(0).cuda()).squeeze(0)
         print(f"===== {str(wavpath):^20} =====")
         for line in topk_lines(output, label_maps, args.topk):
             print(line)
