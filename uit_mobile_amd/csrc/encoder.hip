@@ -236,6 +236,21 @@ __device__ __forceinline__ void layernorm_to_operand(const f4 (&R)[8][3], float 
     }
 }
 
+// Timing experiment (ABL & 64, f16): an MFMA with FILL plain VALU instructions pinned in its shadow -- prices a schedule
+// in which the LN/softmax arithmetic of another token stream is spread over the MLP's MFMA gaps.
+template <int FILL>
+__device__ __forceinline__ f4 mfma32_filled(h8 a, h8 b, f4 c, float& d0, float& d1, float& d2) {
+    if constexpr (FILL == 1)
+        asm volatile("v_mfma_f32_16x16x32_f16 %0, %2, %3, %0\n\tv_fma_f32 %1, %1, %1, %1" : "+v"(c), "+v"(d0) : "v"(a), "v"(b));
+    else if constexpr (FILL == 2)
+        asm volatile("v_mfma_f32_16x16x32_f16 %0, %3, %4, %0\n\tv_fma_f32 %1, %1, %1, %1\n\tv_fma_f32 %2, %2, %2, %2"
+                     : "+v"(c), "+v"(d0), "+v"(d1) : "v"(a), "v"(b));
+    else
+        asm volatile("v_mfma_f32_16x16x32_f16 %0, %4, %5, %0\n\tv_fma_f32 %1, %1, %1, %1\n\tv_fma_f32 %2, %2, %2, %2\n\tv_fma_f32 %3, %3, %3, %3"
+                     : "+v"(c), "+v"(d0), "+v"(d1), "+v"(d2) : "v"(a), "v"(b));
+    return c;
+}
+
 // In-kernel stamps (diagnostic build only, TIMING = true): one asm statement = s_memtime + lgkmcnt(0), fenced.
 __device__ __forceinline__ unsigned long long stamp() {
     unsigned long long t;
@@ -246,7 +261,7 @@ __device__ __forceinline__ unsigned long long stamp() {
 }
 #define TSTAMP(slot) do { if constexpr (TIMING) { const unsigned long long _t = stamp(); tacc[slot] += _t - tlast; tlast = _t; } } while (0)
 
-// ABL: timing experiments only (wrong outputs): 1 skip attention, 2 skip LayerNorms, 4 MLP without ring steps
+// ABL: timing experiments only (wrong outputs; 64|128 = 1..3 filler VALU pinned behind every MLP MFMA): 1 skip attention, 2 skip LayerNorms, 4 MLP without ring steps
 // (no DMA, no barrier), 8 MLP without LDS fragment reads, 16 MLP without ReLU/convert, 32 MLP without bias reads.  The product kernel is ABL = 0.
 template <int PREC, int WAVES, bool SCHED, bool TIMING, int ABL = 0>
 __global__ __launch_bounds__(WAVES * 64, 2) void uit_encoder_kernel(EncoderArgs a) {
@@ -400,6 +415,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void uit_encoder_kernel(EncoderArgs 
     }
 
     // ---- transformer blocks
+    float dmy0 = 1.0f, dmy1 = 0.5f, dmy2 = 0.25f;          // filler chains of the ABL & 192 timing experiment
 #pragma unroll 1
     for (int blk = 0; blk < a.depth; ++blk) {
         const int tb = PE_STAGES + blk * BLOCK_STAGES;
@@ -515,6 +531,10 @@ __global__ __launch_bounds__(WAVES * 64, 2) void uit_encoder_kernel(EncoderArgs 
         // MFMAs of chunk ch-1 run from registers (A2/HX carried across the barrier) and cover the LDS latency; the
         // fc2 fragment reads of chunk ch fly under its fc1 MFMAs.
         v8 A2[8], HX[3];
+        auto mlp_mfma = [&](v8 a_, v8 b_, f4 c_) -> f4 {
+            if constexpr ((ABL & 192) != 0 && PREC == 0) return mfma32_filled<(ABL >> 6) & 3>(a_, b_, c_, dmy0, dmy1, dmy2);
+            else return OP::mfma32(a_, b_, c_);
+        };
         auto fc1_chunk = [&](const char* slot, int ch, const v8 (&A)[8]) {
             f4 b10, b11;
             if constexpr (ABL & 32) { b10 = splat(0.f); b11 = splat(0.f); }
@@ -526,13 +546,13 @@ __global__ __launch_bounds__(WAVES * 64, 2) void uit_encoder_kernel(EncoderArgs 
             for (int ct = 0; ct < 3; ++ct) {
                 H0[ct] = b10;
 #pragma unroll
-                for (int s = 0; s < 4; ++s) H0[ct] = OP::mfma32(A[s], X[s][ct], H0[ct]);
+                for (int s = 0; s < 4; ++s) H0[ct] = mlp_mfma(A[s], X[s][ct], H0[ct]);
             }
 #pragma unroll
             for (int ct = 0; ct < 3; ++ct) {
                 H1[ct] = b11;
 #pragma unroll
-                for (int s = 0; s < 4; ++s) H1[ct] = OP::mfma32(A[4 + s], X[s][ct], H1[ct]);
+                for (int s = 0; s < 4; ++s) H1[ct] = mlp_mfma(A[4 + s], X[s][ct], H1[ct]);
             }
 #pragma unroll
             for (int ct = 0; ct < 3; ++ct) {
@@ -562,7 +582,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void uit_encoder_kernel(EncoderArgs 
 #pragma unroll
             for (int ft = 0; ft < 8; ++ft)                                              // ... under chunk ch-1's fc2
 #pragma unroll
-                for (int ct = 0; ct < 3; ++ct) R[ft][ct] = OP::mfma32(A2[ft], HX[ct], R[ft][ct]);
+                for (int ct = 0; ct < 3; ++ct) R[ft][ct] = mlp_mfma(A2[ft], HX[ct], R[ft][ct]);
             if constexpr (SCHED) __builtin_amdgcn_sched_barrier(0);
             fc1_chunk(slot, ch, A);
             TSTAMP(7);                                                 // MLP chunk compute (sum of 12)
@@ -570,7 +590,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void uit_encoder_kernel(EncoderArgs 
 #pragma unroll
         for (int ft = 0; ft < 8; ++ft)
 #pragma unroll
-            for (int ct = 0; ct < 3; ++ct) R[ft][ct] = OP::mfma32(A2[ft], HX[ct], R[ft][ct]);
+            for (int ct = 0; ct < 3; ++ct) R[ft][ct] = mlp_mfma(A2[ft], HX[ct], R[ft][ct]);
 #pragma unroll
         for (int ft = 0; ft < 8; ++ft) {
             const f4 b2 = *(const f4*)(bias + BIAS_FC2 + 16 * ft + 4 * g);
@@ -748,6 +768,10 @@ hipError_t launch_encoder(const EncoderArgs& a, int precision, int waves, int sc
     if (a.ablate == 31) return launch_enc<0, 8, false, false, 31>(a, stream);
     if (a.ablate == 47) return launch_enc<0, 8, false, false, 47>(a, stream);
     if (a.ablate == 63) return launch_enc<0, 8, false, false, 63>(a, stream);
+    if (a.ablate == 64 + 3) return launch_enc<0, 8, false, false, 64 + 3>(a, stream);      // no LN/attention, 1 filler VALU per MLP MFMA
+    if (a.ablate == 128 + 3) return launch_enc<0, 8, false, false, 128 + 3>(a, stream);    // ... 2 fillers
+    if (a.ablate == 192 + 3) return launch_enc<0, 8, false, false, 192 + 3>(a, stream);    // ... 3 fillers
+    if (a.ablate == 128) return launch_enc<0, 8, false, false, 128>(a, stream);            // full kernel + 2 fillers per MLP MFMA
 #endif
     if (a.timing != nullptr)                              // diagnostic build with in-kernel stamps (f16 only)
         return waves == 4 ? launch_enc<0, 4, false, true>(a, stream) : launch_enc<0, 8, false, true>(a, stream);
