@@ -350,10 +350,10 @@ __global__ __launch_bounds__(FE_WAVES * 64, 2) void mel_frontend_kernel(Frontend
                 const float c = cs.x, s = cs.y;
                 const float Tr = c * Bi - s * Br, Ti = -s * Bi - c * Br;
                 const float xr = Ar + Tr, xi = Ai + Ti, yr = Ar - Tr, yi = Ti - Ai;
-                prow[k] = 0.25f * (xr * xr + xi * xi);
-                prow[256 - k] = 0.25f * (yr * yr + yi * yi);     // k = 0 writes bin 256 (Nyquist)
+                prow[k] = xr * xr + xi * xi;                     // 4 |X[k]|^2: the 1/4 lives in the filterbank operand (pack.cpp)
+                prow[256 - k] = yr * yr + yi * yi;               // k = 0 writes bin 256 (Nyquist)
             }
-            if (p == 0) prow[128] = z128.x * z128.x + z128.y * z128.y;
+            if (p == 0) prow[128] = 4.0f * (z128.x * z128.x + z128.y * z128.y);
         }
         FSTAMP(3);                                       // Z read + split + power write
         __syncthreads();                                 // P[it&1] complete; everyone is done reading P[(it-1)&1]

@@ -136,7 +136,8 @@ int pack_image(const uitk_config* c, const uitk_weights* w, std::vector<char>* o
         for (int st = 0; st < tile_steps[j]; ++st)
             for (int l = 0; l < 64; ++l) {
                 const int k = tile_klo[j] + 4 * st + (l >> 4), m = 16 * j + (l & 15);
-                mb[(size_t)(tile_base[j] + st) * 64 + l] = k < nb ? w->mel_fb[k * NMEL + m] : 0.0f;
+                // x 1/4 (exact): the front-end's power tile holds 4 |X|^2 (the real-FFT split without its two halvings)
+                mb[(size_t)(tile_base[j] + st) * 64 + l] = k < nb ? 0.25f * w->mel_fb[k * NMEL + m] : 0.0f;
             }
 
     // ---- init_bn -> scale/shift
