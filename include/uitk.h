@@ -150,9 +150,10 @@ int uitk_mel_db(uitk_model* m, const void* pcm, int in_dtype, int64_t B, int64_t
  * patch-embed(+pos) and after every block (token = f*6+t as in uit.py:388).  NULL disables (default). */
 int uitk_set_debug_tokens(uitk_model* m, float* dev_buf);
 
-/* Diagnostics: device buffers receiving per-phase shader-cycle sums per wave -- encoder [waves][12] uint64 (LN1,
- * ring wait QK, QK, ring wait VP, attention+proj, LN2, ring waits MLP, MLP, setup, convert, patch embed, pool+head),
- * front-end [waves][8].  A non-NULL buffer selects a separate instrumented kernel build (slower; never use it to
+/* Diagnostics: device buffers receiving per-phase shader-cycle sums per wave -- encoder [waves][20] uint64 (0-7 per
+ * block: LN1, ring wait QK, QK, ring wait VP, attention+proj, LN2, ring waits MLP, MLP; 8-11 once: load wait, prologue
+ * barrier, patch embed, epilogue total; 12-14 prologue detail: stream kick, load issue, clamp; 15-19 epilogue detail:
+ * final LN + pool, head LN + LDS hand-over, barrier, z reads, head tiles + stores), front-end [waves][8].  A non-NULL buffer selects a separate instrumented kernel build (slower; never use it to
  * time the product).  NULL (default) = normal kernels. */
 int uitk_set_timing_buffers(uitk_model* m, unsigned long long* enc_buf, unsigned long long* fe_buf);
 

@@ -11,14 +11,15 @@ dev = torch.device("cuda", 0)
 sd = {k: torch.from_numpy(np.asarray(v)) for k, v in make_state_dict("uit_xs", 13).items()}
 x = synth_batch(8192, 16000, 0, dev, False)
 names = ["LN1", "wait QK", "QK", "wait VP", "attn+proj", "LN2", "wait MLP(12)", "MLP(12)"]
-names2 = ["setup", "PE tile0", "PE tiles1,2", "pool+head"]
+names2 = ["load wait", "prologue barrier", "patch embed", "epilogue total", "stream kick", "load issue", "clamp",
+          "final LN+pool", "head LN+LDS", "epi barrier", "z reads", "head tiles+stores"]
 for waves, B in (("8", 8192),):
     os.environ["UITK_ENC_WAVES"] = waves
     m = models.uit_xs(outputdim=537, target_length=102).to(dev); m.load_state_dict(sd); m.eval()
     xb = x[:B]
     m(xb); torch.cuda.synchronize()
     nw = B // 2
-    buf = torch.zeros((nw, 12), dtype=torch.int64, device=dev)
+    buf = torch.zeros((nw, 20), dtype=torch.int64, device=dev)
     h = m._handle(dev)
     fbuf = torch.zeros((4096, 8), dtype=torch.int64, device=dev)
     _lib.check(_lib.load().uitk_set_timing_buffers(h, ctypes.c_void_p(buf.data_ptr()), ctypes.c_void_p(fbuf.data_ptr())), "timing")
@@ -31,6 +32,10 @@ for waves, B in (("8", 8192),):
           f"12 blocks {12 * med.sum():.0f}; fixed {fixed.sum():.0f}")
     print("   " + "  ".join(f"{n}={v:.0f}" for n, v in zip(names, med)))
     print("   " + "  ".join(f"{n}={v:.0f}" for n, v in zip(names2, fixed)))
+    half = (nw // 2)
+    for tag, sl in (("first-round WGs", slice(0, half)), ("second-round WGs", slice(half, nw))):
+        fx = np.median(raw[sl, 8:], 0)
+        print(f"   {tag}: " + "  ".join(f"{n}={v:.0f}" for n, v in zip(names2, fx)))
     fr = fbuf.cpu().numpy().astype(np.float64)
     fr = fr[fr.sum(1) > 0]
     npass = B * 7 / 512.0

@@ -298,12 +298,13 @@ __global__ __launch_bounds__(WAVES * 64, 2) void uit_encoder_kernel(EncoderArgs 
         }
     }
 
-    unsigned long long tacc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, tlast = 0;
+    unsigned long long tacc[ENC_TIMING_SLOTS] = {}, tlast = 0;
     if constexpr (TIMING) tlast = stamp();
     // ---- kick the weight stream: block-0 biases + the whole patch-embed weight set (4 stages = the whole ring)
     if (a.depth > 0) bias_issue<WAVES>(a.bias, breg, 0, wave, lane);
 #pragma unroll
     for (int i = 0; i < PE_STAGES; ++i) ring_issue<WAVES>(a.wstream, ring, i, wave, lane);
+    TSTAMP(12);                                                           // weight-stream kick
 
     // ---- rows (clip-crops) of this wave, token maps
     const int r0 = (blockIdx.x * WAVES + wave) * 2;
@@ -326,7 +327,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void uit_encoder_kernel(EncoderArgs 
     for (int ct = 0; ct < 3; ++ct) {
         const unsigned short* src = a.mel + ((int64_t)(clip_[ct] ? row_hi : row_lo) * NTOK + tk_[ct]) * 256 + 8 * g;
 #pragma unroll
-        for (int s = 0; s < 8; ++s) XB[ct][s] = *(const v8*)(src + 32 * s);
+        for (int s = 0; s < 8; ++s) { if constexpr (ABL & 256) XB[ct][s] = OP::zero8(); else XB[ct][s] = *(const v8*)(src + 32 * s); }
     }
     // accumulator init (conv bias + positional embeddings) rides the same memory round trip
     f4 R[8][3];
@@ -334,31 +335,46 @@ __global__ __launch_bounds__(WAVES * 64, 2) void uit_encoder_kernel(EncoderArgs 
     for (int ct = 0; ct < 3; ++ct)
 #pragma unroll
         for (int ft = 0; ft < 8; ++ft) R[ft][ct] = *(const f4*)(a.pe_bias + tk_[ct] * DIM + 16 * ft + 4 * g);
+    // init_bn scale / shift of mel bin `lane`: two coalesced dword loads per wave; the 24 (token tile, k-step) clamp
+    // thresholds of a lane are then handed out through a wave-private 512-byte LDS table (zbuf is idle until the head)
+    const float my_sc = a.bn_sc[lane], my_sh = a.bn_sh[lane];
     float amx = a.amax[lane];                                             // 64 slots, one per lane; NaN = untouched slot
+    TSTAMP(13);                                                           // index math + issue of patch / table loads
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) amx = fmaxf(amx, __shfl_xor(amx, o));
     const float floor_db = amx - a.top_db;
-    TSTAMP(8);                                                            // setup
+    TSTAMP(8);                                                            // wait: every load of this wave has landed
 
     // ---- top_db clamp on the normalised operands: y = max(y, sc*floor + sh) for sc >= 0, min(...) for sc < 0
     // (exactly round(init_bn(max(dB, floor))): the affine map and the rounding are monotone).  All 8 operands of a
     // lane's k-step share one mel bin 16pf + 2s + (g>>1).  Masked tokens of short clips -> 0.
+    float* clamp_tab = (float*)(zbuf + wave * 512);                        // [th | sc][pf][g>>1][s]: bin 16pf + 2s + (g>>1)
+    {
+        const int pos = (lane & 48) + 8 * (lane & 1) + ((lane & 15) >> 1);
+        clamp_tab[pos] = floor_db * my_sc + my_sh;
+        clamp_tab[64 + pos] = my_sc;
+        __builtin_amdgcn_wave_barrier();                                  // same-wave LDS ops complete in order
+        asm volatile("" ::: "memory");
+    }
 #pragma unroll
     for (int ct = 0; ct < 3; ++ct) {
         const bool live = pt_[ct] < a.nt;
+        const float* trow = clamp_tab + 16 * pf_[ct] + 8 * (g >> 1);
+        const f4 th_lo = *(const f4*)trow, th_hi = *(const f4*)(trow + 4);
+        const f4 sc_lo = *(const f4*)(trow + 64), sc_hi = *(const f4*)(trow + 68);
 #pragma unroll
         for (int s = 0; s < 8; ++s) {
-            const int fbin = 16 * pf_[ct] + 2 * s + (g >> 1);
-            const float sc = a.bn_sc[fbin], th = floor_db * sc + a.bn_sh[fbin];
+            const float sc = s < 4 ? sc_lo[s & 3] : sc_hi[s & 3], th = s < 4 ? th_lo[s & 3] : th_hi[s & 3];
             const v8 t8 = OP::from_f32x8(splat(th), splat(th));
             const v8 y = sc >= 0.f ? OP::max8(XB[ct][s], t8) : OP::min8(XB[ct][s], t8);
             XB[ct][s] = live ? y : OP::zero8();
         }
     }
+    TSTAMP(14);                                                           // clamp (+ its init_bn table loads)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                      // patch-embed weights landed ...
     __builtin_amdgcn_s_barrier();                                         // ... for every wave
     asm volatile("" ::: "memory");
-    TSTAMP(9);                                                            // convert + weight landing
+    TSTAMP(9);                                                            // barrier: slowest wave of the workgroup
 
     // ---- patch embed: 64 LDS-resident fragments (ft = f/8, s = f%8) x 3 token tiles; accumulators start from the
     // conv bias + positional embeddings table
@@ -604,7 +620,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void uit_encoder_kernel(EncoderArgs 
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // drain the dummy tail stages before the LDS can be re-used
     unsigned long long t_blocks_end = 0;
-    if constexpr (TIMING) t_blocks_end = stamp();
+    if constexpr (TIMING) { t_blocks_end = stamp(); tlast = t_blocks_end; }
     // classifier weights of this wave's first output tile: fetched now, consumed after pooling
     const int ntiles = (a.C + 15) / 16;
     constexpr int HEAD_PRE = 5;                           // tiles per wave held in VGPRs (5 x 8 waves covers C <= 640)
@@ -646,6 +662,16 @@ __global__ __launch_bounds__(WAVES * 64, 2) void uit_encoder_kernel(EncoderArgs 
             pooled[ft] = v;                               // lanes c<8: clip 0, lanes c>=8: clip 1
         }
     }
+    // the residual stream is dead now: fetch the low-order classifier terms of the same tiles as well, so that no
+    // head tile waits on an L2 round trip
+    v8 Hlpre[HEAD_PRE][4];
+#pragma unroll
+    for (int i = 0; i < HEAD_PRE; ++i)
+        if (wave + i * WAVES < ntiles) {
+#pragma unroll
+            for (int s = 0; s < 4; ++s) Hlpre[i][s] = *(const v8*)(a.head_w + ((size_t)((wave + i * WAVES) * 4 + s) * 2 + 1) * FRAG_BYTES + lane * 16);
+        }
+    TSTAMP(15);                                                           // classifier prefetch issue + final LN + pooling
     {
         const float inv_ntok = 1.0f / (float)(GF * a.nt);
         f4 acc = splat(0.f);
@@ -674,7 +700,9 @@ __global__ __launch_bounds__(WAVES * 64, 2) void uit_encoder_kernel(EncoderArgs 
             }
         }
     }
+    TSTAMP(16);                                                           // head LN + operand hand-over through LDS
     __syncthreads();
+    TSTAMP(17);                                                           // barrier
 
     // ---- classifier head once per workgroup: logits^T[class][clip slot] = Whead . z^T
     {
@@ -689,13 +717,14 @@ __global__ __launch_bounds__(WAVES * 64, 2) void uit_encoder_kernel(EncoderArgs 
             const v4 lhi = *(const v4*)(zbuf + 16 * DIM * 2 + (cz * DIM + 32 * s + 16 + 4 * g) * 2);
             Bzl[s] = v8{llo[0], llo[1], llo[2], llo[3], lhi[0], lhi[1], lhi[2], lhi[3]};
         }
+        TSTAMP(18);                                                       // z operand reads
         const int rowg = blockIdx.x * WAVES * 2 + c;
         // logits = (Wh + Wl).(zh + zl) ~ Wh.zh + Wh.zl + Wl.zh : three MFMAs per k-step, fp32 accumulate
-        auto head_tile = [&](int ot, const v8 (&Hc)[4]) {
+        auto head_tile = [&](int ot, const v8 (&Hc)[4], const v8 (&Hlo)[4]) {
             f4 acc = *(const f4*)(a.head_b + 16 * ot + 4 * g);
 #pragma unroll
             for (int s = 0; s < 4; ++s) {
-                const v8 Hl = *(const v8*)(a.head_w + ((size_t)(ot * 4 + s) * 2 + 1) * FRAG_BYTES + lane * 16);
+                const v8 Hl = Hlo[s];
                 acc = OP::mfma32(Hl, Bz[s], acc);
                 acc = OP::mfma32(Hc[s], Bzl[s], acc);
                 acc = OP::mfma32(Hc[s], Bz[s], acc);
@@ -713,20 +742,24 @@ __global__ __launch_bounds__(WAVES * 64, 2) void uit_encoder_kernel(EncoderArgs 
         };
 #pragma unroll
         for (int i = 0; i < HEAD_PRE; ++i)
-            if (wave + i * WAVES < ntiles) head_tile(wave + i * WAVES, Hpre[i]);
+            if (wave + i * WAVES < ntiles) head_tile(wave + i * WAVES, Hpre[i], Hlpre[i]);
         for (int ot = wave + HEAD_PRE * WAVES; ot < ntiles; ot += WAVES) {       // very wide heads: plain loop
-            v8 Hc[4];
+            v8 Hc[4], Hlo[4];
 #pragma unroll
-            for (int s = 0; s < 4; ++s) Hc[s] = *(const v8*)(a.head_w + (size_t)(ot * 4 + s) * 2 * FRAG_BYTES + lane * 16);
-            head_tile(ot, Hc);
+            for (int s = 0; s < 4; ++s) {
+                Hc[s] = *(const v8*)(a.head_w + (size_t)(ot * 4 + s) * 2 * FRAG_BYTES + lane * 16);
+                Hlo[s] = *(const v8*)(a.head_w + ((size_t)(ot * 4 + s) * 2 + 1) * FRAG_BYTES + lane * 16);
+            }
+            head_tile(ot, Hc, Hlo);
         }
     }
     if constexpr (TIMING) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        tacc[11] = stamp() - t_blocks_end;                                // pooling + head + stores
+        TSTAMP(19);                                                       // head tiles + stores
+        tacc[11] = tlast - t_blocks_end;                                  // pooling + head + stores (sum of 15..19)
         if (a.timing != nullptr && lane == 0) {
 #pragma unroll
-            for (int i = 0; i < 12; ++i) a.timing[((size_t)blockIdx.x * WAVES + wave) * 12 + i] = tacc[i];
+            for (int i = 0; i < ENC_TIMING_SLOTS; ++i) a.timing[((size_t)blockIdx.x * WAVES + wave) * ENC_TIMING_SLOTS + i] = tacc[i];
         }
     }
 }
@@ -772,6 +805,9 @@ hipError_t launch_encoder(const EncoderArgs& a, int precision, int waves, int sc
     if (a.ablate == 128 + 3) return launch_enc<0, 8, false, false, 128 + 3>(a, stream);    // ... 2 fillers
     if (a.ablate == 192 + 3) return launch_enc<0, 8, false, false, 192 + 3>(a, stream);    // ... 3 fillers
     if (a.ablate == 128) return launch_enc<0, 8, false, false, 128>(a, stream);            // full kernel + 2 fillers per MLP MFMA
+    if (a.ablate == 512) { EncoderArgs b = a; b.depth = 0; return launch_enc<0, 8, false, false, 0>(b, stream); }     // prologue + epilogue only
+    if (a.ablate == 768) { EncoderArgs b = a; b.depth = 0; return launch_enc<0, 8, false, false, 256>(b, stream); }   // ... without the patch loads
+    if (a.ablate == 256) return launch_enc<0, 8, false, false, 256>(a, stream);                                       // full kernel without the patch loads
 #endif
     if (a.timing != nullptr)                              // diagnostic build with in-kernel stamps (f16 only)
         return waves == 4 ? launch_enc<0, 4, false, true>(a, stream) : launch_enc<0, 8, false, true>(a, stream);

@@ -8,6 +8,7 @@ namespace uitk {
 constexpr int AMAX_SLOTS = 64;          // == UITK_AMAX_SLOTS
 
 // ---- fixed geometry of the uit_* family (models/uit.py:581-635 with target_length 96..111)
+constexpr int ENC_TIMING_SLOTS = 20;   // per-wave phase cycle sums of the diagnostic encoder build (uitk_set_timing_buffers)
 constexpr int DIM = 128;                // embed_dim
 constexpr int NTOK = 24;                // 4 freq patches x 6 time patches, token = f*6 + t (uit.py:388)
 constexpr int GT = 6, GF = 4;
