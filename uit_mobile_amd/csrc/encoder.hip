@@ -718,22 +718,24 @@ __global__ __launch_bounds__(WAVES * 64, 2) void uit_encoder_kernel(EncoderArgs 
             Bzl[s] = v8{llo[0], llo[1], llo[2], llo[3], lhi[0], lhi[1], lhi[2], lhi[3]};
         }
         TSTAMP(18);                                                       // z operand reads
-        const int rowg = blockIdx.x * WAVES * 2 + c;
+        // logits[clip slot][class] = z . Whead^T with z as the A operand (rows = clip slots 4g+r) and the classifier
+        // fragments as B (columns = classes): a store instruction then writes 64-byte runs of one clip's row.
         // logits = (Wh + Wl).(zh + zl) ~ Wh.zh + Wh.zl + Wl.zh : three MFMAs per k-step, fp32 accumulate
+        const int row0 = blockIdx.x * WAVES * 2 + 4 * g;
         auto head_tile = [&](int ot, const v8 (&Hc)[4], const v8 (&Hlo)[4]) {
-            f4 acc = *(const f4*)(a.head_b + 16 * ot + 4 * g);
+            const int cls = 16 * ot + c;
+            f4 acc = splat(a.head_b[cls]);                  // head_b is padded to whole tiles
 #pragma unroll
             for (int s = 0; s < 4; ++s) {
-                const v8 Hl = Hlo[s];
-                acc = OP::mfma32(Hl, Bz[s], acc);
-                acc = OP::mfma32(Hc[s], Bzl[s], acc);
-                acc = OP::mfma32(Hc[s], Bz[s], acc);
+                acc = OP::mfma32(Bz[s], Hlo[s], acc);
+                acc = OP::mfma32(Bzl[s], Hc[s], acc);
+                acc = OP::mfma32(Bz[s], Hc[s], acc);
             }
-            if (c < 2 * WAVES && rowg < a.rows) {
+            if (cls < a.C) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const int cls = 16 * ot + 4 * g + r;
-                    if (cls < a.C) {
+                    const int rowg = row0 + r;
+                    if (4 * g + r < 2 * WAVES && rowg < a.rows) {
                         if (a.logits) a.logits[(int64_t)rowg * a.C + cls] = acc[r];
                         a.probs[(int64_t)rowg * a.C + cls] = __builtin_amdgcn_rcpf(1.0f + __expf(-acc[r]));
                     }
