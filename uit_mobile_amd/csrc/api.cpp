@@ -176,9 +176,7 @@ static int run_frontend(uitk_model* m, const void* pcm, int in_dtype, int64_t B,
     a.tw256 = (const float2*)(m->image + h.off_tw256);
     a.tw512 = (const float2*)(m->image + h.off_tw512);
     a.mel_b = (const float*)(m->image + h.off_mel_b);
-    for (int j = 0; j < 4; ++j) {
-        a.mel_tile_klo[j] = h.mel_tile_klo[j]; a.mel_tile_steps[j] = h.mel_tile_steps[j]; a.mel_tile_base[j] = h.mel_tile_base[j];
-    }
+    a.mel_steps = h.mel_steps;
     a.mel = mel_out; a.amax = m->amax;
     a.bn_sc = (const float*)(m->image + h.off_bn_sc); a.bn_sh = (const float*)(m->image + h.off_bn_sh);
     a.op_bf16 = m->cfg.precision == UITK_PREC_BF16;

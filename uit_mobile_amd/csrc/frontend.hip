@@ -82,7 +82,7 @@ constexpr int FE_PROW = 290;                             // power-tile row strid
 constexpr int FE_P_LDS = 2 * 16 * FE_PROW * 4;           // double-buffered P[16][290]
 constexpr int FE_TAB_LDS = FE_LDS_TABLES ? (256 + 256 + 128) * 8 : 0;   // window pairs, W256^(p*k1) as [k1][p], (cos,sin)(2 pi k/512)
 constexpr int FE_LDS = FE_WAVES * FE_WAVE_LDS + FE_P_LDS + FE_TAB_LDS;
-constexpr int FE_BREG = 40;                              // filterbank k-steps per mel tile held in VGPRs (HTK: <= 40)
+constexpr int FE_BREG = 48;                              // filterbank steps held in VGPRs (HTK 64 mels: S = 49, the rest streams from L2)
 
 template <bool I16>
 __device__ __forceinline__ float load_sample(const void* pcm, int64_t row_off, int T, int s) {
@@ -156,18 +156,16 @@ __global__ __launch_bounds__(FE_WAVES * 64, 2) void mel_frontend_kernel(Frontend
     // per-lane (clip offset, frame) of the 16 slots of a tail pass: slot = 4*wave+q in the FFT phase, 4q+r in the mel phase
     const int tslot = 4 * wave + q;
     const int t_cl = rem ? tslot / rem : 0, t_fr = rem ? tslot - t_cl * rem : 0;
-    int m_cl[4], m_fr[4];
+    int m_cl[4], m_fr[4];                                 // mel phase: rows r of a wave's result = its own slots 4*wave + r
 #pragma unroll
-    for (int r = 0; r < 4; ++r) { m_cl[r] = rem ? (4 * q + r) / rem : 0; m_fr[r] = rem ? (4 * q + r) - m_cl[r] * rem : 0; }
+    for (int r = 0; r < 4; ++r) { m_cl[r] = rem ? (4 * wave + r) / rem : 0; m_fr[r] = rem ? (4 * wave + r) - m_cl[r] * rem : 0; }
     const int T = (int)a.T;
     const bool pair_ok = (T & 1) == 0;                   // pair loads need every row to start pair-aligned
     float lmax = -INFINITY;
     int it = 0;
-    float bnsc[4] = {0.f, 0.f, 0.f, 0.f}, bnsh[4] = {0.f, 0.f, 0.f, 0.f};      // init_bn scale/shift of mel 16j + p
-    if (PATCH) {
-#pragma unroll
-        for (int jj = 0; jj < 4; ++jj) { bnsc[jj] = a.bn_sc[16 * jj + p]; bnsh[jj] = a.bn_sh[16 * jj + p]; }
-    }
+    // mel phase lane map (v_mfma_f32_4x4x1, 16 blocks): lane = 4*group + x; as A operand x = frame row of this wave's
+    // quad, as B operand / result x = mel within the group, i.e. result column = mel `lane`
+    const float bn_sc = PATCH ? a.bn_sc[lane] : 0.f, bn_sh = PATCH ? a.bn_sh[lane] : 0.f;   // init_bn scale/shift of mel `lane`
     // raw (unwindowed) sample pairs of this lane's frame for a pass: z[m1] = (x[32 m1 + 2p], x[32 m1 + 2p + 1])
     auto load_pass = [&](int64_t pass, c32 (&raw)[16]) {
         int b, f;
@@ -205,77 +203,70 @@ __global__ __launch_bounds__(FE_WAVES * 64, 2) void mel_frontend_kernel(Frontend
     unsigned long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tlast = 0;
     if constexpr (TIMING) tlast = fe_stamp();
 
-    // B operands (filterbank band of one 16-mel tile, zero-padded to 8-step chunks by pack.cpp) live in VGPRs
+    // B operands: the banded filterbank, one value per lane and step, constant over passes -> resident in VGPRs
+    const int nst = a.mel_steps;
+    const int klo_g = ((const int*)a.mel_b)[lane];       // first bin of this lane's 4-mel group
+    const float* Bt = a.mel_b + 64 + lane;
     float bw[FE_BREG];
-    auto load_bw = [&](int j) {
-        const int nst = a.mel_tile_steps[j];
-        const float* Bt = a.mel_b + (size_t)a.mel_tile_base[j] * 64 + lane;
 #pragma unroll
-        for (int c = 0; c < FE_BREG / 8; ++c)
-            if (8 * c < nst) {
+    for (int c = 0; c < FE_BREG / 8; ++c)
+        if (8 * c < nst) {
 #pragma unroll
-                for (int s = 0; s < 8; ++s) bw[8 * c + s] = Bt[64 * (8 * c + s)];
-            }
-    };
+            for (int s = 0; s < 8; ++s) bw[8 * c + s] = 8 * c + s < nst ? Bt[64 * (8 * c + s)] : 0.f;
+        }
 
-    // ---- mel phase of one pass (matrix pipe): runs ONE PASS BEHIND the FFT phase, right after the next pass's sample
-    // loads were issued, so their HBM latency hides under these MFMAs, the log and the stores
+    // ---- mel phase of one pass (matrix pipe): mel[frame][m] = sum_k P[frame][k] fb[k][m] for the wave's OWN four frames,
+    // as 16 independent 4x4 blocks (one per 4-mel group, each walking its own bin band) of v_mfma_f32_4x4x1: no power
+    // tile shared between waves, no workgroup barrier.  Runs ONE PASS BEHIND the FFT phase, right after the next pass's
+    // sample loads were issued, so their HBM latency hides under these MFMAs, the log and the stores.
     auto mel_phase = [&](int itp, int64_t passp) {
-        const float* P = Pbase + (itp & 1) * 16 * FE_PROW;
+        const float* Pw = Pbase + ((itp & 1) * FE_WAVES + wave) * 4 * FE_PROW;
         const bool is_tail = passp >= nfull;             // uniform
         const int b = is_tail ? (int)((passp - nfull) * per_tail) : (int)(passp / full);   // (first) clip of the pass
         const int k0 = is_tail ? full : (int)(passp - (int64_t)b * full);
-        const int fbase = 16 * k0;                       // first frame of a full pass
-        const int j = (wave + itp) & 3;                  // this wave's 16-mel tile for that pass (rotates: tiles are unequal)
-        const int klo = a.mel_tile_klo[j], nst = a.mel_tile_steps[j];
-        const float* Bt = a.mel_b + (size_t)a.mel_tile_base[j] * 64 + lane;
-        const float* Ar = P + p * FE_PROW + klo + q;     // A[row = frame p][k = q]  (lane&15 = row, lane>>4 = k)
+        const int fbase = 16 * k0 + 4 * wave;            // first frame of this wave's quad in a full pass
+        const float* Ar = Pw + (lane & 3) * FE_PROW + klo_g;     // A[row = frame lane&3][k = step] of block lane>>2
         f4v acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int c = 0; c < FE_BREG / 8; ++c)
             if (8 * c < nst) {
 #pragma unroll
                 for (int s = 0; s < 8; s += 2) {
-                    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(Ar[4 * (8 * c + s)], bw[8 * c + s], acc0, 0, 0, 0);
-                    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(Ar[4 * (8 * c + s + 1)], bw[8 * c + s + 1], acc1, 0, 0, 0);
+                    acc0 = __builtin_amdgcn_mfma_f32_4x4x1f32(Ar[8 * c + s], bw[8 * c + s], acc0, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_4x4x1f32(Ar[8 * c + s + 1], bw[8 * c + s + 1], acc1, 0, 0, 0);
                 }
             }
-        for (int s = FE_BREG; s < nst; ++s)              // filterbanks wider than FE_BREG steps per tile (not HTK)
-            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(Ar[4 * s], Bt[64 * s], acc0, 0, 0, 0);
-        const f4v acc = acc0 + acc1;                     // D[frame 4q + r][mel 16j + p]
-        float bn_sc = 0.f, bn_sh = 0.f;
-        if (PATCH) {
-            bn_sc = j == 0 ? bnsc[0] : j == 1 ? bnsc[1] : j == 2 ? bnsc[2] : bnsc[3];
-            bn_sh = j == 0 ? bnsh[0] : j == 1 ? bnsh[1] : j == 2 ? bnsh[2] : bnsh[3];
-        }
+        for (int s = FE_BREG; s < nst; ++s)              // bands wider than FE_BREG bins (HTK: one step; dense filterbanks: many)
+            acc0 = __builtin_amdgcn_mfma_f32_4x4x1f32(Ar[s], Bt[64 * s], acc0, 0, 0, 0);
+        const f4v acc = acc0 + acc1;                     // D[frame slot 4*wave + r][mel lane]
         FSTAMP(5);                                       // mel MFMAs
         float db[4];
         int fb[4], ff[4];                                // clip / frame of this lane's 4 rows; fb < 0 = dead slot
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             db[r] = 10.0f * __log10f(fmaxf(acc[r], 1e-10f));
-            if (!is_tail) { fb[r] = b; ff[r] = fbase + 4 * q + r; }
+            if (!is_tail) { fb[r] = b; ff[r] = fbase + r; }
             else { fb[r] = (m_cl[r] < per_tail && b + m_cl[r] < a.B) ? b + m_cl[r] : -1; ff[r] = 16 * full + m_fr[r]; }
             if (fb[r] >= 0) lmax = fmaxf(lmax, db[r]);                                // every frame counts for the top_db amax
         }
         if (!PATCH) {
 #pragma unroll
             for (int r = 0; r < 4; ++r)
-                if (fb[r] >= 0) a.mel[((int64_t)fb[r] * a.nF + ff[r]) * 64 + 16 * j + p] = db[r];
+                if (fb[r] >= 0) a.mel[((int64_t)fb[r] * a.nF + ff[r]) * 64 + lane] = db[r];
         } else {
             // 16-bit operands of the encoder's patch embed: init_bn applied here (y = sc*dB + sh, uit.py:310-313);
             // the top_db clamp commutes with this monotone map and with rounding, so the encoder applies it on y.
             // Layout [clip-crop][token pf*6+pt][mel-in-patch][frame-in-patch].
+            const int pf = lane >> 4, mp = lane & 15;
             unsigned short y[4];
 #pragma unroll
             for (int r = 0; r < 4; ++r) y[r] = to_op16(db[r] * bn_sc + bn_sh, a.op_bf16);
             unsigned short* out = (unsigned short*)a.mel;
             if (a.ncrops == 1) {
-                // the wave holds one whole patch (pf = j, pt = k0): lane = (mel p, frames 4q..4q+3) -> 8 contiguous
-                // bytes per lane, 512 contiguous bytes per wave: ONE store instruction
+                // lane = (mel, frames 4*wave .. 4*wave+3 of time patch k0): 8 contiguous bytes per lane
                 if (!is_tail && k0 < a.nt) {
                     typedef unsigned short us4 __attribute__((ext_vector_type(4)));
-                    *(us4*)(out + (((int64_t)b * 24 + j * 6 + k0) * 16 + p) * 16 + 4 * q) = us4{y[0], y[1], y[2], y[3]};
+                    *(us4*)(out + (((int64_t)b * 24 + pf * 6 + k0) * 16 + mp) * 16 + 4 * wave) = us4{y[0], y[1], y[2], y[3]};
                 }
             } else {
                 // long clips: crops start every target_length frames, not patch aligned -> per-element stores; a frame
@@ -287,10 +278,10 @@ __global__ __launch_bounds__(FE_WAVES * 64, 2) void mel_frontend_kernel(Frontend
                     if (bb < 0) continue;
                     const int cr0 = f / a.tl, t0 = f - cr0 * a.tl;
                     if (cr0 < a.ncrops - 1 && t0 < 96)
-                        out[(((bb * a.ncrops + cr0) * 24 + j * 6 + (t0 >> 4)) * 16 + p) * 16 + (t0 & 15)] = y[r];
+                        out[(((bb * a.ncrops + cr0) * 24 + pf * 6 + (t0 >> 4)) * 16 + mp) * 16 + (t0 & 15)] = y[r];
                     const int t1 = f - (a.nF - a.tl);
                     if (t1 >= 0 && t1 < 96)
-                        out[(((bb * a.ncrops + a.ncrops - 1) * 24 + j * 6 + (t1 >> 4)) * 16 + p) * 16 + (t1 & 15)] = y[r];
+                        out[(((bb * a.ncrops + a.ncrops - 1) * 24 + pf * 6 + (t1 >> 4)) * 16 + mp) * 16 + (t1 & 15)] = y[r];
                 }
             }
         }
@@ -299,13 +290,12 @@ __global__ __launch_bounds__(FE_WAVES * 64, 2) void mel_frontend_kernel(Frontend
 
     int64_t prev = -1;
     for (int64_t pass = blockIdx.x; pass < npass; pass += gridDim.x, ++it) {
-        float* P = Pbase + (it & 1) * 16 * FE_PROW;
+        float* Pq = Pbase + (((it & 1) * FE_WAVES + wave) * 4 + q) * FE_PROW;      // this frame's power row (wave-private)
         const bool is_tail = pass >= nfull;              // uniform
         const bool quad_live = !is_tail || 4 * wave < per_tail * rem;        // uniform per wave: skip fully dead quads
         c32 v[16];
         load_pass(pass, v);                              // issue this pass's sample loads ...
         if (it > 0) mel_phase(it - 1, prev);             // ... and cover their latency with the previous pass's mel phase
-        load_bw((wave + it) & 3);                        // B operands of THIS pass's mel phase: land under the FFT below
         FSTAMP(0);
         // -------------------------------------------------------------------------------- FFT phase
         if (quad_live) {
@@ -340,7 +330,7 @@ __global__ __launch_bounds__(FE_WAVES * 64, 2) void mel_frontend_kernel(Frontend
             }
             const c32 z128 = Z[q * FE_ZROW + 128];
             // power spectrum of bins k and 256-k into the workgroup tile P[frame 4*wave+q][bin]
-            float* prow = P + (4 * wave + q) * FE_PROW;
+            float* prow = Pq;
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
                 const int k = p + 16 * j;
@@ -356,8 +346,9 @@ __global__ __launch_bounds__(FE_WAVES * 64, 2) void mel_frontend_kernel(Frontend
             if (p == 0) prow[128] = 4.0f * (z128.x * z128.x + z128.y * z128.y);
         }
         FSTAMP(3);                                       // Z read + split + power write
-        __syncthreads();                                 // P[it&1] complete; everyone is done reading P[(it-1)&1]
-        FSTAMP(4);                                       // barrier wait
+        __builtin_amdgcn_wave_barrier();                 // the power rows are wave-private: LDS ops of one wave complete in
+        asm volatile("" ::: "memory");                   // order, so the mel phase one pass later needs no workgroup barrier
+        FSTAMP(4);
         prev = pass;
     }
     if (it > 0) mel_phase(it - 1, prev);

@@ -84,21 +84,26 @@ int pack_image(const uitk_config* c, const uitk_weights* w, std::vector<char>* o
     const int prec = c->precision, depth = c->depth, C = c->outputdim;
     const int ntiles = (C + 15) / 16;
     const int nb = c->n_fft / 2 + 1;
-    // ---- mel filterbank as banded MFMA B operands: per 16-mel tile the bin range [klo, klo + 4*steps)
-    int tile_klo[4], tile_steps[4], tile_base[4], total_steps = 0;
-    for (int j = 0; j < 4; ++j) {
-        int first = -1, last = -1;
-        for (int k = 0; k < nb; ++k)
-            for (int m = 16 * j; m < 16 * j + 16; ++m)
-                if (w->mel_fb[k * NMEL + m] != 0.0f) { if (first < 0) first = k; last = k; }
-        tile_klo[j] = first < 0 ? 0 : (first & ~3);
-        tile_steps[j] = first < 0 ? 0 : (last - tile_klo[j]) / 4 + 1;
-        tile_base[j] = total_steps;
-        total_steps += (tile_steps[j] + 7) / 8 * 8;            // table zero-padded to whole 8-step chunks
+    // ---- mel filterbank as banded B operands of v_mfma_f32_4x4x1 (16 independent 4x4 blocks): block g owns mels
+    // 4g..4g+3 and walks its own bin window [klo_g, klo_g + S), S = the widest group's band (HTK, 64 mels: 49 bins)
+    int grp_klo[16], mel_S = 1;
+    {
+        int first[16], last[16];
+        for (int g = 0; g < 16; ++g) {
+            first[g] = -1; last[g] = -1;
+            for (int k = 0; k < nb; ++k)
+                for (int m = 4 * g; m < 4 * g + 4; ++m)
+                    if (w->mel_fb[k * NMEL + m] != 0.0f) { if (first[g] < 0) first[g] = k; last[g] = k; }
+            if (first[g] >= 0 && last[g] - first[g] + 1 > mel_S) mel_S = last[g] - first[g] + 1;
+        }
+        for (int g = 0; g < 16; ++g) {
+            int klo = first[g] < 0 ? 0 : first[g];
+            if (klo > MEL_KMAX - mel_S) klo = MEL_KMAX - mel_S;      // keep every window inside the power row
+            grp_klo[g] = klo < 0 ? 0 : klo;
+        }
     }
     ImageHeader h{};
-    h.magic = IMAGE_MAGIC; h.precision = prec; h.depth = depth; h.outputdim = C; h.mel_steps = total_steps;
-    for (int j = 0; j < 4; ++j) { h.mel_tile_klo[j] = tile_klo[j]; h.mel_tile_steps[j] = tile_steps[j]; h.mel_tile_base[j] = tile_base[j]; }
+    h.magic = IMAGE_MAGIC; h.precision = prec; h.depth = depth; h.outputdim = C; h.mel_steps = mel_S;
     size_t o = align_up(sizeof(ImageHeader), 256);
     auto take = [&](size_t bytes) { size_t r = o; o = align_up(o + bytes, 256); return r; };
     h.off_wstream = take((size_t)(PE_STAGES + depth * BLOCK_STAGES + TAIL_STAGES) * STAGE_BYTES);
@@ -111,7 +116,7 @@ int pack_image(const uitk_config* c, const uitk_weights* w, std::vector<char>* o
     h.off_window = take(512 * 4);
     h.off_tw256 = take(256 * 8);
     h.off_tw512 = take(128 * 8);
-    h.off_mel_b = take((size_t)total_steps * 64 * 4 + 16);
+    h.off_mel_b = take((size_t)(1 + mel_S) * 64 * 4);                 // [64 lane klo (int32)] + [S][64 lanes] floats
     h.total_bytes = o;
     out->assign(o, 0);
     char* img = out->data();
@@ -131,14 +136,15 @@ int pack_image(const uitk_config* c, const uitk_weights* w, std::vector<char>* o
         const double a = 2.0 * M_PI * (double)k / 512.0;
         tw512[2 * k] = (float)std::cos(a); tw512[2 * k + 1] = (float)std::sin(a);
     }
-    float* mb = (float*)(img + h.off_mel_b);
-    for (int j = 0; j < 4; ++j)
-        for (int st = 0; st < tile_steps[j]; ++st)
-            for (int l = 0; l < 64; ++l) {
-                const int k = tile_klo[j] + 4 * st + (l >> 4), m = 16 * j + (l & 15);
-                // x 1/4 (exact): the front-end's power tile holds 4 |X|^2 (the real-FFT split without its two halvings)
-                mb[(size_t)(tile_base[j] + st) * 64 + l] = k < nb ? 0.25f * w->mel_fb[k * NMEL + m] : 0.0f;
-            }
+    int32_t* mklo = (int32_t*)(img + h.off_mel_b);
+    float* mb = (float*)(img + h.off_mel_b) + 64;
+    for (int l = 0; l < 64; ++l) mklo[l] = grp_klo[l >> 2];
+    for (int st = 0; st < mel_S; ++st)
+        for (int l = 0; l < 64; ++l) {                               // lane l = mel l (block l/4, column l%4)
+            const int k = grp_klo[l >> 2] + st;
+            // x 1/4 (exact): the front-end's power tile holds 4 |X|^2 (the real-FFT split without its two halvings)
+            mb[(size_t)st * 64 + l] = k < nb ? 0.25f * w->mel_fb[k * NMEL + l] : 0.0f;
+        }
 
     // ---- init_bn -> scale/shift
     float* sc = (float*)(img + h.off_bn_sc); float* sh = (float*)(img + h.off_bn_sh);

@@ -14,7 +14,7 @@ constexpr uint32_t IMAGE_MAGIC = 0x4b544955u;   // "UITK"
 struct ImageHeader {
     uint32_t magic;
     int32_t precision, depth, outputdim, mel_steps;
-    int32_t mel_tile_klo[4], mel_tile_steps[4], mel_tile_base[4];
+    int32_t _mel_reserved[12];              // (was: per-16-mel-tile band tables)
     int32_t _pad[3];
     uint64_t total_bytes;
     uint64_t off_wstream, off_bias, off_bn_sc, off_bn_sh, off_pe_bias, off_fin, off_head_w, off_head_b;
