@@ -39,6 +39,6 @@ for waves, B in (("8", 8192),):
     fr = fbuf.cpu().numpy().astype(np.float64)
     fr = fr[fr.sum(1) > 0]
     npass = B * 7 / 512.0
-    fn = ["samples+window", "FFT1+tw+Ewrite", "Eread+FFT2+Zwrite", "Zread+split+P", "barrier", "mel MFMA", "tail", "log+store"]
+    fn = ["pass setup+load issue", "load wait+window+FFT1+tw+Ewrite", "Eread+FFT2+Zwrite", "Zread+split+P", "barrier", "mel MFMA", "tail", "log+store"]
     print(f"   frontend per-pass cycles (median over {len(fr)} waves, {npass:.1f} passes/WG): "
           + "  ".join(f"{n}={v:.0f}" for n, v in zip(fn, np.median(fr, 0) / npass)) + f"  total/pass {np.median(fr.sum(1)) / npass:.0f}")

@@ -78,11 +78,12 @@ constexpr int FE_WAVES = 4;
 constexpr int FE_ROW = 17;                               // padded row stride (complex) of the transpose tile
 constexpr int FE_ZROW = 272;                             // per-frame stride (complex) of the natural-order Z tile
 constexpr int FE_WAVE_LDS = 4 * FE_ZROW * 8;             // 8704 B per wave: E[4][16][17] (8704 B) / Z[4][272]
-constexpr int FE_PROW = 290;                             // power-tile row stride (floats): == 2 mod 32, >= 260
-constexpr int FE_P_LDS = 2 * 16 * FE_PROW * 4;           // double-buffered P[16][290]
+constexpr int FE_PROW = MEL_PROW;                        // power row stride (floats): 272 = 16 mod 32 (the four rows of a wave
+                                                         // write disjoint banks), multiple of 4 (b128 operand reads), >= 260
+constexpr int FE_P_LDS = 16 * FE_PROW * 4;               // P[4 waves][4 frames][272], wave-private rows
+constexpr int FE_B_LDS = MEL_BMAX * 64 * 4;              // filterbank B operands [13][64 lanes][4 steps]: 13 KiB
 constexpr int FE_TAB_LDS = FE_LDS_TABLES ? (256 + 256 + 128) * 8 : 0;   // window pairs, W256^(p*k1) as [k1][p], (cos,sin)(2 pi k/512)
-constexpr int FE_LDS = FE_WAVES * FE_WAVE_LDS + FE_P_LDS + FE_TAB_LDS;
-constexpr int FE_BREG = 48;                              // filterbank steps held in VGPRs (HTK 64 mels: S = 49, the rest streams from L2)
+constexpr int FE_LDS = FE_WAVES * FE_WAVE_LDS + FE_P_LDS + FE_B_LDS + FE_TAB_LDS;    // 64 KiB: two workgroups per CU
 
 template <bool I16>
 __device__ __forceinline__ float load_sample(const void* pcm, int64_t row_off, int T, int s) {
@@ -116,10 +117,13 @@ __global__ __launch_bounds__(FE_WAVES * 64, 2) void mel_frontend_kernel(Frontend
     const int lane = tid & 63, q = lane >> 4, p = lane & 15;
     c32* E = (c32*)(smem + wave * FE_WAVE_LDS);          // [4][16][17] transpose tile, then Z[4][272]
     float* Pbase = (float*)(smem + FE_WAVES * FE_WAVE_LDS);
-    for (int i = tid; i < 2 * 16 * FE_PROW; i += FE_WAVES * 64) Pbase[i] = 0.f;   // pad columns must stay finite
+    float* Blds = Pbase + 16 * FE_PROW;
+    for (int i = tid; i < 16 * FE_PROW; i += FE_WAVES * 64) Pbase[i] = 0.f;       // pad columns must stay finite
+    // filterbank operands: the whole banded table if it fits (HTK: 52 steps), zero-padded to MEL_BMAX steps
+    for (int i = tid; i < MEL_BMAX * 64; i += FE_WAVES * 64) Blds[i] = (i >> 8) * 4 < a.mel_steps ? a.mel_b[64 + i] : 0.f;
 #if FE_LDS_TABLES
     // constant tables in LDS (b64 reads, conflict-free across p, broadcast across the 4 frames of a wave)
-    c32* Wwin = (c32*)(smem + FE_WAVES * FE_WAVE_LDS + FE_P_LDS);       // window[(2m, 2m+1)], m = 16 m1 + p
+    c32* Wwin = (c32*)(smem + FE_WAVES * FE_WAVE_LDS + FE_P_LDS + FE_B_LDS);       // window[(2m, 2m+1)], m = 16 m1 + p
     c32* Wtw = Wwin + 256;                                               // W256^(p*k1) at [k1][p]
     c32* Wpw = Wtw + 256;                                                // (cos, sin)(2 pi k / 512), k < 128
     {
@@ -203,41 +207,43 @@ __global__ __launch_bounds__(FE_WAVES * 64, 2) void mel_frontend_kernel(Frontend
     unsigned long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tlast = 0;
     if constexpr (TIMING) tlast = fe_stamp();
 
-    // B operands: the banded filterbank, one value per lane and step, constant over passes -> resident in VGPRs
     const int nst = a.mel_steps;
-    const int klo_g = ((const int*)a.mel_b)[lane];       // first bin of this lane's 4-mel group
-    const float* Bt = a.mel_b + 64 + lane;
-    float bw[FE_BREG];
-#pragma unroll
-    for (int c = 0; c < FE_BREG / 8; ++c)
-        if (8 * c < nst) {
-#pragma unroll
-            for (int s = 0; s < 8; ++s) bw[8 * c + s] = 8 * c + s < nst ? Bt[64 * (8 * c + s)] : 0.f;
-        }
+    const int klo_g = ((const int*)a.mel_b)[lane];       // first bin (multiple of 4) of this lane's 4-mel group
+    typedef float f4a __attribute__((ext_vector_type(4)));
 
     // ---- mel phase of one pass (matrix pipe): mel[frame][m] = sum_k P[frame][k] fb[k][m] for the wave's OWN four frames,
     // as 16 independent 4x4 blocks (one per 4-mel group, each walking its own bin band) of v_mfma_f32_4x4x1: no power
-    // tile shared between waves, no workgroup barrier.  Runs ONE PASS BEHIND the FFT phase, right after the next pass's
-    // sample loads were issued, so their HBM latency hides under these MFMAs, the log and the stores.
-    auto mel_phase = [&](int itp, int64_t passp) {
-        const float* Pw = Pbase + ((itp & 1) * FE_WAVES + wave) * 4 * FE_PROW;
+    // tile shared between waves, no workgroup barrier.  Operands arrive four steps at a time: A = ds_read_b128 of the
+    // lane's power row at its group's band, B = ds_read_b128 of the lane's filterbank column.  One straight-line block of
+    // MEL_BMAX steps (steps past the band multiply zero B operands by finite pad columns), so the reads of later steps fly
+    // under the MFMAs of earlier ones; the next pass's sample loads are already in flight behind it.
+    auto mel_phase = [&](int64_t passp) {
         const bool is_tail = passp >= nfull;             // uniform
         const int b = is_tail ? (int)((passp - nfull) * per_tail) : (int)(passp / full);   // (first) clip of the pass
         const int k0 = is_tail ? full : (int)(passp - (int64_t)b * full);
         const int fbase = 16 * k0 + 4 * wave;            // first frame of this wave's quad in a full pass
-        const float* Ar = Pw + (lane & 3) * FE_PROW + klo_g;     // A[row = frame lane&3][k = step] of block lane>>2
+        const float* Ar = Pbase + (4 * wave + (lane & 3)) * FE_PROW + klo_g;     // A[row = frame lane&3][k = step] of block lane>>2
+        const float* Bl = Blds + lane * 4;
         f4v acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+        if (nst <= MEL_BMAX) {
 #pragma unroll
-        for (int c = 0; c < FE_BREG / 8; ++c)
-            if (8 * c < nst) {
-#pragma unroll
-                for (int s = 0; s < 8; s += 2) {
-                    acc0 = __builtin_amdgcn_mfma_f32_4x4x1f32(Ar[8 * c + s], bw[8 * c + s], acc0, 0, 0, 0);
-                    acc1 = __builtin_amdgcn_mfma_f32_4x4x1f32(Ar[8 * c + s + 1], bw[8 * c + s + 1], acc1, 0, 0, 0);
-                }
+            for (int c = 0; c < MEL_BMAX / 4; ++c) {
+                const f4a A4 = *(const f4a*)(Ar + 4 * c), B4 = *(const f4a*)(Bl + 256 * c);
+                acc0 = __builtin_amdgcn_mfma_f32_4x4x1f32(A4[0], B4[0], acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_4x4x1f32(A4[1], B4[1], acc1, 0, 0, 0);
+                acc0 = __builtin_amdgcn_mfma_f32_4x4x1f32(A4[2], B4[2], acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_4x4x1f32(A4[3], B4[3], acc1, 0, 0, 0);
             }
-        for (int s = FE_BREG; s < nst; ++s)              // bands wider than FE_BREG bins (HTK: one step; dense filterbanks: many)
-            acc0 = __builtin_amdgcn_mfma_f32_4x4x1f32(Ar[s], Bt[64 * s], acc0, 0, 0, 0);
+        } else {                                         // bands wider than MEL_BMAX bins (not HTK; a dense filterbank walks 260)
+            const float* Bg = a.mel_b + 64 + lane * 4;
+            for (int c = 0; c < nst / 4; ++c) {
+                const f4a A4 = *(const f4a*)(Ar + 4 * c), B4 = *(const f4a*)(Bg + 256 * c);
+                acc0 = __builtin_amdgcn_mfma_f32_4x4x1f32(A4[0], B4[0], acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_4x4x1f32(A4[1], B4[1], acc1, 0, 0, 0);
+                acc0 = __builtin_amdgcn_mfma_f32_4x4x1f32(A4[2], B4[2], acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_4x4x1f32(A4[3], B4[3], acc1, 0, 0, 0);
+            }
+        }
         const f4v acc = acc0 + acc1;                     // D[frame slot 4*wave + r][mel lane]
         FSTAMP(5);                                       // mel MFMAs
         float db[4];
@@ -288,15 +294,13 @@ __global__ __launch_bounds__(FE_WAVES * 64, 2) void mel_frontend_kernel(Frontend
         FSTAMP(7);                                       // log + bn + stores
     };
 
-    int64_t prev = -1;
+    float* Pq = Pbase + (4 * wave + q) * FE_PROW;        // this frame's power row (wave-private)
+    c32 v[16];
+    if ((int64_t)blockIdx.x < npass) load_pass(blockIdx.x, v);
     for (int64_t pass = blockIdx.x; pass < npass; pass += gridDim.x, ++it) {
-        float* Pq = Pbase + (((it & 1) * FE_WAVES + wave) * 4 + q) * FE_PROW;      // this frame's power row (wave-private)
         const bool is_tail = pass >= nfull;              // uniform
         const bool quad_live = !is_tail || 4 * wave < per_tail * rem;        // uniform per wave: skip fully dead quads
-        c32 v[16];
-        load_pass(pass, v);                              // issue this pass's sample loads ...
-        if (it > 0) mel_phase(it - 1, prev);             // ... and cover their latency with the previous pass's mel phase
-        FSTAMP(0);
+        FSTAMP(0);                                       // pass bookkeeping
         // -------------------------------------------------------------------------------- FFT phase
         if (quad_live) {
 #pragma unroll
@@ -347,11 +351,13 @@ __global__ __launch_bounds__(FE_WAVES * 64, 2) void mel_frontend_kernel(Frontend
         }
         FSTAMP(3);                                       // Z read + split + power write
         __builtin_amdgcn_wave_barrier();                 // the power rows are wave-private: LDS ops of one wave complete in
-        asm volatile("" ::: "memory");                   // order, so the mel phase one pass later needs no workgroup barrier
-        FSTAMP(4);
-        prev = pass;
+        asm volatile("" ::: "memory");                   // order, so the mel phase below needs no workgroup barrier
+        // the sample registers are free again: issue the NEXT pass's loads now, their HBM latency hides under this pass's
+        // mel MFMAs, log and stores
+        if (pass + gridDim.x < npass) load_pass(pass + gridDim.x, v);
+        FSTAMP(4);                                       // next pass's load issue
+        mel_phase(pass);
     }
-    if (it > 0) mel_phase(it - 1, prev);
     FSTAMP(6);                                                            // (accumulates log + stores of all passes? no: tail only)
     if constexpr (TIMING) {
         if (a.timing != nullptr && lane == 0) {

@@ -86,7 +86,7 @@ int pack_image(const uitk_config* c, const uitk_weights* w, std::vector<char>* o
     const int nb = c->n_fft / 2 + 1;
     // ---- mel filterbank as banded B operands of v_mfma_f32_4x4x1 (16 independent 4x4 blocks): block g owns mels
     // 4g..4g+3 and walks its own bin window [klo_g, klo_g + S), S = the widest group's band (HTK, 64 mels: 49 bins)
-    int grp_klo[16], mel_S = 1;
+    int grp_klo[16], mel_S = 4;
     {
         int first[16], last[16];
         for (int g = 0; g < 16; ++g) {
@@ -94,11 +94,13 @@ int pack_image(const uitk_config* c, const uitk_weights* w, std::vector<char>* o
             for (int k = 0; k < nb; ++k)
                 for (int m = 4 * g; m < 4 * g + 4; ++m)
                     if (w->mel_fb[k * NMEL + m] != 0.0f) { if (first[g] < 0) first[g] = k; last[g] = k; }
-            if (first[g] >= 0 && last[g] - first[g] + 1 > mel_S) mel_S = last[g] - first[g] + 1;
+            const int span = first[g] < 0 ? 0 : last[g] - (first[g] & ~3) + 1;       // windows start on multiples of 4 bins
+            if (span > mel_S) mel_S = (span + 3) & ~3;
         }
+        const int walk = mel_S > MEL_BMAX ? mel_S : MEL_BMAX;       // steps the kernel actually reads
         for (int g = 0; g < 16; ++g) {
-            int klo = first[g] < 0 ? 0 : first[g];
-            if (klo > MEL_KMAX - mel_S) klo = MEL_KMAX - mel_S;      // keep every window inside the power row
+            int klo = first[g] < 0 ? 0 : (first[g] & ~3);
+            if (klo > MEL_PROW - walk) klo = MEL_PROW - walk;       // keep every window inside the power row (272 = 4 * 68)
             grp_klo[g] = klo < 0 ? 0 : klo;
         }
     }
@@ -116,7 +118,7 @@ int pack_image(const uitk_config* c, const uitk_weights* w, std::vector<char>* o
     h.off_window = take(512 * 4);
     h.off_tw256 = take(256 * 8);
     h.off_tw512 = take(128 * 8);
-    h.off_mel_b = take((size_t)(1 + mel_S) * 64 * 4);                 // [64 lane klo (int32)] + [S][64 lanes] floats
+    h.off_mel_b = take((size_t)(1 + mel_S) * 64 * 4);                 // [64 lane klo (int32)] + [S/4][64 lanes][4] floats
     h.total_bytes = o;
     out->assign(o, 0);
     char* img = out->data();
@@ -143,7 +145,7 @@ int pack_image(const uitk_config* c, const uitk_weights* w, std::vector<char>* o
         for (int l = 0; l < 64; ++l) {                               // lane l = mel l (block l/4, column l%4)
             const int k = grp_klo[l >> 2] + st;
             // x 1/4 (exact): the front-end's power tile holds 4 |X|^2 (the real-FFT split without its two halvings)
-            mb[(size_t)st * 64 + l] = k < nb ? 0.25f * w->mel_fb[k * NMEL + l] : 0.0f;
+            mb[((size_t)(st >> 2) * 64 + l) * 4 + (st & 3)] = k < nb ? 0.25f * w->mel_fb[k * NMEL + l] : 0.0f;
         }
 
     // ---- init_bn -> scale/shift

@@ -15,7 +15,8 @@ constexpr int GT = 6, GF = 4;
 constexpr int INNER = 32;               // BNeckAttention inner_dim = dim/4 (uit.py:101), 2 heads x 16
 constexpr int HID = 384;                // mlp hidden
 constexpr int NMEL = 64;
-constexpr int MEL_KMAX = 260;           // mel bin windows end at or before this column of the (zero-padded) power row
+constexpr int MEL_PROW = 272;           // row stride (floats) of the front-end's zero-padded power rows: every mel bin window ends inside it
+constexpr int MEL_BMAX = 52;            // filterbank steps the front-end keeps on chip (its fast path always runs this many)
 
 // ---- weight stream: 16 KiB stages of sixteen 1 KiB MFMA A/B fragments (see pack.cpp / encoder.hip)
 constexpr int FRAG_BYTES = 1024;        // 64 lanes x 8 x 16-bit
@@ -34,9 +35,9 @@ struct FrontendArgs {
     const float* window;    // [512]
     const float2* tw256;    // [16][16]  W256^(p*k1) = (cos, -sin)(2 pi p k1 / 256)
     const float2* tw512;    // [128]     (cos, sin)(2 pi k / 512)
-    const float* mel_b;     // banded filterbank for v_mfma_f32_4x4x1: [64 x int32 first bin of the lane's mel group]
-                            // then [mel_steps][64 lanes] B operands (x 1/4)
-    int mel_steps;          // S: bins every 4-mel group walks
+    const float* mel_b;     // banded filterbank for v_mfma_f32_4x4x1: [64 x int32 first bin of the lane's mel group, a
+                            // multiple of 4] then [mel_steps/4][64 lanes][4 steps] B operands (x 1/4)
+    int mel_steps;          // S: bins every 4-mel group walks (multiple of 4)
     float* mel;             // PATCH layout: 16-bit MFMA operands [B*ncrops][24 tokens][16 frames][16 mels] holding
                             // init_bn(dB) WITHOUT the top_db clamp (the encoder clamps); FRAMES layout (uitk_mel_db
                             // only): fp32 dB [B][nF][64]
