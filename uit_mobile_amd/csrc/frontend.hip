@@ -69,21 +69,25 @@ __device__ __forceinline__ void fft16(c32 (&v)[16]) {
 }
 
 #ifndef FE_LDS_TABLES
-#define FE_LDS_TABLES 0      // 1: window/twiddles in LDS tables; 0: per-lane VGPR constants (measured faster: 0.49 vs 0.54 ms)
+#define FE_LDS_TABLES 0      // mask of constant tables kept in LDS instead of per-lane VGPRs (1 window, 2 W256, 4 W512); 0 measured fastest
 #endif
 #ifndef FE_PREFETCH
 #define FE_PREFETCH 0        // 1: prefetch the next pass's samples during the current pass (measured slower: +0.02 ms)
 #endif
 constexpr int FE_WAVES = 4;
+#ifndef FE_OCC
+#define FE_OCC 2             // workgroups per CU the register allocation aims at
+#endif
 constexpr int FE_ROW = 17;                               // padded row stride (complex) of the transpose tile
 constexpr int FE_ZROW = 272;                             // per-frame stride (complex) of the natural-order Z tile
 constexpr int FE_WAVE_LDS = 4 * FE_ZROW * 8;             // 8704 B per wave: E[4][16][17] (8704 B) / Z[4][272]
 constexpr int FE_PROW = MEL_PROW;                        // power row stride (floats): 272 = 16 mod 32 (the four rows of a wave
                                                          // write disjoint banks), multiple of 4 (b128 operand reads), >= 260
-constexpr int FE_P_LDS = 16 * FE_PROW * 4;               // P[4 waves][4 frames][272], wave-private rows
+constexpr int FE_PSTRIDE = 2 * FE_ZROW + 16;             // a frame's power row overlays the start of its own (dead) Z row, skewed by
+                                                         // 16 floats per frame: row stride 560 = 16 mod 32, rows 16-byte aligned
 constexpr int FE_B_LDS = MEL_BMAX * 64 * 4;              // filterbank B operands [13][64 lanes][4 steps]: 13 KiB
 constexpr int FE_TAB_LDS = FE_LDS_TABLES ? (256 + 256 + 128) * 8 : 0;   // window pairs, W256^(p*k1) as [k1][p], (cos,sin)(2 pi k/512)
-constexpr int FE_LDS = FE_WAVES * FE_WAVE_LDS + FE_P_LDS + FE_B_LDS + FE_TAB_LDS;    // 64 KiB: two workgroups per CU
+constexpr int FE_LDS = FE_WAVES * FE_WAVE_LDS + FE_B_LDS + FE_TAB_LDS;    // 47 KiB: three workgroups per CU
 
 template <bool I16>
 __device__ __forceinline__ float load_sample(const void* pcm, int64_t row_off, int T, int s) {
@@ -110,46 +114,47 @@ __device__ __forceinline__ unsigned long long fe_stamp() {
 #define FSTAMP(slot) do { if constexpr (TIMING) { const unsigned long long _t = fe_stamp(); tacc[slot] += _t - tlast; tlast = _t; } } while (0)
 
 template <bool I16, bool PATCH, bool TIMING>
-__global__ __launch_bounds__(FE_WAVES * 64, 2) void mel_frontend_kernel(FrontendArgs a) {
+__global__ __launch_bounds__(FE_WAVES * 64, FE_OCC) void mel_frontend_kernel(FrontendArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lane = tid & 63, q = lane >> 4, p = lane & 15;
     c32* E = (c32*)(smem + wave * FE_WAVE_LDS);          // [4][16][17] transpose tile, then Z[4][272]
-    float* Pbase = (float*)(smem + FE_WAVES * FE_WAVE_LDS);
-    float* Blds = Pbase + 16 * FE_PROW;
-    for (int i = tid; i < 16 * FE_PROW; i += FE_WAVES * 64) Pbase[i] = 0.f;       // pad columns must stay finite
+    float* Blds = (float*)(smem + FE_WAVES * FE_WAVE_LDS);
+    // the power rows overlay the Z rows; their pad columns (bins 257..271, multiplied by zero filterbank operands) only have
+    // to be finite: stale FFT values are, uninitialised LDS need not be
+    for (int i = tid; i < FE_WAVES * FE_WAVE_LDS / 4; i += FE_WAVES * 64) ((float*)smem)[i] = 0.f;
     // filterbank operands: the whole banded table if it fits (HTK: 52 steps), zero-padded to MEL_BMAX steps
     for (int i = tid; i < MEL_BMAX * 64; i += FE_WAVES * 64) Blds[i] = (i >> 8) * 4 < a.mel_steps ? a.mel_b[64 + i] : 0.f;
-#if FE_LDS_TABLES
-    // constant tables in LDS (b64 reads, conflict-free across p, broadcast across the 4 frames of a wave)
-    c32* Wwin = (c32*)(smem + FE_WAVES * FE_WAVE_LDS + FE_P_LDS + FE_B_LDS);       // window[(2m, 2m+1)], m = 16 m1 + p
+    // per-lane constants: window pairs, W256^(p*k1), (cos, sin)(2 pi k / 512).  Each table lives either in VGPRs (default) or
+    // in LDS (FE_LDS_TABLES mask: 1 window, 2 W256, 4 W512; b64 reads, conflict-free across p, broadcast across the wave's
+    // four frames) -- the LDS forms free 32 / 32 / 16 VGPRs for a higher occupancy target (FE_OCC)
+    c32* Wwin = (c32*)(smem + FE_WAVES * FE_WAVE_LDS + FE_B_LDS);       // window[(2m, 2m+1)], m = 16 m1 + p
     c32* Wtw = Wwin + 256;                                               // W256^(p*k1) at [k1][p]
     c32* Wpw = Wtw + 256;                                                // (cos, sin)(2 pi k / 512), k < 128
-    {
+    if (FE_LDS_TABLES) {
         const int i = tid;                                               // 256 threads
-        Wwin[i] = *(const c32*)(a.window + 2 * i);
-        const float2 t = a.tw256[(i & 15) * 16 + (i >> 4)];              // source is [p][k1]
-        Wtw[i] = c32{t.x, t.y};
-        if (i < 128) { const float2 u = a.tw512[i]; Wpw[i] = c32{u.x, u.y}; }
+        if (FE_LDS_TABLES & 1) Wwin[i] = *(const c32*)(a.window + 2 * i);
+        if (FE_LDS_TABLES & 2) { const float2 t = a.tw256[(i & 15) * 16 + (i >> 4)]; Wtw[i] = c32{t.x, t.y}; }   // source is [p][k1]
+        if ((FE_LDS_TABLES & 4) && i < 128) { const float2 u = a.tw512[i]; Wpw[i] = c32{u.x, u.y}; }
     }
     __syncthreads();
-#define WIN(m1) Wwin[16 * (m1) + p]
-#define TW(k1) Wtw[16 * (k1) + p]
-#define PW(j) Wpw[p + 16 * (j)]
-#else
-    __syncthreads();
     c32 win_[16], tw_[16], pw_[8];                                       // per-lane VGPR constants
+    if (!(FE_LDS_TABLES & 1)) {
 #pragma unroll
-    for (int m1 = 0; m1 < 16; ++m1) win_[m1] = *(const c32*)(a.window + 32 * m1 + 2 * p);
+        for (int m1 = 0; m1 < 16; ++m1) win_[m1] = *(const c32*)(a.window + 32 * m1 + 2 * p);
+    }
+    if (!(FE_LDS_TABLES & 2)) {
 #pragma unroll
-    for (int k1 = 0; k1 < 16; ++k1) { const float2 t = a.tw256[p * 16 + k1]; tw_[k1] = c32{t.x, t.y}; }
+        for (int k1 = 0; k1 < 16; ++k1) { const float2 t = a.tw256[p * 16 + k1]; tw_[k1] = c32{t.x, t.y}; }
+    }
+    if (!(FE_LDS_TABLES & 4)) {
 #pragma unroll
-    for (int j = 0; j < 8; ++j) { const float2 t = a.tw512[p + 16 * j]; pw_[j] = c32{t.x, t.y}; }
-#define WIN(m1) win_[m1]
-#define TW(k1) tw_[k1]
-#define PW(j) pw_[j]
-#endif
+        for (int j = 0; j < 8; ++j) { const float2 t = a.tw512[p + 16 * j]; pw_[j] = c32{t.x, t.y}; }
+    }
+#define WIN(m1) ((FE_LDS_TABLES & 1) ? Wwin[16 * (m1) + p] : win_[m1])
+#define TW(k1) ((FE_LDS_TABLES & 2) ? Wtw[16 * (k1) + p] : tw_[k1])
+#define PW(j) ((FE_LDS_TABLES & 4) ? Wpw[p + 16 * (j)] : pw_[j])
 
     // "full" passes are (clip b, column k): frames 16k..16k+15; the nF % 16 leftover frames of a clip are bundled,
     // per_tail clips at a time, into "tail" passes (for 1 s clips: 6 full passes per clip + one tail pass per 3 clips)
@@ -222,7 +227,7 @@ __global__ __launch_bounds__(FE_WAVES * 64, 2) void mel_frontend_kernel(Frontend
         const int b = is_tail ? (int)((passp - nfull) * per_tail) : (int)(passp / full);   // (first) clip of the pass
         const int k0 = is_tail ? full : (int)(passp - (int64_t)b * full);
         const int fbase = 16 * k0 + 4 * wave;            // first frame of this wave's quad in a full pass
-        const float* Ar = Pbase + (4 * wave + (lane & 3)) * FE_PROW + klo_g;     // A[row = frame lane&3][k = step] of block lane>>2
+        const float* Ar = (const float*)E + (lane & 3) * FE_PSTRIDE + klo_g;     // A[row = frame lane&3][k = step] of block lane>>2
         const float* Bl = Blds + lane * 4;
         f4v acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
         if (nst <= MEL_BMAX) {
@@ -294,7 +299,7 @@ __global__ __launch_bounds__(FE_WAVES * 64, 2) void mel_frontend_kernel(Frontend
         FSTAMP(7);                                       // log + bn + stores
     };
 
-    float* Pq = Pbase + (4 * wave + q) * FE_PROW;        // this frame's power row (wave-private)
+    float* Pq = (float*)E + q * FE_PSTRIDE;              // this frame's power row (wave-private, over its own Z row)
     c32 v[16];
     if ((int64_t)blockIdx.x < npass) load_pass(blockIdx.x, v);
     for (int64_t pass = blockIdx.x; pass < npass; pass += gridDim.x, ++it) {
@@ -333,6 +338,8 @@ __global__ __launch_bounds__(FE_WAVES * 64, 2) void mel_frontend_kernel(Frontend
                 zb[j] = Z[q * FE_ZROW + ((256 - k) & 255)];
             }
             const c32 z128 = Z[q * FE_ZROW + 128];
+            __builtin_amdgcn_wave_barrier();             // every Z value is in registers: the power row may overwrite the Z row
+            asm volatile("" ::: "memory");
             // power spectrum of bins k and 256-k into the workgroup tile P[frame 4*wave+q][bin]
             float* prow = Pq;
 #pragma unroll
@@ -406,7 +413,7 @@ static hipError_t launch_fe(const FrontendArgs& a, int grid, hipStream_t stream)
 hipError_t launch_frontend(const FrontendArgs& a, int in_i16, int patch_layout, int n_cu, hipStream_t stream) {
     const int rem = a.nF & 15;
     const int64_t npass = a.B * (int64_t)(a.nF >> 4) + (rem ? (a.B + 16 / rem - 1) / (16 / rem) : 0);
-    int grid = (int)(npass < (int64_t)n_cu * 2 ? npass : (int64_t)n_cu * 2);      // 2 resident workgroups per CU
+    int grid = (int)(npass < (int64_t)n_cu * FE_OCC ? npass : (int64_t)n_cu * FE_OCC);      // resident workgroups per CU
     if (grid < 1) grid = 1;
     if (a.timing != nullptr && patch_layout && !in_i16) return launch_fe<false, true, true>(a, grid, stream);
     if (patch_layout) return in_i16 ? launch_fe<true, true>(a, grid, stream) : launch_fe<false, true>(a, grid, stream);
