@@ -176,11 +176,13 @@ __global__ __launch_bounds__(FE_WAVES * 64, FE_OCC) void mel_frontend_kernel(Fro
     // quad, as B operand / result x = mel within the group, i.e. result column = mel `lane`
     const float bn_sc = PATCH ? a.bn_sc[lane] : 0.f, bn_sh = PATCH ? a.bn_sh[lane] : 0.f;   // init_bn scale/shift of mel `lane`
     // raw (unwindowed) sample pairs of this lane's frame for a pass: z[m1] = (x[32 m1 + 2p], x[32 m1 + 2p + 1])
-    auto load_pass = [&](int64_t pass, c32 (&raw)[16]) {
+    // (clip, column) of a full pass are tracked incrementally by the pass loop: a 64-bit division costs ~130 scalar
+    // instructions per use
+    auto load_pass = [&](int64_t pass, int pb_, int pk_, c32 (&raw)[16]) {
         int b, f;
         if (pass < nfull) {
-            b = (int)(pass / full);
-            f = 16 * (int)(pass - (int64_t)b * full) + 4 * wave + q;
+            b = pb_;
+            f = 16 * pk_ + 4 * wave + q;
         } else {
             const int64_t cb = (pass - nfull) * per_tail;
             if (4 * wave >= per_tail * rem) return;                       // fully dead quad of a tail pass (uniform)
@@ -222,10 +224,10 @@ __global__ __launch_bounds__(FE_WAVES * 64, FE_OCC) void mel_frontend_kernel(Fro
     // lane's power row at its group's band, B = ds_read_b128 of the lane's filterbank column.  One straight-line block of
     // MEL_BMAX steps (steps past the band multiply zero B operands by finite pad columns), so the reads of later steps fly
     // under the MFMAs of earlier ones; the next pass's sample loads are already in flight behind it.
-    auto mel_phase = [&](int64_t passp) {
+    auto mel_phase = [&](int64_t passp, int pb_, int pk_) {
         const bool is_tail = passp >= nfull;             // uniform
-        const int b = is_tail ? (int)((passp - nfull) * per_tail) : (int)(passp / full);   // (first) clip of the pass
-        const int k0 = is_tail ? full : (int)(passp - (int64_t)b * full);
+        const int b = is_tail ? (int)((passp - nfull) * per_tail) : pb_;   // (first) clip of the pass
+        const int k0 = is_tail ? full : pk_;
         const int fbase = 16 * k0 + 4 * wave;            // first frame of this wave's quad in a full pass
         const float* Ar = (const float*)E + (lane & 3) * FE_PSTRIDE + klo_g;     // A[row = frame lane&3][k = step] of block lane>>2
         const float* Bl = Blds + lane * 4;
@@ -301,7 +303,10 @@ __global__ __launch_bounds__(FE_WAVES * 64, FE_OCC) void mel_frontend_kernel(Fro
 
     float* Pq = (float*)E + q * FE_PSTRIDE;              // this frame's power row (wave-private, over its own Z row)
     c32 v[16];
-    if ((int64_t)blockIdx.x < npass) load_pass(blockIdx.x, v);
+    const unsigned fdiv = full > 0 ? (unsigned)full : 1u;
+    const int gb = (int)(gridDim.x / fdiv), gk = (int)(gridDim.x % fdiv);             // the pass stride as (clips, columns)
+    int cb = (int)(blockIdx.x / fdiv), ck = (int)(blockIdx.x % fdiv);                 // (clip, column) of the current pass
+    if ((int64_t)blockIdx.x < npass) load_pass(blockIdx.x, cb, ck, v);
     for (int64_t pass = blockIdx.x; pass < npass; pass += gridDim.x, ++it) {
         const bool is_tail = pass >= nfull;              // uniform
         const bool quad_live = !is_tail || 4 * wave < per_tail * rem;        // uniform per wave: skip fully dead quads
@@ -361,9 +366,12 @@ __global__ __launch_bounds__(FE_WAVES * 64, FE_OCC) void mel_frontend_kernel(Fro
         asm volatile("" ::: "memory");                   // order, so the mel phase below needs no workgroup barrier
         // the sample registers are free again: issue the NEXT pass's loads now, their HBM latency hides under this pass's
         // mel MFMAs, log and stores
-        if (pass + gridDim.x < npass) load_pass(pass + gridDim.x, v);
+        int nb = cb + gb, nk = ck + gk;
+        if (nk >= full) { nk -= full; ++nb; }
+        if (pass + gridDim.x < npass) load_pass(pass + gridDim.x, nb, nk, v);
         FSTAMP(4);                                       // next pass's load issue
-        mel_phase(pass);
+        mel_phase(pass, cb, ck);
+        cb = nb; ck = nk;
     }
     FSTAMP(6);                                                            // (accumulates log + stores of all passes? no: tail only)
     if constexpr (TIMING) {
