@@ -233,13 +233,22 @@ __global__ __launch_bounds__(FE_WAVES * 64, FE_OCC) void mel_frontend_kernel(Fro
         const float* Bl = Blds + lane * 4;
         f4v acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
         if (nst <= MEL_BMAX) {
+            // operand reads run MEL_AHEAD groups (of four steps) ahead of their MFMAs, so that the LDS latency is covered by
+            // the MFMAs of the groups in between; the sched_barriers pin that order (the scheduler would otherwise sink
+            // every read to just before its use and expose the latency once per group)
+            constexpr int NG = MEL_BMAX / 4, MEL_AHEAD = 6;
+            f4a A4[NG], B4[NG];
 #pragma unroll
-            for (int c = 0; c < MEL_BMAX / 4; ++c) {
-                const f4a A4 = *(const f4a*)(Ar + 4 * c), B4 = *(const f4a*)(Bl + 256 * c);
-                acc0 = __builtin_amdgcn_mfma_f32_4x4x1f32(A4[0], B4[0], acc0, 0, 0, 0);
-                acc1 = __builtin_amdgcn_mfma_f32_4x4x1f32(A4[1], B4[1], acc1, 0, 0, 0);
-                acc0 = __builtin_amdgcn_mfma_f32_4x4x1f32(A4[2], B4[2], acc0, 0, 0, 0);
-                acc1 = __builtin_amdgcn_mfma_f32_4x4x1f32(A4[3], B4[3], acc1, 0, 0, 0);
+            for (int c = 0; c < MEL_AHEAD; ++c) { A4[c] = *(const f4a*)(Ar + 4 * c); B4[c] = *(const f4a*)(Bl + 256 * c); }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int c = 0; c < NG; ++c) {
+                if (c + MEL_AHEAD < NG) { A4[c + MEL_AHEAD] = *(const f4a*)(Ar + 4 * (c + MEL_AHEAD)); B4[c + MEL_AHEAD] = *(const f4a*)(Bl + 256 * (c + MEL_AHEAD)); }
+                acc0 = __builtin_amdgcn_mfma_f32_4x4x1f32(A4[c][0], B4[c][0], acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_4x4x1f32(A4[c][1], B4[c][1], acc1, 0, 0, 0);
+                acc0 = __builtin_amdgcn_mfma_f32_4x4x1f32(A4[c][2], B4[c][2], acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_4x4x1f32(A4[c][3], B4[c][3], acc1, 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
             }
         } else {                                         // bands wider than MEL_BMAX bins (not HTK; a dense filterbank walks 260)
             const float* Bg = a.mel_b + 64 + lane * 4;
