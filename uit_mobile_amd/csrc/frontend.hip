@@ -6,28 +6,29 @@
 // |X|^2 + mel filterbank + 10*log10(max(.,1e-10)) and the batch amax; the top_db clamp itself
 // (max(x, amax-120)) needs the amax of the WHOLE call, so it is applied by the consumer (encoder prologue).
 //
-// Mapping (wave64; a workgroup = 4 waves walks "passes" = (clip, 16-frame column); a clip's last pass is partial
-// and its fully dead quads skip the FFT):
+// Mapping (wave64; a workgroup = 4 waves walks "passes" = (clip, 16-frame column); each wave owns 4 of the 16 frames
+// from the sample loads to the stored operands -- the waves of a workgroup never exchange data and there is no
+// workgroup barrier in the pass loop; a clip's leftover frames are bundled into "tail" passes whose fully dead
+// quads skip the FFT):
 //   FFT phase, per wave, 4 frames x 16 lanes:
 //     * the 512 real samples of a frame are packed as 256 complex z[m] = x[2m] + i x[2m+1]; the 256-point complex
 //       FFT is a 16x16 Cooley-Tukey: lane p holds z[16*m1 + p] (m1 = 0..15), does a 16-point FFT in registers,
 //       multiplies by W256^(p*k1), transposes through a conflict-free padded LDS tile (row stride 17 complex),
 //       does the second 16-point FFT, and the real-FFT split X[k] = ((Z[k]+conj Z[256-k]) - i w^k (Z[k]-conj
 //       Z[256-k]))/2 pairs bins k and 256-k through LDS.  Complex values are float2 => v_pk_* math, b64 LDS ops.
-//     * window and both twiddle sets are per-lane VGPR constants (an LDS-table variant and a next-pass sample
-//       prefetch exist behind FE_LDS_TABLES / FE_PREFETCH; both measured slower on MI355X).
-//     * |X|^2 of the 4 frames goes to a workgroup-shared power tile P[16 frames][290] (double-buffered).
-//   mel phase, ONE workgroup barrier per pass, software-pipelined one pass BEHIND the FFT phase (the next pass's
-//   sample loads are issued first and their HBM latency hides under it):
-//     * mel[16 frames][64] = P[16][257] . fb[257][64] on the matrix pipe with the EXACT-fp32 MFMA
-//       v_mfma_f32_16x16x4_f32 (bitwise an fp32 fma chain, MI355X guide section 3).  The HTK filterbank is banded:
-//       each 16-mel tile only needs its own bin range, 70 k-steps of 4 in total instead of 4 x 65.  Each wave owns
-//       one mel tile per pass; the assignment rotates with the pass so the four (unequal) tiles balance.
+//     * window and both twiddle sets are per-lane VGPR constants (FE_LDS_TABLES moves any of them to LDS; with
+//       FE_OCC=3 that buys a third workgroup per CU -- measured equal, the kernel is VALU-issue bound).
+//     * 4|X|^2 of a frame overwrites the start of its own (dead) Z row; the 1/4 lives in the filterbank operand.
+//   then the NEXT pass's sample loads are issued (the FFT registers are free), and behind them the mel phase:
+//     * mel[4 frames][64] = P[4][257] . fb[257][64] on the matrix pipe with the EXACT-fp32 v_mfma_f32_4x4x1_16b_f32
+//       (bitwise an fp32 fma chain): its 16 independent 4x4 blocks are the sixteen 4-mel groups, each walking its
+//       OWN bin band of the triangular HTK filterbank (52 steps; a 16-mel tile of the 16x16x4 form needs up to 134).
+//       Operands come four steps per ds_read_b128 (A: the lane's power row at its group's band; B: the banded table,
+//       13 KiB of LDS), six groups ahead of their MFMAs.  Result column = mel = lane.
 //     * 10*log10(max(.,1e-10)) -> init_bn -> 16-bit operand, stored PATCH-MAJOR [clip-crop][24 tokens][16 mels][16 frames]
-//       (one 512-byte store per wave for single-crop clips) = exactly the k-slot order
-//       of the encoder's patch-embed MFMA operand (its gather becomes full 128-byte lines; the crop logic of
-//       models/uit.py:468-481 is resolved here: a frame lands in its regular crop and/or the re-cropped tail),
-//       wave-reduced amax -> one atomic per wave at kernel end.
+//       (8 bytes per lane: four frames of one mel) = exactly the k-slot order of the encoder's patch-embed MFMA
+//       operand; the crop logic of models/uit.py:468-481 is resolved here (a frame lands in its regular crop
+//       and/or the re-cropped tail); wave-reduced amax -> one atomic per wave at kernel end.
 //   HBM traffic: the PCM is read once (frames overlap 3.2x, absorbed by L1/L2), output 256 B per frame.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -70,9 +71,6 @@ __device__ __forceinline__ void fft16(c32 (&v)[16]) {
 
 #ifndef FE_LDS_TABLES
 #define FE_LDS_TABLES 0      // mask of constant tables kept in LDS instead of per-lane VGPRs (1 window, 2 W256, 4 W512); 0 measured fastest
-#endif
-#ifndef FE_PREFETCH
-#define FE_PREFETCH 0        // 1: prefetch the next pass's samples during the current pass (measured slower: +0.02 ms)
 #endif
 constexpr int FE_WAVES = 4;
 #ifndef FE_OCC
