@@ -79,10 +79,10 @@ constexpr int FE_WAVES = 4;
 constexpr int FE_ROW = 17;                               // padded row stride (complex) of the transpose tile
 constexpr int FE_ZROW = 272;                             // per-frame stride (complex) of the natural-order Z tile
 constexpr int FE_WAVE_LDS = 4 * FE_ZROW * 8;             // 8704 B per wave: E[4][16][17] (8704 B) / Z[4][272]
-constexpr int FE_PROW = MEL_PROW;                        // power row stride (floats): 272 = 16 mod 32 (the four rows of a wave
-                                                         // write disjoint banks), multiple of 4 (b128 operand reads), >= 260
-constexpr int FE_PSTRIDE = 2 * FE_ZROW + 16;             // a frame's power row overlays the start of its own (dead) Z row, skewed by
-                                                         // 16 floats per frame: row stride 560 = 16 mod 32, rows 16-byte aligned
+constexpr int FE_PSTRIDE = 2 * FE_ZROW + 16;             // a frame's power row (MEL_PROW floats) overlays the start of its own (dead) Z
+                                                         // row, skewed by 16 floats per frame: row stride 560 = 16 mod 32 (the four rows
+                                                         // of a wave hit disjoint banks), rows 16-byte aligned (b128 operand reads)
+static_assert(3 * 16 + MEL_PROW <= 2 * FE_ZROW && MEL_PROW % 4 == 0, "power row must fit inside its Z row");
 constexpr int FE_B_LDS = MEL_BMAX * 64 * 4;              // filterbank B operands [13][64 lanes][4 steps]: 13 KiB
 constexpr int FE_TAB_LDS = FE_LDS_TABLES ? (256 + 256 + 128) * 8 : 0;   // window pairs, W256^(p*k1) as [k1][p], (cos,sin)(2 pi k/512)
 constexpr int FE_LDS = FE_WAVES * FE_WAVE_LDS + FE_B_LDS + FE_TAB_LDS;    // 47 KiB: three workgroups per CU
