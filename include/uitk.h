@@ -132,7 +132,8 @@ int uitk_frontend(uitk_model* m, const void* pcm, int in_dtype, int64_t B, int64
 
 /* Device pointer to the batch amax slots (UITK_AMAX_SLOTS floats; the floor uses their max).  A multi-GPU
  * caller that wants the reference's batch-global floor across shards all-reduces (MAX) these in place
- * between uitk_frontend and uitk_encode. */
+ * between uitk_frontend and uitk_encode.  The pointer is the slot set of the LATEST uitk_frontend call (two sets
+ * alternate, so that no per-call memset is needed): query it after each uitk_frontend. */
 #define UITK_AMAX_SLOTS 64
 float* uitk_amax_ptr(uitk_model* m);
 

@@ -29,7 +29,8 @@ struct uitk_model {
     float* mel = nullptr;         // patch-major 16-bit operands [B*ncrops][24][16][16]
     float* mel_frames = nullptr;  // [B][nF][64], only for uitk_mel_db
     size_t mel_frames_cap = 0;
-    float* amax = nullptr;        // [AMAX_SLOTS]
+    float* amax = nullptr;        // [2][AMAX_SLOTS]: the front-end of call n fills set n&1 and re-arms the other one
+    int amax_cur = 0;             // set of the latest front-end launch
     float* rowprobs = nullptr;    // [B*ncrops][C] (multi-crop only)
     size_t mel_cap = 0, rowprobs_cap = 0;
     float* dbg = nullptr;
@@ -86,10 +87,11 @@ int uitk_create(const uitk_config* cfg, const uitk_weights* w, uitk_model** out)
     if (const char* e = std::getenv("UITK_ENC_STAGGER")) m->enc_stagger = std::atoi(e);
     if (const char* e = std::getenv("UITK_ENC_STAGGER_MODE")) m->enc_stagger_mode = std::atoi(e);
     if (const char* e = std::getenv("UITK_ENC_ABLATE")) m->enc_ablate = std::atoi(e);
-    if (hipMalloc((void**)&m->image, img.size()) != hipSuccess || hipMalloc((void**)&m->amax, AMAX_SLOTS * 4) != hipSuccess) {
+    if (hipMalloc((void**)&m->image, img.size()) != hipSuccess || hipMalloc((void**)&m->amax, 2 * AMAX_SLOTS * 4) != hipSuccess) {
         uitk_destroy(m); return fail(UITK_ERR_HIP, "hipMalloc failed for the parameter image");
     }
-    if (hipMemcpy(m->image, img.data(), img.size(), hipMemcpyHostToDevice) != hipSuccess) {
+    if (hipMemcpy(m->image, img.data(), img.size(), hipMemcpyHostToDevice) != hipSuccess ||
+        hipMemset(m->amax, 0xFF, 2 * AMAX_SLOTS * 4) != hipSuccess) {          // both amax slot sets start armed
         uitk_destroy(m); return fail(UITK_ERR_HIP, "parameter upload failed");
     }
     *out = m;
@@ -147,7 +149,7 @@ int uitk_reserve(uitk_model* m, int64_t B, int64_t T) {
     return UITK_OK;
 }
 
-float* uitk_amax_ptr(uitk_model* m) { return m ? m->amax : nullptr; }
+float* uitk_amax_ptr(uitk_model* m) { return m ? m->amax + m->amax_cur * AMAX_SLOTS : nullptr; }
 
 int uitk_set_debug_tokens(uitk_model* m, float* dev_buf) {
     if (!m) return fail(UITK_ERR_INVALID_ARG, "null model");
@@ -177,12 +179,13 @@ static int run_frontend(uitk_model* m, const void* pcm, int in_dtype, int64_t B,
     a.tw512 = (const float2*)(m->image + h.off_tw512);
     a.mel_b = (const float*)(m->image + h.off_mel_b);
     a.mel_steps = h.mel_steps;
-    a.mel = mel_out; a.amax = m->amax;
+    // no memset per call: this launch fills one set of slots and re-arms (0xFFFFFFFF) the other for the next launch
+    m->amax_cur ^= 1;
+    a.mel = mel_out; a.amax = m->amax + m->amax_cur * AMAX_SLOTS; a.amax_rearm = m->amax + (m->amax_cur ^ 1) * AMAX_SLOTS;
     a.bn_sc = (const float*)(m->image + h.off_bn_sc); a.bn_sh = (const float*)(m->image + h.off_bn_sh);
     a.op_bf16 = m->cfg.precision == UITK_PREC_BF16;
     a.timing = m->timing_fe;
     a.ncrops = uitk_num_crops(m, T); a.tl = m->cfg.target_length; a.nt = crop_nt(m, T);
-    HIP_TRY(hipMemsetAsync(m->amax, 0xFF, AMAX_SLOTS * 4, s));
     HIP_TRY(launch_frontend(a, in_dtype == UITK_IN_I16, patch, m->n_cu, s));
     return UITK_OK;
 }
@@ -205,7 +208,7 @@ int uitk_encode(uitk_model* m, int64_t B, int64_t T, float* probs, float* logits
     hipStream_t s = (hipStream_t)stream;
     const ImageHeader& h = m->hdr;
     EncoderArgs a{};
-    a.mel = (const unsigned short*)m->mel; a.amax = m->amax; a.top_db = m->cfg.top_db;
+    a.mel = (const unsigned short*)m->mel; a.amax = m->amax + m->amax_cur * AMAX_SLOTS; a.top_db = m->cfg.top_db;
     a.rows = (int)(B * nc);
     a.nt = crop_nt(m, T);
     a.depth = m->cfg.depth; a.C = m->cfg.outputdim;
@@ -246,7 +249,7 @@ int uitk_mel_db(uitk_model* m, const void* pcm, int in_dtype, int64_t B, int64_t
         m->mel_frames_cap = need;
     }
     if (int rc = run_frontend(m, pcm, in_dtype, B, T, m->mel_frames, 0, (hipStream_t)stream)) return rc;
-    HIP_TRY(launch_mel_export(m->mel_frames, m->amax, m->cfg.top_db, B, nF, out, (hipStream_t)stream));
+    HIP_TRY(launch_mel_export(m->mel_frames, m->amax + m->amax_cur * AMAX_SLOTS, m->cfg.top_db, B, nF, out, (hipStream_t)stream));
     return UITK_OK;
 }
 

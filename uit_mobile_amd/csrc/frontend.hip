@@ -117,6 +117,7 @@ __global__ __launch_bounds__(FE_WAVES * 64, FE_OCC) void mel_frontend_kernel(Fro
     const int tid = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lane = tid & 63, q = lane >> 4, p = lane & 15;
+    if (blockIdx.x == 0 && tid < AMAX_SLOTS) ((unsigned*)a.amax_rearm)[tid] = 0xFFFFFFFFu;   // arm the NEXT launch's slots
     c32* E = (c32*)(smem + wave * FE_WAVE_LDS);          // [4][16][17] transpose tile, then Z[4][272]
     float* Blds = (float*)(smem + FE_WAVES * FE_WAVE_LDS);
     // the power rows overlay the Z rows; their pad columns (bins 257..271, multiplied by zero filterbank operands) only have

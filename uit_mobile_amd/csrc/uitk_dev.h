@@ -46,7 +46,8 @@ struct FrontendArgs {
     int op_bf16;            // operand type of the PATCH layout: 0 = fp16, 1 = bf16
     unsigned long long* timing;  // diagnostics: [waves][8] phase cycle sums (null = normal build)
     int ncrops, tl, nt;     // crop plan (models/uit.py:468-481): crops per clip, target_length, valid time patches
-    float* amax;            // [AMAX_SLOTS]
+    float* amax;            // [AMAX_SLOTS] filled by this launch (pre-armed with 0xFFFFFFFF)
+    float* amax_rearm;      // [AMAX_SLOTS] the other set: re-armed by this launch for the next one
 };
 
 struct EncoderArgs {
