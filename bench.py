@@ -95,8 +95,8 @@ def cpu_baseline(model_name, sd, T, budget_s):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--steps", type=int, default=200)        # 0.2 s of GPU time: past the clock ramp of the first ~50 steps
+    ap.add_argument("--warmup", type=int, default=50)
     ap.add_argument("--model", default="uit_xs", choices=list(GEMM_FLOP))
     ap.add_argument("--batch-per-gpu", type=int, default=8192)
     ap.add_argument("--precision", default="f16", choices=["f16", "bf16"])
