@@ -107,8 +107,13 @@ template <> struct Op<1> {   // bf16 operands
     static __device__ __forceinline__ v8 zero8() { return v8{(__bf16)0.f, (__bf16)0.f, (__bf16)0.f, (__bf16)0.f, (__bf16)0.f, (__bf16)0.f, (__bf16)0.f, (__bf16)0.f}; }
 };
 
-constexpr int RING_SLOTS = 4;           // >= PREFETCH + 2 (see ring_step)
-constexpr int PREFETCH = 2;             // stages in flight ahead of the one being consumed
+#ifndef UITK_RING_SLOTS
+#define UITK_RING_SLOTS 4
+#define UITK_PREFETCH 2
+#endif
+constexpr int RING_SLOTS = UITK_RING_SLOTS;   // power of two, >= PREFETCH + 2 (see ring_step)
+constexpr int PREFETCH = UITK_PREFETCH;       // stages in flight ahead of the one being consumed
+static_assert((RING_SLOTS & (RING_SLOTS - 1)) == 0 && RING_SLOTS >= PREFETCH + 2 && RING_SLOTS >= PE_STAGES && PREFETCH <= TAIL_STAGES, "ring geometry");
 constexpr int LDS_RING = RING_SLOTS * STAGE_BYTES;            // 64 KiB
 constexpr int LDS_BIAS = 2 * BIAS_FLOATS * 4;                 // 8 KiB (double-buffered per block)
 constexpr int LDS_ZBUF = 2 * 16 * DIM * 2;                    // 8 KiB: up to 16 pooled vectors, 16-bit hi + lo terms
@@ -138,11 +143,9 @@ __device__ __forceinline__ void ring_issue(const char* wstream, char* ring, int 
 template <int WAVES>
 __device__ __forceinline__ void ring_step(const char* wstream, char* ring, int t, int wave, int lane) {
     constexpr int PER_WAVE = STAGE_FRAGS / WAVES;
-    static_assert(PREFETCH == 2 && (PER_WAVE == 2 || PER_WAVE == 4), "vmcnt immediates below");
     ring_issue<WAVES>(wstream, ring, t + PREFETCH, wave, lane);
-    // all but the 2*PER_WAVE youngest LDS-DMAs (stages t+1, t+2) have landed => this wave's share of stage t
-    if constexpr (PER_WAVE == 2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    // all but the PREFETCH*PER_WAVE youngest LDS-DMAs (stages t+1 .. t+PREFETCH) have landed => this wave's share of stage t
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PREFETCH * PER_WAVE) : "memory");
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
 }
@@ -391,8 +394,8 @@ __global__ __launch_bounds__(WAVES * 64, 2) void uit_encoder_kernel(EncoderArgs 
     TSTAMP(10);                                                           // patch-embed MFMAs
     __builtin_amdgcn_s_barrier();                                         // every wave is done with the PE weights
     asm volatile("" ::: "memory");
-    ring_issue<WAVES>(a.wstream, ring, PE_STAGES, wave, lane);
-    ring_issue<WAVES>(a.wstream, ring, PE_STAGES + 1, wave, lane);
+#pragma unroll
+    for (int i = 0; i < PREFETCH; ++i) ring_issue<WAVES>(a.wstream, ring, PE_STAGES + i, wave, lane);
 
     auto dbg_store = [&](int stage) {
 #pragma unroll

@@ -24,7 +24,7 @@ constexpr int STAGE_FRAGS = 16;
 constexpr int STAGE_BYTES = STAGE_FRAGS * FRAG_BYTES;
 constexpr int PE_STAGES = 4;            // patch-embed: 8 out tiles x 8 k-steps
 constexpr int BLOCK_STAGES = 14;        // QK, V+proj, 12 MLP chunks
-constexpr int TAIL_STAGES = 2;          // zero stages after the last block: the ring prefetch never branches
+constexpr int TAIL_STAGES = 4;          // zero stages after the last block: the ring prefetch (<= 4 ahead) never branches
 constexpr int BIAS_FLOATS = 1024;       // per block: qkv 96 | proj 128 | fc1 384 | fc2 128 (padded to 4 KiB)
 constexpr int BIAS_QKV = 0, BIAS_PROJ = 96, BIAS_FC1 = 224, BIAS_FC2 = 608;
 
