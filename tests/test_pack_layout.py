@@ -47,3 +47,33 @@ def test_emulated_kernel_short_clip_masks_tokens():
     got = stages[:, :, :, :].reshape(2, -1, 4, 6, 128)[:, :, :, :3].reshape(2, -1, 12, 128)
     assert np.abs(got - ref["stages"][:, 0]).max() < 2e-2
     assert np.abs(logits - ref["logits"][:, 0]).max() < 1e-3
+
+
+@pytest.mark.parametrize("kind", ["htk", "dense"])
+def test_front_end_filterbank_table_reconstructs_fb(kind):
+    """pack.cpp's banded B-operand table for v_mfma_f32_4x4x1 ([64 lane first-bins][S/4][64 lanes][4 steps], x 1/4):
+    walking every 4-mel group's window must reproduce the state_dict's mel_scale.fb exactly, windows start on
+    multiples of 4 bins and end inside the 272-column power row; HTK fits the on-chip fast path (S <= 52)."""
+    import struct
+    from mfma_emu import HDR_FMT, HDR_FIELDS
+    m, sd = _model("uit_xxxs", 12, "f16")
+    fb = np.array(sd["front_end.0.mel_scale.fb"], dtype=np.float32)
+    if kind == "dense":
+        fb = (fb + 0.001).astype(np.float32)
+        sd = dict(sd); sd["front_end.0.mel_scale.fb"] = fb
+        m.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()}, strict=True)
+    img = m.packed_image()
+    h = dict(zip(HDR_FIELDS, struct.unpack_from(HDR_FMT, img, 0)))
+    S, off = h["mel_steps"], h["off_mel_b"]
+    klo = np.frombuffer(img, np.int32, 64, off)
+    tab = np.frombuffer(img, np.float32, S * 64, off + 256).reshape(S // 4, 64, 4)
+    assert S % 4 == 0 and np.all(klo % 4 == 0) and np.all(klo >= 0) and np.all(klo + max(S, 52) <= 272)
+    assert np.all(klo.reshape(16, 4) == klo.reshape(16, 4)[:, :1])          # one window per 4-mel group
+    assert (S <= 52) == (kind == "htk")
+    rec = np.zeros_like(fb)
+    for st in range(S):
+        k = klo + st
+        ok = k < 257
+        rec[k[ok], np.arange(64)[ok]] = 4.0 * tab[st >> 2, :, st & 3][ok]
+        assert np.all(tab[st >> 2, :, st & 3][~ok] == 0.0)
+    assert np.array_equal(rec, fb)
