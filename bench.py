@@ -7,7 +7,9 @@
 
 A "step" = one pass of the whole path over one batch of synthetic 16 kHz x 1 s clips already resident in HBM:
 uitk_frontend -> (N>1: 256-byte MAX all-reduce of the batch amax) -> uitk_encode -> (N>1: RCCL all-gather of the
-[B/N,537] outputs, asynchronous: it overlaps the next step's kernels; all gathers complete inside the timed region).  Workload = BASELINE.json configs[2]: UiT-XS, 8192 clips per GPU (weak scaling: 65536 at N=8 =
+[B/N,537] outputs).  Both collectives are asynchronous and overlap the NEXT step's kernels: step n+1's front-end is
+enqueued (on a second model replica) before step n's encoder, so its amax all-reduce runs under that encoder, and step
+n's gather runs under step n+1's kernels.  Exactly K front-ends, K encoders and K gathers complete inside the timed region.  Workload = BASELINE.json configs[2]: UiT-XS, 8192 clips per GPU (weak scaling: 65536 at N=8 =
 configs[3]).  Prints ONE JSON line (rank 0).  The CPU baseline (oracle/torch_port.py, never the thing measured on
 the GPU) is timed on rank 0 at N=1 only, on a bounded sample.
 """
@@ -29,7 +31,7 @@ import torch.distributed as dist  # noqa: E402
 
 from synth_weights import make_state_dict  # noqa: E402
 from uit_mobile_amd import models  # noqa: E402
-from uit_mobile_amd.sharded import amax_allreduce, gather_outputs_async  # noqa: E402
+from uit_mobile_amd.sharded import amax_allreduce_async, amax_allreduce_finish, gather_outputs_async  # noqa: E402
 
 GEMM_FLOP = {"uit_xs": 68.66e6, "uit_xxs": 35.18e6, "uit_xxxs": 24.03e6}   # BASELINE.md section 3, per clip
 FRONTEND_VALU_FLOP = 4.56e6                                                 # dense-mel count, BASELINE.md section 3
@@ -103,6 +105,8 @@ def main():
     ap.add_argument("--pcm16", action="store_true", help="feed int16 PCM instead of float32 waves")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--spinup-steps", type=int, default=120,
+                    help="untimed set-up steps that bring the idle GPU's clocks up before the --warmup steps (0 = none)")
     ap.add_argument("--from-host", action="store_true",
                     help="additionally report the PCIe-inclusive rate (pinned int16 host buffers -> HostClipStreamer)")
     args = ap.parse_args()
@@ -122,33 +126,54 @@ def main():
 
     T, Bl = 16000, args.batch_per_gpu
     sd = make_state_dict(args.model, 13)
-    m = getattr(models, args.model)(outputdim=537, target_length=102, precision=args.precision)
-    m.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()}, strict=True)
-    m = m.to(dev).eval()
+    # two replicas of the model (weights 3 MB, workspace 100 MB each): batch n+1's front-end is enqueued on the other
+    # replica BEFORE batch n's encoder, so that at N>1 the 256-byte amax all-reduce of batch n+1 (RCCL's stream) runs
+    # under batch n's encoder instead of idling the GPU between the two kernels.  Same kernels, same order per batch.
+    reps = []
+    for _ in range(2):
+        r = getattr(models, args.model)(outputdim=537, target_length=102, precision=args.precision)
+        r.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()}, strict=True)
+        reps.append(r.to(dev).eval())
+    m = reps[0]
     x = synth_batch(Bl, T, rank * Bl, dev, args.pcm16)
-    # HIP events on the launch stream (torch's current stream is the one handed to the C ABI), three per step:
-    # before the front-end kernel, between the two kernels, after the encoder kernel.
+    # HIP events on the launch stream (torch's current stream is the one handed to the C ABI), four per step:
+    # around the front-end kernel and around the encoder kernel.
     n_ev = args.warmup + args.steps
-    evs = [[torch.cuda.Event(enable_timing=True) for _ in range(3)] for _ in range(n_ev)]
+    evs = [[torch.cuda.Event(enable_timing=True) for _ in range(4)] for _ in range(n_ev)]
     cur = [0]
     import collections
     pending = collections.deque()
 
-    def sync_hook(slots):
-        evs[cur[0]][1].record()
-        if world > 1:
-            amax_allreduce(slots)
+    def fe(n, rec=True):
+        """front-end of step n (+ at N>1 the start of its amax all-reduce)"""
+        r = reps[n & 1]
+        if rec:
+            evs[n][0].record()
+        st = r.frontend(x)
+        if rec:
+            evs[n][1].record()
+        red = amax_allreduce_async(r.amax_tensor(dev)) if world > 1 else None
+        return st, red
 
-    def step(timed):
-        e = evs[cur[0]]
-        e[0].record()
-        probs = m(x, amax_sync=sync_hook)
-        e[2].record()
-        # asynchronous RCCL all-gather: step n's gather overlaps step n+1's kernels; at most 2 in flight
+    def enc(n, st, red, rec=True):
+        """encoder of step n; its gather is asynchronous: at most 2 in flight, all complete inside the timed region"""
+        r = reps[n & 1]
+        if red is not None:
+            amax_allreduce_finish(red)
+        if rec:
+            evs[n][2].record()
+        probs = r.encode(st)
+        if rec:
+            evs[n][3].record()
         pending.append(gather_outputs_async(probs))
-        out = pending.popleft().wait() if len(pending) > 2 else None
-        cur[0] += 1
-        return out
+        return pending.popleft().wait() if len(pending) > 2 else None
+
+    def run(first, count, rec=True):
+        """`count` whole steps starting at event slot `first`: exactly `count` front-ends and `count` encoders"""
+        nxt = fe(first, rec)
+        for n in range(first, first + count):
+            this, nxt = nxt, (fe(n + 1, rec) if n + 1 < first + count else None)
+            enc(n, *this, rec)
 
     def drain():
         out = None
@@ -161,20 +186,33 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    # set-up, not steps: library handles, workspace of the benchmark's batch size and (N>1) the RCCL communicator, so that
+    # neither the W warm-up steps nor the K timed steps contain a hipMalloc or a communicator bootstrap
     with torch.no_grad():
-        for _ in range(args.warmup):
-            step(False)
+        for r in reps:
+            r.reserve(Bl, T, dev)
+            r(x[:64])
+        if world > 1:
+            amax_allreduce_finish(amax_allreduce_async(torch.zeros(64, device=dev)))
+            gather_outputs_async(torch.zeros((64, 537), device=dev)).wait()
+        # device spin-up (disclosed in the JSON line as config.setup): the GPU idles while the synthetic batch and the
+        # models are built, and its clocks take ~100 ms of load to ramp; a short --warmup would otherwise time the ramp
+        run(0, args.spinup_steps, rec=False)
+        drain()
+    barrier()
+    with torch.no_grad():
+        if args.warmup > 0:
+            run(0, args.warmup)
         drain()
         barrier()
         t0 = time.perf_counter()
-        for _ in range(args.steps):
-            step(True)
+        run(args.warmup, args.steps)
         out = drain()                                      # every gather of the timed steps has completed ...
         barrier()                                          # ... on every rank, inside the timed region
         el = time.perf_counter() - t0
     # per-kernel durations of the K timed steps, read after the closing synchronize
     fe_ms = [e[0].elapsed_time(e[1]) for e in evs[args.warmup:]]
-    enc_ms = [e[1].elapsed_time(e[2]) for e in evs[args.warmup:]]
+    enc_ms = [e[2].elapsed_time(e[3]) for e in evs[args.warmup:]]
     assert out.shape == (world * Bl, 537) and bool(torch.isfinite(out).all())
     t = torch.tensor([el], device=dev, dtype=torch.float64)
     if world > 1:
@@ -204,6 +242,8 @@ def main():
                                    f"16 kHz x 1 s clips per GPU ({'int16 PCM' if args.pcm16 else 'float32 wave'} "
                                    f"resident in HBM), global batch {world * Bl}",
                        "global_batch": world * Bl, "clip_samples": T,
+                       "setup": f"handles + workspace + RCCL communicator, then {args.spinup_steps} untimed steps of device "
+                                "spin-up (clock ramp) before the --warmup steps",
                        "parallelism": f"dp{world} (batch shards, RCCL amax MAX all-reduce + all-gather of [B,537])"},
             "roofline": {"bound": "mfma", "kernel": "uit_encoder_kernel", "achieved": round(achieved, 2),
                          "peak": PEAK_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / PEAK_MFMA_TFLOPS, 5),

@@ -8,7 +8,8 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
-from uit_mobile_amd.sharded import ShardedUiT, amax_allreduce, gather_outputs, gather_outputs_async, shard_range
+from uit_mobile_amd.sharded import (ShardedUiT, amax_allreduce, amax_allreduce_async, amax_allreduce_finish, gather_outputs,
+                                    gather_outputs_async, shard_range)
 
 
 def test_shard_range():
@@ -50,6 +51,14 @@ def _worker(rank, world, port, q):
         for i, h in enumerate(hs[:3]):
             ok = ok and torch.equal(h.wait(), torch.tensor([[10. * i] * 2] * 2 + [[10. * i + 1] * 2] * 2))
         ok = ok and torch.equal(hs[3].wait(), expect)
+        # split amax all-reduce (bench.py pipelines the next batch's front-end between the two halves): two in flight
+        sl = [torch.full((64,), float("nan")) for _ in range(2)]
+        sl[0][5 + rank] = 1.0 + rank
+        sl[1][rank] = -3.0 - rank
+        pend = [amax_allreduce_async(t) for t in sl]
+        for t, pnd in zip(sl, pend):
+            amax_allreduce_finish(pnd)
+        ok = ok and bool(torch.all(sl[0] == 2.0)) and bool(torch.all(sl[1] == -3.0))
         q.put((rank, bool(ok)))
     finally:
         dist.destroy_process_group()

@@ -301,6 +301,10 @@ class UITBase(nn.Module):
         data-parallel wrapper to MAX-all-reduce the top_db reference across shards)."""
         if self.training:
             raise RuntimeError("uit_mobile_amd implements inference only: call model.eval() first")
+        if amax_sync is not None:
+            st = self.frontend(x)
+            amax_sync(self.amax_tensor(st[2]))
+            return self.encode(st, return_logits=return_logits)
         x, in_dtype = self._prep_input(x)
         B, T = x.shape
         L = _lib.load()
@@ -310,13 +314,46 @@ class UITBase(nn.Module):
             probs = torch.empty((B, self.outputdim), device=x.device, dtype=torch.float32)
             logits = torch.empty((B, self.num_crops(T), self.outputdim), device=x.device, dtype=torch.float32) if return_logits else None
             lp = ctypes.c_void_p(logits.data_ptr()) if return_logits else None
-            if amax_sync is None:
-                _lib.check(L.uitk_forward(h, ctypes.c_void_p(x.data_ptr()), in_dtype, B, T,
-                                          ctypes.c_void_p(probs.data_ptr()), lp, stream), "uitk_forward")
-            else:
-                _lib.check(L.uitk_frontend(h, ctypes.c_void_p(x.data_ptr()), in_dtype, B, T, stream), "uitk_frontend")
-                amax_sync(self.amax_tensor(x.device))
-                _lib.check(L.uitk_encode(h, B, T, ctypes.c_void_p(probs.data_ptr()), lp, stream), "uitk_encode")
+            _lib.check(L.uitk_forward(h, ctypes.c_void_p(x.data_ptr()), in_dtype, B, T,
+                                      ctypes.c_void_p(probs.data_ptr()), lp, stream), "uitk_forward")
+        return (probs, logits) if return_logits else probs
+
+    def reserve(self, B, T, device="cuda"):
+        """Allocate the workspace for batches of up to B clips of T samples now (uitk_reserve) instead of inside the first
+        forward call; later calls of that size are enqueue-only."""
+        device = torch.device(device)
+        if device.type != "cuda":
+            raise RuntimeError("uit_mobile_amd runs on a HIP device only (no CPU path)")
+        if device.index is None:
+            device = torch.device("cuda", torch.cuda.current_device())
+        with torch.cuda.device(device):
+            _lib.check(_lib.load().uitk_reserve(self._handle(device), int(B), int(T)), "uitk_reserve")
+
+    # the two stages of forward(), for callers that put work between them (the amax all-reduce of the data-parallel
+    # wrapper; a pipelined caller that runs the next batch's front-end on a second replica before this batch's encoder)
+    def frontend(self, x):
+        """Stage 1 (uitk_frontend): log-mel operands of x into this model's workspace + the batch-amax slots.
+        Returns the state `encode` needs.  One batch per model instance may be between its two stages."""
+        if self.training:
+            raise RuntimeError("uit_mobile_amd implements inference only: call model.eval() first")
+        x, in_dtype = self._prep_input(x)
+        B, T = x.shape
+        h = self._handle(x.device)
+        with torch.cuda.device(x.device):
+            stream = ctypes.c_void_p(torch.cuda.current_stream(x.device).cuda_stream)
+            _lib.check(_lib.load().uitk_frontend(h, ctypes.c_void_p(x.data_ptr()), in_dtype, B, T, stream), "uitk_frontend")
+        return (B, T, x.device)
+
+    def encode(self, state, return_logits=False):
+        """Stage 2 (uitk_encode) on the operands of the latest `frontend` call of this instance."""
+        B, T, device = state
+        h = self._handle(device)
+        with torch.cuda.device(device):
+            stream = ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+            probs = torch.empty((B, self.outputdim), device=device, dtype=torch.float32)
+            logits = torch.empty((B, self.num_crops(T), self.outputdim), device=device, dtype=torch.float32) if return_logits else None
+            lp = ctypes.c_void_p(logits.data_ptr()) if return_logits else None
+            _lib.check(_lib.load().uitk_encode(h, B, T, ctypes.c_void_p(probs.data_ptr()), lp, stream), "uitk_encode")
         return (probs, logits) if return_logits else probs
 
     def amax_tensor(self, device):

@@ -31,6 +31,25 @@ def amax_allreduce(slots, group=None):
     return slots
 
 
+def amax_allreduce_async(slots, group=None):
+    """First half of amax_allreduce: local max of the slots + an asynchronous MAX all-reduce on RCCL's stream.  The caller
+    may enqueue unrelated kernels (the next batch's front-end on another replica) before amax_allreduce_finish."""
+    m = torch.nan_to_num(slots, nan=float("-inf")).max().reshape(1)
+    work = None
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+        work = dist.all_reduce(m, op=dist.ReduceOp.MAX, group=group, async_op=True)
+    return slots, m, work
+
+
+def amax_allreduce_finish(pending):
+    """Second half: the current stream waits for the collective, then every slot <- the global max (no host sync)."""
+    slots, m, work = pending
+    if work is not None:
+        work.wait()
+    slots.copy_(m.expand_as(slots))
+    return slots
+
+
 def gather_outputs(local, group=None):
     """[B/R, C] on every rank -> [B, C] on every rank (rank order == row order)."""
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
