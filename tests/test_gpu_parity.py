@@ -346,6 +346,28 @@ def test_filterbank_from_state_dict_is_honoured(kind):
     assert np.abs(l - ref["logits"]).max() < TOL and np.abs(p - ref["probs"]).max() < TOL
 
 
+def test_two_stage_api_interleaved_replicas_match_forward():
+    """model.frontend / model.encode (uitk_frontend / uitk_encode) with another replica's front-end enqueued in between
+    (what bench.py does to hide the amax all-reduce) give bit-identical results to forward(); reserve() pre-allocates."""
+    ma, sd = build("uit_xxxs", 37)
+    mb, _ = build("uit_xxxs", 37)
+    xa = torch.from_numpy(synth_pcm_i16(9, 16000, seed=1)).cuda()
+    xb = torch.from_numpy(synth_pcm_i16(5, 16384, seed=2)).cuda()          # other length: two crops
+    ma.reserve(9, 16000); mb.reserve(5, 16384)
+    want_a, want_b = ma(xa).clone(), mb(xb).clone()
+    for _ in range(3):                                                     # repeated: the amax slot sets alternate per call
+        sa = ma.frontend(xa)
+        sb = mb.frontend(xb)
+        pa = ma.encode(sa)
+        sa2 = ma.frontend(xa)
+        pb, lb = mb.encode(sb, return_logits=True)
+        pa2 = ma.encode(sa2)
+        assert torch.equal(pa, want_a) and torch.equal(pa2, want_a) and torch.equal(pb, want_b)
+        assert lb.shape == (5, 2, 537)
+    with pytest.raises(RuntimeError):
+        ma.reserve(4, 16000, "cpu")
+
+
 def test_device_topk_matches_host_topk():
     """uitk_topk (inference.py:57 `output.topk(k)` on the device): values bit-equal, indices equal; ties -> lower index."""
     from uit_mobile_amd.postprocess import topk
