@@ -38,6 +38,15 @@ def test_create_fails_loudly_without_device():
     assert rc == _lib.ERR_NO_DEVICE and "no CPU path" in _lib.last_error()
     with pytest.raises(RuntimeError):
         m(torch.zeros(1, 16000))
+    with pytest.raises(RuntimeError):                  # the two-stage API and reserve have no CPU path either
+        m.frontend(torch.zeros(1, 16000))
+    with pytest.raises(RuntimeError):
+        m.reserve(4, 16000, "cpu")
+    from uit_mobile_amd.postprocess import kws_transform, topk
+    with pytest.raises(RuntimeError):
+        topk(torch.rand(2, 537), 3)
+    with pytest.raises(RuntimeError):
+        kws_transform(torch.rand(2, 537))
 
 
 @pytest.mark.parametrize("name,depth", [("uit_xs", 12), ("uit_xxs", 6), ("uit_xxxs", 4)])
