@@ -75,3 +75,62 @@ def test_every_patch_element_comes_from_the_right_frame(B, T, hop, tl):
     got, seen = kernel_store_map(B, nF, tl, ncrops, nt)
     assert seen == {(b, f) for b in range(B) for f in range(nF)}        # every frame of every clip feeds the amax, once
     assert got == want                                                   # and every operand is written once, from the right source
+
+
+def test_front_end_tables_and_split_algebra_reproduce_the_oracle_mel():
+    """The kernel's arithmetic, restated with numpy on the PACKED tables (window, W256 twiddles as [p][k1], W512 as
+    (cos, sin), banded filterbank x 1/4): 256-point complex FFT of the even/odd-packed frame as 16x16 Cooley-Tukey,
+    the real-FFT split exactly as frontend.hip writes it (4|X|^2), block-banded mel, 10 log10 -> must equal the oracle's
+    (= the reference's) dB mel."""
+    import struct
+    import torch
+    from mfma_emu import HDR_FMT, HDR_FIELDS
+    from oracle.oracle import Oracle
+    from synth_weights import make_state_dict, synth_pcm_i16
+    from uit_mobile_amd import models
+    sd = make_state_dict("uit_xxxs", 21)
+    m = models.uit_xxxs(outputdim=537, target_length=102)
+    m.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()}, strict=True)
+    img = m.eval().packed_image()
+    h = dict(zip(HDR_FIELDS, struct.unpack_from(HDR_FMT, img, 0)))
+    window = np.frombuffer(img, np.float32, 512, h["off_window"]).astype(np.float64)
+    tw256 = np.frombuffer(img, np.float32, 512, h["off_tw256"]).astype(np.float64).reshape(16, 16, 2)   # [p][k1] (cos, -sin)
+    tw512 = np.frombuffer(img, np.float32, 256, h["off_tw512"]).astype(np.float64).reshape(128, 2)      # (cos, sin)
+    S = h["mel_steps"]
+    klo = np.frombuffer(img, np.int32, 64, h["off_mel_b"])
+    btab = np.frombuffer(img, np.float32, S * 64, h["off_mel_b"] + 256).astype(np.float64).reshape(S // 4, 64, 4)
+    pcm = synth_pcm_i16(2, 16000, seed=5)
+    x = pcm.astype(np.float64) / 32768.0
+    T = x.shape[1]
+    o = Oracle(sd)
+    nF = o.n_frames(T)
+    want, amax = o.melspec_db(pcm)                                     # [B][64][nF], floor applied
+    got = np.empty((2, 64, nF))
+    for b in range(2):
+        for f in range(nF):
+            idx = f * 160 - 256 + np.arange(512)
+            idx = np.where(idx < 0, -idx, idx)
+            idx = np.where(idx >= T, 2 * (T - 1) - idx, idx)           # reflect, edge not repeated
+            fr = x[b, idx] * window
+            z = (fr[0::2] + 1j * fr[1::2]).reshape(16, 16)             # z[m1][p], m = 16 m1 + p
+            y = np.fft.fft(z, axis=0).T                                # [p][k1]: 16-point FFT over m1
+            y = y * (tw256[..., 0] + 1j * tw256[..., 1])               # W256^(p k1)
+            Z = np.fft.fft(y, axis=0)                                  # [k2][k1]: over p -> Z[k1 + 16 k2]
+            Z = Z.reshape(256)                                         # index 16 k2 + k1
+            P = np.zeros(272)
+            for k in range(0, 128):
+                za, zb = Z[k], Z[(256 - k) & 255]
+                Ar, Ai = za.real + zb.real, za.imag - zb.imag
+                Br, Bi = za.real - zb.real, za.imag + zb.imag
+                c, s = tw512[k]
+                Tr, Ti = c * Bi - s * Br, -s * Bi - c * Br
+                P[k] = (Ar + Tr) ** 2 + (Ai + Ti) ** 2                 # 4 |X[k]|^2
+                P[256 - k] = (Ar - Tr) ** 2 + (Ti - Ai) ** 2
+            P[128] = 4.0 * abs(Z[128]) ** 2
+            mel = np.zeros(64)
+            for st in range(S):
+                mel += P[klo + st] * btab[st >> 2, :, st & 3]
+            got[b, :, f] = 10.0 * np.log10(np.maximum(mel, 1e-10))
+    got = np.maximum(got, amax - 120.0)
+    from conftest import assert_mel_close
+    assert_mel_close(got.astype(np.float32), want, scale=1.0)
