@@ -231,7 +231,7 @@ def test_sharded_wrapper_single_rank_matches_plain_forward():
     torch.cuda.synchronize()
     assert torch.equal(plain, sharded)
     slots = m.amax_tensor(x.device)
-    assert slots.shape == (64,) and torch.isfinite(slots).all() and float(slots.max()) == float(slots.min())
+    assert slots.shape == (64,) and not torch.isnan(slots).any() and torch.isfinite(slots.max())
 
 
 def _rccl_worker(rank, world, port, q):

@@ -49,15 +49,24 @@ def test_emulated_kernel_short_clip_masks_tokens():
     assert np.abs(logits - ref["logits"][:, 0]).max() < 1e-3
 
 
-@pytest.mark.parametrize("kind", ["htk", "dense"])
+@pytest.mark.parametrize("kind", ["htk", "dense", "fmin2000", "fmin4000", "fmin6000", "fmax4000"])
 def test_front_end_filterbank_table_reconstructs_fb(kind):
     """pack.cpp's banded B-operand table for v_mfma_f32_4x4x1 ([64 lane first-bins][S/4][64 lanes][4 steps], x 1/4):
     walking every 4-mel group's window must reproduce the state_dict's mel_scale.fb exactly, windows start on
     multiples of 4 bins and end inside the 272-column power row; HTK fits the on-chip fast path (S <= 52)."""
     import struct
     from mfma_emu import HDR_FMT, HDR_FIELDS
-    m, sd = _model("uit_xxxs", 12, "f16")
+    kw = {"fmin2000": dict(f_min=2000), "fmin4000": dict(f_min=4000), "fmin6000": dict(f_min=6000),
+          "fmax4000": dict(f_max=4000)}.get(kind, {})
+    m, sd = _model("uit_xxxs", 12, "f16", **kw)
     fb = np.array(sd["front_end.0.mel_scale.fb"], dtype=np.float32)
+    if kw:
+        # f_min / f_max are reference kwargs (models/uit.py:291-292): narrow bands that start high in frequency; the
+        # window of such a group is clamped down to stay inside the power row and must still cover its whole band
+        fb = getattr(models, "uit_xxxs")(outputdim=537, target_length=102, **kw).state_dict()["front_end.0.mel_scale.fb"].numpy().copy()
+        assert not np.array_equal(fb, np.array(sd["front_end.0.mel_scale.fb"]))
+        sd = dict(sd); sd["front_end.0.mel_scale.fb"] = fb
+        m.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()}, strict=True)
     if kind == "dense":
         fb = (fb + 0.001).astype(np.float32)
         sd = dict(sd); sd["front_end.0.mel_scale.fb"] = fb
@@ -69,7 +78,7 @@ def test_front_end_filterbank_table_reconstructs_fb(kind):
     tab = np.frombuffer(img, np.float32, S * 64, off + 256).reshape(S // 4, 64, 4)
     assert S % 4 == 0 and np.all(klo % 4 == 0) and np.all(klo >= 0) and np.all(klo + max(S, 52) <= 272)
     assert np.all(klo.reshape(16, 4) == klo.reshape(16, 4)[:, :1])          # one window per 4-mel group
-    assert (S <= 52) == (kind == "htk")
+    assert (S <= 52) == (kind != "dense")
     rec = np.zeros_like(fb)
     for st in range(S):
         k = klo + st

@@ -18,11 +18,13 @@ def test_shard_range():
         shard_range(10, 0, 4)
 
 
-def test_amax_allreduce_single_process_ignores_nan_slots():
-    s = torch.full((64,), float("nan"))
+def test_amax_allreduce_single_process_is_identity_on_armed_slots():
+    """Slots are armed with -inf (no NaN): the single-rank path leaves them alone, and their max is the batch amax."""
+    s = torch.full((64,), float("-inf"))
     s[3], s[40] = -12.5, 7.25
-    amax_allreduce(s)
-    assert torch.all(s == 7.25)
+    before = s.clone()
+    assert amax_allreduce(s) is s and torch.equal(s, before)
+    assert float(s.max()) == 7.25
 
 
 def _worker(rank, world, port, q):
@@ -34,11 +36,11 @@ def _worker(rank, world, port, q):
         lo, hi = shard_range(B, rank, world)
 
         def fake_model(x, amax_sync=None):
-            slots = torch.full((64,), float("nan"))
+            slots = torch.full((64,), float("-inf"))          # armed, as the front-end kernel leaves untouched slots
             slots[rank] = float(x.max())                      # this shard's "amax"
-            amax_sync(slots)
-            # output depends on the (now global) amax, like the top_db floor does
-            return torch.cat([x, slots[:1].expand(x.shape[0], 1)], 1)
+            amax_sync(slots)                                  # in-place MAX all-reduce of the 64 slots
+            # output depends on the (now global) amax = max over the slots, like the encoder's top_db floor does
+            return torch.cat([x, slots.max().reshape(1, 1).expand(x.shape[0], 1)], 1)
 
         out = ShardedUiT(fake_model)(full[lo:hi])
         expect = torch.cat([full, torch.full((B, 1), float(full.max()))], 1)
@@ -52,13 +54,14 @@ def _worker(rank, world, port, q):
             ok = ok and torch.equal(h.wait(), torch.tensor([[10. * i] * 2] * 2 + [[10. * i + 1] * 2] * 2))
         ok = ok and torch.equal(hs[3].wait(), expect)
         # split amax all-reduce (bench.py pipelines the next batch's front-end between the two halves): two in flight
-        sl = [torch.full((64,), float("nan")) for _ in range(2)]
+        sl = [torch.full((64,), float("-inf")) for _ in range(2)]
         sl[0][5 + rank] = 1.0 + rank
         sl[1][rank] = -3.0 - rank
         pend = [amax_allreduce_async(t) for t in sl]
         for t, pnd in zip(sl, pend):
             amax_allreduce_finish(pnd)
-        ok = ok and bool(torch.all(sl[0] == 2.0)) and bool(torch.all(sl[1] == -3.0))
+        ok = ok and float(sl[0].max()) == 2.0 and float(sl[1].max()) == -3.0
+        ok = ok and float(sl[0][5]) == 1.0 and float(sl[0][6]) == 2.0 and float(sl[0][7]) == float("-inf")   # slot-wise MAX
         q.put((rank, bool(ok)))
     finally:
         dist.destroy_process_group()

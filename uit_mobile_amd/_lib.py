@@ -72,9 +72,8 @@ def load():
     L.uitk_kws_transform.argtypes = [c_void_p, c_void_p, c_int64, c_int32, c_int32, c_float, c_void_p, c_void_p]
     L.uitk_last_error.restype = c_char_p
     L.uitk_version.restype = c_char_p
-    for name in EXPORTS:
-        if getattr(L, name).restype is c_int:
-            pass
+    for name in EXPORTS:                      # every entry point include/uitk.h declares must be exported
+        getattr(L, name)
     _lib = L
     return L
 

@@ -2,6 +2,7 @@
 // Host code only; the kernels live in frontend.hip / encoder.hip.  There is no CPU compute path here.
 #include <hip/hip_runtime.h>
 
+#include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -39,7 +40,9 @@ struct uitk_model {
     int n_cu = 256;
     int enc_waves = 8;            // waves per encoder workgroup (8 = one WG per CU; 4 = two independent WGs per CU)
     int enc_sched = 0, enc_stagger = 0, enc_stagger_mode = 1, enc_ablate = 0;   // tuning knobs (UITK_ENC_SCHED, UITK_ENC_STAGGER)
+    int fe_wg_per_cu = 0;         // persistent front-end workgroups per CU (0 = the kernel's occupancy target; UITK_FE_WG_PER_CU)
     int device = 0;
+    int64_t fe_B = 0, fe_T = 0;   // shape of the latest uitk_frontend call (uitk_encode must match it)
 };
 
 extern "C" {
@@ -87,11 +90,14 @@ int uitk_create(const uitk_config* cfg, const uitk_weights* w, uitk_model** out)
     if (const char* e = std::getenv("UITK_ENC_STAGGER")) m->enc_stagger = std::atoi(e);
     if (const char* e = std::getenv("UITK_ENC_STAGGER_MODE")) m->enc_stagger_mode = std::atoi(e);
     if (const char* e = std::getenv("UITK_ENC_ABLATE")) m->enc_ablate = std::atoi(e);
+    if (const char* e = std::getenv("UITK_FE_WG_PER_CU")) m->fe_wg_per_cu = std::atoi(e);
     if (hipMalloc((void**)&m->image, img.size()) != hipSuccess || hipMalloc((void**)&m->amax, 2 * AMAX_SLOTS * 4) != hipSuccess) {
         uitk_destroy(m); return fail(UITK_ERR_HIP, "hipMalloc failed for the parameter image");
     }
+    float armed[2 * AMAX_SLOTS];
+    for (float& v : armed) v = -INFINITY;                                       // both amax slot sets start armed (-inf)
     if (hipMemcpy(m->image, img.data(), img.size(), hipMemcpyHostToDevice) != hipSuccess ||
-        hipMemset(m->amax, 0xFF, 2 * AMAX_SLOTS * 4) != hipSuccess) {          // both amax slot sets start armed
+        hipMemcpy(m->amax, armed, sizeof armed, hipMemcpyHostToDevice) != hipSuccess) {
         uitk_destroy(m); return fail(UITK_ERR_HIP, "parameter upload failed");
     }
     *out = m;
@@ -159,6 +165,8 @@ int uitk_set_debug_tokens(uitk_model* m, float* dev_buf) {
 
 int uitk_set_timing_buffers(uitk_model* m, unsigned long long* enc_buf, unsigned long long* fe_buf) {
     if (!m) return fail(UITK_ERR_INVALID_ARG, "null model");
+    if ((enc_buf || fe_buf) && m->cfg.precision != UITK_PREC_F16)
+        return fail(UITK_ERR_UNSUPPORTED, "the instrumented kernel builds exist for precision f16 only");
     m->timing = enc_buf; m->timing_fe = fe_buf;
     return UITK_OK;
 }
@@ -186,7 +194,7 @@ static int run_frontend(uitk_model* m, const void* pcm, int in_dtype, int64_t B,
     a.op_bf16 = m->cfg.precision == UITK_PREC_BF16;
     a.timing = m->timing_fe;
     a.ncrops = uitk_num_crops(m, T); a.tl = m->cfg.target_length; a.nt = crop_nt(m, T);
-    HIP_TRY(launch_frontend(a, in_dtype == UITK_IN_I16, patch, m->n_cu, s));
+    HIP_TRY(launch_frontend(a, in_dtype == UITK_IN_I16, patch, m->n_cu, m->fe_wg_per_cu, s));
     return UITK_OK;
 }
 
@@ -195,14 +203,18 @@ int uitk_frontend(uitk_model* m, const void* pcm, int in_dtype, int64_t B, int64
     if (!pcm) return fail(UITK_ERR_INVALID_ARG, "null pcm");
     if (in_dtype != UITK_IN_F32 && in_dtype != UITK_IN_I16) return fail(UITK_ERR_INVALID_ARG, "unknown in_dtype");
     if (int rc = uitk_reserve(m, B, T)) return rc;
-    return run_frontend(m, pcm, in_dtype, B, T, m->mel, 1, (hipStream_t)stream);
+    m->fe_B = 0; m->fe_T = 0;
+    if (int rc = run_frontend(m, pcm, in_dtype, B, T, m->mel, 1, (hipStream_t)stream)) return rc;
+    m->fe_B = B; m->fe_T = T;
+    return UITK_OK;
 }
 
 int uitk_encode(uitk_model* m, int64_t B, int64_t T, float* probs, float* logits, void* stream) {
     if (int rc = check_shape(m, B, T)) return rc;
     if (!probs) return fail(UITK_ERR_INVALID_ARG, "null probs");
     const int nF = uitk_num_frames(m, T), nc = uitk_num_crops(m, T), tl = m->cfg.target_length;
-    if ((size_t)B * nc * NTOK * 256 * 2 > m->mel_cap) return fail(UITK_ERR_WORKSPACE, "uitk_encode without a matching uitk_frontend");
+    if ((size_t)B * nc * NTOK * 256 * 2 > m->mel_cap || B != m->fe_B || T != m->fe_T)
+        return fail(UITK_ERR_WORKSPACE, "uitk_encode without a matching uitk_frontend (same B and T) before it");
     (void)nF; (void)tl;
     if (B * nc >= (int64_t)1 << 31) return fail(UITK_ERR_INVALID_ARG, "batch too large");
     hipStream_t s = (hipStream_t)stream;
@@ -248,6 +260,7 @@ int uitk_mel_db(uitk_model* m, const void* pcm, int in_dtype, int64_t B, int64_t
         HIP_TRY(hipMalloc((void**)&m->mel_frames, need));
         m->mel_frames_cap = need;
     }
+    m->fe_B = 0; m->fe_T = 0;                                  // the amax slots now belong to this call, not to the operands
     if (int rc = run_frontend(m, pcm, in_dtype, B, T, m->mel_frames, 0, (hipStream_t)stream)) return rc;
     HIP_TRY(launch_mel_export(m->mel_frames, m->amax + m->amax_cur * AMAX_SLOTS, m->cfg.top_db, B, nF, out, (hipStream_t)stream));
     return UITK_OK;

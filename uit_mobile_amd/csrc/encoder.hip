@@ -27,6 +27,7 @@
 //     once per workgroup (16 clips = one full column tile) instead of once per wave.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <atomic>
 #include "uitk_dev.h"
 
 namespace uitk {
@@ -341,7 +342,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void uit_encoder_kernel(EncoderArgs 
     // init_bn scale / shift of mel bin `lane`: two coalesced dword loads per wave; the 24 (token tile, k-step) clamp
     // thresholds of a lane are then handed out through a wave-private 512-byte LDS table (zbuf is idle until the head)
     const float my_sc = a.bn_sc[lane], my_sh = a.bn_sh[lane];
-    float amx = a.amax[lane];                                             // 64 slots, one per lane; NaN = untouched slot
+    float amx = a.amax[lane];                                             // 64 slots, one per lane; -inf = untouched slot
     TSTAMP(13);                                                           // index math + issue of patch / table loads
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) amx = fmaxf(amx, __shfl_xor(amx, o));
@@ -786,12 +787,16 @@ __global__ void crop_reduce_kernel(const float* __restrict__ rp, float* __restri
 
 template <int PREC, int WAVES, bool SCHED, bool TIMING = false, int ABL = 0>
 static hipError_t launch_enc(const EncoderArgs& a, hipStream_t stream) {
-    static bool attr_done = false;
-    if (!attr_done) {
+    // the attribute is per device: one bit per device, set once (see launch_fe)
+    static std::atomic<unsigned long long> attr_done{0};
+    int dev = 0;
+    if (hipError_t e = hipGetDevice(&dev); e != hipSuccess) return e;
+    const unsigned long long bit = 1ull << (dev & 63);
+    if (!(attr_done.load(std::memory_order_acquire) & bit)) {
         hipError_t e = hipFuncSetAttribute((const void*)uit_encoder_kernel<PREC, WAVES, SCHED, TIMING, ABL>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, ENC_LDS);
         if (e != hipSuccess) return e;
-        attr_done = true;
+        attr_done.fetch_or(bit, std::memory_order_release);
     }
     const int grid = (a.rows + 2 * WAVES - 1) / (2 * WAVES);
     hipLaunchKernelGGL((uit_encoder_kernel<PREC, WAVES, SCHED, TIMING, ABL>), dim3(grid), dim3(WAVES * 64), ENC_LDS, stream, a);

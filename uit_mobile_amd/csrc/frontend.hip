@@ -32,6 +32,7 @@
 //   HBM traffic: the PCM is read once (frames overlap 3.2x, absorbed by L1/L2), output 256 B per frame.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <atomic>
 #include "uitk_dev.h"
 
 namespace uitk {
@@ -117,7 +118,7 @@ __global__ __launch_bounds__(FE_WAVES * 64, FE_OCC) void mel_frontend_kernel(Fro
     const int tid = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lane = tid & 63, q = lane >> 4, p = lane & 15;
-    if (blockIdx.x == 0 && tid < AMAX_SLOTS) ((unsigned*)a.amax_rearm)[tid] = 0xFFFFFFFFu;   // arm the NEXT launch's slots
+    if (blockIdx.x == 0 && tid < AMAX_SLOTS) ((unsigned*)a.amax_rearm)[tid] = 0xFF800000u;   // arm the NEXT launch's slots with -inf
     c32* E = (c32*)(smem + wave * FE_WAVE_LDS);          // [4][16][17] transpose tile, then Z[4][272]
     float* Blds = (float*)(smem + FE_WAVES * FE_WAVE_LDS);
     // the power rows overlay the Z rows; their pad columns (bins 257..271, multiplied by zero filterbank operands) only have
@@ -388,13 +389,15 @@ __global__ __launch_bounds__(FE_WAVES * 64, FE_OCC) void mel_frontend_kernel(Fro
             for (int i = 0; i < 8; ++i) a.timing[((size_t)blockIdx.x * FE_WAVES + wave) * 8 + i] = tacc[i];
         }
     }
-    // batch amax: wave reduce, then one atomic per wave into one of UITK_AMAX_SLOTS slots.  Slots are
-    // initialised to 0xFFFFFFFF (hipMemsetAsync 0xFF): signed-max for v >= 0, unsigned-min for v < 0.
+    // batch amax: wave reduce, then one atomic per wave into one of UITK_AMAX_SLOTS slots.  Slots are armed with -inf
+    // (0xFF800000), so they can be MAX-reduced as plain floats (no NaN).  Float max by integer atomics on the bits: a value with
+    // the sign bit clear wins by signed max (every negative float, -inf included, is a negative int), a value with the sign
+    // bit set (-0.0 included) by unsigned min (larger magnitude = larger unsigned; any non-negative value is smaller still).
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) lmax = fmaxf(lmax, __shfl_xor(lmax, o));
     if (lane == 0 && lmax > -INFINITY) {
         float* slot = a.amax + (blockIdx.x & (AMAX_SLOTS - 1));
-        if (lmax >= 0.f) atomicMax((int*)slot, __float_as_int(lmax));
+        if ((__float_as_uint(lmax) >> 31) == 0u) atomicMax((int*)slot, __float_as_int(lmax));
         else atomicMin((unsigned*)slot, __float_as_uint(lmax));
     }
 }
@@ -416,20 +419,25 @@ __global__ void mel_export_kernel(const float* __restrict__ mel, const float* __
 
 template <bool I16, bool PATCH, bool TIMING = false>
 static hipError_t launch_fe(const FrontendArgs& a, int grid, hipStream_t stream) {
-    static bool attr_done = false;
-    if (!attr_done) {
+    // the attribute is per device (one model handle per device may live in one process): one bit per device, set once
+    static std::atomic<unsigned long long> attr_done{0};
+    int dev = 0;
+    if (hipError_t e = hipGetDevice(&dev); e != hipSuccess) return e;
+    const unsigned long long bit = 1ull << (dev & 63);
+    if (!(attr_done.load(std::memory_order_acquire) & bit)) {
         hipError_t e = hipFuncSetAttribute((const void*)mel_frontend_kernel<I16, PATCH, TIMING>, hipFuncAttributeMaxDynamicSharedMemorySize, FE_LDS);
         if (e != hipSuccess) return e;
-        attr_done = true;
+        attr_done.fetch_or(bit, std::memory_order_release);
     }
     hipLaunchKernelGGL((mel_frontend_kernel<I16, PATCH, TIMING>), dim3(grid), dim3(FE_WAVES * 64), FE_LDS, stream, a);
     return hipGetLastError();
 }
 
-hipError_t launch_frontend(const FrontendArgs& a, int in_i16, int patch_layout, int n_cu, hipStream_t stream) {
+hipError_t launch_frontend(const FrontendArgs& a, int in_i16, int patch_layout, int n_cu, int wg_per_cu, hipStream_t stream) {
     const int rem = a.nF & 15;
     const int64_t npass = a.B * (int64_t)(a.nF >> 4) + (rem ? (a.B + 16 / rem - 1) / (16 / rem) : 0);
-    int grid = (int)(npass < (int64_t)n_cu * FE_OCC ? npass : (int64_t)n_cu * FE_OCC);      // resident workgroups per CU
+    const int64_t resident = (int64_t)n_cu * (wg_per_cu > 0 ? wg_per_cu : FE_OCC);       // persistent workgroups
+    int grid = (int)(npass < resident ? npass : resident);
     if (grid < 1) grid = 1;
     if (a.timing != nullptr && patch_layout && !in_i16) return launch_fe<false, true, true>(a, grid, stream);
     if (patch_layout) return in_i16 ? launch_fe<true, true>(a, grid, stream) : launch_fe<false, true>(a, grid, stream);

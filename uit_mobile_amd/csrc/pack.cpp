@@ -94,14 +94,25 @@ int pack_image(const uitk_config* c, const uitk_weights* w, std::vector<char>* o
             for (int k = 0; k < nb; ++k)
                 for (int m = 4 * g; m < 4 * g + 4; ++m)
                     if (w->mel_fb[k * NMEL + m] != 0.0f) { if (first[g] < 0) first[g] = k; last[g] = k; }
-            const int span = first[g] < 0 ? 0 : last[g] - (first[g] & ~3) + 1;       // windows start on multiples of 4 bins
-            if (span > mel_S) mel_S = (span + 3) & ~3;
         }
-        const int walk = mel_S > MEL_BMAX ? mel_S : MEL_BMAX;       // steps the kernel actually reads
-        for (int g = 0; g < 16; ++g) {
-            int klo = first[g] < 0 ? 0 : (first[g] & ~3);
-            if (klo > MEL_PROW - walk) klo = MEL_PROW - walk;       // keep every window inside the power row (272 = 4 * 68)
-            grp_klo[g] = klo < 0 ? 0 : klo;
+        // A window starts on a multiple of 4 bins and must end inside the power row (272 = 4 * 68 columns): a group whose band
+        // starts high is clamped DOWN, which widens the span it has to walk -- so the span is measured from the clamped start
+        // and the clamp repeated until the walk length is stable (it only grows, bounded by the row).
+        int walk = MEL_BMAX;                                         // steps the kernel actually reads
+        for (int iter = 0; iter < 64; ++iter) {
+            int S = 4;
+            for (int g = 0; g < 16; ++g) {
+                int klo = first[g] < 0 ? 0 : (first[g] & ~3);
+                if (klo > MEL_PROW - walk) klo = MEL_PROW - walk;
+                if (klo < 0) klo = 0;
+                grp_klo[g] = klo;
+                const int span = first[g] < 0 ? 0 : last[g] - klo + 1;
+                if (span > S) S = (span + 3) & ~3;
+            }
+            mel_S = S;
+            const int nw = S > MEL_BMAX ? S : MEL_BMAX;
+            if (nw == walk) break;
+            walk = nw;
         }
     }
     ImageHeader h{};

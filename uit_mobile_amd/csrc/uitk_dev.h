@@ -38,7 +38,7 @@ struct FrontendArgs {
     const float* mel_b;     // banded filterbank for v_mfma_f32_4x4x1: [64 x int32 first bin of the lane's mel group, a
                             // multiple of 4] then [mel_steps/4][64 lanes][4 steps] B operands (x 1/4)
     int mel_steps;          // S: bins every 4-mel group walks (multiple of 4)
-    float* mel;             // PATCH layout: 16-bit MFMA operands [B*ncrops][24 tokens][16 frames][16 mels] holding
+    float* mel;             // PATCH layout: 16-bit MFMA operands [B*ncrops][24 tokens][16 mels][16 frames] holding
                             // init_bn(dB) WITHOUT the top_db clamp (the encoder clamps); FRAMES layout (uitk_mel_db
                             // only): fp32 dB [B][nF][64]
     const float* bn_sc;     // [64] init_bn scale / shift (PATCH layout only)
@@ -76,7 +76,7 @@ struct EncoderArgs {
     int stagger_mode;       // 1 = by workgroup generation, 2 = by hardware wave slot
 };
 
-hipError_t launch_frontend(const FrontendArgs& a, int in_i16, int patch_layout, int n_cu, hipStream_t stream);
+hipError_t launch_frontend(const FrontendArgs& a, int in_i16, int patch_layout, int n_cu, int wg_per_cu, hipStream_t stream);
 hipError_t launch_mel_export(const float* mel, const float* amax, float top_db, int64_t B, int nF, float* out,
                              hipStream_t stream);
 hipError_t launch_encoder(const EncoderArgs& a, int precision, int waves, int sched, hipStream_t stream);

@@ -203,7 +203,14 @@ class UITBase(nn.Module):
 
     # ------------------------------------------------------------------ C-ABI plumbing
     def _stamp(self):
-        return sum(int(p._version) for p in list(self.parameters()) + list(self.buffers()))
+        """Identity of the weights the uploaded image was packed from: (storage pointer, version counter) per tensor, so
+        in-place edits, re-assigned `.data` and dtype/device round trips all invalidate the handle.  Edits that change
+        neither (e.g. writes through a raw numpy view) need an explicit `refresh()`."""
+        return tuple((t.data_ptr(), int(t._version)) for t in list(self.parameters()) + list(self.buffers()))
+
+    def refresh(self):
+        """Drop the uploaded parameter images: the next call re-packs the current weights."""
+        self._handles.clear()
 
     def _config(self):
         return _lib.Config(depth=self.depth, embed_dim=self.embed_dim, num_heads=self.num_heads,

@@ -3,7 +3,8 @@
 The path is embarrassingly parallel over clips: rank r of R owns the contiguous rows
 [r*B/R, (r+1)*B/R) of the batch and a full replica of the (<= 3 MB) packed weights.  There are exactly two
 collectives, both on torch.distributed's "nccl" backend (= RCCL on ROCm):
-  * a 256-byte MAX all-reduce of the batch-amax slots between the two kernels, so the top_db floor is the one the
+  * a 256-byte in-place MAX all-reduce of the 64 batch-amax slots between the two kernels (the slots are armed with -inf,
+    so there is no other kernel between the two HIP kernels), so the top_db floor is the one the
     reference computes for the WHOLE batch (models/uit.py:307 via torchaudio's packed-channel reshape) and the
     result does not depend on R;
   * one all-gather of the [B/R, outputdim] fp32 outputs into [B, outputdim] on every rank (what evaluate.py's
@@ -23,30 +24,28 @@ def shard_range(B, rank, world):
 
 
 def amax_allreduce(slots, group=None):
-    """In-place: every slot <- max over all ranks and slots.  Untouched slots hold NaN (0xFFFFFFFF) and are ignored."""
-    m = torch.nan_to_num(slots, nan=float("-inf")).max().reshape(1)
+    """In-place MAX all-reduce of the 64 batch-amax slots (256 bytes): ONE collective on the device slots themselves, nothing
+    else between the two HIP kernels.  Untouched slots hold -inf (the front-end arms them so), which MAX ignores; the encoder
+    takes the max over the 64 slots itself."""
     if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
-        dist.all_reduce(m, op=dist.ReduceOp.MAX, group=group)
-    slots.copy_(m.expand_as(slots))          # stream-ordered, no host sync
+        dist.all_reduce(slots, op=dist.ReduceOp.MAX, group=group)
     return slots
 
 
 def amax_allreduce_async(slots, group=None):
-    """First half of amax_allreduce: local max of the slots + an asynchronous MAX all-reduce on RCCL's stream.  The caller
-    may enqueue unrelated kernels (the next batch's front-end on another replica) before amax_allreduce_finish."""
-    m = torch.nan_to_num(slots, nan=float("-inf")).max().reshape(1)
+    """The same collective, asynchronous on RCCL's stream.  The caller may enqueue unrelated kernels (the next batch's
+    front-end on another replica) before amax_allreduce_finish."""
     work = None
     if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
-        work = dist.all_reduce(m, op=dist.ReduceOp.MAX, group=group, async_op=True)
-    return slots, m, work
+        work = dist.all_reduce(slots, op=dist.ReduceOp.MAX, group=group, async_op=True)
+    return slots, work
 
 
 def amax_allreduce_finish(pending):
-    """Second half: the current stream waits for the collective, then every slot <- the global max (no host sync)."""
-    slots, m, work = pending
+    """Second half: the current stream waits for the collective (no host sync, no extra kernel)."""
+    slots, work = pending
     if work is not None:
         work.wait()
-    slots.copy_(m.expand_as(slots))
     return slots
 
 

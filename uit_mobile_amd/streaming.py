@@ -30,6 +30,9 @@ class HostClipStreamer:
         if batch.is_pinned() and batch.dtype == self.dtype:
             src = batch                                         # producer wrote straight into pinned memory: no CPU copy
         else:
+            # the H2D copy issued two batches ago may still be reading this pinned buffer: the HOST must wait for it
+            # (the `free` event below only orders the copy stream against the kernels)
+            self.ready[slot].synchronize()
             self.host[slot][:n].copy_(batch)                    # CPU memcpy (+ dtype conversion) into the staging buffer
             src = self.host[slot][:n]
         with torch.cuda.stream(self.copy_stream):
