@@ -57,3 +57,11 @@ def kws_loop_restatement(y_pred, y, threshold, num_fillers=527):
             if score >= threshold:
                 y_pred[i][idx] = 0.0
     return y_pred, yy
+
+
+def centred(tokens):
+    """Residual-stream tokens minus their per-token channel mean.  The kernel keeps its residual stream centred (pack.cpp
+    removes the channel-mean of everything added to it; every consumer is a LayerNorm, which cannot see a common offset), so
+    stage-level comparisons with the reference's stream are made on the centred values."""
+    tokens = np.asarray(tokens)
+    return tokens - tokens.mean(-1, keepdims=True)

@@ -20,7 +20,7 @@ sys.path.insert(0, str(HERE))
 # imported BEFORE the stand-in torchaudio module is installed (transformers probes for the real package)
 from transformers.audio_utils import mel_filter_bank, spectrogram  # noqa: E402
 import _ref_shims  # noqa: E402
-from synth_weights import make_state_dict, synth_pcm_i16  # noqa: E402
+from synth_weights import make_state_dict, make_trained_like_state_dict, synth_pcm_i16  # noqa: E402
 
 REF = Path("/root/reference")
 uit = _ref_shims.import_reference_uit(str(REF))
@@ -33,6 +33,15 @@ def build_ref(name, seed, scale, outputdim=537, eval_avg="mean"):
     sd = {k: torch.from_numpy(np.asarray(v)) for k, v in make_state_dict(name, seed, scale, outputdim).items()}
     missing = set(m.state_dict().keys()) ^ set(sd.keys())
     assert not missing, missing
+    m.load_state_dict(sd, strict=True)
+    return m.eval()
+
+
+def build_ref_trained(name, seed, outputdim=537, eval_avg="mean"):
+    """The reference's own UITBase carrying the trained-like checkpoint of synth_weights.make_trained_like_state_dict."""
+    m = getattr(uit, name)(outputdim=outputdim, target_length=102, eval_avg=eval_avg)
+    sd = {k: torch.from_numpy(np.asarray(v)) for k, v in make_trained_like_state_dict(name, seed, outputdim).items()}
+    assert not (set(m.state_dict().keys()) ^ set(sd.keys()))
     m.load_state_dict(sd, strict=True)
     return m.eval()
 
@@ -93,7 +102,41 @@ def crosscheck_frontend():
     return float(d_fb), float(d_db)
 
 
+def main_round2():
+    """Round-2 fixtures: trained-checkpoint magnitudes (|logit| >= 10), the 10-crop 160 000-sample clip, a short clip on
+    trained-like weights."""
+    pcm = synth_pcm_i16(8, 16000, seed=0)
+    pcm[5] = 0
+    for name, seed in (("uit_xs", 1), ("uit_xxxs", 2)):
+        m = build_ref_trained(name, seed)
+        r = run_ref(m, pcm, stages_for=2)
+        assert np.abs(r["logits"]).max() >= 10.0, np.abs(r["logits"]).max()
+        np.savez_compressed(HERE / f"trained_{name}.npz", pcm=pcm, seed=seed, probs=r["probs"], logits=r["logits"],
+                            stages=r["stages"])
+        print("trained-like", name, "logit range", r["logits"].min(), r["logits"].max(), "probs max", r["probs"].max())
+    # short clips (51 frames -> 3 time patches: masked padding tokens in the kernel) on trained-like weights: sharp attention
+    pcm_short = synth_pcm_i16(3, 8000, seed=4)
+    r = run_ref(build_ref_trained("uit_xxxs", 2), pcm_short)
+    np.savez_compressed(HERE / "trained_short_uit_xxxs.npz", pcm=pcm_short, seed=2, probs=r["probs"], logits=r["logits"])
+    # AudioSet-style 10 s clip: 160 000 samples -> 1001 frames -> 10 crops, the last one re-cropped (models/uit.py:468-488)
+    pcm10 = synth_pcm_i16(2, 160000, seed=6)[1:2]            # clip index 1 of the generator = a loud tone; keep one noise clip too
+    pcm10 = np.concatenate([pcm10, synth_pcm_i16(1, 160000, seed=7)])
+    for avg in ("mean", "max"):
+        m = build_ref("uit_xxxs", 11, 1.0, eval_avg=avg)
+        r = run_ref(m, pcm10)
+        assert r["logits"].shape[1] == 10
+        if avg == "mean":
+            np.savez_compressed(HERE / "long10_uit_xxxs.npz", pcm=pcm10, seed=11, probs_mean=r["probs"], logits=r["logits"])
+            out10 = dict(np.load(HERE / "long10_uit_xxxs.npz"))
+        else:
+            out10["probs_max"] = r["probs"]
+            np.savez_compressed(HERE / "long10_uit_xxxs.npz", **out10)
+    print("long10", out10["logits"].shape)
+
+
 def main():
+    if "--round2" in sys.argv:
+        return main_round2()
     d_fb, d_db = crosscheck_frontend()
     meta = dict(crosscheck_fb=d_fb, crosscheck_db=d_db)
 
@@ -157,6 +200,7 @@ def main():
     r = run_ref(m.eval(), pcm[:2])
     np.savez_compressed(HERE / "posresize_uit_xxxs.npz", pcm=pcm[:2], seed=11, probs=r["probs"])
     np.savez(HERE / "meta.npz", **meta)
+    main_round2()
     print("done")
 
 

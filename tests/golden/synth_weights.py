@@ -97,3 +97,74 @@ def synth_pcm_i16(B, T, seed=0):
         if b % 8 == 3:
             x[b] *= 0.001
     return np.clip(np.round(x * 32768.0), -32768, 32767).astype(np.int16)
+
+
+def make_trained_like_state_dict(name="uit_xs", seed=0, outputdim=537, target_length=102, dim=128, n_mels=64):
+    """A seeded checkpoint with the MAGNITUDES of a trained UiT (no trained weights are reachable from the build
+    container; the reference's published outputs -- `Speech 1.0000`, `Keyword: on 0.9999`, README.md:124-127 -- show
+    logits beyond +-9, and AudioSet taggers sit at logits around -5..-9 for the hundreds of absent classes):
+
+      * classifier: weights std 0.1 (row norm ~1.1), biases -4.5 +- 2  =>  reference logits span about -15..+4;
+      * matmul weights 3-4x the init scale (sharper attention: q.k logits of a few units; MLP updates comparable to the
+        residual stream instead of a small perturbation of it), non-zero biases everywhere;
+      * LayerNorm gains far from 1 (0.3..2.5, a few negative) and shifts of a few tenths;
+      * a residual stream with structure the init never has: a COMMON per-token offset (every channel shifted the same way by
+        the positional embeddings and the projection biases, so the per-token mean is several times the per-token standard
+        deviation of the bulk) plus three "massive activation" channels (tens of units, as trained ViTs have);
+      * init_bn running statistics with the spectral tilt of real log-mel data (-18 dB at the bottom to -48 dB at the top,
+        variance 120..520) and gains/shifts away from (1, 0).
+    Same key set / shapes as make_state_dict (loaded with strict=True into the reference's own UITBase by make_golden.py)."""
+    depth = DEPTH[name]
+    rng = np.random.default_rng(7000 + seed)
+    gt, gf, inner, hidden = target_length // 16, n_mels // 16, dim // 4, int(dim * 3.0)
+
+    def nrm(*shape, std=1.0, mean=0.0):
+        return (mean + std * rng.standard_normal(shape)).astype(np.float32)
+
+    def gain(n):
+        g = np.exp(rng.normal(0.0, 0.45, n)).astype(np.float32)          # log-normal gains 0.3..2.5
+        g[rng.integers(0, n, 2)] *= -1.0                                  # a couple of negative gains
+        return g
+
+    massive = rng.choice(dim, 3, replace=False)
+    sd = {}
+    sd["cls_token"] = nrm(1, 1, dim, std=0.02)
+    sd["token_pos_embed"] = nrm(1, dim, std=0.1)
+    sd["time_pos_embed"] = nrm(1, dim, 1, gt, std=0.25, mean=2.0)        # common offset: same sign on every channel
+    sd["freq_pos_embed"] = nrm(1, dim, gf, 1, std=0.25, mean=2.0)
+    sd["front_end.0.spectrogram.window"] = hann_periodic(512)
+    sd["front_end.0.mel_scale.fb"] = melscale_fbanks(257, 0.0, 8000.0, n_mels, 16000)
+    tilt = np.linspace(-18.0, -48.0, n_mels)
+    sd["init_bn.1.weight"] = nrm(n_mels, std=0.25, mean=1.1)
+    sd["init_bn.1.bias"] = nrm(n_mels, std=0.3)
+    sd["init_bn.1.running_mean"] = (tilt + 3.0 * rng.standard_normal(n_mels)).astype(np.float32)
+    sd["init_bn.1.running_var"] = (120.0 + 400.0 * rng.random(n_mels)).astype(np.float32)
+    sd["init_bn.1.num_batches_tracked"] = np.array(250000, dtype=np.int64)
+    sd["patch_embed.proj.weight"] = nrm(dim, 1, 16, 16, std=0.05)
+    pe_b = nrm(dim, std=0.3, mean=0.8)
+    pe_b[massive] += np.array([28.0, -22.0, 17.0], np.float32)            # massive-activation channels
+    sd["patch_embed.proj.bias"] = pe_b
+    for b in range(depth):
+        p = f"blocks.{b}."
+        sd[p + "norm1.weight"] = gain(dim)
+        sd[p + "norm1.bias"] = nrm(dim, std=0.3)
+        sd[p + "attn.qkv.weight"] = nrm(3 * inner, dim, std=0.08)
+        sd[p + "attn.qkv.bias"] = nrm(3 * inner, std=0.3)
+        sd[p + "attn.proj.weight"] = nrm(dim, inner, std=0.08)
+        sd[p + "attn.proj.bias"] = nrm(dim, std=0.2, mean=0.15)           # keeps feeding the common offset
+        sd[p + "norm2.weight"] = gain(dim)
+        sd[p + "norm2.bias"] = nrm(dim, std=0.3)
+        sd[p + "mlp.fc1.weight"] = nrm(hidden, dim, std=0.07)
+        sd[p + "mlp.fc1.bias"] = nrm(hidden, std=0.3, mean=-0.2)
+        sd[p + "mlp.fc2.weight"] = nrm(dim, hidden, std=0.06)
+        fc2_b = nrm(dim, std=0.2, mean=0.15)
+        if b == 1:
+            fc2_b[massive] += np.array([35.0, 30.0, -40.0], np.float32)   # ... and grow in an early block, as observed
+        sd[p + "mlp.fc2.bias"] = fc2_b
+    sd["norm.weight"] = gain(dim)
+    sd["norm.bias"] = nrm(dim, std=0.3)
+    sd["outputlayer.0.weight"] = gain(dim)
+    sd["outputlayer.0.bias"] = nrm(dim, std=0.3)
+    sd["outputlayer.1.weight"] = nrm(outputdim, dim, std=0.1)
+    sd["outputlayer.1.bias"] = nrm(outputdim, std=2.0, mean=-4.5)
+    return sd

@@ -116,3 +116,37 @@ def test_torch_port_matches_reference_fixtures(golden, name):
     tp = TorchPort(make_state_dict("uit_xxxs", int(g["seed"])), eval_avg="max")
     p = tp.forward(torch.from_numpy(g["pcm"].astype(np.float32) / 32768.0))
     assert np.abs(p.numpy() - g["probs"]).max() < 1e-5
+
+
+# ---------------------------------------------------------------- round-2 fixtures (trained-checkpoint magnitudes, 10 crops)
+@pytest.mark.parametrize("name", ["uit_xs", "uit_xxxs"])
+def test_trained_like_checkpoint(golden, name):
+    """The oracle at trained-checkpoint magnitudes: reference logits beyond -10 (tests/golden/make_golden.py main_round2,
+    weights from synth_weights.make_trained_like_state_dict loaded into the reference's own UITBase)."""
+    from conftest import centred
+    from synth_weights import make_trained_like_state_dict
+    g = golden(f"trained_{name}")
+    assert np.abs(g["logits"]).max() >= 10.0
+    r = Oracle(make_trained_like_state_dict(name, int(g["seed"]))).forward(g["pcm"], want_stages=True)
+    assert np.abs(r["logits"] - g["logits"]).max() < 2e-4          # fp32 summation-order noise at |logit| ~ 10
+    assert np.abs(r["probs"] - g["probs"]).max() < 5e-5
+    assert np.abs(centred(r["stages"][0]) - centred(g["stages"][0])).max() < 2e-4
+
+
+def test_trained_like_short_clip(golden):
+    from synth_weights import make_trained_like_state_dict
+    g = golden("trained_short_uit_xxxs")
+    r = Oracle(make_trained_like_state_dict("uit_xxxs", int(g["seed"]))).forward(g["pcm"])
+    assert np.abs(r["logits"] - g["logits"]).max() < 2e-4
+    assert np.abs(r["probs"] - g["probs"]).max() < 5e-5
+
+
+@pytest.mark.parametrize("avg", ["mean", "max"])
+def test_ten_crop_clip(golden, avg):
+    """160 000 samples -> 1001 frames -> 10 crops, the last one re-cropped to the final 102 frames (models/uit.py:468-488)."""
+    g = golden("long10_uit_xxxs")
+    o = _oracle("uit_xxxs", g["seed"], eval_avg=avg)
+    assert o.num_crops(g["pcm"].shape[1]) == 10
+    r = o.forward(g["pcm"])
+    assert np.abs(r["logits"] - g["logits"]).max() < 1e-4
+    assert np.abs(r["probs"] - g[f"probs_{avg}"]).max() < 5e-5

@@ -1,0 +1,89 @@
+"""The reference's only published known answers for this path: README.md:86-139 (top-k scores to 4 decimals, pretrained
+uit_xs / uit_xxs on its own sample clips).  They need the zenodo checkpoints of models/uit.py:639-655, which are not reachable
+from the build container or the GPU box (no network) -- so these tests SKIP unless
+
+    UIT_CKPT_DIR=/path/holding/uit_xs_mAP3409.pt[,uit_xxs_mAP3221.pt]
+
+is set.  With a checkpoint they pin the WHOLE path, torchaudio front-end included, to the reference's real outputs:
+the CPU oracle (not gpu) and the HIP path (-m gpu), at 1e-3 + the README's 4-decimal rounding.  The clips' PCM comes from
+the committed fixtures (tests/golden/samples_uit_xs.npz holds three of the reference's sample clips).
+"""
+import os
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+# README.md:86-91, 104-109 (uit_xs on water_000 / water_003), :124-127 (uit_xs on the GSC clip), :136-139 (uit_xxs)
+KNOWN = {
+    ("uit_xs", "water_000"): [("Water", 0.4467), ("Trickle, dribble", 0.3263), ("Gush", 0.1718), ("Stream", 0.1509),
+                              ("Speech", 0.1239)],
+    ("uit_xs", "water_003"): [("Trickle, dribble", 0.5570), ("Water", 0.4017), ("Pour", 0.2454), ("Stream", 0.2454),
+                              ("Liquid", 0.1546)],
+    ("uit_xs", "85b877b5_nohash_0"): [("Speech", 1.0000), ("Keyword: on", 0.9999), ("Inside, small room", 0.0001)],
+    ("uit_xxs", "85b877b5_nohash_0"): [("Speech", 0.9999), ("Keyword: on", 0.9885), ("Clicking", 0.0196)],
+}
+CKPT_FILE = {"uit_xs": "uit_xs_mAP3409.pt", "uit_xxs": "uit_xxs_mAP3221.pt", "uit_xxxs": "uit_xxxs_mAP3097.pt"}   # uit.py:643-653
+TOL = 1e-3 + 5e-5          # the parity gate + half a unit of the README's last printed digit
+
+
+def _ckpt(name):
+    d = os.environ.get("UIT_CKPT_DIR")
+    if not d:
+        pytest.skip("UIT_CKPT_DIR not set: the zenodo checkpoints (models/uit.py:639-655) are not reachable offline")
+    p = Path(d) / CKPT_FILE[name]
+    if not p.exists():
+        pytest.skip(f"{p} not present")
+    import torch
+    sd = torch.load(p, map_location="cpu", weights_only=False)
+    return sd["model"] if "model" in sd else sd
+
+
+def _label_index():
+    from uit_mobile_amd.inference import load_label_map
+    idx = {}
+    for i, n in load_label_map().items():
+        idx[f"Keyword: {n}" if i > 526 else n] = i
+    return idx
+
+
+def _check(probs, name, clip):
+    idx = _label_index()
+    want = KNOWN[(name, clip)]
+    for label, score in want:
+        assert abs(float(probs[idx[label]]) - score) < TOL, (name, clip, label, float(probs[idx[label]]), score)
+    order = np.argsort(-probs)[:len(want)]
+    top = sorted(float(probs[i]) for i in order)
+    assert np.allclose(top, sorted(s for _, s in want), atol=TOL)           # and they ARE the top-k
+
+
+def test_known_answer_table_is_wired_to_the_label_map():
+    """Runs without a checkpoint: every README label resolves to one class index ('Keyword: ' prefix above 526)."""
+    idx = _label_index()
+    for (_, _), rows in KNOWN.items():
+        for label, _ in rows:
+            assert label in idx
+    assert idx["Keyword: on"] > 526 and idx["Speech"] == 0
+
+
+@pytest.mark.parametrize("name,clip", sorted(KNOWN))
+def test_oracle_reproduces_readme(golden, name, clip):
+    from oracle.oracle import Oracle
+    sd = {k: v.numpy() for k, v in _ckpt(name).items()}
+    pcm = golden("samples_uit_xs")[f"{clip}_pcm"]
+    _check(Oracle(sd).forward(pcm[None])["probs"][0], name, clip)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,clip", sorted(KNOWN))
+def test_hip_path_reproduces_readme(golden, name, clip):
+    import torch
+    from uit_mobile_amd import models
+    sd = _ckpt(name)
+    m = models.PRETRAINED_CHECKPOINTS[name]["model"](**models.PRETRAINED_CHECKPOINTS[name]["model_kwargs"])
+    m.load_state_dict(sd, strict=True)
+    m = m.to("cuda").eval()
+    pcm = golden("samples_uit_xs")[f"{clip}_pcm"]
+    with torch.no_grad():
+        p = m(torch.from_numpy(pcm[None]).cuda())[0].cpu().numpy()
+    _check(p, name, clip)

@@ -205,8 +205,9 @@ __device__ __forceinline__ float dpp_mov(float v) {
 }
 
 // LayerNorm statistics (fp32) of one token column held as R[ft][ct], ft = 0..7.  One pass: var = E[x^2] - mean^2; the
-// cancellation error is ~6e-8 * E[x^2], harmless while |mean| is not orders of magnitude above the deviation (residual
-// streams are not); it saves the 32 subtractions per column tile of the two-pass form (UITK_LN_TWO_PASS restores it).
+// cancellation error is ~6e-8 * E[x^2] / var.  pack.cpp removes the channel-mean of everything that is added to the residual
+// stream (LayerNorm is invariant to it), so |mean| stays at rounding level whatever common offset the checkpoint's own stream
+// carries and E[x^2] ~ var; it saves the 32 subtractions per column tile of the two-pass form (UITK_LN_TWO_PASS restores it).
 __device__ __forceinline__ void ln_stats(const f4 (&R)[8][3], int ct, float eps, float& mean, float& rstd) {
 #ifdef UITK_LN_TWO_PASS
     f4 acc = R[0][ct];
@@ -267,7 +268,9 @@ __device__ __forceinline__ unsigned long long stamp() {
 
 // ABL: timing experiments only (wrong outputs; 64|128 = 1..3 filler VALU pinned behind every MLP MFMA): 1 skip attention, 2 skip LayerNorms, 4 MLP without ring steps
 // (no DMA, no barrier), 8 MLP without LDS fragment reads, 16 MLP without ReLU/convert, 32 MLP without bias reads.  The product kernel is ABL = 0.
-template <int PREC, int WAVES, bool SCHED, bool TIMING, int ABL = 0>
+// SHORT: clips with fewer than 6 time patches (masked padding tokens; a separate instantiation keeps the full-clip kernel's
+// register allocation untouched).
+template <int PREC, int WAVES, bool SHORT, bool TIMING, int ABL = 0>
 __global__ __launch_bounds__(WAVES * 64, 2) void uit_encoder_kernel(EncoderArgs a) {
     using OP = Op<PREC>;
     using v8 = typename OP::v8;
@@ -504,7 +507,16 @@ __global__ __launch_bounds__(WAVES * 64, 2) void uit_encoder_kernel(EncoderArgs 
 #pragma unroll
                 for (int i = 0; i < 7; ++i) {
                     S[i] = OP::mfma16(Kh[h][TJ[i]], Qh[h][TI[i]], splat(0.f));
-                    tm[i] = tvalid[i] ? hmax(S[i]) : -INFINITY;
+                    if constexpr (SHORT) {
+                        // padding tokens (time patch >= nt) of the query's own clip must not set the running max: a large score of
+                        // one of them would underflow every valid probability (sum 0 -> rcp(0)).  Per-key select, short clips only.
+                        f4 sv;
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) sv[r] = ((r < 2 ? pmask[i][0] : pmask[i][1]) >> (16 * (r & 1))) & 1u ? S[i][r] : -INFINITY;
+                        tm[i] = hmax(sv);
+                    } else {
+                        tm[i] = tvalid[i] ? hmax(S[i]) : -INFINITY;
+                    }
                 }
                 float mx[3];
                 mx[0] = xmax(fmaxf(tm[0], tm[1]));
@@ -603,7 +615,6 @@ __global__ __launch_bounds__(WAVES * 64, 2) void uit_encoder_kernel(EncoderArgs 
             for (int ft = 0; ft < 8; ++ft)                                              // ... under chunk ch-1's fc2
 #pragma unroll
                 for (int ct = 0; ct < 3; ++ct) R[ft][ct] = mlp_mfma(A2[ft], HX[ct], R[ft][ct]);
-            if constexpr (SCHED) __builtin_amdgcn_sched_barrier(0);
             fc1_chunk(slot, ch, A);
             TSTAMP(7);                                                 // MLP chunk compute (sum of 12)
         }
@@ -785,7 +796,7 @@ __global__ void crop_reduce_kernel(const float* __restrict__ rp, float* __restri
     }
 }
 
-template <int PREC, int WAVES, bool SCHED, bool TIMING = false, int ABL = 0>
+template <int PREC, int WAVES, bool SHORT, bool TIMING = false, int ABL = 0>
 static hipError_t launch_enc(const EncoderArgs& a, hipStream_t stream) {
     // the attribute is per device: one bit per device, set once (see launch_fe)
     static std::atomic<unsigned long long> attr_done{0};
@@ -793,13 +804,13 @@ static hipError_t launch_enc(const EncoderArgs& a, hipStream_t stream) {
     if (hipError_t e = hipGetDevice(&dev); e != hipSuccess) return e;
     const unsigned long long bit = 1ull << (dev & 63);
     if (!(attr_done.load(std::memory_order_acquire) & bit)) {
-        hipError_t e = hipFuncSetAttribute((const void*)uit_encoder_kernel<PREC, WAVES, SCHED, TIMING, ABL>,
+        hipError_t e = hipFuncSetAttribute((const void*)uit_encoder_kernel<PREC, WAVES, SHORT, TIMING, ABL>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, ENC_LDS);
         if (e != hipSuccess) return e;
         attr_done.fetch_or(bit, std::memory_order_release);
     }
     const int grid = (a.rows + 2 * WAVES - 1) / (2 * WAVES);
-    hipLaunchKernelGGL((uit_encoder_kernel<PREC, WAVES, SCHED, TIMING, ABL>), dim3(grid), dim3(WAVES * 64), ENC_LDS, stream, a);
+    hipLaunchKernelGGL((uit_encoder_kernel<PREC, WAVES, SHORT, TIMING, ABL>), dim3(grid), dim3(WAVES * 64), ENC_LDS, stream, a);
     return hipGetLastError();
 }
 
@@ -819,9 +830,10 @@ hipError_t launch_encoder(const EncoderArgs& a, int precision, int waves, int sc
     if (a.ablate == 768) { EncoderArgs b = a; b.depth = 0; return launch_enc<0, 8, false, false, 256>(b, stream); }   // ... without the patch loads
     if (a.ablate == 256) return launch_enc<0, 8, false, false, 256>(a, stream);                                       // full kernel without the patch loads
 #endif
-    if (a.timing != nullptr)                              // diagnostic build with in-kernel stamps (f16 only)
+    if (a.timing != nullptr)                              // diagnostic build with in-kernel stamps (f16, full clips only)
         return waves == 4 ? launch_enc<0, 4, false, true>(a, stream) : launch_enc<0, 8, false, true>(a, stream);
-    if (sched) {
+    (void)sched;
+    if (a.nt < GT) {                                      // short clips: masked padding tokens
         if (waves == 4) return precision == 0 ? launch_enc<0, 4, true>(a, stream) : launch_enc<1, 4, true>(a, stream);
         return precision == 0 ? launch_enc<0, 8, true>(a, stream) : launch_enc<1, 8, true>(a, stream);
     }

@@ -7,6 +7,11 @@
 //   * LayerNorm affine of norm1 / norm2 (:223, 235)           -> folded into qkv / fc1 weights and biases
 //   * attention scale (dim//heads)^-0.5 = 0.125 (:99-100,115), times log2(e) (softmax computed with exp2)
 //                                                             -> folded into the q rows of qkv
+//   * residual-stream centring: every consumer of the residual stream is a LayerNorm (norm1, norm2, final norm), which is
+//     invariant to adding c*1 to a token.  So the channel-mean of everything that is ADDED to the stream is removed here:
+//     column means of the patch-embed / proj / fc2 weights over their 128 output channels, the means of the bias table,
+//     proj bias and fc2 bias.  The kernel's residual stream then has (up to rounding) zero mean per token, and its one-pass
+//     variance E[x^2] - mean^2 cannot cancel however large the common offset of the checkpoint's stream is.
 // Fragment order: see uitk_dev.h and encoder.hip.  A "fragment" is the 1 KiB A/B operand of one
 // mfma_f32_16x16x32: lane l (c = l&15, g = l>>4), element j  <->  W[16*ft + c][ 32*s + 16*(j>>2) + 4*g + (j&3) ]
 // (the k-order a C/D tile pair has after in-register conversion, so activations never move between lanes).
@@ -169,10 +174,15 @@ int pack_image(const uitk_config* c, const uitk_weights* w, std::vector<char>* o
     float* peb = (float*)(img + h.off_pe_bias);
     const int gt_model = c->target_length / 16;
     for (int pf = 0; pf < GF; ++pf)
-        for (int pt = 0; pt < GT; ++pt)
-            for (int oc = 0; oc < DIM; ++oc)
-                peb[(pf * GT + pt) * DIM + oc] =
-                    (float)((double)w->pe_b[oc] + (double)w->time_pos[oc * gt_model + pt] + (double)w->freq_pos[oc * GF + pf]);
+        for (int pt = 0; pt < GT; ++pt) {
+            double row[DIM], mean = 0.0;
+            for (int oc = 0; oc < DIM; ++oc) {
+                row[oc] = (double)w->pe_b[oc] + (double)w->time_pos[oc * gt_model + pt] + (double)w->freq_pos[oc * GF + pf];
+                mean += row[oc];
+            }
+            mean /= DIM;                                                // residual centring (see the file header)
+            for (int oc = 0; oc < DIM; ++oc) peb[(pf * GT + pt) * DIM + oc] = (float)(row[oc] - mean);
+        }
     // ---- final norms
     float* fin = (float*)(img + h.off_fin);
     std::memcpy(fin + 0 * DIM, w->norm_w, DIM * 4); std::memcpy(fin + 1 * DIM, w->norm_b, DIM * 4);
@@ -183,6 +193,11 @@ int pack_image(const uitk_config* c, const uitk_weights* w, std::vector<char>* o
     auto frag_ptr = [&](int stage, int f) { return ws + ((size_t)stage * STAGE_FRAGS + f) * (FRAG_BYTES / 2); };
     // patch embed: k-slot (s,g,j) <-> (mel-in-patch fi = 2s + (g>>1), frame-in-patch ti = 8(g&1) + j), i.e. operand
     // offset fi*16 + ti = 32s + 8g + j in the front-end's [mel][frame] patch; Conv2d weight [oc][0][fi][ti]
+    std::vector<double> pe_colmean(256, 0.0);                          // residual centring: mean over the 128 output channels
+    for (int k = 0; k < 256; ++k) {
+        for (int oc = 0; oc < DIM; ++oc) pe_colmean[k] += (double)w->pe_w[oc * 256 + k];
+        pe_colmean[k] /= DIM;
+    }
     for (int i = 0; i < PE_STAGES; ++i)
         for (int f = 0; f < STAGE_FRAGS; ++f) {
             const int ft = 2 * i + f / 8, s = f % 8;
@@ -190,7 +205,7 @@ int pack_image(const uitk_config* c, const uitk_weights* w, std::vector<char>* o
             for (int l = 0; l < 64; ++l)
                 for (int j = 0; j < 8; ++j) {
                     const int g = l >> 4, fi = 2 * s + (g >> 1), ti = 8 * (g & 1) + j;
-                    dst[l * 8 + j] = cvt(w->pe_w[(16 * ft + (l & 15)) * 256 + fi * 16 + ti], prec);
+                    dst[l * 8 + j] = cvt((double)w->pe_w[(16 * ft + (l & 15)) * 256 + fi * 16 + ti] - pe_colmean[fi * 16 + ti], prec);
                 }
         }
     float* bias = (float*)(img + h.off_bias);
@@ -201,21 +216,26 @@ int pack_image(const uitk_config* c, const uitk_weights* w, std::vector<char>* o
         // head_dim = dim // num_heads (uit.py:99-100); log2(e) rides along so the kernel's softmax is exp2
         const double scale = 1.0 / std::sqrt((double)(DIM / 2)) * 1.4426950408889634074;
         auto Wqkv = [&](int r, int k) { return (double)bw.qkv_w[r * DIM + k] * (double)bw.norm1_w[k] * (r < INNER ? scale : 1.0); };
-        auto Wproj = [&](int r, int k) { return (double)bw.proj_w[r * INNER + k]; };
+        double proj_cm[INNER], fc2_cm[HID], proj_bm = 0.0, fc2_bm = 0.0;      // residual centring: output-channel means
+        for (int k = 0; k < INNER; ++k) { proj_cm[k] = 0.0; for (int r = 0; r < DIM; ++r) proj_cm[k] += (double)bw.proj_w[r * INNER + k]; proj_cm[k] /= DIM; }
+        for (int k = 0; k < HID; ++k) { fc2_cm[k] = 0.0; for (int r = 0; r < DIM; ++r) fc2_cm[k] += (double)bw.fc2_w[r * HID + k]; fc2_cm[k] /= DIM; }
+        for (int r = 0; r < DIM; ++r) { proj_bm += (double)bw.proj_b[r]; fc2_bm += (double)bw.fc2_b[r]; }
+        proj_bm /= DIM; fc2_bm /= DIM;
+        auto Wproj = [&](int r, int k) { return (double)bw.proj_w[r * INNER + k] - proj_cm[k]; };
         auto Wfc1 = [&](int r, int k) { return (double)bw.fc1_w[r * DIM + k] * (double)bw.norm2_w[k]; };
-        auto Wfc2 = [&](int r, int k) { return (double)bw.fc2_w[r * HID + k]; };
+        auto Wfc2 = [&](int r, int k) { return (double)bw.fc2_w[r * HID + k] - fc2_cm[k]; };
         for (int r = 0; r < 3 * INNER; ++r) {
             double acc = bw.qkv_b[r];
             for (int k = 0; k < DIM; ++k) acc += (double)bw.qkv_w[r * DIM + k] * (double)bw.norm1_b[k];
             bb[BIAS_QKV + r] = (float)(acc * (r < INNER ? scale : 1.0));
         }
-        for (int r = 0; r < DIM; ++r) bb[BIAS_PROJ + r] = bw.proj_b[r];
+        for (int r = 0; r < DIM; ++r) bb[BIAS_PROJ + r] = (float)((double)bw.proj_b[r] - proj_bm);
         for (int r = 0; r < HID; ++r) {
             double acc = bw.fc1_b[r];
             for (int k = 0; k < DIM; ++k) acc += (double)bw.fc1_w[r * DIM + k] * (double)bw.norm2_b[k];
             bb[BIAS_FC1 + r] = (float)acc;
         }
-        for (int r = 0; r < DIM; ++r) bb[BIAS_FC2 + r] = bw.fc2_b[r];
+        for (int r = 0; r < DIM; ++r) bb[BIAS_FC2 + r] = (float)((double)bw.fc2_b[r] - fc2_bm);
         // stage QK: ft = f/4 over qkv rows 0..63 (q h0, q h1, k h0, k h1), s = f%4
         for (int f = 0; f < 16; ++f) pack_frag(frag_ptr(st, f), prec, Wqkv, f / 4, f % 4);
         // stage VP: V rows 64..95 (tile 4 + h), then proj (K = 32: one k-step)
