@@ -93,16 +93,14 @@ class EncoderEmu:
         return round_op(x, self.prec)
 
     def layernorm_to_operand(self, R, eps):
+        """LayerNorm as the kernel computes it: the stream is centred by pack.cpp, so x_hat = x * rsqrt(E[x^2] + eps)
+        (no mean term; csrc/encoder.hip ln_stats)."""
         X = [[None] * 3 for _ in range(4)]
         for ct in range(3):
-            tot = sum(R[ft][ct].sum(1) for ft in range(8))                      # per lane
-            tot = tot.reshape(4, 16).sum(0)[C_]                                   # xsum over g
-            mean = tot / 128.0
-            var = sum(((R[ft][ct] - mean[:, None]) ** 2).sum(1) for ft in range(8)).reshape(4, 16).sum(0)[C_] / 128.0
-            rstd = 1.0 / np.sqrt(var + eps)
+            ex2 = sum((R[ft][ct] ** 2).sum(1) for ft in range(8)).reshape(4, 16).sum(0)[C_] / 128.0
+            rstd = 1.0 / np.sqrt(ex2 + eps)
             for s in range(4):
-                X[s][ct] = self.pack8((R[2 * s][ct] - mean[:, None]) * rstd[:, None],
-                                      (R[2 * s + 1][ct] - mean[:, None]) * rstd[:, None])
+                X[s][ct] = self.pack8(R[2 * s][ct] * rstd[:, None], R[2 * s + 1][ct] * rstd[:, None])
         return X
 
     def run_wave(self, mel2, floor_db, nt=6):
@@ -216,11 +214,9 @@ class EncoderEmu:
         # final norm + masked mean pool (per clip) -- done directly on the dumped layout semantics
         xn = []
         for ct in range(3):
-            tot = sum(R[ft][ct].sum(1) for ft in range(8)).reshape(4, 16).sum(0)[C_]
-            mean = tot / 128.0
-            var = sum(((R[ft][ct] - mean[:, None]) ** 2).sum(1) for ft in range(8)).reshape(4, 16).sum(0)[C_] / 128.0
-            rstd = np.where(pt[ct] < nt, 1.0 / np.sqrt(var + 1e-6), 0.0)
-            xn.append([(R[ft][ct] - mean[:, None]) * rstd[:, None] for ft in range(8)])
+            ex2 = sum((R[ft][ct] ** 2).sum(1) for ft in range(8)).reshape(4, 16).sum(0)[C_] / 128.0
+            rstd = np.where(pt[ct] < nt, 1.0 / np.sqrt(ex2 + 1e-6), 0.0)
+            xn.append([R[ft][ct] * rstd[:, None] for ft in range(8)])
         lo = (C_ < 8)[:, None]
         pooled = []
         for ft in range(8):

@@ -204,12 +204,14 @@ __device__ __forceinline__ float dpp_mov(float v) {
     return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, true));
 }
 
-// LayerNorm statistics (fp32) of one token column held as R[ft][ct], ft = 0..7.  One pass: var = E[x^2] - mean^2; the
-// cancellation error is ~6e-8 * E[x^2] / var.  pack.cpp removes the channel-mean of everything that is added to the residual
-// stream (LayerNorm is invariant to it), so |mean| stays at rounding level whatever common offset the checkpoint's own stream
-// carries and E[x^2] ~ var; it saves the 32 subtractions per column tile of the two-pass form (UITK_LN_TWO_PASS restores it).
+// LayerNorm statistics (fp32) of one token column held as R[ft][ct], ft = 0..7.
+// pack.cpp removes the channel-mean of everything that is ever added to the residual stream (LayerNorm cannot see a common
+// offset, so this is exact algebra): the kernel's stream has zero mean per token up to the rounding of the 16-bit weights
+// (measured |mean| < 1e-5 of the token's deviation, 25x below the operand rounding).  So LayerNorm(x) = x * rsqrt(E[x^2] + eps):
+// no mean, no subtraction, no cancellation -- 40 VALU instructions less per column tile than the one-pass form with a mean.
+// -DUITK_LN_WITH_MEAN restores var = E[x^2] - mean^2 with the mean subtracted, -DUITK_LN_TWO_PASS the textbook two-pass form.
 __device__ __forceinline__ void ln_stats(const f4 (&R)[8][3], int ct, float eps, float& mean, float& rstd) {
-#ifdef UITK_LN_TWO_PASS
+#if defined(UITK_LN_TWO_PASS)
     f4 acc = R[0][ct];
 #pragma unroll
     for (int ft = 1; ft < 8; ++ft) acc = acc + R[ft][ct];
@@ -218,13 +220,19 @@ __device__ __forceinline__ void ln_stats(const f4 (&R)[8][3], int ct, float eps,
 #pragma unroll
     for (int ft = 0; ft < 8; ++ft) { const f4 d = R[ft][ct] - splat(mean); q = q + d * d; }
     rstd = __builtin_amdgcn_rsqf(xsum(hsum(q)) * (1.0f / DIM) + eps);
-#else
+#elif defined(UITK_LN_WITH_MEAN)
     f4 acc = R[0][ct], q = R[0][ct] * R[0][ct];
 #pragma unroll
     for (int ft = 1; ft < 8; ++ft) { acc = acc + R[ft][ct]; q = __builtin_elementwise_fma(R[ft][ct], R[ft][ct], q); }
     mean = xsum(hsum(acc)) * (1.0f / DIM);
     const float ex2 = xsum(hsum(q)) * (1.0f / DIM);
     rstd = __builtin_amdgcn_rsqf(fmaxf(__builtin_fmaf(-mean, mean, ex2), 0.f) + eps);
+#else
+    f4 q = R[0][ct] * R[0][ct];
+#pragma unroll
+    for (int ft = 1; ft < 8; ++ft) q = __builtin_elementwise_fma(R[ft][ct], R[ft][ct], q);
+    mean = 0.f;
+    rstd = __builtin_amdgcn_rsqf(xsum(hsum(q)) * (1.0f / DIM) + eps);
 #endif
 }
 
@@ -235,9 +243,15 @@ __device__ __forceinline__ void layernorm_to_operand(const f4 (&R)[8][3], float 
     for (int ct = 0; ct < 3; ++ct) {
         float mean, rstd;
         ln_stats(R, ct, eps, mean, rstd);
-        const f4 nm = splat(-mean * rstd), rs = splat(rstd);
+        const f4 rs = splat(rstd);
+#if defined(UITK_LN_TWO_PASS) || defined(UITK_LN_WITH_MEAN)
+        const f4 nm = splat(-mean * rstd);
 #pragma unroll
         for (int s = 0; s < 4; ++s) X[s][ct] = Op<PREC>::pack8(R[2 * s][ct] * rs + nm, R[2 * s + 1][ct] * rs + nm);
+#else
+#pragma unroll
+        for (int s = 0; s < 4; ++s) X[s][ct] = Op<PREC>::pack8(R[2 * s][ct] * rs, R[2 * s + 1][ct] * rs);
+#endif
     }
 }
 
