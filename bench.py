@@ -31,7 +31,7 @@ import torch.distributed as dist  # noqa: E402
 
 from synth_weights import make_state_dict  # noqa: E402
 from uit_mobile_amd import models  # noqa: E402
-from uit_mobile_amd.sharded import amax_allreduce_async, amax_allreduce_finish, gather_outputs_async  # noqa: E402
+from uit_mobile_amd.sharded import PeerGather, amax_allreduce_async, amax_allreduce_finish, gather_outputs_async  # noqa: E402
 
 GEMM_FLOP = {"uit_xs": 68.66e6, "uit_xxs": 35.18e6, "uit_xxxs": 24.03e6}   # BASELINE.md section 3, per clip
 FRONTEND_ALG_FLOP = 1.34e6       # algorithmic fp32 work per clip, mel counted sparse: (11 520 rFFT + 771 power + ~1 000
@@ -169,6 +169,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--spinup-steps", type=int, default=120,
                     help="untimed set-up steps that bring the idle GPU's clocks up before the --warmup steps (0 = none)")
+    ap.add_argument("--gather", default="rccl", choices=["rccl", "peer"],
+                    help="N>1: RCCL all_gather_into_tensor (default) or the copy-engine fan-out into IPC-mapped peer buffers")
     ap.add_argument("--from-host", action="store_true",
                     help="additionally report the PCIe-inclusive rate (pinned int16 host buffers -> HostClipStreamer)")
     args = ap.parse_args()
@@ -205,6 +207,8 @@ def main():
     cur = [0]
     import collections
     pending = collections.deque()
+    # 4 rotating buffers: at most 2 gathers are in flight and one result is being read
+    peer = PeerGather(Bl, 537, dev, nbuf=4) if (world > 1 and args.gather == "peer") else None
 
     def fe(n, rec=True):
         """front-end of step n (+ at N>1 the start of its amax all-reduce)"""
@@ -227,7 +231,7 @@ def main():
         probs = r.encode(st)
         if rec:
             evs[n][3].record()
-        pending.append(gather_outputs_async(probs))
+        pending.append(peer.gather_async(probs) if peer is not None else gather_outputs_async(probs))
         return pending.popleft().wait() if len(pending) > 2 else None
 
     def run(first, count, rec=True):
@@ -306,7 +310,8 @@ def main():
                        "global_batch": world * Bl, "clip_samples": T,
                        "setup": f"handles + workspace + RCCL communicator, then {args.spinup_steps} untimed steps of device "
                                 "spin-up (clock ramp) before the --warmup steps",
-                       "parallelism": f"dp{world} (batch shards, RCCL amax MAX all-reduce + all-gather of [B,537])"},
+                       "parallelism": f"dp{world} (batch shards, in-place RCCL MAX all-reduce of the 64 amax slots + "
+                                      f"{'copy-engine peer fan-out' if peer is not None else 'RCCL all-gather'} of [B,537])"},
             "roofline": {"bound": "mfma", "kernel": "uit_encoder_kernel", "achieved": round(achieved, 2),
                          "peak": PEAK_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / PEAK_MFMA_TFLOPS, 5),
                          "traffic": traffic, "launch_ms": round(enc, 4),

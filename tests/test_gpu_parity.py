@@ -302,7 +302,7 @@ def test_sharded_wrapper_single_rank_matches_plain_forward():
     assert slots.shape == (64,) and not torch.isnan(slots).any() and torch.isfinite(slots.max())
 
 
-def _rccl_worker(rank, world, port, q):
+def _rccl_worker(rank, world, port, q, gather):
     import os
     import torch.distributed as dist
     from uit_mobile_amd.sharded import ShardedUiT, shard_range
@@ -314,7 +314,7 @@ def _rccl_worker(rank, world, port, q):
         m = m.to(f"cuda:{rank}")
         pcm = synth_pcm_i16(16, 16000, seed=13)               # clip 1 is the loud tone, clip 2 has a silent tail
         lo, hi = shard_range(16, rank, world)
-        out = ShardedUiT(m)(torch.from_numpy(pcm[lo:hi]).cuda())
+        out = ShardedUiT(m, gather=gather)(torch.from_numpy(pcm[lo:hi]).cuda())
         torch.cuda.synchronize()
         q.put((rank, out.cpu().numpy()))
     finally:
@@ -322,24 +322,78 @@ def _rccl_worker(rank, world, port, q):
 
 
 @pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs 2 GPUs (RCCL)")
-def test_two_rank_rccl_matches_single_rank_oracle():
-    """R-invariance: batch shards + MAX all-reduce of the amax + all-gather == the single-call result (the silent
-    tail of clip 2 sits on the top_db floor set by the loud clip 1, which lives on the other rank)."""
+@pytest.mark.parametrize("gather", ["rccl", "peer"])
+def test_two_rank_rccl_is_bitwise_the_single_rank_result(gather):
+    """R-invariance: batch shards + in-place MAX all-reduce of the amax slots + gather == the single-rank GPU
+    result BIT FOR BIT (shards start on even rows; the silent tail of clip 2 sits on the top_db floor set by the loud
+    clip 1, which lives on the other rank), and within 1e-3 of the oracle."""
     import torch.multiprocessing as mp
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_rccl_worker, args=(r, 2, 29400 + os.getpid() % 500, q)) for r in range(2)]
+    procs = [ctx.Process(target=_rccl_worker, args=(r, 2, 29400 + os.getpid() % 500, q, gather)) for r in range(2)]
     for p in procs:
         p.start()
     res = dict(q.get(timeout=300) for _ in procs)
     for p in procs:
         p.join(timeout=60)
-    _, sd = build("uit_xxxs", 32)
-    ref = Oracle(sd).forward(synth_pcm_i16(16, 16000, seed=13))
+    m, sd = build("uit_xxxs", 32)
+    pcm = synth_pcm_i16(16, 16000, seed=13)
+    single, _ = run(m, pcm)
+    ref = Oracle(sd).forward(pcm)
     for r in range(2):
         assert res[r].shape == (16, 537)
+        assert np.array_equal(res[r], single)
         assert np.abs(res[r] - ref["probs"]).max() < TOL
-    assert np.array_equal(res[0], res[1])
+
+
+def _one_gpu_worker(rank, world, port, q, rows_per_rank):
+    """Two ranks sharing ONE GPU: gloo for the control plane (RCCL refuses two ranks on one device), the amax MAX all-reduce
+    staged through the host, the outputs gathered by PeerGather's device-to-device copies into IPC-mapped buffers."""
+    import os
+    import torch.distributed as dist
+    from uit_mobile_amd.sharded import ShardedUiT
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        m, sd = build("uit_xxxs", 32)
+        pcm = synth_pcm_i16(world * rows_per_rank, 16000, seed=13)
+        lo = rank * rows_per_rank
+        sh = ShardedUiT(m, gather="peer")
+        outs = []
+        for rep in range(3):                                   # repeated: the gather buffers rotate, the amax slot sets alternate
+            out = sh(torch.from_numpy(pcm[lo:lo + rows_per_rank]).cuda())
+            torch.cuda.synchronize()
+            outs.append(out.cpu().numpy())
+        q.put((rank, outs))
+        dist.barrier()                                         # keep the IPC-mapped buffers alive until both ranks have read
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("rows_per_rank", [8, 6])
+def test_two_ranks_on_one_gpu_peer_gather_is_bitwise_the_single_rank_result(rows_per_rank):
+    """The N>1 data path on a 1-GPU box: 2 processes, batch shards, MAX all-reduce of the amax slots, copy-engine gather
+    through IPC-mapped peer buffers -> every rank holds the full [B, 537] output, bit for bit the single-rank result
+    (R-invariance; shards start on even rows) and within 1e-3 of the oracle."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_one_gpu_worker, args=(r, 2, 29900 + os.getpid() % 500, q, rows_per_rank)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=300) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+    m, sd = build("uit_xxxs", 32)
+    pcm = synth_pcm_i16(2 * rows_per_rank, 16000, seed=13)
+    single, _ = run(m, pcm)
+    ref = Oracle(sd).forward(pcm)
+    for r in range(2):
+        for out in res[r]:
+            assert out.shape == (2 * rows_per_rank, 537)
+            assert np.array_equal(out, single)
+            assert np.abs(out - ref["probs"]).max() < TOL
 
 
 def test_host_clip_streamer_matches_direct_calls():
