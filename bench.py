@@ -163,7 +163,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=50)
     ap.add_argument("--model", default="uit_xs", choices=list(GEMM_FLOP))
     ap.add_argument("--batch-per-gpu", type=int, default=8192)
-    ap.add_argument("--precision", default="f16", choices=["f16", "bf16"])
+    ap.add_argument("--precision", default="f16", choices=["f16", "bf16", "fp8"])
     ap.add_argument("--pcm16", action="store_true", help="feed int16 PCM instead of float32 waves")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")

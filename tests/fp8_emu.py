@@ -1,0 +1,88 @@
+"""CPU restatement of what precision='fp8' (BASELINE config #5) is SUPPOSED to compute -- test infrastructure.
+
+The fp8 mode is a different network from the reference's (it quantises): qkv / fc1 / fc2 weights are OCP e4m3 with MX block
+scales (one power-of-two scale per 32-element hardware block of a row, pack.cpp pack_frag8), the activations entering those
+three linears (LayerNorm outputs, ReLU(hidden)) are e4m3 with scale 1, everything else (patch embed, q/k/v/P/O, proj, head)
+is 16-bit as in precision='f16'.  This file restates that quantised network in fp64 so that the GPU test can separate
+"the kernel implements the intended quantisation" (GPU vs this file: small) from "what the quantisation costs" (this file vs the
+reference goldens: large, documented, outside the 1e-3 gate).
+"""
+import numpy as np
+import torch
+
+
+def e4m3(x):
+    """round-to-nearest-even onto OCP e4m3fn, saturating at +-448 (what pack.cpp's f32_to_e4m3 and the kernel's clamp + cvt do)"""
+    t = torch.as_tensor(x, dtype=torch.float64).clamp(-448.0, 448.0)
+    return t.to(torch.float32).to(torch.float8_e4m3fn).to(torch.float64)
+
+
+def f16(x):
+    return torch.as_tensor(x, dtype=torch.float64).to(torch.float16).to(torch.float64)
+
+
+def mx_quant_rows(W):
+    """W [rows, K] with K a multiple of 128 -> dequantised e4m3 x 2^e weights.  Hardware block beta of a 128-wide k-group:
+    beta(k) = 2 (k >> 6) + ((k >> 3) & 1)  (uitk_dev.h: lanes g = 2(beta&1)..+1, bytes 16(beta>>1)..+15, k = 16(j>>2) + 4g + (j&3))."""
+    W = torch.as_tensor(W, dtype=torch.float64)
+    out = torch.empty_like(W)
+    k = torch.arange(128)
+    beta = 2 * (k >> 6) + ((k >> 3) & 1)
+    for base in range(0, W.shape[1], 128):
+        blk = W[:, base:base + 128]
+        for b in range(4):
+            sel = (beta == b).nonzero().flatten()
+            v = blk[:, sel]
+            m = v.abs().max(dim=1, keepdim=True)[0]
+            e = torch.where(m > 0, torch.ceil(torch.log2(m / 448.0)), torch.zeros_like(m))
+            e = torch.where(m / torch.exp2(e) > 448.0, e + 1, e)
+            e = torch.where((m > 0) & (m / torch.exp2(e - 1) <= 448.0), e - 1, e)
+            out[:, base + sel] = e4m3(v / torch.exp2(e)) * torch.exp2(e)
+    return out
+
+
+def ln(x, eps):
+    m = x.mean(-1, keepdim=True)
+    v = ((x - m) ** 2).mean(-1, keepdim=True)
+    return (x - m) / torch.sqrt(v + eps)
+
+
+def forward(sd, mel_bn, depth):
+    """mel_bn [B, 64, >= 96] = init_bn(front-end dB) in fp64 -> logits [B, C] of the quantised network."""
+    g = lambda k: torch.as_tensor(np.asarray(sd[k]), dtype=torch.float64)
+    B = mel_bn.shape[0]
+    x = mel_bn[:, :, :96].reshape(B, 4, 16, 6, 16).permute(0, 1, 3, 2, 4).reshape(B, 24, 256)
+    W = g("patch_embed.proj.weight").reshape(128, 256)
+    tok = f16(x) @ f16(W - W.mean(0, keepdim=True)).T + g("patch_embed.proj.bias")      # centred, as pack.cpp rounds them
+    tp, fp = g("time_pos_embed")[0, :, 0, :6], g("freq_pos_embed")[0, :, :, 0]
+    tok = tok + (fp.T[:, None, :] + tp.T[None, :, :]).reshape(24, 128)
+    scale = (128 // 2) ** -0.5 * 1.4426950408889634
+    for b in range(depth):
+        p = f"blocks.{b}."
+        w1, b1 = g(p + "norm1.weight"), g(p + "norm1.bias")
+        Wq, bq = g(p + "attn.qkv.weight"), g(p + "attn.qkv.bias")
+        Wf, bf = Wq * w1[None], bq + Wq @ b1
+        Wf = torch.cat([Wf[:32] * scale, Wf[32:]]); bf = torch.cat([bf[:32] * scale, bf[32:]])
+        qkv = e4m3(ln(tok, 1e-6)) @ mx_quant_rows(Wf).T + bf.to(torch.float32).to(torch.float64)
+        qkv = f16(qkv).reshape(B, 24, 3, 2, 16).permute(2, 0, 3, 1, 4)
+        q, k, v = qkv[0], qkv[1], qkv[2]
+        s = q @ k.transpose(-1, -2)
+        pr = f16(torch.exp2(s - s.max(-1, keepdim=True)[0]))
+        o = ((pr @ v) / pr.sum(-1, keepdim=True)).transpose(1, 2).reshape(B, 24, 32)
+        Wp = g(p + "attn.proj.weight")
+        tok = tok + f16(o) @ f16(Wp - Wp.mean(0, keepdim=True)).T + g(p + "attn.proj.bias")
+        w2, b2 = g(p + "norm2.weight"), g(p + "norm2.bias")
+        W1, c1 = g(p + "mlp.fc1.weight"), g(p + "mlp.fc1.bias")
+        h = e4m3(ln(tok, 1e-6)) @ mx_quant_rows(W1 * w2[None]).T + (c1 + W1 @ b2).to(torch.float32).to(torch.float64)
+        h = e4m3(torch.relu(h))
+        W2 = g(p + "mlp.fc2.weight")
+        tok = tok + h @ mx_quant_rows(W2 - W2.mean(0, keepdim=True)).T + g(p + "mlp.fc2.bias")
+    z = (ln(tok, 1e-6) * g("norm.weight") + g("norm.bias")).mean(1)
+    z = ln(z, 1e-5) * g("outputlayer.0.weight") + g("outputlayer.0.bias")
+    return z @ g("outputlayer.1.weight").T + g("outputlayer.1.bias")
+
+
+def mel_bn_from_oracle(sd, mel_db):
+    s = np.asarray(sd["init_bn.1.weight"], np.float64) / np.sqrt(np.asarray(sd["init_bn.1.running_var"], np.float64) + 1e-5)
+    return torch.from_numpy((mel_db.astype(np.float64) - np.asarray(sd["init_bn.1.running_mean"], np.float64)[None, :, None])
+                            * s[None, :, None] + np.asarray(sd["init_bn.1.bias"], np.float64)[None, :, None])

@@ -270,6 +270,123 @@ __device__ __forceinline__ f4 mfma32_filled(h8 a, h8 b, f4 c, float& d0, float& 
     return c;
 }
 
+typedef unsigned u2 __attribute__((ext_vector_type(2)));
+typedef int v8i __attribute__((ext_vector_type(8)));
+
+// Score tiles (jt,it) of the 48 token columns of a wave (two clips): S^T[j = 16jt+4g+r][i = 16it+c]; tile (0,2)/(2,0) never
+// mixes tokens of one clip and is skipped.
+__device__ constexpr int TJ[7] = {0, 1, 0, 1, 2, 1, 2};
+__device__ constexpr int TI[7] = {0, 0, 1, 1, 1, 2, 2};
+
+// Attention of one block on 16x16x16 MFMAs (K = head_dim 16 exactly) + the proj linear into the residual stream R.
+//   Qh/Kh[h][ct]: q, k of head h as C/D tiles packed to 16 bits (feature-major);  Vh[ct][h]: V token-major (A operand of P.V)
+//   tvalid / pmask: see the kernel;  proj: the eight 1 KiB proj fragments (K = 32 = (head, d));  bias: this block's bias table
+template <class OP, bool SHORT>
+__device__ __forceinline__ void attention_proj(f4 (&R)[8][3], const typename OP::v4 (&Qh)[2][3], const typename OP::v4 (&Kh)[2][3],
+                                               const typename OP::v4 (&Vh)[3][2], const bool (&tvalid)[7], const u2 (&pmask)[7],
+                                               const char* proj, const float* bias, int lane, int g) {
+    using v8 = typename OP::v8;
+    using v4 = typename OP::v4;
+    f4 O[2][3];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        // S^T = K.Q^T in the log2 domain (0.125*log2(e) folded into Wq/bq by pack.cpp)
+        f4 S[7];
+        float tm[7];
+#pragma unroll
+        for (int i = 0; i < 7; ++i) {
+            S[i] = OP::mfma16(Kh[h][TJ[i]], Qh[h][TI[i]], splat(0.f));
+            if constexpr (SHORT) {
+                // padding tokens (time patch >= nt) of the query's own clip must not set the running max: a large score of
+                // one of them would underflow every valid probability (sum 0 -> rcp(0)).  Per-key select, short clips only.
+                f4 sv;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) sv[r] = ((r < 2 ? pmask[i][0] : pmask[i][1]) >> (16 * (r & 1))) & 1u ? S[i][r] : -INFINITY;
+                tm[i] = hmax(sv);
+            } else {
+                tm[i] = tvalid[i] ? hmax(S[i]) : -INFINITY;
+            }
+        }
+        float mx[3];
+        mx[0] = xmax(fmaxf(tm[0], tm[1]));
+        mx[1] = xmax(fmaxf(fmaxf(tm[2], tm[3]), tm[4]));
+        mx[2] = xmax(fmaxf(tm[5], tm[6]));
+        // P = 2^(S - max), converted, masked on the packed bits; row sums by a ones-row MFMA (sums exactly the
+        // rounded probabilities that multiply V; every output row holds the column sum => no cross-lane step)
+        f4 Lsum[3];
+#pragma unroll
+        for (int it = 0; it < 3; ++it) { O[h][it] = splat(0.f); Lsum[it] = splat(0.f); }
+#pragma unroll
+        for (int i = 0; i < 7; ++i) {
+            f4 p;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) p[r] = __builtin_amdgcn_exp2f(S[i][r] - mx[TI[i]]);
+            const u2 bits = __builtin_bit_cast(u2, OP::pack4(p)) & pmask[i];
+            const v4 Pm = __builtin_bit_cast(v4, bits);
+            O[h][TI[i]] = OP::mfma16(Vh[TJ[i]][h], Pm, O[h][TI[i]]);
+            Lsum[TI[i]] = OP::mfma16(OP::ones4(), Pm, Lsum[TI[i]]);
+        }
+#pragma unroll
+        for (int it = 0; it < 3; ++it) O[h][it] = O[h][it] * splat(__builtin_amdgcn_rcpf(Lsum[it][0]));
+    }
+    // proj: K = 32 = (head, d); slots j<4 head 0, j>=4 head 1 (same universal k-order as pack_frag)
+    v8 A[8];
+#pragma unroll
+    for (int ft = 0; ft < 8; ++ft) A[ft] = *(const v8*)(proj + ft * FRAG_BYTES + lane * 16);
+    v8 OX[3];
+#pragma unroll
+    for (int ct = 0; ct < 3; ++ct) OX[ct] = OP::pack8(O[0][ct], O[1][ct]);
+#pragma unroll
+    for (int ft = 0; ft < 8; ++ft) {
+        const f4 bp = *(const f4*)(bias + BIAS_PROJ + 16 * ft + 4 * g);
+#pragma unroll
+        for (int ct = 0; ct < 3; ++ct) R[ft][ct] = OP::mfma32(A[ft], OX[ct], add4s(R[ft][ct], bp));
+    }
+}
+
+// ---- precision fp8 (BASELINE config #5): OCP e4m3 operands of v_mfma_scale_f32_16x16x128_f8f6f4 ---------------------
+// four f32 -> four e4m3 bytes of one dword (round to nearest even; the conversion does NOT saturate -- 1000.f gives NaN 0x7f,
+// tools/probe/mx_layout.hip -- so values are clamped to the format's +-448 first)
+__device__ __forceinline__ int cvt4_fp8(f4 x) {
+    int w = __builtin_amdgcn_cvt_pk_fp8_f32(__builtin_amdgcn_fmed3f(x[0], -448.f, 448.f), __builtin_amdgcn_fmed3f(x[1], -448.f, 448.f), 0, false);
+    return __builtin_amdgcn_cvt_pk_fp8_f32(__builtin_amdgcn_fmed3f(x[2], -448.f, 448.f), __builtin_amdgcn_fmed3f(x[3], -448.f, 448.f), w, true);
+}
+__device__ __forceinline__ int relu_cvt4_fp8(f4 x) {             // relu and the clamp are one v_med3 per element
+    int w = __builtin_amdgcn_cvt_pk_fp8_f32(__builtin_amdgcn_fmed3f(x[0], 0.f, 448.f), __builtin_amdgcn_fmed3f(x[1], 0.f, 448.f), 0, false);
+    return __builtin_amdgcn_cvt_pk_fp8_f32(__builtin_amdgcn_fmed3f(x[2], 0.f, 448.f), __builtin_amdgcn_fmed3f(x[3], 0.f, 448.f), w, true);
+}
+// a fragment8: two lane-linear 1 KiB halves (conflict-free ds_read_b128 each)
+__device__ __forceinline__ v8i lds_frag8(const char* base, int lane) {
+    typedef int v4i __attribute__((ext_vector_type(4)));
+    const v4i lo = *(const v4i*)(base + lane * 16), hi = *(const v4i*)(base + 1024 + lane * 16);
+    return v8i{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+}
+constexpr int E8M0_ONE = 127;
+// D = A.B + C with MX block scales; WSEL = byte of the weight operand's scale dword (the activation operand's scale is 1.0)
+template <int WSEL>
+__device__ __forceinline__ f4 mfma8_wa(v8i w, v8i x, f4 c, int wscale) {      // weights as A (rows = output features)
+    return __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(w, x, c, 0, 0, WSEL, wscale, 0, E8M0_ONE);
+}
+template <int WSEL>
+__device__ __forceinline__ f4 mfma8_wb(v8i x, v8i w, f4 c, int wscale) {      // weights as B (columns = output features)
+    return __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(x, w, c, 0, 0, 0, E8M0_ONE, WSEL, wscale);
+}
+__device__ __forceinline__ f4 mfma8_wa_sel(int sel, v8i w, v8i x, f4 c, int wscale) {
+    switch (sel & 3) { case 0: return mfma8_wa<0>(w, x, c, wscale); case 1: return mfma8_wa<1>(w, x, c, wscale);
+                       case 2: return mfma8_wa<2>(w, x, c, wscale); default: return mfma8_wa<3>(w, x, c, wscale); }
+}
+// LN (mean-free on the centred stream, see ln_stats) -> the 128 features of each token column as 32 e4m3 bytes per lane
+__device__ __forceinline__ void layernorm_to_fp8(const f4 (&R)[8][3], float eps, v8i (&X8)[3]) {
+#pragma unroll
+    for (int ct = 0; ct < 3; ++ct) {
+        float mean, rstd;
+        ln_stats(R, ct, eps, mean, rstd);
+        const f4 rs = splat(rstd), nm = splat(-mean * rstd);
+#pragma unroll
+        for (int ft = 0; ft < 8; ++ft) X8[ct][ft] = cvt4_fp8(R[ft][ct] * rs + nm);
+    }
+}
+
 // In-kernel stamps (diagnostic build only, TIMING = true): one asm statement = s_memtime + lgkmcnt(0), fenced.
 __device__ __forceinline__ unsigned long long stamp() {
     unsigned long long t;
@@ -286,10 +403,10 @@ __device__ __forceinline__ unsigned long long stamp() {
 // register allocation untouched).
 template <int PREC, int WAVES, bool SHORT, bool TIMING, int ABL = 0>
 __global__ __launch_bounds__(WAVES * 64, 2) void uit_encoder_kernel(EncoderArgs a) {
-    using OP = Op<PREC>;
+    constexpr int OPC = PREC == 2 ? 0 : PREC;              // precision fp8: patch embed, attention, proj and head stay f16
+    using OP = Op<OPC>;
     using v8 = typename OP::v8;
     using v4 = typename OP::v4;
-    typedef unsigned u2 __attribute__((ext_vector_type(2)));
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* ring = smem;
     char* breg = smem + LDS_RING;
@@ -403,7 +520,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void uit_encoder_kernel(EncoderArgs 
     for (int ft = 0; ft < 8; ++ft) {
         v8 A[8];
 #pragma unroll
-        for (int s = 0; s < 8; ++s) A[s] = lds_frag<PREC>(ring, ft * 8 + s, lane);
+        for (int s = 0; s < 8; ++s) A[s] = lds_frag<OPC>(ring, ft * 8 + s, lane);
 #pragma unroll
         for (int s = 0; s < 8; ++s)
 #pragma unroll
@@ -432,8 +549,6 @@ __global__ __launch_bounds__(WAVES * 64, 2) void uit_encoder_kernel(EncoderArgs 
     //   tvalid[i]: this lane's 4 keys of tile i belong to the query's clip (uniform over r: 24 = 16 + 8 and the
     //              key index is 4g+r) -> used for the row max;
     //   pmask[i] : per-element AND mask on the packed probabilities (clip membership AND key time-patch < nt).
-    constexpr int TJ[7] = {0, 1, 0, 1, 2, 1, 2};
-    constexpr int TI[7] = {0, 0, 1, 1, 1, 2, 2};
     bool tvalid[7];
     u2 pmask[7];
 #pragma unroll
@@ -455,10 +570,92 @@ __global__ __launch_bounds__(WAVES * 64, 2) void uit_encoder_kernel(EncoderArgs 
     float dmy0 = 1.0f, dmy1 = 0.5f, dmy2 = 0.25f;          // filler chains of the ABL & 192 timing experiment
 #pragma unroll 1
     for (int blk = 0; blk < a.depth; ++blk) {
+      if constexpr (PREC == 2) {
+        // ================= precision fp8: 8 ring stages per block (uitk_dev.h) =================
+        const int tb = PE_STAGES + blk * BLOCK_STAGES_FP8;
+        const float* bias = (const float*)(breg + (blk & 1) * BIAS_FLOATS * 4);
+        v8i X8[3];
+        layernorm_to_fp8(R, 1e-6f, X8);
+        // ----- stage 0: q (h0, h1), k (h0, h1) with the weights as A; v (h0, h1) token-major with the weights as B
+        ring_step<WAVES>(a.wstream, ring, tb, wave, lane);
+        if (blk + 1 < a.depth) bias_issue<WAVES>(a.bias, breg, blk + 1, wave, lane);
+        v4 Qh[2][3], Kh[2][3], Vh[3][2];
+        {
+            const char* slot = ring + (tb & (RING_SLOTS - 1)) * STAGE_BYTES;
+            const int sq0 = *(const int*)(slot + FP8_QKV_SCALES + lane * 4), sq1 = *(const int*)(slot + FP8_QKV_SCALES + 256 + lane * 4);
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const v8i A = lds_frag8(slot + t * FRAG8_BYTES, lane);
+                const f4 bq = *(const f4*)(bias + BIAS_QKV + 16 * t + 4 * g);
+#pragma unroll
+                for (int ct = 0; ct < 3; ++ct) {
+                    const f4 acc = mfma8_wa_sel(t, A, X8[ct], bq, sq0);
+                    if (t < 2) Qh[t][ct] = OP::pack4(acc); else Kh[t - 2][ct] = OP::pack4(acc);
+                }
+            }
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const v8i Bw = lds_frag8(slot + (4 + h) * FRAG8_BYTES, lane);
+                const f4 bv = splat(bias[BIAS_QKV + 64 + 16 * h + c]);
+#pragma unroll
+                for (int ct = 0; ct < 3; ++ct)
+                    Vh[ct][h] = OP::pack4(h == 0 ? mfma8_wb<0>(X8[ct], Bw, bv, sq1) : mfma8_wb<1>(X8[ct], Bw, bv, sq1));
+            }
+        }
+        // ----- stage 1: attention (f16, as in the 16-bit modes) + proj (f16 fragments); MLP scale dwords
+        ring_step<WAVES>(a.wstream, ring, tb + 1, wave, lane);
+        int s1[6], s2[6];
+        {
+            const char* slot = ring + ((tb + 1) & (RING_SLOTS - 1)) * STAGE_BYTES;
+#pragma unroll
+            for (int d = 0; d < 6; ++d) {
+                s1[d] = *(const int*)(slot + FP8_MLP_SCALES + d * 256 + lane * 4);
+                s2[d] = *(const int*)(slot + FP8_MLP_SCALES + (6 + d) * 256 + lane * 4);
+            }
+            attention_proj<OP, SHORT>(R, Qh, Kh, Vh, tvalid, pmask, slot, bias, lane, g);
+        }
+        // ----- MLP: three k-groups of 128 hidden features: fc1 tiles 8q..8q+7 -> relu -> e4m3 -> fc2 k-group q
+        layernorm_to_fp8(R, 1e-6f, X8);
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+            ring_step<WAVES>(a.wstream, ring, tb + 2 + 2 * q, wave, lane);
+            v8i HX8[3];
+            {
+                const char* slot = ring + ((tb + 2 + 2 * q) & (RING_SLOTS - 1)) * STAGE_BYTES;
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const v8i A = lds_frag8(slot + i * FRAG8_BYTES, lane);
+                    const f4 b1 = *(const f4*)(bias + BIAS_FC1 + 16 * (8 * q + i) + 4 * g);
+#pragma unroll
+                    for (int ct = 0; ct < 3; ++ct) HX8[ct][i] = relu_cvt4_fp8(mfma8_wa_sel(i, A, X8[ct], b1, s1[2 * q + (i >> 2)]));
+                }
+            }
+            ring_step<WAVES>(a.wstream, ring, tb + 3 + 2 * q, wave, lane);
+            {
+                const char* slot = ring + ((tb + 3 + 2 * q) & (RING_SLOTS - 1)) * STAGE_BYTES;
+#pragma unroll
+                for (int ft = 0; ft < 8; ++ft) {
+                    const v8i A = lds_frag8(slot + ft * FRAG8_BYTES, lane);
+#pragma unroll
+                    for (int ct = 0; ct < 3; ++ct) R[ft][ct] = mfma8_wa_sel(ft, A, HX8[ct], R[ft][ct], s2[2 * q + (ft >> 2)]);
+                }
+            }
+        }
+#pragma unroll
+        for (int ft = 0; ft < 8; ++ft) {
+            const f4 b2 = *(const f4*)(bias + BIAS_FC2 + 16 * ft + 4 * g);
+#pragma unroll
+            for (int ct = 0; ct < 3; ++ct) R[ft][ct] = add4s(R[ft][ct], b2);
+        }
+        if (a.dbg != nullptr) {
+            dbg_store(blk + 1);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+      } else {
         const int tb = PE_STAGES + blk * BLOCK_STAGES;
         const float* bias = (const float*)(breg + (blk & 1) * BIAS_FLOATS * 4);
         v8 X[4][3];
-        if constexpr (!(ABL & 2)) layernorm_to_operand<PREC>(R, 1e-6f, X);
+        if constexpr (!(ABL & 2)) layernorm_to_operand<OPC>(R, 1e-6f, X);
         else { for (int s = 0; s < 4; ++s) for (int ct = 0; ct < 3; ++ct) X[s][ct] = OP::pack8(R[s][ct], R[s + 4][ct]); }
         TSTAMP(0);                                                     // LN1
 
@@ -471,12 +668,12 @@ __global__ __launch_bounds__(WAVES * 64, 2) void uit_encoder_kernel(EncoderArgs 
             const char* slot = ring + (tb & (RING_SLOTS - 1)) * STAGE_BYTES;
             v8 A[16];
 #pragma unroll
-            for (int f = 0; f < 8; ++f) A[f] = lds_frag<PREC>(slot, f, lane);
+            for (int f = 0; f < 8; ++f) A[f] = lds_frag<OPC>(slot, f, lane);
 #pragma unroll
             for (int ft = 0; ft < 4; ++ft) {
                 if (ft == 1) {
 #pragma unroll
-                    for (int f = 8; f < 16; ++f) A[f] = lds_frag<PREC>(slot, f, lane);
+                    for (int f = 8; f < 16; ++f) A[f] = lds_frag<OPC>(slot, f, lane);
                 }
                 const f4 bq = *(const f4*)(bias + BIAS_QKV + 16 * ft + 4 * g);
 #pragma unroll
@@ -499,7 +696,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void uit_encoder_kernel(EncoderArgs 
             {
                 v8 Bw[8];
 #pragma unroll
-                for (int f = 0; f < 8; ++f) Bw[f] = lds_frag<PREC>(slot, f, lane);
+                for (int f = 0; f < 8; ++f) Bw[f] = lds_frag<OPC>(slot, f, lane);
 #pragma unroll
                 for (int h = 0; h < 2; ++h) {
                     const f4 bv = splat(bias[BIAS_QKV + 64 + 16 * h + c]);
@@ -512,66 +709,12 @@ __global__ __launch_bounds__(WAVES * 64, 2) void uit_encoder_kernel(EncoderArgs 
                     }
                 }
             }
-            f4 O[2][3];
-#pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                // S^T = K.Q^T in the log2 domain (0.125*log2(e) folded into Wq/bq by pack.cpp)
-                f4 S[7];
-                float tm[7];
-#pragma unroll
-                for (int i = 0; i < 7; ++i) {
-                    S[i] = OP::mfma16(Kh[h][TJ[i]], Qh[h][TI[i]], splat(0.f));
-                    if constexpr (SHORT) {
-                        // padding tokens (time patch >= nt) of the query's own clip must not set the running max: a large score of
-                        // one of them would underflow every valid probability (sum 0 -> rcp(0)).  Per-key select, short clips only.
-                        f4 sv;
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) sv[r] = ((r < 2 ? pmask[i][0] : pmask[i][1]) >> (16 * (r & 1))) & 1u ? S[i][r] : -INFINITY;
-                        tm[i] = hmax(sv);
-                    } else {
-                        tm[i] = tvalid[i] ? hmax(S[i]) : -INFINITY;
-                    }
-                }
-                float mx[3];
-                mx[0] = xmax(fmaxf(tm[0], tm[1]));
-                mx[1] = xmax(fmaxf(fmaxf(tm[2], tm[3]), tm[4]));
-                mx[2] = xmax(fmaxf(tm[5], tm[6]));
-                // P = 2^(S - max), converted, masked on the packed bits; row sums by a ones-row MFMA (sums exactly the
-                // rounded probabilities that multiply V; every output row holds the column sum => no cross-lane step)
-                f4 Lsum[3];
-#pragma unroll
-                for (int it = 0; it < 3; ++it) { O[h][it] = splat(0.f); Lsum[it] = splat(0.f); }
-#pragma unroll
-                for (int i = 0; i < 7; ++i) {
-                    f4 p;
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) p[r] = __builtin_amdgcn_exp2f(S[i][r] - mx[TI[i]]);
-                    const u2 bits = __builtin_bit_cast(u2, OP::pack4(p)) & pmask[i];
-                    const v4 Pm = __builtin_bit_cast(v4, bits);
-                    O[h][TI[i]] = OP::mfma16(Vh[TJ[i]][h], Pm, O[h][TI[i]]);
-                    Lsum[TI[i]] = OP::mfma16(OP::ones4(), Pm, Lsum[TI[i]]);
-                }
-#pragma unroll
-                for (int it = 0; it < 3; ++it) O[h][it] = O[h][it] * splat(__builtin_amdgcn_rcpf(Lsum[it][0]));
-            }
-            // proj: K = 32 = (head, d); slots j<4 head 0, j>=4 head 1 (same universal k-order as pack_frag)
-            v8 A[8];
-#pragma unroll
-            for (int ft = 0; ft < 8; ++ft) A[ft] = lds_frag<PREC>(slot, 8 + ft, lane);
-            v8 OX[3];
-#pragma unroll
-            for (int ct = 0; ct < 3; ++ct) OX[ct] = OP::pack8(O[0][ct], O[1][ct]);
-#pragma unroll
-            for (int ft = 0; ft < 8; ++ft) {
-                const f4 bp = *(const f4*)(bias + BIAS_PROJ + 16 * ft + 4 * g);
-#pragma unroll
-                for (int ct = 0; ct < 3; ++ct) R[ft][ct] = OP::mfma32(A[ft], OX[ct], add4s(R[ft][ct], bp));
-            }
+            attention_proj<OP, SHORT>(R, Qh, Kh, Vh, tvalid, pmask, slot + 8 * FRAG_BYTES, bias, lane, g);
         }
 
         TSTAMP(4);                                                     // V + attention + proj
         // ===== MLP: 12 stages; stage ch = fc1 rows 32ch..32ch+31 (frags j*4+s) and fc2 k-step ch (frags 8+ft)
-        if constexpr (!(ABL & 2)) layernorm_to_operand<PREC>(R, 1e-6f, X);
+        if constexpr (!(ABL & 2)) layernorm_to_operand<OPC>(R, 1e-6f, X);
         TSTAMP(5);                                                     // LN2
         // Software-pipelined over the 12 stages: at stage ch the fc1 fragment reads are issued first, then the fc2
         // MFMAs of chunk ch-1 run from registers (A2/HX carried across the barrier) and cover the LDS latency; the
@@ -586,7 +729,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void uit_encoder_kernel(EncoderArgs 
             if constexpr (ABL & 32) { b10 = splat(0.f); b11 = splat(0.f); }
             else { b10 = *(const f4*)(bias + BIAS_FC1 + 32 * ch + 4 * g); b11 = *(const f4*)(bias + BIAS_FC1 + 32 * ch + 16 + 4 * g); }
 #pragma unroll
-            for (int f = 0; f < 8; ++f) { if constexpr (!(ABL & 8)) A2[f] = lds_frag<PREC>(slot, 8 + f, lane); else A2[f] = A[f]; }   // fc2 fragments of this chunk
+            for (int f = 0; f < 8; ++f) { if constexpr (!(ABL & 8)) A2[f] = lds_frag<OPC>(slot, 8 + f, lane); else A2[f] = A[f]; }   // fc2 fragments of this chunk
             f4 H0[3], H1[3];
 #pragma unroll
             for (int ct = 0; ct < 3; ++ct) {
@@ -612,7 +755,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void uit_encoder_kernel(EncoderArgs 
             const char* slot = ring + ((tb + 2) & (RING_SLOTS - 1)) * STAGE_BYTES;
             v8 A[8];
 #pragma unroll
-            for (int f = 0; f < 8; ++f) A[f] = lds_frag<PREC>(slot, f, lane);
+            for (int f = 0; f < 8; ++f) A[f] = lds_frag<OPC>(slot, f, lane);
             fc1_chunk(slot, 0, A);
             TSTAMP(7);
         }
@@ -624,7 +767,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void uit_encoder_kernel(EncoderArgs 
             const char* slot = ring + (t & (RING_SLOTS - 1)) * STAGE_BYTES;
             v8 A[8];
 #pragma unroll
-            for (int f = 0; f < 8; ++f) { if constexpr (ABL & 8) A[f] = A2[f]; else A[f] = lds_frag<PREC>(slot, f, lane); }   // fc1 fragments: in flight ...
+            for (int f = 0; f < 8; ++f) { if constexpr (ABL & 8) A[f] = A2[f]; else A[f] = lds_frag<OPC>(slot, f, lane); }   // fc1 fragments: in flight ...
 #pragma unroll
             for (int ft = 0; ft < 8; ++ft)                                              // ... under chunk ch-1's fc2
 #pragma unroll
@@ -646,6 +789,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void uit_encoder_kernel(EncoderArgs 
             dbg_store(blk + 1);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
+      }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // drain the dummy tail stages before the LDS can be re-used
     unsigned long long t_blocks_end = 0;
@@ -847,6 +991,9 @@ hipError_t launch_encoder(const EncoderArgs& a, int precision, int waves, int sc
     if (a.timing != nullptr)                              // diagnostic build with in-kernel stamps (f16, full clips only)
         return waves == 4 ? launch_enc<0, 4, false, true>(a, stream) : launch_enc<0, 8, false, true>(a, stream);
     (void)sched;
+    if (precision == 2) {                                 // fp8 weights / activations on the MX-scaled 16x16x128 MFMA (8-wave workgroups)
+        return a.nt < GT ? launch_enc<2, 8, true>(a, stream) : launch_enc<2, 8, false>(a, stream);
+    }
     if (a.nt < GT) {                                      // short clips: masked padding tokens
         if (waves == 4) return precision == 0 ? launch_enc<0, 4, true>(a, stream) : launch_enc<1, 4, true>(a, stream);
         return precision == 0 ? launch_enc<0, 8, true>(a, stream) : launch_enc<1, 8, true>(a, stream);

@@ -53,7 +53,57 @@ static uint16_t f32_to_bf16(float f) {
     return (uint16_t)(x >> 16);
 }
 
+// 16-bit operand of the f16-class paths; precision fp8 keeps every 16-bit operand (patch embed, proj, head) in f16
 static inline uint16_t cvt(double v, int prec) { return prec == UITK_PREC_BF16 ? f32_to_bf16((float)v) : f32_to_f16((float)v); }
+
+// OCP e4m3fn: 1-4-3, bias 7, max 448 (0x7e), no infinity, subnormal step 2^-9; round-to-nearest-even, saturating
+static uint8_t f32_to_e4m3(double x) {
+    const uint8_t s = std::signbit(x) ? 0x80 : 0;
+    const double a = std::fabs(x);
+    if (!(a == a)) return 0x7f;
+    if (a >= 464.0) return (uint8_t)(s | 0x7e);                       // beyond the midpoint above 448: saturate
+    if (a <= std::ldexp(1.0, -10)) return s;                           // at most half the smallest subnormal -> 0 (ties to even)
+    int e;
+    (void)std::frexp(a, &e);
+    int E = e - 1;                                                     // exponent of the leading bit
+    if (E < -6) E = -6;                                                // subnormal range
+    double r = std::nearbyint(a / std::ldexp(1.0, E - 3));             // units of the last mantissa bit, ties to even
+    if (r >= 16.0) { r = 8.0; E += 1; }
+    if (E > 8 || (E == 8 && r > 14.0)) return (uint8_t)(s | 0x7e);
+    if (r < 8.0) return (uint8_t)(s | (uint8_t)r);                     // subnormal (exponent field 0)
+    return (uint8_t)(s | ((E + 7) << 3) | ((int)r - 8));
+}
+
+// one 2 KiB fragment8 (see uitk_dev.h) of rows 16*tile .. +15, k = kbase + [0, 128) from an accessor W(row, k) -> double, plus the
+// four MX scale bytes of every row: scales[lane = (row, g' = beta)] = E8M0 exponent byte of block beta
+static void pack_frag8(uint8_t* dst, uint8_t* scales, const std::function<double(int, int)>& W, int tile, int kbase) {
+    double v[64][32];
+    for (int l = 0; l < 64; ++l)
+        for (int j = 0; j < 32; ++j) v[l][j] = W(16 * tile + (l & 15), kbase + 16 * (j >> 2) + 4 * (l >> 4) + (j & 3));
+    int ex[16][4];
+    for (int row = 0; row < 16; ++row)
+        for (int beta = 0; beta < 4; ++beta) {
+            double m = 0.0;
+            for (int gg = 0; gg < 2; ++gg)
+                for (int b = 0; b < 16; ++b) m = std::fmax(m, std::fabs(v[(2 * (beta & 1) + gg) * 16 + row][16 * (beta >> 1) + b]));
+            int e = 0;
+            if (m > 0.0) {                                             // smallest e with m / 2^e <= 448
+                e = (int)std::ceil(std::log2(m / 448.0));
+                while (m / std::ldexp(1.0, e) > 448.0) ++e;
+                while (m / std::ldexp(1.0, e - 1) <= 448.0) --e;
+            }
+            if (e < -126) e = -126;
+            if (e > 126) e = 126;
+            ex[row][beta] = e;
+            scales[beta * 16 + row] = (uint8_t)(127 + e);
+        }
+    for (int l = 0; l < 64; ++l)
+        for (int j = 0; j < 32; ++j) {
+            const int beta = 2 * (j >> 4) + (l >> 5);                  // hardware block of (lane group g = l>>4, byte j)
+            const uint8_t q = f32_to_e4m3(v[l][j] / std::ldexp(1.0, ex[l & 15][beta]));
+            dst[(j >> 4) * 1024 + l * 16 + (j & 15)] = q;              // two lane-linear 1 KiB halves
+        }
+}
 
 static size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
@@ -71,7 +121,7 @@ int validate_config(const uitk_config* c, const char** why) {
     if (c->depth < 1 || c->depth > 64) return bad("depth out of range");
     if (c->outputdim < 1 || c->outputdim > 65536) return bad("outputdim out of range");
     if (c->eval_avg != UITK_AVG_MEAN && c->eval_avg != UITK_AVG_MAX) return bad("unknown eval_avg");
-    if (c->precision != UITK_PREC_F16 && c->precision != UITK_PREC_BF16) return bad("unknown precision");
+    if (c->precision != UITK_PREC_F16 && c->precision != UITK_PREC_BF16 && c->precision != UITK_PREC_FP8) return bad("unknown precision");
     return UITK_OK;
 }
 
@@ -124,7 +174,8 @@ int pack_image(const uitk_config* c, const uitk_weights* w, std::vector<char>* o
     h.magic = IMAGE_MAGIC; h.precision = prec; h.depth = depth; h.outputdim = C; h.mel_steps = mel_S;
     size_t o = align_up(sizeof(ImageHeader), 256);
     auto take = [&](size_t bytes) { size_t r = o; o = align_up(o + bytes, 256); return r; };
-    h.off_wstream = take((size_t)(PE_STAGES + depth * BLOCK_STAGES + TAIL_STAGES) * STAGE_BYTES);
+    const int blk_stages = prec == UITK_PREC_FP8 ? BLOCK_STAGES_FP8 : BLOCK_STAGES;
+    h.off_wstream = take((size_t)(PE_STAGES + depth * blk_stages + TAIL_STAGES) * STAGE_BYTES);
     h.off_bias = take((size_t)depth * BIAS_FLOATS * 4);
     h.off_bn_sc = take(NMEL * 4); h.off_bn_sh = take(NMEL * 4);
     h.off_pe_bias = take(NTOK * DIM * 4);
@@ -211,7 +262,7 @@ int pack_image(const uitk_config* c, const uitk_weights* w, std::vector<char>* o
     float* bias = (float*)(img + h.off_bias);
     for (int b = 0; b < depth; ++b) {
         const uitk_block_weights& bw = w->blocks[b];
-        const int st = PE_STAGES + b * BLOCK_STAGES;
+        const int st = PE_STAGES + b * blk_stages;
         float* bb = bias + (size_t)b * BIAS_FLOATS;
         // head_dim = dim // num_heads (uit.py:99-100); log2(e) rides along so the kernel's softmax is exp2
         const double scale = 1.0 / std::sqrt((double)(DIM / 2)) * 1.4426950408889634074;
@@ -236,6 +287,30 @@ int pack_image(const uitk_config* c, const uitk_weights* w, std::vector<char>* o
             bb[BIAS_FC1 + r] = (float)acc;
         }
         for (int r = 0; r < DIM; ++r) bb[BIAS_FC2 + r] = (float)((double)bw.fc2_b[r] - fc2_bm);
+        if (prec == UITK_PREC_FP8) {
+            // fp8 stream (uitk_dev.h): stage 0 qkv, stage 1 proj (f16) + MLP scales, then fc1 / fc2 per k-group q
+            uint8_t* s0 = (uint8_t*)frag_ptr(st, 0);
+            uint8_t* s1 = (uint8_t*)frag_ptr(st + 1, 0);
+            uint8_t sc[64];
+            for (int t = 0; t < 6; ++t) {
+                pack_frag8(s0 + t * FRAG8_BYTES, sc, Wqkv, t, 0);
+                for (int l = 0; l < 64; ++l) s0[FP8_QKV_SCALES + (t >> 2) * 256 + l * 4 + (t & 3)] = sc[l];
+            }
+            for (int ft = 0; ft < 8; ++ft) pack_frag(frag_ptr(st + 1, ft), prec, Wproj, ft, 0);
+            for (int q = 0; q < 3; ++q) {
+                uint8_t* sf1 = (uint8_t*)frag_ptr(st + 2 + 2 * q, 0);
+                uint8_t* sf2 = (uint8_t*)frag_ptr(st + 3 + 2 * q, 0);
+                for (int i = 0; i < 8; ++i) {
+                    const int t1 = 8 * q + i;                          // fc1 tile (hidden rows 16 t1 ..), all 128 inputs
+                    pack_frag8(sf1 + i * FRAG8_BYTES, sc, Wfc1, t1, 0);
+                    for (int l = 0; l < 64; ++l) s1[FP8_MLP_SCALES + (t1 >> 2) * 256 + l * 4 + (t1 & 3)] = sc[l];
+                    const int t2 = 8 * q + i;                          // fc2 fragment: output tile ft = i, hidden k-group q
+                    pack_frag8(sf2 + i * FRAG8_BYTES, sc, Wfc2, i, 128 * q);
+                    for (int l = 0; l < 64; ++l) s1[FP8_MLP_SCALES + 6 * 256 + (t2 >> 2) * 256 + l * 4 + (t2 & 3)] = sc[l];
+                }
+            }
+            continue;
+        }
         // stage QK: ft = f/4 over qkv rows 0..63 (q h0, q h1, k h0, k h1), s = f%4
         for (int f = 0; f < 16; ++f) pack_frag(frag_ptr(st, f), prec, Wqkv, f / 4, f % 4);
         // stage VP: V rows 64..95 (tile 4 + h), then proj (K = 32: one k-step)

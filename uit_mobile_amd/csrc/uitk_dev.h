@@ -25,6 +25,18 @@ constexpr int STAGE_BYTES = STAGE_FRAGS * FRAG_BYTES;
 constexpr int PE_STAGES = 4;            // patch-embed: 8 out tiles x 8 k-steps
 constexpr int BLOCK_STAGES = 14;        // QK, V+proj, 12 MLP chunks
 constexpr int TAIL_STAGES = 4;          // zero stages after the last block: the ring prefetch (<= 4 ahead) never branches
+// ---- fp8 weight stream (precision fp8: qkv / fc1 / fc2 as OCP e4m3 operands of v_mfma_scale_f32_16x16x128_f8f6f4)
+// A "fragment8" is the 2 KiB A/B operand of one 16x16x128 MFMA, stored as two lane-linear 1 KiB halves (bytes 0..15 and
+// 16..31 of every lane).  Lane l = (row/col c = l&15, g = l>>4) byte j  <->  W[row][ base + 16*(j>>2) + 4*g + (j&3) ]: the k-order
+// a stack of eight C/D tiles has after in-register conversion (4 bytes = one tile's 4 rows).  MX block scales (E8M0): the
+// hardware's 32-element scale block beta (0..3) of a row is {lanes g = 2(beta&1), 2(beta&1)+1} x {bytes 16(beta>>1) .. +15}, and
+// the scale byte is supplied by lane (row, g' = beta)  (tools/probe/mx_layout.hip).
+// Stages of one block: 0 qkv (6 fragment8 + scale dwords at FP8_QKV_SCALES), 1 proj (8 f16 fragments) + fc1/fc2 scale
+// dwords, then for q = 0..2: fc1 tiles 8q..8q+7, fc2 fragments (ft = 0..7, k-group q).
+constexpr int BLOCK_STAGES_FP8 = 8;
+constexpr int FRAG8_BYTES = 2048;
+constexpr int FP8_QKV_SCALES = 6 * FRAG8_BYTES;                 // 2 dwords per lane: bytes = tiles 0..3 | 4, 5
+constexpr int FP8_MLP_SCALES = 8 * FRAG_BYTES;                  // stage 1: 6 dwords per lane for fc1 tiles, then 6 for fc2 (q*8 + ft)
 constexpr int BIAS_FLOATS = 1024;       // per block: qkv 96 | proj 128 | fc1 384 | fc2 128 (padded to 4 KiB)
 constexpr int BIAS_QKV = 0, BIAS_PROJ = 96, BIAS_FC1 = 224, BIAS_FC2 = 608;
 

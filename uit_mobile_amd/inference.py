@@ -74,7 +74,7 @@ def main(argv=None):
     ap.add_argument("-m", "--model", type=str, nargs="?", default="uit_xs",
                     metavar=f"Public Checkpoint [{','.join(PRETRAINED_CHECKPOINTS)}] or Experiment Path")
     ap.add_argument("-k", "--topk", type=int, default=3, help="Print top-k results")
-    ap.add_argument("--precision", default="f16", choices=["f16", "bf16"])
+    ap.add_argument("--precision", default="f16", choices=["f16", "bf16", "fp8"])
     args = ap.parse_args(argv)
     label_maps = load_label_map()
     model = build_model(args.model, precision=args.precision)

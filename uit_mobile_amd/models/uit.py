@@ -153,7 +153,7 @@ class UITBase(nn.Module):
         if not qkv_bias: unsupported.append("qkv_bias must be True")
         if unsupported:
             raise NotImplementedError("uit_mobile_amd implements the uit_xs/xxs/xxxs family only: " + "; ".join(unsupported))
-        if precision not in ('f16', 'bf16'):
+        if precision not in ('f16', 'bf16', 'fp8'):
             raise ValueError(f"Unknown precision ({precision})")
 
         self.front_end = nn.Sequential(
@@ -218,7 +218,7 @@ class UITBase(nn.Module):
                            n_mels=self.n_mels, n_fft=self.n_fft, hop_size=self.hop_size, win_size=self.win_size,
                            patch_size=self.patch_size, center=int(bool(self.center)),
                            eval_avg={'mean': _lib.AVG_MEAN, 'max': _lib.AVG_MAX}.get(self.eval_avg, -1),
-                           precision={'f16': _lib.PREC_F16, 'bf16': _lib.PREC_BF16}[self.precision], top_db=120.0)
+                           precision={'f16': _lib.PREC_F16, 'bf16': _lib.PREC_BF16, 'fp8': _lib.PREC_FP8}[self.precision], top_db=120.0)
 
     def _host_weights(self):
         """-> (Weights struct, keep-alive list) with fp32 host pointers in reference layout."""
