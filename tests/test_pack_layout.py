@@ -88,3 +88,43 @@ def test_front_end_filterbank_table_reconstructs_fb(kind):
         rec[k[ok], np.arange(64)[ok]] = 4.0 * tab[st >> 2, :, st & 3][ok]
         assert np.all(tab[st >> 2, :, st & 3][~ok] == 0.0)
     assert np.array_equal(rec, fb)
+
+
+def test_fp8_weight_stream_reconstructs_the_folded_weights():
+    """precision='fp8' (config #5): the fragment8 layout of pack.cpp (uitk_dev.h) -- two lane-linear 1 KiB halves, byte j of
+    lane (c, g) = W[16 tile + c][16 (j >> 2) + 4 g + (j & 3)], MX scale byte of hardware block beta supplied by lane (row, beta),
+    beta = 2 (j >> 4) + (g >> 1) -- decoded on the CPU must give back the folded fc1 weights to e4m3 precision (2^-4 of the
+    block maximum), with every block's maximum inside the format's top binade (scales chosen as tight as the format allows)."""
+    import struct
+    from mfma_emu import HDR_FMT, HDR_FIELDS
+    m, sd = _model("uit_xxxs", 12, "fp8")
+    img = m.packed_image()
+    h = dict(zip(HDR_FIELDS, struct.unpack_from(HDR_FMT, img, 0)))
+    assert h["precision"] == 2
+    STAGE, FRAG8, PE_ST, BLK8 = 16384, 2048, 4, 8
+    assert h["off_bias"] - h["off_wstream"] >= (PE_ST + 4 * BLK8 + 4) * STAGE
+    lut = torch.arange(256, dtype=torch.uint8).view(torch.float8_e4m3fn).to(torch.float32).numpy()
+    w2 = np.asarray(sd["blocks.0.norm2.weight"], np.float64)
+    W1 = np.asarray(sd["blocks.0.mlp.fc1.weight"], np.float64) * w2[None]              # folded (pack.cpp Wfc1)
+    s1 = h["off_wstream"] + (PE_ST + 1) * STAGE                                          # stage 1 of block 0: proj + MLP scales
+    for q in range(3):
+        st = h["off_wstream"] + (PE_ST + 2 + 2 * q) * STAGE
+        for i in range(8):
+            t = 8 * q + i
+            raw = np.frombuffer(img, np.uint8, FRAG8, st + i * FRAG8).reshape(2, 64, 16)
+            sc = np.frombuffer(img, np.uint8, 256, s1 + 8192 + (t >> 2) * 256).reshape(64, 4)[:, t & 3].astype(np.int32) - 127
+            rec = np.zeros((16, 128))
+            for lane in range(64):
+                c, g = lane & 15, lane >> 4
+                for j in range(32):
+                    beta = 2 * (j >> 4) + (g >> 1)
+                    e = sc[beta * 16 + c]                                              # lane (row c, g' = beta) holds the scale
+                    rec[c, 16 * (j >> 2) + 4 * g + (j & 3)] = lut[raw[j >> 4, lane, j & 15]] * 2.0 ** e
+            want = W1[16 * t:16 * t + 16]
+            k = np.arange(128)
+            blk = 2 * (k >> 6) + ((k >> 3) & 1)
+            for b in range(4):
+                mx = np.abs(want[:, blk == b]).max(1, keepdims=True)
+                assert np.all(np.abs(rec[:, blk == b] - want[:, blk == b]) <= mx * 2.0 ** -4 + 1e-12)
+                e = sc[b * 16 + np.arange(16)][:, None]
+                assert np.all(mx / 2.0 ** e <= 448.0) and np.all(mx / 2.0 ** e > 224.0)
