@@ -21,7 +21,7 @@ HDR_FIELDS = (["magic", "precision", "depth", "outputdim", "mel_steps"] + [f"mel
               "off_wstream", "off_bias", "off_bn_sc", "off_bn_sh", "off_pe_bias", "off_fin", "off_head_w",
               "off_head_b", "off_window", "off_tw256", "off_tw512", "off_mel_b"])
 FRAG, STAGE = 1024, 16384
-PE_STAGES, BLOCK_STAGES, BIAS_FLOATS = 4, 14, 1024
+PE_HI_STAGES, PE_STAGES, BLOCK_STAGES, BIAS_FLOATS = 4, 8, 14, 1024     # PE: 4 stages of weights + 4 of their low-order terms
 BIAS_QKV, BIAS_PROJ, BIAS_FC1, BIAS_FC2 = 0, 96, 224, 608
 
 
@@ -128,11 +128,11 @@ class EncoderEmu:
                 XB[s][ct] = round_op(x, prec) * (pt[ct] < nt)[:, None]
         r4 = np.arange(4)[None]
         R = [[pe_bias[tk[ct][:, None], 16 * ft + 4 * G_[:, None] + r4].copy() for ct in range(3)] for ft in range(8)]
-        for i in range(PE_STAGES):
+        for i in range(PE_HI_STAGES):
             for f in range(16):
-                A = self.frag(i, f)
-                for ct in range(3):
-                    R[2 * i + f // 8][ct] = mfma32(A, XB[f % 8][ct], R[2 * i + f // 8][ct])
+                for A in (self.frag(i, f), self.frag(PE_HI_STAGES + i, f)):          # W = hi + lo (8-wave workgroups)
+                    for ct in range(3):
+                        R[2 * i + f // 8][ct] = mfma32(A, XB[f % 8][ct], R[2 * i + f // 8][ct])
         stages = np.zeros((2, self.depth + 1, 24, 128), np.float32)
 
         def dump(st):

@@ -101,7 +101,7 @@ def test_fp8_weight_stream_reconstructs_the_folded_weights():
     img = m.packed_image()
     h = dict(zip(HDR_FIELDS, struct.unpack_from(HDR_FMT, img, 0)))
     assert h["precision"] == 2
-    STAGE, FRAG8, PE_ST, BLK8 = 16384, 2048, 4, 8
+    STAGE, FRAG8, PE_ST, BLK8 = 16384, 2048, 8, 8
     assert h["off_bias"] - h["off_wstream"] >= (PE_ST + 4 * BLK8 + 4) * STAGE
     lut = torch.arange(256, dtype=torch.uint8).view(torch.float8_e4m3fn).to(torch.float32).numpy()
     w2 = np.asarray(sd["blocks.0.norm2.weight"], np.float64)

@@ -114,11 +114,13 @@ template <> struct Op<1> {   // bf16 operands
 #endif
 constexpr int RING_SLOTS = UITK_RING_SLOTS;   // power of two, >= PREFETCH + 2 (see ring_step)
 constexpr int PREFETCH = UITK_PREFETCH;       // stages in flight ahead of the one being consumed
-static_assert((RING_SLOTS & (RING_SLOTS - 1)) == 0 && RING_SLOTS >= PREFETCH + 2 && RING_SLOTS >= PE_STAGES && PREFETCH <= TAIL_STAGES, "ring geometry");
+static_assert((RING_SLOTS & (RING_SLOTS - 1)) == 0 && RING_SLOTS >= PREFETCH + 2 && RING_SLOTS >= PE_HI_STAGES && PREFETCH <= TAIL_STAGES, "ring geometry");
 constexpr int LDS_RING = RING_SLOTS * STAGE_BYTES;            // 64 KiB
 constexpr int LDS_BIAS = 2 * BIAS_FLOATS * 4;                 // 8 KiB (double-buffered per block)
 constexpr int LDS_ZBUF = 2 * 16 * DIM * 2;                    // 8 KiB: up to 16 pooled vectors, 16-bit hi + lo terms
-constexpr int ENC_LDS = LDS_RING + LDS_BIAS + LDS_ZBUF;
+constexpr int LDS_PELO = PE_HI_STAGES * STAGE_BYTES;          // 64 KiB: low-order patch-embed weights (prologue only; 8-wave workgroups)
+constexpr int ENC_LDS = LDS_RING + LDS_BIAS + LDS_ZBUF;       // 80 KiB (4-wave workgroups: two per CU)
+constexpr int ENC_LDS_SPLIT_PE = ENC_LDS + LDS_PELO;          // 144 KiB (8-wave workgroups: one per CU anyway, by registers)
 
 #define GPTR(p) ((const __attribute__((address_space(1))) void*)(p))
 #define LPTR(p) ((__attribute__((address_space(3))) void*)(p))
@@ -499,7 +501,22 @@ __global__ __launch_bounds__(WAVES * 64, 2) void uit_encoder_kernel(EncoderArgs 
     // ---- kick the weight stream: block-0 biases + the whole patch-embed weight set (4 stages = the whole ring)
     if (a.depth > 0) bias_issue<WAVES>(a.bias, breg, 0, wave, lane);
 #pragma unroll
-    for (int i = 0; i < PE_STAGES; ++i) ring_issue<WAVES>(a.wstream, ring, i, wave, lane);
+    for (int i = 0; i < PE_HI_STAGES; ++i) ring_issue<WAVES>(a.wstream, ring, i, wave, lane);
+    // split patch embed (W = hi + lo): the low-order fragments go to their own 64 KiB behind the ring; 8-wave workgroups only
+    // (a 4-wave workgroup shares its CU's LDS with a second one and runs the single-term patch embed)
+    constexpr bool SPLIT_PE = WAVES == 8;
+    char* pelo = smem + ENC_LDS;
+    if constexpr (SPLIT_PE) {
+        constexpr int PER_WAVE = STAGE_FRAGS / WAVES;
+#pragma unroll
+        for (int i = 0; i < PE_HI_STAGES; ++i)
+#pragma unroll
+            for (int k = 0; k < PER_WAVE; ++k) {
+                const int piece = wave * PER_WAVE + k;
+                __builtin_amdgcn_global_load_lds(GPTR(a.wstream + (size_t)(PE_HI_STAGES + i) * STAGE_BYTES + piece * FRAG_BYTES + lane * 16),
+                                                 LPTR(pelo + i * STAGE_BYTES + piece * FRAG_BYTES), 16, 0, 0);
+            }
+    }
     TSTAMP(12);                                                           // weight-stream kick
 
     // ---- rows (clip-crops) of this wave, token maps
@@ -583,6 +600,14 @@ __global__ __launch_bounds__(WAVES * 64, 2) void uit_encoder_kernel(EncoderArgs 
         for (int s = 0; s < 8; ++s)
 #pragma unroll
             for (int ct = 0; ct < 3; ++ct) R[ft][ct] = OP::mfma32(A[s], XB[ct][s], R[ft][ct]);
+        if constexpr (SPLIT_PE) {
+#pragma unroll
+            for (int s = 0; s < 8; ++s) A[s] = lds_frag<OPC>(pelo, ft * 8 + s, lane);
+#pragma unroll
+            for (int s = 0; s < 8; ++s)
+#pragma unroll
+                for (int ct = 0; ct < 3; ++ct) R[ft][ct] = OP::mfma32(A[s], XB[ct][s], R[ft][ct]);
+        }
     }
     TSTAMP(10);                                                           // patch-embed MFMAs
     __builtin_amdgcn_s_barrier();                                         // every wave is done with the PE weights
@@ -1021,12 +1046,13 @@ static hipError_t launch_enc(const EncoderArgs& a, hipStream_t stream) {
     const unsigned long long bit = 1ull << (dev & 63);
     if (!(attr_done.load(std::memory_order_acquire) & bit)) {
         hipError_t e = hipFuncSetAttribute((const void*)uit_encoder_kernel<PREC, WAVES, SHORT, TIMING, ABL>,
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, ENC_LDS);
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, WAVES == 8 ? ENC_LDS_SPLIT_PE : ENC_LDS);
         if (e != hipSuccess) return e;
         attr_done.fetch_or(bit, std::memory_order_release);
     }
     const int grid = (a.rows + 2 * WAVES - 1) / (2 * WAVES);
-    hipLaunchKernelGGL((uit_encoder_kernel<PREC, WAVES, SHORT, TIMING, ABL>), dim3(grid), dim3(WAVES * 64), ENC_LDS, stream, a);
+    hipLaunchKernelGGL((uit_encoder_kernel<PREC, WAVES, SHORT, TIMING, ABL>), dim3(grid), dim3(WAVES * 64),
+                       WAVES == 8 ? ENC_LDS_SPLIT_PE : ENC_LDS, stream, a);
     return hipGetLastError();
 }
 

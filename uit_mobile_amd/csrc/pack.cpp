@@ -249,14 +249,24 @@ int pack_image(const uitk_config* c, const uitk_weights* w, std::vector<char>* o
         for (int oc = 0; oc < DIM; ++oc) pe_colmean[k] += (double)w->pe_w[oc * 256 + k];
         pe_colmean[k] /= DIM;
     }
-    for (int i = 0; i < PE_STAGES; ++i)
+    // 16-bit value back to double (the split operands' low-order terms are the rounding residuals of the high-order ones)
+    auto op16_to_double = [&](uint16_t u) -> double {
+        if (prec == UITK_PREC_BF16) { uint32_t x = (uint32_t)u << 16; float f; std::memcpy(&f, &x, 4); return f; }
+        const uint32_t sign = (u >> 15) & 1u, e = (u >> 10) & 31u, m = u & 1023u;
+        double v = e == 0 ? std::ldexp((double)m, -24) : std::ldexp((double)(m | 1024u), (int)e - 25);
+        return sign ? -v : v;
+    };
+    for (int i = 0; i < PE_HI_STAGES; ++i)
         for (int f = 0; f < STAGE_FRAGS; ++f) {
             const int ft = 2 * i + f / 8, s = f % 8;
             uint16_t* dst = frag_ptr(i, f);
+            uint16_t* dlo = frag_ptr(PE_HI_STAGES + i, f);              // low-order term, same fragment order
             for (int l = 0; l < 64; ++l)
                 for (int j = 0; j < 8; ++j) {
                     const int g = l >> 4, fi = 2 * s + (g >> 1), ti = 8 * (g & 1) + j;
-                    dst[l * 8 + j] = cvt((double)w->pe_w[(16 * ft + (l & 15)) * 256 + fi * 16 + ti] - pe_colmean[fi * 16 + ti], prec);
+                    const double wv = (double)w->pe_w[(16 * ft + (l & 15)) * 256 + fi * 16 + ti] - pe_colmean[fi * 16 + ti];
+                    dst[l * 8 + j] = cvt(wv, prec);
+                    dlo[l * 8 + j] = cvt(wv - op16_to_double(dst[l * 8 + j]), prec);
                 }
         }
     float* bias = (float*)(img + h.off_bias);

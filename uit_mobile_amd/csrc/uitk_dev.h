@@ -22,7 +22,9 @@ constexpr int MEL_BMAX = 52;            // filterbank steps the front-end keeps 
 constexpr int FRAG_BYTES = 1024;        // 64 lanes x 8 x 16-bit
 constexpr int STAGE_FRAGS = 16;
 constexpr int STAGE_BYTES = STAGE_FRAGS * FRAG_BYTES;
-constexpr int PE_STAGES = 4;            // patch-embed: 8 out tiles x 8 k-steps
+constexpr int PE_HI_STAGES = 4;         // patch-embed: 8 out tiles x 8 k-steps of 16-bit weights ...
+constexpr int PE_STAGES = 8;            // ... plus the same 64 fragments of the weights' low-order terms (W = hi + lo: the conv weights'
+                                        // rounding is the same for every token and survives the mean-pool)
 constexpr int BLOCK_STAGES = 14;        // QK, V+proj, 12 MLP chunks
 constexpr int TAIL_STAGES = 4;          // zero stages after the last block: the ring prefetch (<= 4 ahead) never branches
 // ---- fp8 weight stream (precision fp8: qkv / fc1 / fc2 as OCP e4m3 operands of v_mfma_scale_f32_16x16x128_f8f6f4)
