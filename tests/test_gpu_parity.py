@@ -4,8 +4,8 @@ CPU oracle on seeded inputs.
 
 Tolerance (BASELINE.json north_star): outputs within 1e-3 abs of the reference PyTorch CPU path -- asserted on both
 the probabilities the reference returns and the pre-sigmoid logits, for the default precision (fp16 MFMA operands,
-fp32 accumulate; the classifier head runs on split hi+lo operands).  The bf16-operand mode has ~8x the operand rounding
-and is held to 1e-3 on probabilities and 3e-3 on logits (measured 1.2e-3); it is not the parity default.
+fp32 accumulate; the classifier head runs on split hi+lo operands).  The bf16-operand and fp8 modes are measured, non-parity modes:
+their tests assert measured bounds and say so.
 """
 import os
 
@@ -186,9 +186,10 @@ def test_golden_527_classes_and_pos_resize(golden):
 
 
 def test_scaled_weights_precision_modes(golden):
-    """x3 weights (trained-like magnitudes): logits span +-2.5.  fp16 operands with the split-operand classifier head
-    stay within 1e-3 on logits AND probabilities (measured 7.1e-4 / 1.6e-4); bf16 operands are the measured-fast mode:
-    probabilities within 2e-3 (measured 1.2e-3), logits within 8e-3 (measured 4.8e-3)."""
+    """x3 weights: logits span +-2.5.  fp16 operands stay within 1e-3 on logits AND probabilities (measured 5.5e-4 / 1.3e-4).
+    ... and outside it as soon as the weights grow: bf16 blocks carry 8x the operand rounding (measured 4.9e-3 on logits,
+    1.2e-3 on probabilities here; 5e-3 on a trained-like checkpoint by emulation).  These bounds are the MEASURED error of a
+    non-parity mode, asserted so that it cannot silently get worse -- not a parity claim."""
     g = golden("synth1s_uit_xs_scale3")
     m, _ = build("uit_xs", g["seed"], g["scale"])
     p, l = run(m, g["pcm"])
@@ -224,11 +225,13 @@ def test_fp8_mode_is_the_intended_quantised_network_and_its_error_is_on_record(g
 
 
 def test_bf16_mode_init_scale(golden):
+    """bf16 operands (a measured, non-parity mode: DESIGN.md 2.1).  With the split-weight patch embed and the split head the
+    plain-bf16 blocks are what is left: inside 1e-3 at init-scale weights (measured 7.5e-4 / 1.9e-4) ..."""
     g = golden("synth1s_uit_xs")
     m, _ = build("uit_xs", g["seed"], prec="bf16")
     p, l = run(m, g["pcm"])
-    assert np.abs(p - g["probs"]).max() < TOL          # measured 3.1e-4
-    assert np.abs(l - g["logits"]).max() < 3e-3        # measured 1.2e-3
+    assert np.abs(p - g["probs"]).max() < TOL
+    assert np.abs(l - g["logits"]).max() < TOL
 
 
 @pytest.mark.parametrize("B", [1, 2, 3, 15, 16, 17, 33])
