@@ -378,6 +378,44 @@ def test_two_rank_rccl_is_bitwise_the_single_rank_result(gather):
         assert np.abs(res[r] - ref["probs"]).max() < TOL
 
 
+def _rccl_one_rank_worker(port, q):
+    import os
+    import torch.distributed as dist
+    from uit_mobile_amd.sharded import ShardedUiT
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        m, _ = build("uit_xxxs", 32)
+        x = torch.from_numpy(synth_pcm_i16(8, 16000, seed=13)).cuda()
+        want = m(x).clone()
+        st = m.frontend(x)
+        slots = m.amax_tensor(x.device)
+        before = slots.clone()
+        dist.all_reduce(slots, op=dist.ReduceOp.MAX, async_op=True).wait()     # RCCL on the library-owned slots (foreign pointer)
+        p = m.encode(st)
+        out = torch.empty((8, 537), device="cuda")
+        dist.all_gather_into_tensor(out, p)
+        torch.cuda.synchronize()
+        q.put((bool(torch.equal(before, slots)), bool(torch.equal(out, want)), bool(torch.equal(ShardedUiT(m)(x), want))))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_rccl_collectives_accept_the_library_owned_amax_slots():
+    """What bench.py does at N > 1, on a one-rank RCCL group (a 1-GPU box cannot host two RCCL ranks): the in-place MAX
+    all-reduce runs on the device slots uitk_amax_ptr hands out -- memory torch's allocator does not own -- and the all-gather
+    on the encoder's output."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_rccl_one_rank_worker, args=(29300 + os.getpid() % 500, q))
+    p.start()
+    res = q.get(timeout=300)
+    p.join(timeout=60)
+    assert res == (True, True, True)
+
+
 def _one_gpu_worker(rank, world, port, q, rows_per_rank):
     """Two ranks sharing ONE GPU: gloo for the control plane (RCCL refuses two ranks on one device), the amax MAX all-reduce
     staged through the host, the outputs gathered by PeerGather's device-to-device copies into IPC-mapped buffers."""
