@@ -64,13 +64,17 @@ typedef struct uitk_config {
     int32_t eval_avg;      /* uitk_eval_avg   uit.py:294 */
     int32_t precision;     /* uitk_precision */
     float top_db;          /* 120  uit.py:307 */
+    int32_t attention_full;/* 0 = BNeckAttention (uit.py:89-122: qkv 128->96, proj 32->128; the uit_* family)
+                              1 = Attention (uit.py:124-178: qkv 128->384, proj 128->128, 2 heads x 64; the
+                                  audio_transformer_h128_* factories uit.py:514-579)                      */
+    int32_t act_gelu;      /* 0 = nn.ReLU (uit.py:591, 610, 629), 1 = nn.GELU (UITBase default, uit.py:344) */
 } uitk_config;
 
 /* Per-block parameters, fp32 host pointers in the reference's state_dict layout (blocks.N.*). */
 typedef struct uitk_block_weights {
     const float* norm1_w; const float* norm1_b; /* [128]      uit.py:223  (eps 1e-6, :337) */
-    const float* qkv_w;   const float* qkv_b;   /* [96,128],[96]   uit.py:103 */
-    const float* proj_w;  const float* proj_b;  /* [128,32],[128]  uit.py:105 */
+    const float* qkv_w;   const float* qkv_b;   /* [96,128],[96]   uit.py:103   (attention_full: [384,128],[384]  uit.py:139) */
+    const float* proj_w;  const float* proj_b;  /* [128,32],[128]  uit.py:105   (attention_full: [128,128],[128]  uit.py:141) */
     const float* norm2_w; const float* norm2_b; /* [128]      uit.py:235 */
     const float* fc1_w;   const float* fc1_b;   /* [384,128],[384] uit.py:192 */
     const float* fc2_w;   const float* fc2_b;   /* [128,384],[128] uit.py:194 */

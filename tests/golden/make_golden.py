@@ -134,9 +134,29 @@ def main_round2():
     print("long10", out10["logits"].shape)
 
 
+def main_variants():
+    """the other factories of models/uit.py (:514-579) -- full-width Attention (2 heads x 64), GELU or ReLU MLP,
+    mean pooling -- at init scale and (ReLU, GELU d4) at trained-like magnitudes; per-block tokens for two clips."""
+    pcm = synth_pcm_i16(8, 16000, seed=0)
+    pcm[5] = 0
+    for name, seed, trained in (("audio_transformer_h128_d4_m3_relu", 21, False), ("audio_transformer_h128_d4_m3", 22, False),
+                                ("audio_transformer_h128_d6_m3_relu", 23, True), ("audio_transformer_h128_d6_m3", 24, True)):
+        m = getattr(uit, name)(outputdim=537, target_length=102)
+        mk = make_trained_like_state_dict if trained else make_state_dict
+        sd = {k: torch.from_numpy(np.asarray(v)) for k, v in mk(name, seed, attention="full").items()}
+        assert not (set(m.state_dict().keys()) ^ set(sd.keys()))
+        m.load_state_dict(sd, strict=True)
+        r = run_ref(m.eval(), pcm, stages_for=2)
+        np.savez_compressed(HERE / f"variant_{name}.npz", pcm=pcm, seed=seed, trained=trained, probs=r["probs"], logits=r["logits"],
+                            stages=r["stages"])
+        print("variant", name, "trained-like" if trained else "init", "logit range", r["logits"].min(), r["logits"].max())
+
+
 def main():
     if "--round2" in sys.argv:
         return main_round2()
+    if "--variants" in sys.argv:
+        return main_variants()
     d_fb, d_db = crosscheck_frontend()
     meta = dict(crosscheck_fb=d_fb, crosscheck_db=d_db)
 
@@ -201,6 +221,7 @@ def main():
     np.savez_compressed(HERE / "posresize_uit_xxxs.npz", pcm=pcm[:2], seed=11, probs=r["probs"])
     np.savez(HERE / "meta.npz", **meta)
     main_round2()
+    main_variants()
     print("done")
 
 

@@ -13,7 +13,9 @@ import math
 
 import numpy as np
 
-DEPTH = {"uit_xs": 12, "uit_xxs": 6, "uit_xxxs": 4}
+DEPTH = {"uit_xs": 12, "uit_xxs": 6, "uit_xxxs": 4,
+         "audio_transformer_h128_d4_m3": 4, "audio_transformer_h128_d4_m3_relu": 4,
+         "audio_transformer_h128_d6_m3": 6, "audio_transformer_h128_d6_m3_relu": 6}
 
 
 def hann_periodic(n):
@@ -34,10 +36,12 @@ def melscale_fbanks(n_freqs=257, f_min=0.0, f_max=8000.0, n_mels=64, sample_rate
     return np.maximum(0.0, np.minimum(down, up)).astype(np.float32)
 
 
-def make_state_dict(name="uit_xs", seed=0, scale=1.0, outputdim=537, target_length=102, dim=128, n_mels=64):
+def make_state_dict(name="uit_xs", seed=0, scale=1.0, outputdim=537, target_length=102, dim=128, n_mels=64, attention="bneck"):
+    """attention: 'bneck' (BNeckAttention, inner = dim/4: the uit_* family) or 'full' (Attention, inner = dim: the
+    audio_transformer_h128_* factories, models/uit.py:514-579)."""
     depth = DEPTH[name]
     rng = np.random.default_rng(seed)
-    gt, gf, inner, hidden = target_length // 16, n_mels // 16, dim // 4, int(dim * 3.0)
+    gt, gf, inner, hidden = target_length // 16, n_mels // 16, (dim if attention == "full" else dim // 4), int(dim * 3.0)
 
     def tn(*shape, std=0.02):
         return (np.clip(rng.standard_normal(shape), -2.0, 2.0) * std * scale).astype(np.float32)
@@ -99,7 +103,7 @@ def synth_pcm_i16(B, T, seed=0):
     return np.clip(np.round(x * 32768.0), -32768, 32767).astype(np.int16)
 
 
-def make_trained_like_state_dict(name="uit_xs", seed=0, outputdim=537, target_length=102, dim=128, n_mels=64):
+def make_trained_like_state_dict(name="uit_xs", seed=0, outputdim=537, target_length=102, dim=128, n_mels=64, attention="bneck"):
     """A seeded checkpoint with the MAGNITUDES of a trained UiT (no trained weights are reachable from the build
     container; the reference's published outputs -- `Speech 1.0000`, `Keyword: on 0.9999`, README.md:124-127 -- show
     logits beyond +-9, and AudioSet taggers sit at logits around -5..-9 for the hundreds of absent classes):
@@ -116,7 +120,7 @@ def make_trained_like_state_dict(name="uit_xs", seed=0, outputdim=537, target_le
     Same key set / shapes as make_state_dict (loaded with strict=True into the reference's own UITBase by make_golden.py)."""
     depth = DEPTH[name]
     rng = np.random.default_rng(7000 + seed)
-    gt, gf, inner, hidden = target_length // 16, n_mels // 16, dim // 4, int(dim * 3.0)
+    gt, gf, inner, hidden = target_length // 16, n_mels // 16, (dim if attention == "full" else dim // 4), int(dim * 3.0)
 
     def nrm(*shape, std=1.0, mean=0.0):
         return (mean + std * rng.standard_normal(shape)).astype(np.float32)

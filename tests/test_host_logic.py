@@ -63,6 +63,26 @@ def test_state_dict_matches_reference_layout(name, depth):
     assert models.PRETRAINED_CHECKPOINTS[name]["model_kwargs"] == dict(outputdim=537, target_length=102)
 
 
+@pytest.mark.parametrize("name,depth,gelu", [("audio_transformer_h128_d4_m3", 4, True), ("audio_transformer_h128_d4_m3_relu", 4, False),
+                                             ("audio_transformer_h128_d6_m3", 6, True), ("audio_transformer_h128_d6_m3_relu", 6, False)])
+def test_other_factories_match_reference_layout(name, depth, gelu):
+    """the non-bottleneck factories (models/uit.py:514-579): full-width Attention (qkv 128->384, proj 128->128),
+    GELU unless `_relu`, mean pooling.  The same synthetic checkpoints are loaded strict=True into the REAL reference by
+    make_golden.py --variants, which pins the key set and shapes."""
+    m = getattr(models, name)(outputdim=537, target_length=102)
+    sd = make_state_dict(name, 0, attention="full")
+    mine = m.state_dict()
+    assert set(mine) == set(sd)
+    for k in sd:
+        assert tuple(mine[k].shape) == tuple(np.asarray(sd[k]).shape), k
+    assert tuple(mine["blocks.0.attn.qkv.weight"].shape) == (384, 128) and tuple(mine["blocks.0.attn.proj.weight"].shape) == (128, 128)
+    assert m.depth == depth and m.attention_full and m.act_gelu == gelu and m.pooling == "mean"
+    img = m.eval().packed_image()                   # host-only packing of the 20-stage layout works without a GPU
+    assert len(img) > (8 + 20 * depth) * 16384
+    with pytest.raises(NotImplementedError):
+        getattr(models, name)(outputdim=537, target_length=102, precision="fp8")
+
+
 def test_strict_load_and_pos_embed_resize():
     m = models.uit_xxxs(outputdim=537, target_length=102)
     sd = {k: torch.from_numpy(np.asarray(v)) for k, v in make_state_dict("uit_xxxs", 1).items()}
@@ -83,6 +103,10 @@ def test_unsupported_variants_raise():
     with pytest.raises(NotImplementedError):
         models.UITBase(embed_dim=128, depth=4, num_heads=2, mlp_ratio=3.0, pooling="token",
                        attention_type="BNeckAttention", act_layer=torch.nn.ReLU)
+    with pytest.raises(NotImplementedError):
+        models.uit_xs(pooling="dm")
+    with pytest.raises(NotImplementedError):
+        models.uit_xs(act_layer=torch.nn.SiLU)
     m = models.uit_xs(embed_dim=256)                # geometry outside the kernels' family -> C ABI rejects it
     with pytest.raises(ValueError):
         m.packed_image()

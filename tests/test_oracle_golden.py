@@ -150,3 +150,21 @@ def test_ten_crop_clip(golden, avg):
     r = o.forward(g["pcm"])
     assert np.abs(r["logits"] - g["logits"]).max() < 1e-4
     assert np.abs(r["probs"] - g[f"probs_{avg}"]).max() < 5e-5
+
+
+VARIANTS = [("audio_transformer_h128_d4_m3_relu", "relu"), ("audio_transformer_h128_d4_m3", "gelu"),
+            ("audio_transformer_h128_d6_m3_relu", "relu"), ("audio_transformer_h128_d6_m3", "gelu")]
+
+
+@pytest.mark.parametrize("name,act", VARIANTS)
+def test_other_factories_full_attention_and_gelu(golden, name, act):
+    """full-width Attention (models/uit.py:124-178) and the exact-erf GELU MLP of the non-bottleneck factories
+    (:514-579), d4 at init scale, d6 at trained-like magnitudes, against the imported reference (make_golden.py --variants)."""
+    from conftest import centred
+    from synth_weights import make_trained_like_state_dict
+    g = golden(f"variant_{name}")
+    mk = make_trained_like_state_dict if bool(g["trained"]) else make_state_dict
+    r = Oracle(mk(name, int(g["seed"]), attention="full"), act=act).forward(g["pcm"], want_stages=True)
+    assert np.abs(r["logits"] - g["logits"]).max() < 3e-4
+    assert np.abs(r["probs"] - g["probs"]).max() < 5e-5
+    assert np.abs(centred(r["stages"][0]) - centred(g["stages"][0])).max() < 2e-4

@@ -447,6 +447,20 @@ __device__ __forceinline__ void layernorm_to_fp8(const f4 (&R)[8][3], float eps,
     }
 }
 
+// ---- exact (erf) GELU of the non-uit factories (nn.GELU(), models/uit.py:344): 0.5 x (1 + erf(x / sqrt 2)) with
+// Abramowitz & Stegun 7.1.26 (|erf error| <= 1.5e-7): erf(z) = 1 - (a1 t + .. + a5 t^5) exp(-z^2), t = 1 / (1 + p z), z >= 0.
+__device__ __forceinline__ float gelu1(float x) {
+    const float z = fabsf(x) * 0.70710678118654752f;
+    const float t = __builtin_amdgcn_rcpf(__builtin_fmaf(0.3275911f, z, 1.0f));
+    float p = __builtin_fmaf(1.061405429f, t, -1.453152027f);
+    p = __builtin_fmaf(p, t, 1.421413741f);
+    p = __builtin_fmaf(p, t, -0.284496736f);
+    p = __builtin_fmaf(p, t, 0.254829592f);
+    const float y = p * t * __builtin_amdgcn_exp2f(-1.4426950408889634f * z * z);       // 1 - erf(z)
+    return 0.5f * x * (x >= 0.f ? 2.0f - y : y);                                       // 1 + erf(x / sqrt 2) = 2 - y | y
+}
+__device__ __forceinline__ f4 gelu4(f4 x) { return f4{gelu1(x[0]), gelu1(x[1]), gelu1(x[2]), gelu1(x[3])}; }
+
 // In-kernel stamps (diagnostic build only, TIMING = true): one asm statement = s_memtime + lgkmcnt(0), fenced.
 __device__ __forceinline__ unsigned long long stamp() {
     unsigned long long t;
@@ -461,7 +475,8 @@ __device__ __forceinline__ unsigned long long stamp() {
 // (no DMA, no barrier), 8 MLP without LDS fragment reads, 16 MLP without ReLU/convert, 32 MLP without bias reads.  The product kernel is ABL = 0.
 // SHORT: clips with fewer than 6 time patches (masked padding tokens; a separate instantiation keeps the full-clip kernel's
 // register allocation untouched).
-template <int PREC, int WAVES, bool SHORT, bool TIMING, int ABL = 0>
+// ATT: 0 = BNeckAttention (the uit_* family), 1 = full-width Attention (2 heads x 64; 20 ring stages per block).  ACT: 0 ReLU, 1 GELU.
+template <int PREC, int WAVES, bool SHORT, bool TIMING, int ABL = 0, int ATT = 0, int ACT = 0>
 __global__ __launch_bounds__(WAVES * 64, 2) void uit_encoder_kernel(EncoderArgs a) {
     constexpr int OPC = PREC == 2 ? 0 : PREC;              // precision fp8: patch embed, attention, proj and head stay f16
     using OP = Op<OPC>;
@@ -735,13 +750,132 @@ __global__ __launch_bounds__(WAVES * 64, 2) void uit_encoder_kernel(EncoderArgs 
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
       } else {
-        const int tb = PE_STAGES + blk * BLOCK_STAGES;
+        constexpr int BLK_ST = ATT ? BLOCK_STAGES_ATT : BLOCK_STAGES, MLP0 = ATT ? 8 : 2;      // stages per block, first MLP stage
+        constexpr int B_FC1 = ATT ? BIASF_FC1 : BIAS_FC1, B_FC2 = ATT ? BIASF_FC2 : BIAS_FC2;
+        const int tb = PE_STAGES + blk * BLK_ST;
         const float* bias = (const float*)(breg + (blk & 1) * BIAS_FLOATS * 4);
         v8 X[4][3];
         if constexpr (!(ABL & 2)) layernorm_to_operand<OPC>(R, 1e-6f, X);
         else { for (int s = 0; s < 4; ++s) for (int ct = 0; ct < 3; ++ct) X[s][ct] = OP::pack8(R[s][ct], R[s + 4][ct]); }
         TSTAMP(0);                                                     // LN1
 
+        if constexpr (ATT) {
+        // ===== full-width Attention (models/uit.py:124-178): per head three ring stages (q_h, k_h, v_h: 16 fragments each =
+        // 4 d-tiles x 4 k-steps), scores between k_h and v_h (q and k die before v is produced), then two stages of proj.
+        // The LN1 operand is recomputed for head 1 instead of being kept alive across head 0's attention.
+        v8 OX[4][3];                                                   // attention output, k-order of proj: k-step 2h + dt/2
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            if (h == 1) layernorm_to_operand<OPC>(R, 1e-6f, X);
+            v4 Qp[4][3], Kp[4][3];
+#pragma unroll
+            for (int which = 0; which < 2; ++which) {
+                ring_step<WAVES>(a.wstream, ring, tb + 3 * h + which, wave, lane);
+                if (h == 0 && which == 0 && blk + 1 < a.depth) bias_issue<WAVES>(a.bias, breg, blk + 1, wave, lane);
+                const char* slot = ring + ((tb + 3 * h + which) & (RING_SLOTS - 1)) * STAGE_BYTES;
+#pragma unroll
+                for (int dt = 0; dt < 4; ++dt) {
+                    v8 A[4];
+#pragma unroll
+                    for (int sk = 0; sk < 4; ++sk) A[sk] = lds_frag<OPC>(slot, dt * 4 + sk, lane);
+                    const f4 bq = *(const f4*)(bias + BIASF_QKV + 128 * which + 64 * h + 16 * dt + 4 * g);
+#pragma unroll
+                    for (int ct = 0; ct < 3; ++ct) {
+                        f4 acc = bq;
+#pragma unroll
+                        for (int sk = 0; sk < 4; ++sk) acc = OP::mfma32(A[sk], X[sk][ct], acc);
+                        if (which == 0) Qp[dt][ct] = OP::pack4(acc); else Kp[dt][ct] = OP::pack4(acc);
+                    }
+                }
+            }
+            // S^T = K.Q^T over the 64-wide head: four chained K = 16 MFMAs per score tile (log2 domain, scale folded into Wq)
+            f4 S[7];
+            float tm[7], mx[3];
+#pragma unroll
+            for (int i = 0; i < 7; ++i) {
+                f4 acc = splat(0.f);
+#pragma unroll
+                for (int dt = 0; dt < 4; ++dt) acc = OP::mfma16(Kp[dt][TJ[i]], Qp[dt][TI[i]], acc);
+                S[i] = acc;
+                if constexpr (SHORT) {
+                    f4 sv;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) sv[r] = ((r < 2 ? pmask[i][0] : pmask[i][1]) >> (16 * (r & 1))) & 1u ? S[i][r] : -INFINITY;
+                    tm[i] = hmax(sv);
+                } else {
+                    tm[i] = tvalid[i] ? hmax(S[i]) : -INFINITY;
+                }
+            }
+            mx[0] = xmax(fmaxf(tm[0], tm[1]));
+            mx[1] = xmax(fmaxf(fmaxf(tm[2], tm[3]), tm[4]));
+            mx[2] = xmax(fmaxf(tm[5], tm[6]));
+            // v_h token-major (operand roles swapped: tokens are the rows)
+            ring_step<WAVES>(a.wstream, ring, tb + 3 * h + 2, wave, lane);
+            v4 Vp[3][4];
+            {
+                const char* slot = ring + ((tb + 3 * h + 2) & (RING_SLOTS - 1)) * STAGE_BYTES;
+#pragma unroll
+                for (int dt = 0; dt < 4; ++dt) {
+                    v8 Bw[4];
+#pragma unroll
+                    for (int sk = 0; sk < 4; ++sk) Bw[sk] = lds_frag<OPC>(slot, dt * 4 + sk, lane);
+                    const f4 bv = splat(bias[BIASF_QKV + 256 + 64 * h + 16 * dt + c]);
+#pragma unroll
+                    for (int ct = 0; ct < 3; ++ct) {
+                        f4 acc = bv;
+#pragma unroll
+                        for (int sk = 0; sk < 4; ++sk) acc = OP::mfma32(X[sk][ct], Bw[sk], acc);
+                        Vp[ct][dt] = OP::pack4(acc);
+                    }
+                }
+            }
+            f4 O[4][3], Lsum[3];
+#pragma unroll
+            for (int it = 0; it < 3; ++it) {
+                Lsum[it] = splat(0.f);
+#pragma unroll
+                for (int dt = 0; dt < 4; ++dt) O[dt][it] = splat(0.f);
+            }
+#pragma unroll
+            for (int i = 0; i < 7; ++i) {
+                f4 p;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) p[r] = __builtin_amdgcn_exp2f(S[i][r] - mx[TI[i]]);
+                const u2 bits = __builtin_bit_cast(u2, OP::pack4(p)) & pmask[i];
+                const v4 Pm = __builtin_bit_cast(v4, bits);
+#pragma unroll
+                for (int dt = 0; dt < 4; ++dt) O[dt][TI[i]] = OP::mfma16(Vp[TJ[i]][dt], Pm, O[dt][TI[i]]);
+                Lsum[TI[i]] = OP::mfma16(OP::ones4(), Pm, Lsum[TI[i]]);
+            }
+#pragma unroll
+            for (int it = 0; it < 3; ++it) {
+                const f4 inv = splat(__builtin_amdgcn_rcpf(Lsum[it][0]));
+                OX[2 * h][it] = OP::pack8(O[0][it] * inv, O[1][it] * inv);
+                OX[2 * h + 1][it] = OP::pack8(O[2][it] * inv, O[3][it] * inv);
+            }
+        }
+        // proj 128 -> 128: fragment ft*4 + s over two stages
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            ring_step<WAVES>(a.wstream, ring, tb + 6 + half, wave, lane);
+            const char* slot = ring + ((tb + 6 + half) & (RING_SLOTS - 1)) * STAGE_BYTES;
+#pragma unroll
+            for (int fl = 0; fl < 4; ++fl) {
+                const int ft = 4 * half + fl;
+                v8 A[4];
+#pragma unroll
+                for (int sk = 0; sk < 4; ++sk) A[sk] = lds_frag<OPC>(slot, fl * 4 + sk, lane);
+                const f4 bp = *(const f4*)(bias + BIASF_PROJ + 16 * ft + 4 * g);
+#pragma unroll
+                for (int ct = 0; ct < 3; ++ct) {
+                    f4 acc = add4s(R[ft][ct], bp);
+#pragma unroll
+                    for (int sk = 0; sk < 4; ++sk) acc = OP::mfma32(A[sk], OX[sk][ct], acc);
+                    R[ft][ct] = acc;
+                }
+            }
+        }
+        } else {
         // ===== stage QK: fragments (ft = f/4 in {q h0, q h1, k h0, k h1}, s = f%4)
         ring_step<WAVES>(a.wstream, ring, tb, wave, lane);
         TSTAMP(1);                                                     // ring wait QK
@@ -795,6 +929,8 @@ __global__ __launch_bounds__(WAVES * 64, 2) void uit_encoder_kernel(EncoderArgs 
             attention_proj<OP, SHORT>(R, Qh, Kh, Vh, tvalid, pmask, slot + 8 * FRAG_BYTES, bias, lane, g);
         }
 
+        }
+
         TSTAMP(4);                                                     // V + attention + proj
         // ===== MLP: 12 stages; stage ch = fc1 rows 32ch..32ch+31 (frags j*4+s) and fc2 k-step ch (frags 8+ft)
         if constexpr (!(ABL & 2)) layernorm_to_operand<OPC>(R, 1e-6f, X);
@@ -810,7 +946,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void uit_encoder_kernel(EncoderArgs 
         auto fc1_chunk = [&](const char* slot, int ch, const v8 (&A)[8]) {
             f4 b10, b11;
             if constexpr (ABL & 32) { b10 = splat(0.f); b11 = splat(0.f); }
-            else { b10 = *(const f4*)(bias + BIAS_FC1 + 32 * ch + 4 * g); b11 = *(const f4*)(bias + BIAS_FC1 + 32 * ch + 16 + 4 * g); }
+            else { b10 = *(const f4*)(bias + B_FC1 + 32 * ch + 4 * g); b11 = *(const f4*)(bias + B_FC1 + 32 * ch + 16 + 4 * g); }
 #pragma unroll
             for (int f = 0; f < 8; ++f) { if constexpr (!(ABL & 8)) A2[f] = lds_frag<OPC>(slot, 8 + f, lane); else A2[f] = A[f]; }   // fc2 fragments of this chunk
             f4 H0[3], H1[3];
@@ -829,13 +965,14 @@ __global__ __launch_bounds__(WAVES * 64, 2) void uit_encoder_kernel(EncoderArgs 
 #pragma unroll
             for (int ct = 0; ct < 3; ++ct) {
                 if constexpr (ABL & 16) { asm volatile("" :: "v"(H0[ct]), "v"(H1[ct])); if (ch == 0) HX[ct] = X[0][ct]; }
+                else if constexpr (ACT == 1) HX[ct] = OP::pack8(gelu4(H0[ct]), gelu4(H1[ct]));
                 else HX[ct] = OP::relu_pack8(H0[ct], H1[ct]);
             }
         };
         {   // chunk 0 (peeled: defines A2 / HX before the steady-state loop)
-            if constexpr (!(ABL & 4)) ring_step<WAVES>(a.wstream, ring, tb + 2, wave, lane);
+            if constexpr (!(ABL & 4)) ring_step<WAVES>(a.wstream, ring, tb + MLP0, wave, lane);
             TSTAMP(6);
-            const char* slot = ring + ((tb + 2) & (RING_SLOTS - 1)) * STAGE_BYTES;
+            const char* slot = ring + ((tb + MLP0) & (RING_SLOTS - 1)) * STAGE_BYTES;
             v8 A[8];
 #pragma unroll
             for (int f = 0; f < 8; ++f) A[f] = lds_frag<OPC>(slot, f, lane);
@@ -844,7 +981,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void uit_encoder_kernel(EncoderArgs 
         }
 #pragma unroll 1
         for (int ch = 1; ch < 12; ++ch) {
-            const int t = tb + 2 + ch;
+            const int t = tb + MLP0 + ch;
             if constexpr (!(ABL & 4)) ring_step<WAVES>(a.wstream, ring, t, wave, lane);
             TSTAMP(6);                                                 // ring wait MLP (sum of 12)
             const char* slot = ring + (t & (RING_SLOTS - 1)) * STAGE_BYTES;
@@ -864,7 +1001,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void uit_encoder_kernel(EncoderArgs 
             for (int ct = 0; ct < 3; ++ct) R[ft][ct] = mlp_mfma(A2[ft], HX[ct], R[ft][ct]);
 #pragma unroll
         for (int ft = 0; ft < 8; ++ft) {
-            const f4 b2 = *(const f4*)(bias + BIAS_FC2 + 16 * ft + 4 * g);
+            const f4 b2 = *(const f4*)(bias + B_FC2 + 16 * ft + 4 * g);
 #pragma unroll
             for (int ct = 0; ct < 3; ++ct) R[ft][ct] = add4s(R[ft][ct], b2);
         }
@@ -1037,7 +1174,7 @@ __global__ void crop_reduce_kernel(const float* __restrict__ rp, float* __restri
     }
 }
 
-template <int PREC, int WAVES, bool SHORT, bool TIMING = false, int ABL = 0>
+template <int PREC, int WAVES, bool SHORT, bool TIMING = false, int ABL = 0, int ATT = 0, int ACT = 0>
 static hipError_t launch_enc(const EncoderArgs& a, hipStream_t stream) {
     // the attribute is per device: one bit per device, set once (see launch_fe)
     static std::atomic<unsigned long long> attr_done{0};
@@ -1045,13 +1182,13 @@ static hipError_t launch_enc(const EncoderArgs& a, hipStream_t stream) {
     if (hipError_t e = hipGetDevice(&dev); e != hipSuccess) return e;
     const unsigned long long bit = 1ull << (dev & 63);
     if (!(attr_done.load(std::memory_order_acquire) & bit)) {
-        hipError_t e = hipFuncSetAttribute((const void*)uit_encoder_kernel<PREC, WAVES, SHORT, TIMING, ABL>,
+        hipError_t e = hipFuncSetAttribute((const void*)uit_encoder_kernel<PREC, WAVES, SHORT, TIMING, ABL, ATT, ACT>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, WAVES == 8 ? ENC_LDS_SPLIT_PE : ENC_LDS);
         if (e != hipSuccess) return e;
         attr_done.fetch_or(bit, std::memory_order_release);
     }
     const int grid = (a.rows + 2 * WAVES - 1) / (2 * WAVES);
-    hipLaunchKernelGGL((uit_encoder_kernel<PREC, WAVES, SHORT, TIMING, ABL>), dim3(grid), dim3(WAVES * 64),
+    hipLaunchKernelGGL((uit_encoder_kernel<PREC, WAVES, SHORT, TIMING, ABL, ATT, ACT>), dim3(grid), dim3(WAVES * 64),
                        WAVES == 8 ? ENC_LDS_SPLIT_PE : ENC_LDS, stream, a);
     return hipGetLastError();
 }
@@ -1075,6 +1212,14 @@ hipError_t launch_encoder(const EncoderArgs& a, int precision, int waves, int sc
     if (a.timing != nullptr)                              // diagnostic build with in-kernel stamps (f16, full clips only)
         return waves == 4 ? launch_enc<0, 4, false, true>(a, stream) : launch_enc<0, 8, false, true>(a, stream);
     (void)sched;
+    if (a.attention_full || a.act_gelu) {                 // SURVEY 8f-4 variants: f16 / bf16, 8-wave workgroups
+        if (precision == 2 || a.timing != nullptr) return hipErrorInvalidValue;
+#define UITK_VARIANT(P, SH) (a.attention_full ? (a.act_gelu ? launch_enc<P, 8, SH, false, 0, 1, 1>(a, stream) : launch_enc<P, 8, SH, false, 0, 1, 0>(a, stream)) \
+                                               : launch_enc<P, 8, SH, false, 0, 0, 1>(a, stream))
+        if (a.nt < GT) return precision == 0 ? UITK_VARIANT(0, true) : UITK_VARIANT(1, true);
+        return precision == 0 ? UITK_VARIANT(0, false) : UITK_VARIANT(1, false);
+#undef UITK_VARIANT
+    }
     if (precision == 2) {                                 // fp8 weights / activations on the MX-scaled 16x16x128 MFMA
         if (waves == 4) return a.nt < GT ? launch_enc<2, 4, true>(a, stream) : launch_enc<2, 4, false>(a, stream);
         return a.nt < GT ? launch_enc<2, 8, true>(a, stream) : launch_enc<2, 8, false>(a, stream);

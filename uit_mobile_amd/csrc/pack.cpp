@@ -122,6 +122,8 @@ int validate_config(const uitk_config* c, const char** why) {
     if (c->outputdim < 1 || c->outputdim > 65536) return bad("outputdim out of range");
     if (c->eval_avg != UITK_AVG_MEAN && c->eval_avg != UITK_AVG_MAX) return bad("unknown eval_avg");
     if (c->precision != UITK_PREC_F16 && c->precision != UITK_PREC_BF16 && c->precision != UITK_PREC_FP8) return bad("unknown precision");
+    if ((c->attention_full != 0 && c->attention_full != 1) || (c->act_gelu != 0 && c->act_gelu != 1)) return bad("attention_full / act_gelu must be 0 or 1");
+    if ((c->attention_full || c->act_gelu) && c->precision == UITK_PREC_FP8) return bad("precision fp8 is built for the uit_* family (BNeckAttention, ReLU) only");
     return UITK_OK;
 }
 
@@ -174,7 +176,10 @@ int pack_image(const uitk_config* c, const uitk_weights* w, std::vector<char>* o
     h.magic = IMAGE_MAGIC; h.precision = prec; h.depth = depth; h.outputdim = C; h.mel_steps = mel_S;
     size_t o = align_up(sizeof(ImageHeader), 256);
     auto take = [&](size_t bytes) { size_t r = o; o = align_up(o + bytes, 256); return r; };
-    const int blk_stages = prec == UITK_PREC_FP8 ? BLOCK_STAGES_FP8 : BLOCK_STAGES;
+    const bool full = c->attention_full != 0;
+    const int inner = full ? DIM : INNER;                                // qkv = Linear(dim, 3 * inner), proj = Linear(inner, dim)
+    const int blk_stages = full ? BLOCK_STAGES_ATT : (prec == UITK_PREC_FP8 ? BLOCK_STAGES_FP8 : BLOCK_STAGES);
+    const int b_proj = full ? BIASF_PROJ : BIAS_PROJ, b_fc1 = full ? BIASF_FC1 : BIAS_FC1, b_fc2 = full ? BIASF_FC2 : BIAS_FC2;
     h.off_wstream = take((size_t)(PE_STAGES + depth * blk_stages + TAIL_STAGES) * STAGE_BYTES);
     h.off_bias = take((size_t)depth * BIAS_FLOATS * 4);
     h.off_bn_sc = take(NMEL * 4); h.off_bn_sh = take(NMEL * 4);
@@ -276,27 +281,27 @@ int pack_image(const uitk_config* c, const uitk_weights* w, std::vector<char>* o
         float* bb = bias + (size_t)b * BIAS_FLOATS;
         // head_dim = dim // num_heads (uit.py:99-100); log2(e) rides along so the kernel's softmax is exp2
         const double scale = 1.0 / std::sqrt((double)(DIM / 2)) * 1.4426950408889634074;
-        auto Wqkv = [&](int r, int k) { return (double)bw.qkv_w[r * DIM + k] * (double)bw.norm1_w[k] * (r < INNER ? scale : 1.0); };
-        double proj_cm[INNER], fc2_cm[HID], proj_bm = 0.0, fc2_bm = 0.0;      // residual centring: output-channel means
-        for (int k = 0; k < INNER; ++k) { proj_cm[k] = 0.0; for (int r = 0; r < DIM; ++r) proj_cm[k] += (double)bw.proj_w[r * INNER + k]; proj_cm[k] /= DIM; }
+        auto Wqkv = [&](int r, int k) { return (double)bw.qkv_w[r * DIM + k] * (double)bw.norm1_w[k] * (r < inner ? scale : 1.0); };
+        double proj_cm[DIM], fc2_cm[HID], proj_bm = 0.0, fc2_bm = 0.0;        // residual centring: output-channel means
+        for (int k = 0; k < inner; ++k) { proj_cm[k] = 0.0; for (int r = 0; r < DIM; ++r) proj_cm[k] += (double)bw.proj_w[r * inner + k]; proj_cm[k] /= DIM; }
         for (int k = 0; k < HID; ++k) { fc2_cm[k] = 0.0; for (int r = 0; r < DIM; ++r) fc2_cm[k] += (double)bw.fc2_w[r * HID + k]; fc2_cm[k] /= DIM; }
         for (int r = 0; r < DIM; ++r) { proj_bm += (double)bw.proj_b[r]; fc2_bm += (double)bw.fc2_b[r]; }
         proj_bm /= DIM; fc2_bm /= DIM;
-        auto Wproj = [&](int r, int k) { return (double)bw.proj_w[r * INNER + k] - proj_cm[k]; };
+        auto Wproj = [&](int r, int k) { return (double)bw.proj_w[r * inner + k] - proj_cm[k]; };
         auto Wfc1 = [&](int r, int k) { return (double)bw.fc1_w[r * DIM + k] * (double)bw.norm2_w[k]; };
         auto Wfc2 = [&](int r, int k) { return (double)bw.fc2_w[r * HID + k] - fc2_cm[k]; };
-        for (int r = 0; r < 3 * INNER; ++r) {
+        for (int r = 0; r < 3 * inner; ++r) {
             double acc = bw.qkv_b[r];
             for (int k = 0; k < DIM; ++k) acc += (double)bw.qkv_w[r * DIM + k] * (double)bw.norm1_b[k];
-            bb[BIAS_QKV + r] = (float)(acc * (r < INNER ? scale : 1.0));
+            bb[BIAS_QKV + r] = (float)(acc * (r < inner ? scale : 1.0));
         }
-        for (int r = 0; r < DIM; ++r) bb[BIAS_PROJ + r] = (float)((double)bw.proj_b[r] - proj_bm);
+        for (int r = 0; r < DIM; ++r) bb[b_proj + r] = (float)((double)bw.proj_b[r] - proj_bm);
         for (int r = 0; r < HID; ++r) {
             double acc = bw.fc1_b[r];
             for (int k = 0; k < DIM; ++k) acc += (double)bw.fc1_w[r * DIM + k] * (double)bw.norm2_b[k];
-            bb[BIAS_FC1 + r] = (float)acc;
+            bb[b_fc1 + r] = (float)acc;
         }
-        for (int r = 0; r < DIM; ++r) bb[BIAS_FC2 + r] = (float)((double)bw.fc2_b[r] - fc2_bm);
+        for (int r = 0; r < DIM; ++r) bb[b_fc2 + r] = (float)((double)bw.fc2_b[r] - fc2_bm);
         if (prec == UITK_PREC_FP8) {
             // fp8 stream (uitk_dev.h): stage 0 qkv, stage 1 proj (f16) + MLP scales, then fc1 / fc2 per k-group q
             uint8_t* s0 = (uint8_t*)frag_ptr(st, 0);
@@ -318,6 +323,18 @@ int pack_image(const uitk_config* c, const uitk_weights* w, std::vector<char>* o
                     pack_frag8(sf2 + i * FRAG8_BYTES, sc, Wfc2, i, 128 * q);
                     for (int l = 0; l < 64; ++l) s1[FP8_MLP_SCALES + 6 * 256 + (t2 >> 2) * 256 + l * 4 + (t2 & 3)] = sc[l];
                 }
+            }
+            continue;
+        }
+        if (full) {
+            // full-width Attention (uitk_dev.h): qkv row = which*128 + head*64 + d (uit.py:147-148) -> row tile which*8 + head*4 + dt
+            for (int hd = 0; hd < 2; ++hd)
+                for (int which = 0; which < 3; ++which)
+                    for (int f = 0; f < 16; ++f) pack_frag(frag_ptr(st + 3 * hd + which, f), prec, Wqkv, which * 8 + hd * 4 + f / 4, f % 4);
+            for (int i = 0; i < 32; ++i) pack_frag(frag_ptr(st + 6 + (i >> 4), i & 15), prec, Wproj, i / 4, i % 4);
+            for (int ch = 0; ch < 12; ++ch) {
+                for (int f = 0; f < 8; ++f) pack_frag(frag_ptr(st + 8 + ch, f), prec, Wfc1, 2 * ch + f / 4, f % 4);
+                for (int ft = 0; ft < 8; ++ft) pack_frag(frag_ptr(st + 8 + ch, 8 + ft), prec, Wfc2, ft, ch);
             }
             continue;
         }

@@ -35,6 +35,11 @@ constexpr int TAIL_STAGES = 4;          // zero stages after the last block: the
 // the scale byte is supplied by lane (row, g' = beta)  (tools/probe/mx_layout.hip).
 // Stages of one block: 0 qkv (6 fragment8 + scale dwords at FP8_QKV_SCALES), 1 proj (8 f16 fragments) + fc1/fc2 scale
 // dwords, then for q = 0..2: fc1 tiles 8q..8q+7, fc2 fragments (ft = 0..7, k-group q).
+// ---- full-width Attention (models/uit.py:124-178): qkv 128->384 = (q|k|v) x (head 0|1) x 64, proj 128->128.
+// 20 stages per block: for head h = 0, 1: [q_h: d-tile dt = f/4, k-step s = f%4] [k_h] [v_h, used as the B operand];
+// 2 stages proj (fragment ft*4 + s); 12 MLP stages as in the bottleneck layout.  Bias block (exactly BIAS_FLOATS):
+constexpr int BLOCK_STAGES_ATT = 20;
+constexpr int BIASF_QKV = 0, BIASF_PROJ = 384, BIASF_FC1 = 512, BIASF_FC2 = 896;
 constexpr int BLOCK_STAGES_FP8 = 8;
 constexpr int FRAG8_BYTES = 2048;
 constexpr int FP8_QKV_SCALES = 6 * FRAG8_BYTES;                 // 2 dwords per lane: bytes = tiles 0..3 | 4, 5
@@ -84,6 +89,8 @@ struct EncoderArgs {
     float* logits;          // [rows][C] or null
     float* dbg;             // [rows][depth+1][24][128] or null
     unsigned long long* timing;  // diagnostics: [waves][12] phase cycle sums (null = off, normal build)
+    int attention_full;     // 0 = BNeckAttention, 1 = Attention (full width, 2 heads x 64)
+    int act_gelu;           // MLP activation: 0 = ReLU, 1 = exact (erf) GELU
     int ablate;             // timing experiments (builds with -DUITK_ABLATION_BUILDS only): ABL template value
     int stagger;            // 0 = off, else shader cycles to delay every other workgroup generation
     int stagger_group;      // workgroups per generation (= CU count)

@@ -23,7 +23,9 @@ import torch.nn as nn
 
 from .. import _lib
 
-__all__ = ["UITBase", "uit_xs", "uit_xxs", "uit_xxxs", "PRETRAINED_CHECKPOINTS"]
+__all__ = ["UITBase", "uit_xs", "uit_xxs", "uit_xxxs", "PRETRAINED_CHECKPOINTS",
+           "audio_transformer_h128_d4_m3", "audio_transformer_h128_d4_m3_relu",
+           "audio_transformer_h128_d6_m3", "audio_transformer_h128_d6_m3_relu"]
 
 
 # ----------------------------------------------------------------------------- parameter holders
@@ -68,10 +70,13 @@ class _PatchEmbedParams(nn.Module):
 
 
 class _AttnParams(nn.Module):
-    def __init__(self, dim, qkv_bias):
+    """BNeckAttention (uit.py:89-122: inner = dim/4) or Attention (uit.py:124-178: inner = dim) parameter shapes."""
+
+    def __init__(self, dim, qkv_bias, full=False):
         super().__init__()
-        self.qkv = nn.Linear(dim, (dim // 4) * 3, bias=qkv_bias)
-        self.proj = nn.Linear(dim // 4, dim)
+        inner = dim if full else dim // 4
+        self.qkv = nn.Linear(dim, inner * 3, bias=qkv_bias)
+        self.proj = nn.Linear(inner, dim)
 
 
 class _MlpParams(nn.Module):
@@ -82,10 +87,10 @@ class _MlpParams(nn.Module):
 
 
 class _BlockParams(nn.Module):
-    def __init__(self, dim, hidden, qkv_bias):
+    def __init__(self, dim, hidden, qkv_bias, full_attention=False):
         super().__init__()
         self.norm1 = nn.LayerNorm(dim, eps=1e-6)
-        self.attn = _AttnParams(dim, qkv_bias)
+        self.attn = _AttnParams(dim, qkv_bias, full_attention)
         self.norm2 = nn.LayerNorm(dim, eps=1e-6)
         self.mlp = _MlpParams(dim, hidden)
 
@@ -140,12 +145,14 @@ class UITBase(nn.Module):
         self.num_heads = num_heads
         self.mlp_hidden = int(embed_dim * mlp_ratio)
         self.n_fft = n_fft
-        # what the HIP kernels are built for: the uit_* family (uit.py:581-635)
+        # what the HIP kernels are built for: the uit_* family (uit.py:581-635: BNeckAttention + ReLU) and the other
+        # factories of models/uit.py (:514-579: full-width Attention, ReLU or the default exact GELU); mean pooling
         unsupported = []
-        if pooling != 'mean': unsupported.append("pooling must be 'mean'")
-        if attention_type != 'BNeckAttention': unsupported.append("attention_type must be 'BNeckAttention'")
-        if act_layer is not None and act_layer is not nn.ReLU: unsupported.append("act_layer must be nn.ReLU")
-        if act_layer is None: unsupported.append("act_layer must be nn.ReLU (GELU variants are out of scope)")
+        if pooling != 'mean': unsupported.append("pooling must be 'mean' ('token' / 'dm' are not built)")
+        if attention_type not in ('BNeckAttention', 'Attention'): unsupported.append("attention_type must be 'BNeckAttention' or 'Attention'")
+        if act_layer is not None and act_layer not in (nn.ReLU, nn.GELU): unsupported.append("act_layer must be nn.ReLU or nn.GELU / None")
+        self.attention_full = attention_type == 'Attention'
+        self.act_gelu = act_layer is None or act_layer is nn.GELU
         if not init_bn: unsupported.append("init_bn must be True")
         if init_values: unsupported.append("LayerScale (init_values) is not supported")
         if patch_size != 16 or patch_stride != 16: unsupported.append("patch 16x16 stride 16 only")
@@ -155,6 +162,8 @@ class UITBase(nn.Module):
             raise NotImplementedError("uit_mobile_amd implements the uit_xs/xxs/xxxs family only: " + "; ".join(unsupported))
         if precision not in ('f16', 'bf16', 'fp8'):
             raise ValueError(f"Unknown precision ({precision})")
+        if precision == 'fp8' and (self.attention_full or self.act_gelu):
+            raise NotImplementedError("precision='fp8' is built for the uit_* family (BNeckAttention + ReLU) only")
 
         self.front_end = nn.Sequential(
             _MelSpectrogramParams(n_fft, self.win_size, f_min, f_max, self.n_mels, 16000), nn.Identity())
@@ -164,7 +173,7 @@ class UITBase(nn.Module):
         self.token_pos_embed = nn.Parameter(torch.randn(1, embed_dim) * .02)
         self.time_pos_embed = nn.Parameter(torch.randn(1, embed_dim, 1, self.patch_embed.grid_size[1]) * .02)
         self.freq_pos_embed = nn.Parameter(torch.randn(1, embed_dim, self.patch_embed.grid_size[0], 1) * .02)
-        self.blocks = nn.Sequential(*[_BlockParams(embed_dim, self.mlp_hidden, qkv_bias) for _ in range(depth)])
+        self.blocks = nn.Sequential(*[_BlockParams(embed_dim, self.mlp_hidden, qkv_bias, self.attention_full) for _ in range(depth)])
         self.norm = nn.LayerNorm(embed_dim, eps=1e-6)
         self.outputlayer = nn.Sequential(nn.LayerNorm(embed_dim), nn.Linear(embed_dim, outputdim))
         self.apply(self.init_weights)
@@ -218,7 +227,8 @@ class UITBase(nn.Module):
                            n_mels=self.n_mels, n_fft=self.n_fft, hop_size=self.hop_size, win_size=self.win_size,
                            patch_size=self.patch_size, center=int(bool(self.center)),
                            eval_avg={'mean': _lib.AVG_MEAN, 'max': _lib.AVG_MAX}.get(self.eval_avg, -1),
-                           precision={'f16': _lib.PREC_F16, 'bf16': _lib.PREC_BF16, 'fp8': _lib.PREC_FP8}[self.precision], top_db=120.0)
+                           precision={'f16': _lib.PREC_F16, 'bf16': _lib.PREC_BF16, 'fp8': _lib.PREC_FP8}[self.precision], top_db=120.0,
+                           attention_full=int(self.attention_full), act_gelu=int(self.act_gelu))
 
     def _host_weights(self):
         """-> (Weights struct, keep-alive list) with fp32 host pointers in reference layout."""
@@ -404,6 +414,31 @@ def _family(depth, **kwargs):
                         init_bn=True, drop_path_rate=0.0, act_layer=nn.ReLU, attention_type='BNeckAttention')
     model_kwargs = {**model_kwargs, **kwargs}
     return UITBase(**model_kwargs)
+
+
+def _h128(depth, act_layer, **kwargs):
+    """The non-bottleneck factories (uit.py:514-579): full-width Attention (the UITBase default attention_type), mean pooling."""
+    model_kwargs = dict(patch_size=16, embed_dim=128, depth=depth, num_heads=2, mlp_ratio=3.0, pooling='mean',
+                        init_bn=True, drop_path_rate=0.0)
+    if act_layer is not None:
+        model_kwargs['act_layer'] = act_layer
+    return UITBase(**{**model_kwargs, **kwargs})
+
+
+def audio_transformer_h128_d4_m3_relu(**kwargs):    # uit.py:514-529
+    return _h128(4, nn.ReLU, **kwargs)
+
+
+def audio_transformer_h128_d4_m3(**kwargs):         # uit.py:532-546  (act_layer default: nn.GELU, uit.py:344)
+    return _h128(4, None, **kwargs)
+
+
+def audio_transformer_h128_d6_m3(**kwargs):         # uit.py:548-562
+    return _h128(6, None, **kwargs)
+
+
+def audio_transformer_h128_d6_m3_relu(**kwargs):    # uit.py:564-579
+    return _h128(6, nn.ReLU, **kwargs)
 
 
 def uit_xs(**kwargs):      # uit.py:581-597
