@@ -173,6 +173,10 @@ def main():
                     help="untimed set-up steps that bring the idle GPU's clocks up before the --warmup steps (0 = none)")
     ap.add_argument("--gather", default="rccl", choices=["rccl", "peer"],
                     help="N>1: RCCL all_gather_into_tensor (default) or the copy-engine fan-out into IPC-mapped peer buffers")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="torch.distributed backend (nccl = RCCL; gloo only for exercising the N>1 code path on a 1-GPU box)")
+    ap.add_argument("--all-ranks-on-device0", action="store_true",
+                    help="test hook: every rank uses cuda:0 (with --backend gloo; RCCL refuses two ranks on one device)")
     ap.add_argument("--from-host", action="store_true",
                     help="additionally report the PCIe-inclusive rate (pinned int16 host buffers -> HostClipStreamer)")
     args = ap.parse_args()
@@ -184,11 +188,16 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run for N>1")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device (there is no CPU path to benchmark)")
+    if args.all_ranks_on_device0:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
 
     T, Bl = 16000, args.batch_per_gpu
     sd = make_state_dict(args.model, 13)

@@ -651,3 +651,25 @@ def test_device_kws_transform_matches_reference_loop():
             a, ya = output_transform_kws(y_pred.cuda(), y.cuda(), thr)
             b, yb = kws_loop_restatement(y_pred, y, thr)
             assert torch.equal(a.cpu(), b) and torch.equal(ya.cpu(), yb)
+
+
+@pytest.mark.parametrize("gather", ["rccl", "peer"])
+def test_bench_two_rank_pipeline_runs_on_one_gpu(gather):
+    """bench.py's N > 1 code path (shards, pipelined front-end / amax all-reduce / encoder / asynchronous gathers, barrier
+    + max-over-ranks timing) exercised end to end with two ranks on one GPU over gloo -- RCCL itself needs one GPU per rank;
+    what is checked is that the pipeline runs, every gather completes and rank 0 prints one well-formed JSON line."""
+    import json
+    import subprocess
+    import sys
+    from pathlib import Path
+    root = Path(__file__).resolve().parents[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(29700 + os.getpid() % 200), str(root / "bench.py"), "--gpus", "2", "--steps", "6", "--warmup", "2",
+           "--spinup-steps", "2", "--batch-per-gpu", "512", "--backend", "gloo", "--all-ranks-on-device0", "--gather", gather]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=str(root))
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 6 and d["config"]["global_batch"] == 1024 and d["value"] > 0
+    assert d["scaling"] == "weak" and "cpu_baseline" not in d and ("peer" in d["config"]["parallelism"]) == (gather == "peer")
