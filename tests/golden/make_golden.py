@@ -118,6 +118,15 @@ def main_round2():
     pcm_short = synth_pcm_i16(3, 8000, seed=4)
     r = run_ref(build_ref_trained("uit_xxxs", 2), pcm_short)
     np.savez_compressed(HERE / "trained_short_uit_xxxs.npz", pcm=pcm_short, seed=2, probs=r["probs"], logits=r["logits"])
+    # the reference's own sample clips (real audio: water, a GSC keyword) through the trained-like XS checkpoint
+    m = build_ref_trained("uit_xs", 1)
+    out = {}
+    for wav in ("water_000.wav", "water_003.wav", "85b877b5_nohash_0.wav"):
+        r = run_ref(m, read_wav_i16(REF / "samples" / wav)[None])
+        key = wav.split(".")[0]
+        out[f"{key}_probs"], out[f"{key}_logits"] = r["probs"][0], r["logits"][0]
+        print("trained-like uit_xs on", wav, "logit range", r["logits"].min(), r["logits"].max())
+    np.savez_compressed(HERE / "trained_samples_uit_xs.npz", seed=1, **out)      # PCM: samples_uit_xs.npz
     # AudioSet-style 10 s clip: 160 000 samples -> 1001 frames -> 10 crops, the last one re-cropped (models/uit.py:468-488)
     pcm10 = synth_pcm_i16(2, 160000, seed=6)[1:2]            # clip index 1 of the generator = a loud tone; keep one noise clip too
     pcm10 = np.concatenate([pcm10, synth_pcm_i16(1, 160000, seed=7)])

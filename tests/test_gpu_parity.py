@@ -101,6 +101,18 @@ def test_golden_trained_like_checkpoint(golden, name):
     assert np.abs(centred(toks) - centred(g["stages"][:, 0])).max() < 2e-2
 
 
+def test_golden_trained_like_checkpoint_on_the_reference_sample_clips(golden):
+    """Real audio (the reference's water / keyword sample clips, two crops each for the water clips) through the trained-like
+    XS checkpoint: reference logits down to -11."""
+    g, pcm = golden("trained_samples_uit_xs"), golden("samples_uit_xs")
+    m, _ = build_trained("uit_xs", g["seed"])
+    for key in ("water_000", "water_003", "85b877b5_nohash_0"):
+        p, l = run(m, pcm[f"{key}_pcm"][None])
+        assert l.shape[1] == g[f"{key}_logits"].shape[0]
+        assert np.abs(l[0] - g[f"{key}_logits"]).max() < TOL
+        assert np.abs(p[0] - g[f"{key}_probs"]).max() < TOL
+
+
 def test_golden_trained_like_short_clip(golden):
     """Short clips leave masked padding tokens in the wave; with the sharp attention of trained-like weights their scores must
     not set the softmax's running max (per-key masking of the max in the SHORT instantiation of the encoder)."""

@@ -133,6 +133,16 @@ def test_trained_like_checkpoint(golden, name):
     assert np.abs(centred(r["stages"][0]) - centred(g["stages"][0])).max() < 2e-4
 
 
+def test_trained_like_checkpoint_on_sample_clips(golden):
+    from synth_weights import make_trained_like_state_dict
+    g, pcm = golden("trained_samples_uit_xs"), golden("samples_uit_xs")
+    o = Oracle(make_trained_like_state_dict("uit_xs", int(g["seed"])))
+    for key in ("water_000", "water_003", "85b877b5_nohash_0"):
+        r = o.forward(pcm[f"{key}_pcm"][None])
+        assert np.abs(r["logits"][0] - g[f"{key}_logits"]).max() < 2e-4
+        assert np.abs(r["probs"][0] - g[f"{key}_probs"]).max() < 5e-5
+
+
 def test_trained_like_short_clip(golden):
     from synth_weights import make_trained_like_state_dict
     g = golden("trained_short_uit_xxxs")
