@@ -1,0 +1,41 @@
+// Sanitizer driver for the host-only packer (csrc/pack.cpp): test infrastructure.  Built by tests/test_sanitizers.py with
+// g++ -fsanitize=address,undefined (GPU AddressSanitizer is not available on the pool; the packer is plain host C++).
+// Packs random weights for every precision / attention layout and checks the image size against the header.
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+#include "../../uit_mobile_amd/csrc/pack.h"
+
+int main() {
+    std::vector<float> pool(1 << 20);
+    for (size_t i = 0; i < pool.size(); ++i) pool[i] = (float)((double)rand() / RAND_MAX - 0.5) * 0.2f;
+    for (float& v : pool) if (v == 0.f) v = 0.01f;
+    const float* p = pool.data();
+    int fails = 0;
+    for (int full = 0; full < 2; ++full)
+        for (int prec = 0; prec < 3; ++prec) {
+            if (full && prec == 2) continue;
+            for (int depth : {1, 4}) {
+                uitk_config c{};
+                c.depth = depth; c.embed_dim = 128; c.num_heads = 2; c.mlp_hidden = 384; c.outputdim = 537; c.target_length = 102;
+                c.n_mels = 64; c.n_fft = 512; c.hop_size = 160; c.win_size = 512; c.patch_size = 16; c.center = 1; c.eval_avg = 0;
+                c.precision = prec; c.top_db = 120.f; c.attention_full = full; c.act_gelu = full;
+                std::vector<uitk_block_weights> blocks(depth);
+                for (auto& b : blocks) {
+                    b.norm1_w = p; b.norm1_b = p + 128; b.qkv_w = p + 1000; b.qkv_b = p + 60000; b.proj_w = p + 70000; b.proj_b = p + 90000;
+                    b.norm2_w = p + 256; b.norm2_b = p + 384; b.fc1_w = p + 100000; b.fc1_b = p + 160000; b.fc2_w = p + 170000; b.fc2_b = p + 230000;
+                }
+                uitk_weights w{};
+                w.window = p; w.mel_fb = p + 300000; w.bn_weight = p + 512; w.bn_bias = p + 576; w.bn_mean = p + 640;
+                std::vector<float> var(64, 300.f); w.bn_var = var.data();
+                w.pe_w = p + 400000; w.pe_b = p + 700; w.time_pos = p + 2000; w.freq_pos = p + 4000; w.norm_w = p + 5000; w.norm_b = p + 5200;
+                w.head_ln_w = p + 5400; w.head_ln_b = p + 5600; w.head_w = p + 500000; w.head_b = p + 8000; w.blocks = blocks.data();
+                const char* why = "";
+                if (uitk::validate_config(&c, &why)) { std::printf("validate failed: %s\n", why); ++fails; continue; }
+                std::vector<char> img; uitk::ImageHeader h{};
+                if (uitk::pack_image(&c, &w, &img, &h) || img.size() != h.total_bytes || h.magic != uitk::IMAGE_MAGIC) ++fails;
+            }
+        }
+    std::printf("pack sanitizer run: %d failures\n", fails);
+    return fails;
+}
