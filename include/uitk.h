@@ -68,6 +68,9 @@ typedef struct uitk_config {
                               1 = Attention (uit.py:124-178: qkv 128->384, proj 128->128, 2 heads x 64; the
                                   audio_transformer_h128_* factories uit.py:514-579)                      */
     int32_t act_gelu;      /* 0 = nn.ReLU (uit.py:591, 610, 629), 1 = nn.GELU (UITBase default, uit.py:344) */
+    int32_t pooling_dm;    /* 0 = pooling 'mean' (uit.py:402-404; every factory), 1 = pooling 'dm' (uit.py:405-412): per time patch
+                              the mean over the frequency patches -> outputlayer -> sigmoid, then the mean over time patches.
+                              No pre-sigmoid output exists for it: uitk_forward / uitk_encode reject a non-NULL `logits`. */
 } uitk_config;
 
 /* Per-block parameters, fp32 host pointers in the reference's state_dict layout (blocks.N.*). */

@@ -18,7 +18,7 @@ class OracleCfg(ctypes.Structure):
     _fields_ = [(n, ctypes.c_int) for n in
                 ("depth", "dim", "heads", "hidden", "outputdim", "n_mels", "n_fft", "hop", "win",
                  "target_length", "patch", "eval_avg")] + [("top_db", ctypes.c_float), ("attn_full", ctypes.c_int),
-                                                           ("act_gelu", ctypes.c_int)]
+                                                           ("act_gelu", ctypes.c_int), ("pool_dm", ctypes.c_int)]
 
 
 def build(force=False):
@@ -69,7 +69,7 @@ def _np(x):
 
 
 class Oracle:
-    def __init__(self, state_dict, target_length=102, eval_avg="mean", hop=160, heads=2, act="relu"):
+    def __init__(self, state_dict, target_length=102, eval_avg="mean", hop=160, heads=2, act="relu", pooling="mean"):
         sd = {k: _np(v) for k, v in state_dict.items() if k != "init_bn.1.num_batches_tracked"}
         depth = 1 + max(int(k.split(".")[1]) for k in sd if k.startswith("blocks."))
         dim = sd["norm.weight"].shape[0]
@@ -82,7 +82,7 @@ class Oracle:
                              eval_avg={"mean": 0, "max": 1}[eval_avg], top_db=120.0,
                              # BNeckAttention: qkv rows 3*dim/4; Attention: 3*dim  (models/uit.py:103 / :139)
                              attn_full=int(sd["blocks.0.attn.qkv.weight"].shape[0] == 3 * dim),
-                             act_gelu={"relu": 0, "gelu": 1}[act])
+                             act_gelu={"relu": 0, "gelu": 1}[act], pool_dm={"mean": 0, "dm": 1}[pooling])
         self._keep = [sd[k] for k in _GLOBAL_KEYS]
         for b in range(depth):
             self._keep += [sd[f"blocks.{b}.{k}"] for k in _BLOCK_KEYS]

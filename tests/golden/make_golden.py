@@ -161,7 +161,31 @@ def main_variants():
         print("variant", name, "trained-like" if trained else "init", "logit range", r["logits"].min(), r["logits"].max())
 
 
+def main_dm():
+    """pooling='dm' (models/uit.py:405-412) on the uit_* family: init-scale 3XS incl. a short clip batch, trained-like XS."""
+    pcm = synth_pcm_i16(8, 16000, seed=0)
+    pcm[5] = 0
+    out = {}
+    for tag, name, seed, trained in (("xxxs", "uit_xxxs", 31, False), ("xs_trained", "uit_xs", 3, True)):
+        m = getattr(uit, name)(outputdim=537, target_length=102, pooling="dm")
+        mk = make_trained_like_state_dict if trained else make_state_dict
+        m.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in mk(name, seed).items()}, strict=True)
+        m.eval()
+        with torch.no_grad():
+            out[f"{tag}_probs"] = m(torch.from_numpy(pcm.astype(np.float32) / 32768.0)).numpy()
+            if not trained:
+                short = synth_pcm_i16(3, 8000, seed=4)
+                out["xxxs_short_pcm"], out["xxxs_short_probs"] = short, m(torch.from_numpy(short.astype(np.float32) / 32768.0)).numpy()
+                two = synth_pcm_i16(2, 16384, seed=5)                  # two crops
+                out["xxxs_crops_pcm"], out["xxxs_crops_probs"] = two, m(torch.from_numpy(two.astype(np.float32) / 32768.0)).numpy()
+        out[f"{tag}_seed"] = seed
+        print("dm", name, "probs range", out[f"{tag}_probs"].min(), out[f"{tag}_probs"].max())
+    np.savez_compressed(HERE / "pooling_dm.npz", pcm=pcm, **out)
+
+
 def main():
+    if "--dm" in sys.argv:
+        return main_dm()
     if "--round2" in sys.argv:
         return main_round2()
     if "--variants" in sys.argv:
@@ -231,6 +255,7 @@ def main():
     np.savez(HERE / "meta.npz", **meta)
     main_round2()
     main_variants()
+    main_dm()
     print("done")
 
 

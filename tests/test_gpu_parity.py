@@ -153,6 +153,45 @@ def test_golden_other_factories(golden, name, act):
         assert np.abs(l - ref["logits"]).max() < tol_l and np.abs(p - ref["probs"]).max() < TOL
 
 
+def test_golden_pooling_dm(golden):
+    """pooling='dm' (models/uit.py:405-412) -- per time patch the mean over the four frequency patches through
+    outputlayer and the sigmoid, then the mean over the time patches -- on the POOL = 1 instantiation: init-scale 3XS (8 clips,
+    short clips with 3 time patches, two crops) and trained-like XS against the imported reference, 1e-3 on the probabilities
+    (this pooling has no pre-sigmoid output: asking for logits is an error)."""
+    g = golden("pooling_dm")
+    sd = make_state_dict("uit_xxxs", int(g["xxxs_seed"]))
+    m = models.uit_xxxs(outputdim=537, target_length=102, pooling="dm")
+    m.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()}, strict=True)
+    m = m.to("cuda").eval()
+    for pcm, want in ((g["pcm"], g["xxxs_probs"]), (g["xxxs_short_pcm"], g["xxxs_short_probs"]), (g["xxxs_crops_pcm"], g["xxxs_crops_probs"])):
+        with torch.no_grad():
+            p = m(torch.from_numpy(pcm).cuda()).cpu().numpy()
+        assert np.abs(p - want).max() < TOL
+    with pytest.raises(ValueError):
+        m(torch.from_numpy(g["pcm"]).cuda(), return_logits=True)
+    o = Oracle(sd, pooling="dm")
+    for B in (1, 3, 17):
+        pcm = synth_pcm_i16(B, 16000, seed=60 + B)
+        with torch.no_grad():
+            p = m(torch.from_numpy(pcm).cuda()).cpu().numpy()
+        assert np.abs(p - o.forward(pcm)["probs"]).max() < TOL
+    sd = make_trained_like_state_dict("uit_xs", int(g["xs_trained_seed"]))
+    m = models.uit_xs(outputdim=537, target_length=102, pooling="dm")
+    m.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()}, strict=True)
+    with torch.no_grad():
+        p = m.to("cuda").eval()(torch.from_numpy(g["pcm"]).cuda()).cpu().numpy()
+    print(f"pooling dm, trained-like uit_xs: max|dprob| {np.abs(p - g['xs_trained_probs']).max():.2e}")
+    assert np.abs(p - g["xs_trained_probs"]).max() < TOL
+    # and on the full-width-attention GELU factory, against the oracle
+    sd = make_state_dict("audio_transformer_h128_d4_m3", 41, attention="full")
+    m = models.audio_transformer_h128_d4_m3(outputdim=537, target_length=102, pooling="dm")
+    m.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()}, strict=True)
+    pcm = synth_pcm_i16(5, 16000, seed=8)
+    with torch.no_grad():
+        p = m.to("cuda").eval()(torch.from_numpy(pcm).cuda()).cpu().numpy()
+    assert np.abs(p - Oracle(sd, act="gelu", pooling="dm").forward(pcm)["probs"]).max() < TOL
+
+
 @pytest.mark.parametrize("avg", ["mean", "max"])
 def test_golden_ten_crop_clip(golden, avg):
     """AudioSet-style 10 s clips: 160 000 samples -> 1001 frames -> 10 crops, tail re-cropped (models/uit.py:468-488;

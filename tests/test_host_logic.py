@@ -103,8 +103,9 @@ def test_unsupported_variants_raise():
     with pytest.raises(NotImplementedError):
         models.UITBase(embed_dim=128, depth=4, num_heads=2, mlp_ratio=3.0, pooling="token",
                        attention_type="BNeckAttention", act_layer=torch.nn.ReLU)
+    assert models.uit_xs(pooling="dm").pooling == "dm"          # built (POOL = 1 instantiation); 'token' is not
     with pytest.raises(NotImplementedError):
-        models.uit_xs(pooling="dm")
+        models.uit_xs(pooling="dm", precision="bf16")
     with pytest.raises(NotImplementedError):
         models.uit_xs(act_layer=torch.nn.SiLU)
     m = models.uit_xs(embed_dim=256)                # geometry outside the kernels' family -> C ABI rejects it

@@ -178,3 +178,14 @@ def test_other_factories_full_attention_and_gelu(golden, name, act):
     assert np.abs(r["logits"] - g["logits"]).max() < 3e-4
     assert np.abs(r["probs"] - g["probs"]).max() < 5e-5
     assert np.abs(centred(r["stages"][0]) - centred(g["stages"][0])).max() < 2e-4
+
+
+def test_pooling_dm(golden):
+    """pooling='dm' (models/uit.py:405-412) against the imported reference: 3XS (full, short, two-crop clips), trained-like XS."""
+    from synth_weights import make_trained_like_state_dict
+    g = golden("pooling_dm")
+    o = Oracle(make_state_dict("uit_xxxs", int(g["xxxs_seed"])), pooling="dm")
+    for pcm, want in ((g["pcm"], g["xxxs_probs"]), (g["xxxs_short_pcm"], g["xxxs_short_probs"]), (g["xxxs_crops_pcm"], g["xxxs_crops_probs"])):
+        assert np.abs(o.forward(pcm)["probs"] - want).max() < 5e-5
+    o = Oracle(make_trained_like_state_dict("uit_xs", int(g["xs_trained_seed"])), pooling="dm")
+    assert np.abs(o.forward(g["pcm"])["probs"] - g["xs_trained_probs"]).max() < 5e-5

@@ -165,7 +165,7 @@ int uitk_set_debug_tokens(uitk_model* m, float* dev_buf) {
 
 int uitk_set_timing_buffers(uitk_model* m, unsigned long long* enc_buf, unsigned long long* fe_buf) {
     if (!m) return fail(UITK_ERR_INVALID_ARG, "null model");
-    if ((enc_buf || fe_buf) && (m->cfg.precision != UITK_PREC_F16 || m->cfg.attention_full || m->cfg.act_gelu))
+    if ((enc_buf || fe_buf) && (m->cfg.precision != UITK_PREC_F16 || m->cfg.attention_full || m->cfg.act_gelu || m->cfg.pooling_dm))
         return fail(UITK_ERR_UNSUPPORTED, "the instrumented kernel builds exist for precision f16, BNeckAttention + ReLU only");
     m->timing = enc_buf; m->timing_fe = fe_buf;
     return UITK_OK;
@@ -212,6 +212,7 @@ int uitk_frontend(uitk_model* m, const void* pcm, int in_dtype, int64_t B, int64
 int uitk_encode(uitk_model* m, int64_t B, int64_t T, float* probs, float* logits, void* stream) {
     if (int rc = check_shape(m, B, T)) return rc;
     if (!probs) return fail(UITK_ERR_INVALID_ARG, "null probs");
+    if (logits && m->cfg.pooling_dm) return fail(UITK_ERR_UNSUPPORTED, "pooling 'dm' has no pre-sigmoid output (models/uit.py:405-412): pass logits = NULL");
     const int nF = uitk_num_frames(m, T), nc = uitk_num_crops(m, T), tl = m->cfg.target_length;
     if ((size_t)B * nc * NTOK * 256 * 2 > m->mel_cap || B != m->fe_B || T != m->fe_T)
         return fail(UITK_ERR_WORKSPACE, "uitk_encode without a matching uitk_frontend (same B and T) before it");
@@ -235,7 +236,7 @@ int uitk_encode(uitk_model* m, int64_t B, int64_t T, float* probs, float* logits
     a.probs = nc > 1 ? m->rowprobs : probs;
     a.logits = logits; a.dbg = m->dbg;
     a.timing = m->timing; a.ablate = m->enc_ablate;
-    a.attention_full = m->cfg.attention_full; a.act_gelu = m->cfg.act_gelu;
+    a.attention_full = m->cfg.attention_full; a.act_gelu = m->cfg.act_gelu; a.pooling_dm = m->cfg.pooling_dm;
     a.stagger = m->enc_stagger; a.stagger_group = m->n_cu; a.stagger_mode = m->enc_stagger_mode;
     HIP_TRY(launch_encoder(a, m->cfg.precision, m->enc_waves, m->enc_sched, s));
     if (nc > 1) HIP_TRY(launch_crop_reduce(m->rowprobs, probs, B, nc, a.C, m->cfg.eval_avg, s));

@@ -476,7 +476,8 @@ __device__ __forceinline__ unsigned long long stamp() {
 // SHORT: clips with fewer than 6 time patches (masked padding tokens; a separate instantiation keeps the full-clip kernel's
 // register allocation untouched).
 // ATT: 0 = BNeckAttention (the uit_* family), 1 = full-width Attention (2 heads x 64; 20 ring stages per block).  ACT: 0 ReLU, 1 GELU.
-template <int PREC, int WAVES, bool SHORT, bool TIMING, int ABL = 0, int ATT = 0, int ACT = 0>
+// POOL: 0 = pooling 'mean', 1 = pooling 'dm' (models/uit.py:405-412).
+template <int PREC, int WAVES, bool SHORT, bool TIMING, int ABL = 0, int ATT = 0, int ACT = 0, int POOL = 0>
 __global__ __launch_bounds__(WAVES * 64, 2) void uit_encoder_kernel(EncoderArgs a) {
     constexpr int OPC = PREC == 2 ? 0 : PREC;              // precision fp8: patch embed, attention, proj and head stay f16
     using OP = Op<OPC>;
@@ -1012,6 +1013,116 @@ __global__ __launch_bounds__(WAVES * 64, 2) void uit_encoder_kernel(EncoderArgs 
       }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // drain the dummy tail stages before the LDS can be re-used
+    if constexpr (POOL == 1) {
+        // ===== pooling 'dm' (models/uit.py:405-412): for every time patch t the mean over the four frequency patches goes through
+        // outputlayer (LayerNorm 1e-5 + Linear) and the sigmoid; the output is the mean over the nt time patches.  The mean-pool
+        // machinery below runs once per time patch with the token mask (pt == t); probabilities accumulate in registers.
+        const int ntiles = (a.C + 15) / 16;
+        constexpr int HEAD_PRE = 5;                       // class tiles per wave (5 x 8 waves covers C <= 640; pack.cpp enforces it)
+        float rstd[3], mean3[3];
+#pragma unroll
+        for (int ct = 0; ct < 3; ++ct) ln_stats(R, ct, 1e-6f, mean3[ct], rstd[ct]);
+        f4 pacc[HEAD_PRE];
+#pragma unroll
+        for (int i = 0; i < HEAD_PRE; ++i) pacc[i] = splat(0.f);
+        const bool lo = c < 8;
+        const int row0 = blockIdx.x * WAVES * 2 + 4 * g;
+#pragma unroll 1
+        for (int tsel = 0; tsel < a.nt; ++tsel) {
+            f4 pooled[8];
+            const float r0 = pt_[0] == tsel ? rstd[0] : 0.f, r1 = pt_[1] == tsel ? rstd[1] : 0.f, r2 = pt_[2] == tsel ? rstd[2] : 0.f;
+#pragma unroll
+            for (int ft = 0; ft < 8; ++ft) {
+                const f4 x0 = (R[ft][0] - splat(mean3[0])) * splat(r0), x1 = (R[ft][1] - splat(mean3[1])) * splat(r1);
+                const f4 x2 = (R[ft][2] - splat(mean3[2])) * splat(r2);
+                const f4 A = lo ? x0 + x1 : x0;           // clip 0 = tile 0 (all lanes) + tile 1 lanes c<8
+                const f4 B = lo ? x2 : x2 + x1;           // clip 1 = tile 2 (all lanes) + tile 1 lanes c>=8
+                const f4 keep = lo ? A : B, send = lo ? B : A;
+                f4 v;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    float t = keep[r] + dpp_mov<0x140>(send[r]);
+                    t = dpp_add<0x141>(t);
+                    t = dpp_add<0x4E>(t);
+                    t = dpp_add<0xB1>(t);
+                    v[r] = t;
+                }
+                pooled[ft] = v;
+            }
+            {
+                f4 acc = splat(0.f);
+#pragma unroll
+                for (int ft = 0; ft < 8; ++ft) {
+                    const f4 gw = *(const f4*)(a.fin + 0 * DIM + 16 * ft + 4 * g);
+                    const f4 gb = *(const f4*)(a.fin + 1 * DIM + 16 * ft + 4 * g);
+                    pooled[ft] = pooled[ft] * splat(1.0f / (float)GF) * gw + gb;
+                    acc = acc + pooled[ft];
+                }
+                const float mean = xsum(hsum(acc)) * (1.0f / DIM);
+                f4 q = splat(0.f);
+#pragma unroll
+                for (int ft = 0; ft < 8; ++ft) { const f4 d = pooled[ft] - splat(mean); q = q + d * d; }
+                const float rs = __builtin_amdgcn_rsqf(xsum(hsum(q)) * (1.0f / DIM) + 1e-5f);
+                const int slot_clip = 2 * wave + (c >= 8 ? 1 : 0);
+#pragma unroll
+                for (int ft = 0; ft < 8; ++ft) {
+                    const f4 gw = *(const f4*)(a.fin + 2 * DIM + 16 * ft + 4 * g);
+                    const f4 gb = *(const f4*)(a.fin + 3 * DIM + 16 * ft + 4 * g);
+                    const f4 z = (pooled[ft] - splat(mean)) * splat(rs) * gw + gb;
+                    if ((c & 7) == 0) {
+                        const v4 zh = OP::pack4(z);
+                        *(v4*)(zbuf + (slot_clip * DIM + 16 * ft + 4 * g) * 2) = zh;
+                        *(v4*)(zbuf + 16 * DIM * 2 + (slot_clip * DIM + 16 * ft + 4 * g) * 2) = OP::pack4(z - OP::unpack4(zh));
+                    }
+                }
+            }
+            __syncthreads();
+            {
+                const int cz = c < 2 * WAVES ? c : 0;
+                v8 Bz[4], Bzl[4];
+#pragma unroll
+                for (int s = 0; s < 4; ++s) {
+                    const v4 l0 = *(const v4*)(zbuf + (cz * DIM + 32 * s + 4 * g) * 2);
+                    const v4 h0 = *(const v4*)(zbuf + (cz * DIM + 32 * s + 16 + 4 * g) * 2);
+                    Bz[s] = v8{l0[0], l0[1], l0[2], l0[3], h0[0], h0[1], h0[2], h0[3]};
+                    const v4 l1 = *(const v4*)(zbuf + 16 * DIM * 2 + (cz * DIM + 32 * s + 4 * g) * 2);
+                    const v4 h1 = *(const v4*)(zbuf + 16 * DIM * 2 + (cz * DIM + 32 * s + 16 + 4 * g) * 2);
+                    Bzl[s] = v8{l1[0], l1[1], l1[2], l1[3], h1[0], h1[1], h1[2], h1[3]};
+                }
+#pragma unroll
+                for (int i = 0; i < HEAD_PRE; ++i) {
+                    const int ot = wave + i * WAVES;
+                    if (ot < ntiles) {
+                        f4 acc = splat(a.head_b[16 * ot + c]);
+#pragma unroll
+                        for (int s = 0; s < 4; ++s) {
+                            const v8 Hc = *(const v8*)(a.head_w + (size_t)(ot * 4 + s) * 2 * FRAG_BYTES + lane * 16);
+                            const v8 Hlo = *(const v8*)(a.head_w + ((size_t)(ot * 4 + s) * 2 + 1) * FRAG_BYTES + lane * 16);
+                            acc = OP::mfma32(Bz[s], Hlo, acc);
+                            acc = OP::mfma32(Bzl[s], Hc, acc);
+                            acc = OP::mfma32(Bz[s], Hc, acc);
+                        }
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) pacc[i][r] += __builtin_amdgcn_rcpf(1.0f + __expf(-acc[r]));
+                    }
+                }
+            }
+            __syncthreads();                              // zbuf is rewritten for the next time patch
+        }
+        const float inv_nt = 1.0f / (float)a.nt;
+#pragma unroll
+        for (int i = 0; i < HEAD_PRE; ++i) {
+            const int cls = 16 * (wave + i * WAVES) + c;
+            if (wave + i * WAVES < ntiles && cls < a.C) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int rowg = row0 + r;
+                    if (4 * g + r < 2 * WAVES && rowg < a.rows) a.probs[(int64_t)rowg * a.C + cls] = pacc[i][r] * inv_nt;
+                }
+            }
+        }
+        return;
+    }
     unsigned long long t_blocks_end = 0;
     if constexpr (TIMING) { t_blocks_end = stamp(); tlast = t_blocks_end; }
     // classifier weights of this wave's first output tile: fetched now, consumed after pooling
@@ -1174,7 +1285,7 @@ __global__ void crop_reduce_kernel(const float* __restrict__ rp, float* __restri
     }
 }
 
-template <int PREC, int WAVES, bool SHORT, bool TIMING = false, int ABL = 0, int ATT = 0, int ACT = 0>
+template <int PREC, int WAVES, bool SHORT, bool TIMING = false, int ABL = 0, int ATT = 0, int ACT = 0, int POOL = 0>
 static hipError_t launch_enc(const EncoderArgs& a, hipStream_t stream) {
     // the attribute is per device: one bit per device, set once (see launch_fe)
     static std::atomic<unsigned long long> attr_done{0};
@@ -1182,13 +1293,13 @@ static hipError_t launch_enc(const EncoderArgs& a, hipStream_t stream) {
     if (hipError_t e = hipGetDevice(&dev); e != hipSuccess) return e;
     const unsigned long long bit = 1ull << (dev & 63);
     if (!(attr_done.load(std::memory_order_acquire) & bit)) {
-        hipError_t e = hipFuncSetAttribute((const void*)uit_encoder_kernel<PREC, WAVES, SHORT, TIMING, ABL, ATT, ACT>,
+        hipError_t e = hipFuncSetAttribute((const void*)uit_encoder_kernel<PREC, WAVES, SHORT, TIMING, ABL, ATT, ACT, POOL>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, WAVES == 8 ? ENC_LDS_SPLIT_PE : ENC_LDS);
         if (e != hipSuccess) return e;
         attr_done.fetch_or(bit, std::memory_order_release);
     }
     const int grid = (a.rows + 2 * WAVES - 1) / (2 * WAVES);
-    hipLaunchKernelGGL((uit_encoder_kernel<PREC, WAVES, SHORT, TIMING, ABL, ATT, ACT>), dim3(grid), dim3(WAVES * 64),
+    hipLaunchKernelGGL((uit_encoder_kernel<PREC, WAVES, SHORT, TIMING, ABL, ATT, ACT, POOL>), dim3(grid), dim3(WAVES * 64),
                        WAVES == 8 ? ENC_LDS_SPLIT_PE : ENC_LDS, stream, a);
     return hipGetLastError();
 }
@@ -1212,6 +1323,13 @@ hipError_t launch_encoder(const EncoderArgs& a, int precision, int waves, int sc
     if (a.timing != nullptr)                              // diagnostic build with in-kernel stamps (f16, full clips only)
         return waves == 4 ? launch_enc<0, 4, false, true>(a, stream) : launch_enc<0, 8, false, true>(a, stream);
     (void)sched;
+    if (a.pooling_dm) {                                   // pooling 'dm' (f16, 8-wave workgroups), any attention / activation
+        if (precision != 0 || a.timing != nullptr) return hipErrorInvalidValue;
+#define UITK_DM(SH) (a.attention_full ? (a.act_gelu ? launch_enc<0, 8, SH, false, 0, 1, 1, 1>(a, stream) : launch_enc<0, 8, SH, false, 0, 1, 0, 1>(a, stream)) \
+                                      : (a.act_gelu ? launch_enc<0, 8, SH, false, 0, 0, 1, 1>(a, stream) : launch_enc<0, 8, SH, false, 0, 0, 0, 1>(a, stream)))
+        return a.nt < GT ? UITK_DM(true) : UITK_DM(false);
+#undef UITK_DM
+    }
     if (a.attention_full || a.act_gelu) {                 // SURVEY 8f-4 variants: f16 / bf16, 8-wave workgroups
         if (precision == 2 || a.timing != nullptr) return hipErrorInvalidValue;
 #define UITK_VARIANT(P, SH) (a.attention_full ? (a.act_gelu ? launch_enc<P, 8, SH, false, 0, 1, 1>(a, stream) : launch_enc<P, 8, SH, false, 0, 1, 0>(a, stream)) \

@@ -123,7 +123,10 @@ int validate_config(const uitk_config* c, const char** why) {
     if (c->eval_avg != UITK_AVG_MEAN && c->eval_avg != UITK_AVG_MAX) return bad("unknown eval_avg");
     if (c->precision != UITK_PREC_F16 && c->precision != UITK_PREC_BF16 && c->precision != UITK_PREC_FP8) return bad("unknown precision");
     if ((c->attention_full != 0 && c->attention_full != 1) || (c->act_gelu != 0 && c->act_gelu != 1)) return bad("attention_full / act_gelu must be 0 or 1");
-    if ((c->attention_full || c->act_gelu) && c->precision == UITK_PREC_FP8) return bad("precision fp8 is built for the uit_* family (BNeckAttention, ReLU) only");
+    if ((c->attention_full || c->act_gelu || c->pooling_dm) && c->precision == UITK_PREC_FP8) return bad("precision fp8 is built for the uit_* family (BNeckAttention, ReLU, mean pooling) only");
+    if (c->pooling_dm != 0 && c->pooling_dm != 1) return bad("pooling_dm must be 0 or 1");
+    if (c->pooling_dm && c->precision != UITK_PREC_F16) return bad("pooling 'dm' is built for precision f16");
+    if (c->pooling_dm && c->outputdim > 640) return bad("pooling 'dm' is built for outputdim <= 640");
     return UITK_OK;
 }
 

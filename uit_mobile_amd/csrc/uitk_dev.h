@@ -91,6 +91,7 @@ struct EncoderArgs {
     unsigned long long* timing;  // diagnostics: [waves][12] phase cycle sums (null = off, normal build)
     int attention_full;     // 0 = BNeckAttention, 1 = Attention (full width, 2 heads x 64)
     int act_gelu;           // MLP activation: 0 = ReLU, 1 = exact (erf) GELU
+    int pooling_dm;         // 0 = mean over the tokens, 1 = 'dm' (per time patch: mean over frequency patches -> head -> sigmoid; mean over time)
     int ablate;             // timing experiments (builds with -DUITK_ABLATION_BUILDS only): ABL template value
     int stagger;            // 0 = off, else shader cycles to delay every other workgroup generation
     int stagger_group;      // workgroups per generation (= CU count)
