@@ -53,7 +53,8 @@ def forward(sd, mel_bn, depth):
     B = mel_bn.shape[0]
     x = mel_bn[:, :, :96].reshape(B, 4, 16, 6, 16).permute(0, 1, 3, 2, 4).reshape(B, 24, 256)
     W = g("patch_embed.proj.weight").reshape(128, 256)
-    tok = f16(x) @ (W - W.mean(0, keepdim=True)).T + g("patch_embed.proj.bias")           # split conv weights (hi + lo): ~exact
+    tok = f16(x) @ f16(W - W.mean(0, keepdim=True)).T + g("patch_embed.proj.bias")      # (pack.cpp rounds these structurally:
+    # the same values up to a few near-tie flips -- far below what this emulation resolves)
     tp, fp = g("time_pos_embed")[0, :, 0, :6], g("freq_pos_embed")[0, :, :, 0]
     tok = tok + (fp.T[:, None, :] + tp.T[None, :, :]).reshape(24, 128)
     scale = (128 // 2) ** -0.5 * 1.4426950408889634

@@ -40,6 +40,8 @@ struct uitk_model {
     int n_cu = 256;
     int enc_waves = 8;            // waves per encoder workgroup (8 = one WG per CU; 4 = two independent WGs per CU)
     int enc_sched = 0, enc_stagger = 0, enc_stagger_mode = 1, enc_ablate = 0;   // tuning knobs (UITK_ENC_SCHED, UITK_ENC_STAGGER)
+    int split_pe = 0;             // UITK_SPLIT_PE=1: patch embed on split weights (W = hi + lo); measured no better than the
+                                  // structured rounding of pack.cpp, +1.6 % encoder time: off by default
     int fe_wg_per_cu = 0;         // persistent front-end workgroups per CU (0 = the kernel's occupancy target; UITK_FE_WG_PER_CU)
     int device = 0;
     int64_t fe_B = 0, fe_T = 0;   // shape of the latest uitk_frontend call (uitk_encode must match it)
@@ -91,6 +93,7 @@ int uitk_create(const uitk_config* cfg, const uitk_weights* w, uitk_model** out)
     if (const char* e = std::getenv("UITK_ENC_STAGGER_MODE")) m->enc_stagger_mode = std::atoi(e);
     if (const char* e = std::getenv("UITK_ENC_ABLATE")) m->enc_ablate = std::atoi(e);
     if (const char* e = std::getenv("UITK_FE_WG_PER_CU")) m->fe_wg_per_cu = std::atoi(e);
+    if (const char* e = std::getenv("UITK_SPLIT_PE")) m->split_pe = std::atoi(e) != 0;
     if (hipMalloc((void**)&m->image, img.size()) != hipSuccess || hipMalloc((void**)&m->amax, 2 * AMAX_SLOTS * 4) != hipSuccess) {
         uitk_destroy(m); return fail(UITK_ERR_HIP, "hipMalloc failed for the parameter image");
     }
@@ -236,6 +239,7 @@ int uitk_encode(uitk_model* m, int64_t B, int64_t T, float* probs, float* logits
     a.probs = nc > 1 ? m->rowprobs : probs;
     a.logits = logits; a.dbg = m->dbg;
     a.timing = m->timing; a.ablate = m->enc_ablate;
+    a.split_pe = m->split_pe;
     a.attention_full = m->cfg.attention_full; a.act_gelu = m->cfg.act_gelu; a.pooling_dm = m->cfg.pooling_dm;
     a.stagger = m->enc_stagger; a.stagger_group = m->n_cu; a.stagger_mode = m->enc_stagger_mode;
     HIP_TRY(launch_encoder(a, m->cfg.precision, m->enc_waves, m->enc_sched, s));

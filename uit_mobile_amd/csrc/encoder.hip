@@ -522,7 +522,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void uit_encoder_kernel(EncoderArgs 
     // (a 4-wave workgroup shares its CU's LDS with a second one and runs the single-term patch embed)
     constexpr bool SPLIT_PE = WAVES == 8;
     char* pelo = smem + ENC_LDS;
-    if constexpr (SPLIT_PE) {
+    if (SPLIT_PE && a.split_pe) {
         constexpr int PER_WAVE = STAGE_FRAGS / WAVES;
 #pragma unroll
         for (int i = 0; i < PE_HI_STAGES; ++i)
@@ -616,7 +616,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void uit_encoder_kernel(EncoderArgs 
         for (int s = 0; s < 8; ++s)
 #pragma unroll
             for (int ct = 0; ct < 3; ++ct) R[ft][ct] = OP::mfma32(A[s], XB[ct][s], R[ft][ct]);
-        if constexpr (SPLIT_PE) {
+        if (SPLIT_PE && a.split_pe) {
 #pragma unroll
             for (int s = 0; s < 8; ++s) A[s] = lds_frag<OPC>(pelo, ft * 8 + s, lane);
 #pragma unroll

@@ -23,8 +23,8 @@ constexpr int FRAG_BYTES = 1024;        // 64 lanes x 8 x 16-bit
 constexpr int STAGE_FRAGS = 16;
 constexpr int STAGE_BYTES = STAGE_FRAGS * FRAG_BYTES;
 constexpr int PE_HI_STAGES = 4;         // patch-embed: 8 out tiles x 8 k-steps of 16-bit weights ...
-constexpr int PE_STAGES = 8;            // ... plus the same 64 fragments of the weights' low-order terms (W = hi + lo: the conv weights'
-                                        // rounding is the same for every token and survives the mean-pool)
+constexpr int PE_STAGES = 8;            // ... plus the same 64 fragments of the weights' low-order terms (W = hi + lo), used only with
+                                        // UITK_SPLIT_PE=1: pack.cpp's structured rounding makes them unnecessary
 constexpr int BLOCK_STAGES = 14;        // QK, V+proj, 12 MLP chunks
 constexpr int TAIL_STAGES = 4;          // zero stages after the last block: the ring prefetch (<= 4 ahead) never branches
 // ---- fp8 weight stream (precision fp8: qkv / fc1 / fc2 as OCP e4m3 operands of v_mfma_scale_f32_16x16x128_f8f6f4)
@@ -92,6 +92,7 @@ struct EncoderArgs {
     int attention_full;     // 0 = BNeckAttention, 1 = Attention (full width, 2 heads x 64)
     int act_gelu;           // MLP activation: 0 = ReLU, 1 = exact (erf) GELU
     int pooling_dm;         // 0 = mean over the tokens, 1 = 'dm' (per time patch: mean over frequency patches -> head -> sigmoid; mean over time)
+    int split_pe;           // 1 = patch embed on split weights (W = hi + lo, 8-wave workgroups only); 0 = high-order term only
     int ablate;             // timing experiments (builds with -DUITK_ABLATION_BUILDS only): ABL template value
     int stagger;            // 0 = off, else shader cycles to delay every other workgroup generation
     int stagger_group;      // workgroups per generation (= CU count)
