@@ -128,3 +128,34 @@ def test_fp8_weight_stream_reconstructs_the_folded_weights():
                 assert np.all(np.abs(rec[:, blk == b] - want[:, blk == b]) <= mx * 2.0 ** -4 + 1e-12)
                 e = sc[b * 16 + np.arange(16)][:, None]
                 assert np.all(mx / 2.0 ** e <= 448.0) and np.all(mx / 2.0 ** e > 224.0)
+
+
+def test_structured_rounding_preserves_group_sums_of_the_conv_weights():
+    """pack.cpp round_structured: the packed patch-embed weights are 16-bit neighbours of the exact (column-centred) conv
+    weights -- never more than one step away -- and inside every group of 16 frame-columns of a mel row the SUMMED rounding
+    error is several times smaller than round-to-nearest leaves it (the error cannot see a spectrum that is constant along the
+    patch's frames), at nearly unchanged per-element error."""
+    import struct
+    from mfma_emu import HDR_FMT, HDR_FIELDS
+    m, sd = _model("uit_xxxs", 12, "f16")
+    img = m.packed_image()
+    h = dict(zip(HDR_FIELDS, struct.unpack_from(HDR_FMT, img, 0)))
+    W = np.asarray(sd["patch_embed.proj.weight"], np.float64).reshape(128, 256)
+    W = W - W.mean(0, keepdims=True)                                       # residual centring
+    Q = np.zeros_like(W)
+    for i in range(4):                                                     # the four high-order stages
+        for f in range(16):
+            raw = np.frombuffer(img, np.float16, 512, h["off_wstream"] + (i * 16 + f) * 1024).reshape(64, 8).astype(np.float64)
+            ft, s = 2 * i + f // 8, f % 8
+            for lane in range(64):
+                g, c = lane >> 4, lane & 15
+                for j in range(8):
+                    Q[16 * ft + c, (2 * s + (g >> 1)) * 16 + 8 * (g & 1) + j] = raw[lane, j]
+    rtn = W.astype(np.float16).astype(np.float64)
+    step = np.abs(np.spacing(W.astype(np.float16))).astype(np.float64)
+    assert np.all(np.abs(Q - W) <= step * 2.0001)                          # a neighbour (the step doubles across a binade boundary)
+    assert np.mean(np.abs(Q - W) > step * 1.0001) < 1e-3
+    assert np.mean(Q != rtn) < 0.25                                        # a minority of roundings (the nearest ties) was flipped
+    gs = lambda A: (A - W).reshape(128, 16, 16).sum(-1)                    # summed error per (row, mel row)
+    assert np.sqrt((gs(Q) ** 2).mean()) < 0.25 * np.sqrt((gs(rtn) ** 2).mean())
+    assert np.sqrt(((Q - W) ** 2).mean()) < 1.1 * np.sqrt(((rtn - W) ** 2).mean())
