@@ -68,9 +68,12 @@ typedef struct uitk_config {
                               1 = Attention (uit.py:124-178: qkv 128->384, proj 128->128, 2 heads x 64; the
                                   audio_transformer_h128_* factories uit.py:514-579)                      */
     int32_t act_gelu;      /* 0 = nn.ReLU (uit.py:591, 610, 629), 1 = nn.GELU (UITBase default, uit.py:344) */
-    int32_t pooling_dm;    /* 0 = pooling 'mean' (uit.py:402-404; every factory), 1 = pooling 'dm' (uit.py:405-412): per time patch
-                              the mean over the frequency patches -> outputlayer -> sigmoid, then the mean over time patches.
-                              No pre-sigmoid output exists for it: uitk_forward / uitk_encode reject a non-NULL `logits`. */
+    int32_t pooling;       /* 0 = 'mean' (uit.py:402-404; every factory);
+                              1 = 'dm' (uit.py:405-412): per time patch the mean over the frequency patches -> outputlayer ->
+                                  sigmoid, then the mean over time patches.  No pre-sigmoid output exists for it: uitk_forward /
+                                  uitk_encode reject a non-NULL `logits`;
+                              2 = 'token' (uit.py:389-392, 399-401; the UITBase default): cls_token + token_pos_embed is
+                                  prepended as a 25th token and its output row alone feeds outputlayer                     */
 } uitk_config;
 
 /* Per-block parameters, fp32 host pointers in the reference's state_dict layout (blocks.N.*). */
@@ -102,6 +105,8 @@ typedef struct uitk_weights {
     const float* head_w;     /* outputlayer.1.weight [outputdim,128]       uit.py:360 */
     const float* head_b;     /* outputlayer.1.bias [outputdim]                     */
     const uitk_block_weights* blocks; /* [depth]                                   */
+    const float* cls_token;  /* cls_token [1,1,128]          uit.py:329   (read for pooling 'token' only; may be NULL otherwise) */
+    const float* token_pos;  /* token_pos_embed [1,128]      uit.py:332 */
 } uitk_weights;
 
 typedef struct uitk_model uitk_model;

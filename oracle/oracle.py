@@ -55,7 +55,7 @@ _GLOBAL_KEYS = [
     "init_bn.1.weight", "init_bn.1.bias", "init_bn.1.running_mean", "init_bn.1.running_var",
     "patch_embed.proj.weight", "patch_embed.proj.bias", "time_pos_embed", "freq_pos_embed",
     "norm.weight", "norm.bias", "outputlayer.0.weight", "outputlayer.0.bias",
-    "outputlayer.1.weight", "outputlayer.1.bias",
+    "outputlayer.1.weight", "outputlayer.1.bias", "cls_token", "token_pos_embed",
 ]
 _BLOCK_KEYS = ["norm1.weight", "norm1.bias", "attn.qkv.weight", "attn.qkv.bias", "attn.proj.weight",
                "attn.proj.bias", "norm2.weight", "norm2.bias", "mlp.fc1.weight", "mlp.fc1.bias",
@@ -82,7 +82,7 @@ class Oracle:
                              eval_avg={"mean": 0, "max": 1}[eval_avg], top_db=120.0,
                              # BNeckAttention: qkv rows 3*dim/4; Attention: 3*dim  (models/uit.py:103 / :139)
                              attn_full=int(sd["blocks.0.attn.qkv.weight"].shape[0] == 3 * dim),
-                             act_gelu={"relu": 0, "gelu": 1}[act], pool_dm={"mean": 0, "dm": 1}[pooling])
+                             act_gelu={"relu": 0, "gelu": 1}[act], pool_dm={"mean": 0, "dm": 1, "token": 2}[pooling])
         self._keep = [sd[k] for k in _GLOBAL_KEYS]
         for b in range(depth):
             self._keep += [sd[f"blocks.{b}.{k}"] for k in _BLOCK_KEYS]
@@ -120,7 +120,7 @@ class Oracle:
         B, T = pcm.shape
         c = self.cfg
         nF, nc = self.n_frames(T), self.num_crops(T)
-        N = (c.n_mels // c.patch) * (min(nF, c.target_length) // c.patch)
+        N = (c.n_mels // c.patch) * (min(nF, c.target_length) // c.patch) + (1 if c.pool_dm == 2 else 0)
         probs = np.empty((B, c.outputdim), np.float32)
         logits = np.empty((B, nc, c.outputdim), np.float32)
         mel = np.empty((B, c.n_mels, nF), np.float32)

@@ -183,7 +183,32 @@ def main_dm():
     np.savez_compressed(HERE / "pooling_dm.npz", pcm=pcm, **out)
 
 
+def main_token():
+    """pooling='token' (models/uit.py:389-392, 399-401; the UITBase default): a cls token in front of the 24 patch tokens."""
+    pcm = synth_pcm_i16(8, 16000, seed=0)
+    pcm[5] = 0
+    out = {}
+    for tag, name, seed, trained, att in (("xxxs", "uit_xxxs", 51, False, "bneck"), ("xs_trained", "uit_xs", 4, True, "bneck"),
+                                          ("h128", "audio_transformer_h128_d4_m3", 52, False, "full")):
+        m = getattr(uit, name)(outputdim=537, target_length=102, pooling="token")
+        mk = make_trained_like_state_dict if trained else make_state_dict
+        sd = {k: torch.from_numpy(np.asarray(v)) for k, v in mk(name, seed, attention=att).items()}
+        sd["cls_token"] = sd["cls_token"] * (0.0 if False else 1.0) + 0.3 * torch.randn(1, 1, 128, generator=torch.Generator().manual_seed(seed))
+        m.load_state_dict(sd, strict=True)
+        r = run_ref(m.eval(), pcm)
+        out[f"{tag}_probs"], out[f"{tag}_logits"], out[f"{tag}_seed"] = r["probs"], r["logits"], seed
+        out[f"{tag}_cls_token"] = sd["cls_token"].numpy()
+        if tag == "xxxs":
+            short = synth_pcm_i16(3, 8000, seed=4)
+            r = run_ref(m, short)
+            out["xxxs_short_pcm"], out["xxxs_short_probs"], out["xxxs_short_logits"] = short, r["probs"], r["logits"]
+        print("token", name, "logit range", out[f"{tag}_logits"].min(), out[f"{tag}_logits"].max())
+    np.savez_compressed(HERE / "pooling_token.npz", pcm=pcm, **out)
+
+
 def main():
+    if "--token" in sys.argv:
+        return main_token()
     if "--dm" in sys.argv:
         return main_dm()
     if "--round2" in sys.argv:
@@ -256,6 +281,7 @@ def main():
     main_round2()
     main_variants()
     main_dm()
+    main_token()
     print("done")
 
 

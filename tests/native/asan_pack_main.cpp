@@ -29,7 +29,7 @@ int main() {
                 w.window = p; w.mel_fb = p + 300000; w.bn_weight = p + 512; w.bn_bias = p + 576; w.bn_mean = p + 640;
                 std::vector<float> var(64, 300.f); w.bn_var = var.data();
                 w.pe_w = p + 400000; w.pe_b = p + 700; w.time_pos = p + 2000; w.freq_pos = p + 4000; w.norm_w = p + 5000; w.norm_b = p + 5200;
-                w.head_ln_w = p + 5400; w.head_ln_b = p + 5600; w.head_w = p + 500000; w.head_b = p + 8000; w.blocks = blocks.data();
+                w.head_ln_w = p + 5400; w.head_ln_b = p + 5600; w.head_w = p + 500000; w.head_b = p + 8000; w.blocks = blocks.data(); w.cls_token = p + 9000; w.token_pos = p + 9200;
                 const char* why = "";
                 if (uitk::validate_config(&c, &why)) { std::printf("validate failed: %s\n", why); ++fails; continue; }
                 std::vector<char> img; uitk::ImageHeader h{};

@@ -192,6 +192,33 @@ def test_golden_pooling_dm(golden):
     assert np.abs(p - Oracle(sd, act="gelu", pooling="dm").forward(pcm)["probs"]).max() < TOL
 
 
+def test_golden_pooling_token(golden):
+    """pooling='token' (models/uit.py:389-392, 399-401; the UITBase default) on the POOL = 2 instantiation -- one clip
+    per wave, column 0 = cls_token + token_pos_embed, columns 1..24 the patch tokens, the rest dead -- against the imported
+    reference: init-scale 3XS (incl. short clips), trained-like XS (|logit| 12), the full-width-attention GELU factory; ragged
+    batches and two crops against the oracle."""
+    g = golden("pooling_token")
+    for tag, name, trained, att, act in (("xxxs", "uit_xxxs", False, "bneck", "relu"), ("xs_trained", "uit_xs", True, "bneck", "relu"),
+                                         ("h128", "audio_transformer_h128_d4_m3", False, "full", "gelu")):
+        sd = dict((make_trained_like_state_dict if trained else make_state_dict)(name, int(g[f"{tag}_seed"]), attention=att))
+        sd["cls_token"] = g[f"{tag}_cls_token"]
+        m = getattr(models, name)(outputdim=537, target_length=102, pooling="token")
+        m.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()}, strict=True)
+        m = m.to("cuda").eval()
+        p, l = run(m, g["pcm"])
+        dl, dp = np.abs(l - g[f"{tag}_logits"]).max(), np.abs(p - g[f"{tag}_probs"]).max()
+        print(f"pooling token {name}: |logit|max {np.abs(g[f'{tag}_logits']).max():.1f} max|dlogit| {dl:.2e} max|dprob| {dp:.2e}")
+        assert dl < (1.5e-3 if trained else TOL) and dp < TOL
+        if tag == "xxxs":
+            p, l = run(m, g["xxxs_short_pcm"])
+            assert np.abs(l - g["xxxs_short_logits"]).max() < TOL
+            o = Oracle(sd, act=act, pooling="token")
+            for pcm in (synth_pcm_i16(1, 16000, seed=1), synth_pcm_i16(9, 16000, seed=2), synth_pcm_i16(3, 16384, seed=3)):
+                ref = o.forward(pcm)
+                p, l = run(m, pcm)
+                assert np.abs(l - ref["logits"]).max() < TOL and np.abs(p - ref["probs"]).max() < TOL
+
+
 @pytest.mark.parametrize("avg", ["mean", "max"])
 def test_golden_ten_crop_clip(golden, avg):
     """AudioSet-style 10 s clips: 160 000 samples -> 1001 frames -> 10 crops, tail re-cropped (models/uit.py:468-488;

@@ -101,9 +101,16 @@ def test_strict_load_and_pos_embed_resize():
 
 def test_unsupported_variants_raise():
     with pytest.raises(NotImplementedError):
-        models.UITBase(embed_dim=128, depth=4, num_heads=2, mlp_ratio=3.0, pooling="token",
+        models.UITBase(embed_dim=128, depth=4, num_heads=2, mlp_ratio=3.0, pooling="mean", init_bn=False,
                        attention_type="BNeckAttention", act_layer=torch.nn.ReLU)
-    assert models.uit_xs(pooling="dm").pooling == "dm"          # built (POOL = 1 instantiation); 'token' is not
+    with pytest.raises(NotImplementedError):
+        models.uit_xs(patch_size=8, patch_stride=8)
+    with pytest.raises(NotImplementedError):
+        models.uit_xs(init_values=1e-4)                          # LayerScale
+    assert models.uit_xs(pooling="dm").pooling == "dm"          # POOL = 1 instantiation
+    assert models.UITBase(embed_dim=128, depth=4, num_heads=2, mlp_ratio=3.0).pooling == "token"   # the reference's defaults: POOL = 2
+    with pytest.raises(NotImplementedError):
+        models.uit_xs(pooling="token", precision="bf16")
     with pytest.raises(NotImplementedError):
         models.uit_xs(pooling="dm", precision="bf16")
     with pytest.raises(NotImplementedError):

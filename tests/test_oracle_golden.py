@@ -189,3 +189,18 @@ def test_pooling_dm(golden):
         assert np.abs(o.forward(pcm)["probs"] - want).max() < 5e-5
     o = Oracle(make_trained_like_state_dict("uit_xs", int(g["xs_trained_seed"])), pooling="dm")
     assert np.abs(o.forward(g["pcm"])["probs"] - g["xs_trained_probs"]).max() < 5e-5
+
+
+def test_pooling_token(golden):
+    """pooling='token' (models/uit.py:389-392, 399-401; the UITBase default) against the imported reference."""
+    from synth_weights import make_trained_like_state_dict
+    g = golden("pooling_token")
+    for tag, name, trained, att, act in (("xxxs", "uit_xxxs", False, "bneck", "relu"), ("xs_trained", "uit_xs", True, "bneck", "relu"),
+                                         ("h128", "audio_transformer_h128_d4_m3", False, "full", "gelu")):
+        sd = dict((make_trained_like_state_dict if trained else make_state_dict)(name, int(g[f"{tag}_seed"]), attention=att))
+        sd["cls_token"] = g[f"{tag}_cls_token"]
+        o = Oracle(sd, act=act, pooling="token")
+        r = o.forward(g["pcm"])
+        assert np.abs(r["logits"] - g[f"{tag}_logits"]).max() < 2e-4 and np.abs(r["probs"] - g[f"{tag}_probs"]).max() < 5e-5
+        if tag == "xxxs":
+            assert np.abs(o.forward(g["xxxs_short_pcm"])["logits"] - g["xxxs_short_logits"]).max() < 1e-4

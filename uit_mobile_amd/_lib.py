@@ -26,7 +26,7 @@ class Config(Structure):
     _fields_ = [(n, c_int32) for n in ("depth", "embed_dim", "num_heads", "mlp_hidden", "outputdim",
                                        "target_length", "n_mels", "n_fft", "hop_size", "win_size", "patch_size",
                                        "center", "eval_avg", "precision")] + [("top_db", c_float), ("attention_full", c_int32),
-                                                                                 ("act_gelu", c_int32), ("pooling_dm", c_int32)]
+                                                                                 ("act_gelu", c_int32), ("pooling", c_int32)]
 
 
 _BLOCK_FIELDS = ["norm1_w", "norm1_b", "qkv_w", "qkv_b", "proj_w", "proj_b", "norm2_w", "norm2_b",
@@ -40,7 +40,8 @@ class BlockWeights(Structure):
 
 
 class Weights(Structure):
-    _fields_ = [(n, c_void_p) for n in _GLOBAL_FIELDS] + [("blocks", POINTER(BlockWeights))]
+    _fields_ = [(n, c_void_p) for n in _GLOBAL_FIELDS] + [("blocks", POINTER(BlockWeights)), ("cls_token", c_void_p),
+                                                          ("token_pos", c_void_p)]
 
 
 _lib = None

@@ -162,13 +162,14 @@ float* uitk_amax_ptr(uitk_model* m) { return m ? m->amax + m->amax_cur * AMAX_SL
 
 int uitk_set_debug_tokens(uitk_model* m, float* dev_buf) {
     if (!m) return fail(UITK_ERR_INVALID_ARG, "null model");
+    if (dev_buf && m->cfg.pooling == 2) return fail(UITK_ERR_UNSUPPORTED, "the token dump is laid out for 24 tokens per clip (not for pooling 'token')");
     m->dbg = dev_buf;
     return UITK_OK;
 }
 
 int uitk_set_timing_buffers(uitk_model* m, unsigned long long* enc_buf, unsigned long long* fe_buf) {
     if (!m) return fail(UITK_ERR_INVALID_ARG, "null model");
-    if ((enc_buf || fe_buf) && (m->cfg.precision != UITK_PREC_F16 || m->cfg.attention_full || m->cfg.act_gelu || m->cfg.pooling_dm))
+    if ((enc_buf || fe_buf) && (m->cfg.precision != UITK_PREC_F16 || m->cfg.attention_full || m->cfg.act_gelu || m->cfg.pooling))
         return fail(UITK_ERR_UNSUPPORTED, "the instrumented kernel builds exist for precision f16, BNeckAttention + ReLU only");
     m->timing = enc_buf; m->timing_fe = fe_buf;
     return UITK_OK;
@@ -215,7 +216,7 @@ int uitk_frontend(uitk_model* m, const void* pcm, int in_dtype, int64_t B, int64
 int uitk_encode(uitk_model* m, int64_t B, int64_t T, float* probs, float* logits, void* stream) {
     if (int rc = check_shape(m, B, T)) return rc;
     if (!probs) return fail(UITK_ERR_INVALID_ARG, "null probs");
-    if (logits && m->cfg.pooling_dm) return fail(UITK_ERR_UNSUPPORTED, "pooling 'dm' has no pre-sigmoid output (models/uit.py:405-412): pass logits = NULL");
+    if (logits && m->cfg.pooling == 1) return fail(UITK_ERR_UNSUPPORTED, "pooling 'dm' has no pre-sigmoid output (models/uit.py:405-412): pass logits = NULL");
     const int nF = uitk_num_frames(m, T), nc = uitk_num_crops(m, T), tl = m->cfg.target_length;
     if ((size_t)B * nc * NTOK * 256 * 2 > m->mel_cap || B != m->fe_B || T != m->fe_T)
         return fail(UITK_ERR_WORKSPACE, "uitk_encode without a matching uitk_frontend (same B and T) before it");
@@ -240,7 +241,7 @@ int uitk_encode(uitk_model* m, int64_t B, int64_t T, float* probs, float* logits
     a.logits = logits; a.dbg = m->dbg;
     a.timing = m->timing; a.ablate = m->enc_ablate;
     a.split_pe = m->split_pe;
-    a.attention_full = m->cfg.attention_full; a.act_gelu = m->cfg.act_gelu; a.pooling_dm = m->cfg.pooling_dm;
+    a.attention_full = m->cfg.attention_full; a.act_gelu = m->cfg.act_gelu; a.pooling = m->cfg.pooling;
     a.stagger = m->enc_stagger; a.stagger_group = m->n_cu; a.stagger_mode = m->enc_stagger_mode;
     HIP_TRY(launch_encoder(a, m->cfg.precision, m->enc_waves, m->enc_sched, s));
     if (nc > 1) HIP_TRY(launch_crop_reduce(m->rowprobs, probs, B, nc, a.C, m->cfg.eval_avg, s));

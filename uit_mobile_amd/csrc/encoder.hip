@@ -476,7 +476,8 @@ __device__ __forceinline__ unsigned long long stamp() {
 // SHORT: clips with fewer than 6 time patches (masked padding tokens; a separate instantiation keeps the full-clip kernel's
 // register allocation untouched).
 // ATT: 0 = BNeckAttention (the uit_* family), 1 = full-width Attention (2 heads x 64; 20 ring stages per block).  ACT: 0 ReLU, 1 GELU.
-// POOL: 0 = pooling 'mean', 1 = pooling 'dm' (models/uit.py:405-412).
+// POOL: 0 = pooling 'mean', 1 = pooling 'dm' (models/uit.py:405-412), 2 = pooling 'token' (:389-392, 399-401): ONE clip per wave,
+// column 0 = the cls token, columns 1..24 = the patch tokens, columns 25..47 dead (masked as keys, never read as outputs).
 template <int PREC, int WAVES, bool SHORT, bool TIMING, int ABL = 0, int ATT = 0, int ACT = 0, int POOL = 0>
 __global__ __launch_bounds__(WAVES * 64, 2) void uit_encoder_kernel(EncoderArgs a) {
     constexpr int OPC = PREC == 2 ? 0 : PREC;              // precision fp8: patch embed, attention, proj and head stay f16
@@ -536,16 +537,28 @@ __global__ __launch_bounds__(WAVES * 64, 2) void uit_encoder_kernel(EncoderArgs 
     TSTAMP(12);                                                           // weight-stream kick
 
     // ---- rows (clip-crops) of this wave, token maps
-    const int r0 = (blockIdx.x * WAVES + wave) * 2;
-    const int row_lo = r0 < a.rows ? r0 : a.rows - 1, row_hi = r0 + 1 < a.rows ? r0 + 1 : a.rows - 1;
+    constexpr bool TOK = POOL == 2;
+    constexpr bool PERKEY = SHORT || TOK;                   // softmax maxima with per-key masks (padding / dead columns exist)
+    const int r0 = TOK ? blockIdx.x * WAVES + wave : (blockIdx.x * WAVES + wave) * 2;
+    const int row_lo = r0 < a.rows ? r0 : a.rows - 1, row_hi = TOK ? row_lo : (r0 + 1 < a.rows ? r0 + 1 : a.rows - 1);
     int clip_[3], tk_[3], pf_[3], pt_[3];
+    bool patch_[3];                                         // the column holds a patch token (TOK: not the cls token, not dead)
 #pragma unroll
     for (int ct = 0; ct < 3; ++ct) {
         const int col = 16 * ct + c;
-        clip_[ct] = col >= NTOK ? 1 : 0;
-        tk_[ct] = col - NTOK * clip_[ct];
-        pf_[ct] = tk_[ct] / GT;
-        pt_[ct] = tk_[ct] - GT * pf_[ct];
+        if constexpr (TOK) {
+            clip_[ct] = 0;
+            patch_[ct] = col >= 1 && col <= NTOK;
+            tk_[ct] = patch_[ct] ? col - 1 : 0;                              // patch index (clamped for cls / dead columns)
+            pf_[ct] = tk_[ct] / GT;
+            pt_[ct] = patch_[ct] ? tk_[ct] - GT * pf_[ct] : (col == 0 ? 0 : 99);   // cls: always valid; dead: never
+        } else {
+            clip_[ct] = col >= NTOK ? 1 : 0;
+            patch_[ct] = true;
+            tk_[ct] = col - NTOK * clip_[ct];
+            pf_[ct] = tk_[ct] / GT;
+            pt_[ct] = tk_[ct] - GT * pf_[ct];
+        }
     }
     // ---- issue ALL patch loads now (3 token tiles x 8 k-steps x 16 B per lane).  The front-end wrote each token's
     // 256 operands contiguously in k-slot order ((s,g,j) <-> mel 2s+(g>>1), frame 8(g&1)+j = offset 32s+8g+j),
@@ -563,7 +576,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void uit_encoder_kernel(EncoderArgs 
 #pragma unroll
     for (int ct = 0; ct < 3; ++ct)
 #pragma unroll
-        for (int ft = 0; ft < 8; ++ft) R[ft][ct] = *(const f4*)(a.pe_bias + tk_[ct] * DIM + 16 * ft + 4 * g);
+        for (int ft = 0; ft < 8; ++ft) R[ft][ct] = *(const f4*)(a.pe_bias + (patch_[ct] ? tk_[ct] : NTOK) * DIM + 16 * ft + 4 * g);   // row 24: cls
     // init_bn scale / shift of mel bin `lane`: two coalesced dword loads per wave; the 24 (token tile, k-step) clamp
     // thresholds of a lane are then handed out through a wave-private 512-byte LDS table (zbuf is idle until the head)
     const float my_sc = a.bn_sc[lane], my_sh = a.bn_sh[lane];
@@ -587,7 +600,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void uit_encoder_kernel(EncoderArgs 
     }
 #pragma unroll
     for (int ct = 0; ct < 3; ++ct) {
-        const bool live = pt_[ct] < a.nt;
+        const bool live = patch_[ct] && pt_[ct] < a.nt;                   // cls / dead columns carry no patch: operand 0
         const float* trow = clamp_tab + 16 * pf_[ct] + 8 * (g >> 1);
         const f4 th_lo = *(const f4*)trow, th_hi = *(const f4*)(trow + 4);
         const f4 sc_lo = *(const f4*)(trow + 64), sc_hi = *(const f4*)(trow + 68);
@@ -654,13 +667,17 @@ __global__ __launch_bounds__(WAVES * 64, 2) void uit_encoder_kernel(EncoderArgs 
     for (int i = 0; i < 7; ++i) {
         const int qc = (16 * TI[i] + c) >= NTOK ? 1 : 0;
         const int jc = (16 * TJ[i] + 4 * g) >= NTOK ? 1 : 0;
-        tvalid[i] = jc == qc;
+        tvalid[i] = TOK ? true : jc == qc;
         unsigned m[4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int j = 16 * TJ[i] + 4 * g + r;
-            const int jt = (j - NTOK * jc) % GT;
-            m[r] = (jc == qc && jt < a.nt) ? 0xFFFFu : 0u;
+            if constexpr (TOK) {                           // one clip: key column j is the cls token, a valid patch token, or dead
+                m[r] = (j == 0 || (j <= NTOK && ((j - 1) % GT) < a.nt)) ? 0xFFFFu : 0u;
+            } else {
+                const int jt = (j - NTOK * jc) % GT;
+                m[r] = (jc == qc && jt < a.nt) ? 0xFFFFu : 0u;
+            }
         }
         pmask[i] = u2{m[0] | (m[1] << 16), m[2] | (m[3] << 16)};
     }
@@ -711,7 +728,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void uit_encoder_kernel(EncoderArgs 
                 s1[d] = *(const int*)(slot + FP8_MLP_SCALES + d * 256 + lane * 4);
                 s2[d] = *(const int*)(slot + FP8_MLP_SCALES + (6 + d) * 256 + lane * 4);
             }
-            attention_proj<OP, SHORT>(R, Qh, Kh, Vh, tvalid, pmask, slot, bias, lane, g);
+            attention_proj<OP, PERKEY>(R, Qh, Kh, Vh, tvalid, pmask, slot, bias, lane, g);
         }
         // ----- MLP: three k-groups of 128 hidden features: fc1 tiles 8q..8q+7 -> relu -> e4m3 -> fc2 k-group q
         layernorm_to_fp8(R, 1e-6f, X8);
@@ -798,7 +815,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void uit_encoder_kernel(EncoderArgs 
 #pragma unroll
                 for (int dt = 0; dt < 4; ++dt) acc = OP::mfma16(Kp[dt][TJ[i]], Qp[dt][TI[i]], acc);
                 S[i] = acc;
-                if constexpr (SHORT) {
+                if constexpr (PERKEY) {
                     f4 sv;
 #pragma unroll
                     for (int r = 0; r < 4; ++r) sv[r] = ((r < 2 ? pmask[i][0] : pmask[i][1]) >> (16 * (r & 1))) & 1u ? S[i][r] : -INFINITY;
@@ -927,7 +944,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void uit_encoder_kernel(EncoderArgs 
                     }
                 }
             }
-            attention_proj<OP, SHORT>(R, Qh, Kh, Vh, tvalid, pmask, slot + 8 * FRAG_BYTES, bias, lane, g);
+            attention_proj<OP, PERKEY>(R, Qh, Kh, Vh, tvalid, pmask, slot + 8 * FRAG_BYTES, bias, lane, g);
         }
 
         }
@@ -1123,6 +1140,76 @@ __global__ __launch_bounds__(WAVES * 64, 2) void uit_encoder_kernel(EncoderArgs 
         }
         return;
     }
+    if constexpr (POOL == 2) {
+        // ===== pooling 'token' (models/uit.py:399-401): the cls row (column 0 = tile 0, lanes c == 0) of norm(x) -> outputlayer
+        // -> sigmoid.  One clip per wave: WAVES clip slots per workgroup.
+        const int ntiles = (a.C + 15) / 16;
+        float mean0, rstd0;
+        ln_stats(R, 0, 1e-6f, mean0, rstd0);
+        f4 pooled[8];
+        {
+            f4 acc = splat(0.f);
+#pragma unroll
+            for (int ft = 0; ft < 8; ++ft) {
+                const f4 gw = *(const f4*)(a.fin + 0 * DIM + 16 * ft + 4 * g);
+                const f4 gb = *(const f4*)(a.fin + 1 * DIM + 16 * ft + 4 * g);
+                pooled[ft] = (R[ft][0] - splat(mean0)) * splat(rstd0) * gw + gb;
+                acc = acc + pooled[ft];
+            }
+            const float mean = xsum(hsum(acc)) * (1.0f / DIM);
+            f4 q = splat(0.f);
+#pragma unroll
+            for (int ft = 0; ft < 8; ++ft) { const f4 d = pooled[ft] - splat(mean); q = q + d * d; }
+            const float rs = __builtin_amdgcn_rsqf(xsum(hsum(q)) * (1.0f / DIM) + 1e-5f);
+#pragma unroll
+            for (int ft = 0; ft < 8; ++ft) {
+                const f4 gw = *(const f4*)(a.fin + 2 * DIM + 16 * ft + 4 * g);
+                const f4 gb = *(const f4*)(a.fin + 3 * DIM + 16 * ft + 4 * g);
+                const f4 z = (pooled[ft] - splat(mean)) * splat(rs) * gw + gb;
+                if (c == 0) {
+                    const v4 zh = OP::pack4(z);
+                    *(v4*)(zbuf + (wave * DIM + 16 * ft + 4 * g) * 2) = zh;
+                    *(v4*)(zbuf + 16 * DIM * 2 + (wave * DIM + 16 * ft + 4 * g) * 2) = OP::pack4(z - OP::unpack4(zh));
+                }
+            }
+        }
+        __syncthreads();
+        const int cz = c < WAVES ? c : 0;
+        v8 Bz[4], Bzl[4];
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const v4 l0 = *(const v4*)(zbuf + (cz * DIM + 32 * s + 4 * g) * 2);
+            const v4 h0 = *(const v4*)(zbuf + (cz * DIM + 32 * s + 16 + 4 * g) * 2);
+            Bz[s] = v8{l0[0], l0[1], l0[2], l0[3], h0[0], h0[1], h0[2], h0[3]};
+            const v4 l1 = *(const v4*)(zbuf + 16 * DIM * 2 + (cz * DIM + 32 * s + 4 * g) * 2);
+            const v4 h1 = *(const v4*)(zbuf + 16 * DIM * 2 + (cz * DIM + 32 * s + 16 + 4 * g) * 2);
+            Bzl[s] = v8{l1[0], l1[1], l1[2], l1[3], h1[0], h1[1], h1[2], h1[3]};
+        }
+        const int row0 = blockIdx.x * WAVES + 4 * g;
+        for (int ot = wave; ot < ntiles; ot += WAVES) {
+            const int cls = 16 * ot + c;
+            f4 acc = splat(a.head_b[cls]);
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                const v8 Hc = *(const v8*)(a.head_w + (size_t)(ot * 4 + s) * 2 * FRAG_BYTES + lane * 16);
+                const v8 Hlo = *(const v8*)(a.head_w + ((size_t)(ot * 4 + s) * 2 + 1) * FRAG_BYTES + lane * 16);
+                acc = OP::mfma32(Bz[s], Hlo, acc);
+                acc = OP::mfma32(Bzl[s], Hc, acc);
+                acc = OP::mfma32(Bz[s], Hc, acc);
+            }
+            if (cls < a.C) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int rowg = row0 + r;
+                    if (4 * g + r < WAVES && rowg < a.rows) {
+                        if (a.logits) a.logits[(int64_t)rowg * a.C + cls] = acc[r];
+                        a.probs[(int64_t)rowg * a.C + cls] = __builtin_amdgcn_rcpf(1.0f + __expf(-acc[r]));
+                    }
+                }
+            }
+        }
+        return;
+    }
     unsigned long long t_blocks_end = 0;
     if constexpr (TIMING) { t_blocks_end = stamp(); tlast = t_blocks_end; }
     // classifier weights of this wave's first output tile: fetched now, consumed after pooling
@@ -1298,7 +1385,8 @@ static hipError_t launch_enc(const EncoderArgs& a, hipStream_t stream) {
         if (e != hipSuccess) return e;
         attr_done.fetch_or(bit, std::memory_order_release);
     }
-    const int grid = (a.rows + 2 * WAVES - 1) / (2 * WAVES);
+    const int per_wg = POOL == 2 ? WAVES : 2 * WAVES;     // clip rows per workgroup (pooling 'token': one clip per wave)
+    const int grid = (a.rows + per_wg - 1) / per_wg;
     hipLaunchKernelGGL((uit_encoder_kernel<PREC, WAVES, SHORT, TIMING, ABL, ATT, ACT, POOL>), dim3(grid), dim3(WAVES * 64),
                        WAVES == 8 ? ENC_LDS_SPLIT_PE : ENC_LDS, stream, a);
     return hipGetLastError();
@@ -1323,12 +1411,13 @@ hipError_t launch_encoder(const EncoderArgs& a, int precision, int waves, int sc
     if (a.timing != nullptr)                              // diagnostic build with in-kernel stamps (f16, full clips only)
         return waves == 4 ? launch_enc<0, 4, false, true>(a, stream) : launch_enc<0, 8, false, true>(a, stream);
     (void)sched;
-    if (a.pooling_dm) {                                   // pooling 'dm' (f16, 8-wave workgroups), any attention / activation
+    if (a.pooling) {                                      // pooling 'dm' / 'token' (f16, 8-wave workgroups), any attention / activation
         if (precision != 0 || a.timing != nullptr) return hipErrorInvalidValue;
-#define UITK_DM(SH) (a.attention_full ? (a.act_gelu ? launch_enc<0, 8, SH, false, 0, 1, 1, 1>(a, stream) : launch_enc<0, 8, SH, false, 0, 1, 0, 1>(a, stream)) \
-                                      : (a.act_gelu ? launch_enc<0, 8, SH, false, 0, 0, 1, 1>(a, stream) : launch_enc<0, 8, SH, false, 0, 0, 0, 1>(a, stream)))
-        return a.nt < GT ? UITK_DM(true) : UITK_DM(false);
-#undef UITK_DM
+#define UITK_POOL(SH, PL) (a.attention_full ? (a.act_gelu ? launch_enc<0, 8, SH, false, 0, 1, 1, PL>(a, stream) : launch_enc<0, 8, SH, false, 0, 1, 0, PL>(a, stream)) \
+                                            : (a.act_gelu ? launch_enc<0, 8, SH, false, 0, 0, 1, PL>(a, stream) : launch_enc<0, 8, SH, false, 0, 0, 0, PL>(a, stream)))
+        if (a.pooling == 2) return UITK_POOL(true, 2);     // per-key softmax masks always (dead columns)
+        return a.nt < GT ? UITK_POOL(true, 1) : UITK_POOL(false, 1);
+#undef UITK_POOL
     }
     if (a.attention_full || a.act_gelu) {                 // SURVEY 8f-4 variants: f16 / bf16, 8-wave workgroups
         if (precision == 2 || a.timing != nullptr) return hipErrorInvalidValue;

@@ -181,10 +181,10 @@ int validate_config(const uitk_config* c, const char** why) {
     if (c->eval_avg != UITK_AVG_MEAN && c->eval_avg != UITK_AVG_MAX) return bad("unknown eval_avg");
     if (c->precision != UITK_PREC_F16 && c->precision != UITK_PREC_BF16 && c->precision != UITK_PREC_FP8) return bad("unknown precision");
     if ((c->attention_full != 0 && c->attention_full != 1) || (c->act_gelu != 0 && c->act_gelu != 1)) return bad("attention_full / act_gelu must be 0 or 1");
-    if ((c->attention_full || c->act_gelu || c->pooling_dm) && c->precision == UITK_PREC_FP8) return bad("precision fp8 is built for the uit_* family (BNeckAttention, ReLU, mean pooling) only");
-    if (c->pooling_dm != 0 && c->pooling_dm != 1) return bad("pooling_dm must be 0 or 1");
-    if (c->pooling_dm && c->precision != UITK_PREC_F16) return bad("pooling 'dm' is built for precision f16");
-    if (c->pooling_dm && c->outputdim > 640) return bad("pooling 'dm' is built for outputdim <= 640");
+    if ((c->attention_full || c->act_gelu || c->pooling) && c->precision == UITK_PREC_FP8) return bad("precision fp8 is built for the uit_* family (BNeckAttention, ReLU, mean pooling) only");
+    if (c->pooling < 0 || c->pooling > 2) return bad("pooling must be 0 (mean), 1 (dm) or 2 (token)");
+    if (c->pooling && c->precision != UITK_PREC_F16) return bad("pooling 'dm' / 'token' are built for precision f16");
+    if (c->pooling == 1 && c->outputdim > 640) return bad("pooling 'dm' is built for outputdim <= 640");
     return UITK_OK;
 }
 
@@ -244,7 +244,7 @@ int pack_image(const uitk_config* c, const uitk_weights* w, std::vector<char>* o
     h.off_wstream = take((size_t)(PE_STAGES + depth * blk_stages + TAIL_STAGES) * STAGE_BYTES);
     h.off_bias = take((size_t)depth * BIAS_FLOATS * 4);
     h.off_bn_sc = take(NMEL * 4); h.off_bn_sh = take(NMEL * 4);
-    h.off_pe_bias = take(NTOK * DIM * 4);
+    h.off_pe_bias = take((NTOK + 1) * DIM * 4);                       // + the cls row (pooling 'token')
     h.off_fin = take(4 * DIM * 4);
     h.off_head_w = take((size_t)ntiles * 4 * 2 * FRAG_BYTES);         // hi + lo term per fragment
     h.off_head_b = take((size_t)ntiles * 16 * 4);
@@ -300,6 +300,15 @@ int pack_image(const uitk_config* c, const uitk_weights* w, std::vector<char>* o
             mean /= DIM;                                                // residual centring (see the file header)
             for (int oc = 0; oc < DIM; ++oc) peb[(pf * GT + pt) * DIM + oc] = (float)(row[oc] - mean);
         }
+    {   // row 24: the cls token of pooling 'token' (cls_token + token_pos_embed, uit.py:389-391), centred like the others
+        double row[DIM], mean = 0.0;
+        for (int oc = 0; oc < DIM; ++oc) {
+            row[oc] = (w->cls_token ? (double)w->cls_token[oc] : 0.0) + (w->token_pos ? (double)w->token_pos[oc] : 0.0);
+            mean += row[oc];
+        }
+        mean /= DIM;
+        for (int oc = 0; oc < DIM; ++oc) peb[NTOK * DIM + oc] = (float)(row[oc] - mean);
+    }
     // ---- final norms
     float* fin = (float*)(img + h.off_fin);
     std::memcpy(fin + 0 * DIM, w->norm_w, DIM * 4); std::memcpy(fin + 1 * DIM, w->norm_b, DIM * 4);

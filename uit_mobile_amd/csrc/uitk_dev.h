@@ -81,7 +81,7 @@ struct EncoderArgs {
     const float* bias;      // [depth][BIAS_FLOATS]
     const float* bn_sc;     // [64]  w / sqrt(var + 1e-5)
     const float* bn_sh;     // [64]  b - mean * sc
-    const float* pe_bias;   // [24][128] conv bias + time_pos + freq_pos
+    const float* pe_bias;   // [25][128] conv bias + time_pos + freq_pos (rows 0..23), cls_token + token_pos_embed (row 24); centred
     const float* fin;       // [4][128] norm.w, norm.b, head_ln.w, head_ln.b
     const char* head_w;     // [ceil(C/16)][4] fragments
     const float* head_b;    // [ceil(C/16)*16]
@@ -91,7 +91,8 @@ struct EncoderArgs {
     unsigned long long* timing;  // diagnostics: [waves][12] phase cycle sums (null = off, normal build)
     int attention_full;     // 0 = BNeckAttention, 1 = Attention (full width, 2 heads x 64)
     int act_gelu;           // MLP activation: 0 = ReLU, 1 = exact (erf) GELU
-    int pooling_dm;         // 0 = mean over the tokens, 1 = 'dm' (per time patch: mean over frequency patches -> head -> sigmoid; mean over time)
+    int pooling;            // 0 = mean over the tokens, 1 = 'dm' (per time patch: mean over frequency patches -> head -> sigmoid; mean over
+                            // time), 2 = 'token' (a cls token in column 0 of a ONE-clip wave; its row feeds the head)
     int split_pe;           // 1 = patch embed on split weights (W = hi + lo, 8-wave workgroups only); 0 = high-order term only
     int ablate;             // timing experiments (builds with -DUITK_ABLATION_BUILDS only): ABL template value
     int stagger;            // 0 = off, else shader cycles to delay every other workgroup generation

@@ -148,7 +148,7 @@ class UITBase(nn.Module):
         # what the HIP kernels are built for: the uit_* family (uit.py:581-635: BNeckAttention + ReLU) and the other
         # factories of models/uit.py (:514-579: full-width Attention, ReLU or the default exact GELU); mean pooling
         unsupported = []
-        if pooling not in ('mean', 'dm'): unsupported.append("pooling must be 'mean' or 'dm' ('token' is not built)")
+
         if attention_type not in ('BNeckAttention', 'Attention'): unsupported.append("attention_type must be 'BNeckAttention' or 'Attention'")
         if act_layer is not None and act_layer not in (nn.ReLU, nn.GELU): unsupported.append("act_layer must be nn.ReLU or nn.GELU / None")
         self.attention_full = attention_type == 'Attention'
@@ -162,10 +162,10 @@ class UITBase(nn.Module):
             raise NotImplementedError("uit_mobile_amd implements the uit_xs/xxs/xxxs family only: " + "; ".join(unsupported))
         if precision not in ('f16', 'bf16', 'fp8'):
             raise ValueError(f"Unknown precision ({precision})")
-        if precision == 'fp8' and (self.attention_full or self.act_gelu or pooling == 'dm'):
+        if precision == 'fp8' and (self.attention_full or self.act_gelu or pooling != 'mean'):
             raise NotImplementedError("precision='fp8' is built for the uit_* family (BNeckAttention + ReLU, mean pooling) only")
-        if pooling == 'dm' and precision != 'f16':
-            raise NotImplementedError("pooling='dm' is built for precision='f16'")
+        if pooling != 'mean' and precision != 'f16':
+            raise NotImplementedError("pooling='dm' / 'token' are built for precision='f16'")
 
         self.front_end = nn.Sequential(
             _MelSpectrogramParams(n_fft, self.win_size, f_min, f_max, self.n_mels, 16000), nn.Identity())
@@ -231,7 +231,7 @@ class UITBase(nn.Module):
                            eval_avg={'mean': _lib.AVG_MEAN, 'max': _lib.AVG_MAX}.get(self.eval_avg, -1),
                            precision={'f16': _lib.PREC_F16, 'bf16': _lib.PREC_BF16, 'fp8': _lib.PREC_FP8}[self.precision], top_db=120.0,
                            attention_full=int(self.attention_full), act_gelu=int(self.act_gelu),
-                           pooling_dm=int(self.pooling == 'dm'))
+                           pooling={'mean': 0, 'dm': 1, 'token': 2}[self.pooling])
 
     def _host_weights(self):
         """-> (Weights struct, keep-alive list) with fp32 host pointers in reference layout."""
@@ -259,7 +259,8 @@ class UITBase(nn.Module):
                          time_pos=ptr("time_pos_embed"), freq_pos=ptr("freq_pos_embed"),
                          norm_w=ptr("norm.weight"), norm_b=ptr("norm.bias"),
                          head_ln_w=ptr("outputlayer.0.weight"), head_ln_b=ptr("outputlayer.0.bias"),
-                         head_w=ptr("outputlayer.1.weight"), head_b=ptr("outputlayer.1.bias"), blocks=blocks)
+                         head_w=ptr("outputlayer.1.weight"), head_b=ptr("outputlayer.1.bias"), blocks=blocks,
+                         cls_token=ptr("cls_token"), token_pos=ptr("token_pos_embed"))
         return w, keep
 
     def packed_image(self):
