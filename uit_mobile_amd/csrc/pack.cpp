@@ -232,6 +232,32 @@ int pack_image(const uitk_config* c, const uitk_weights* w, std::vector<char>* o
             if (nw == walk) break;
             walk = nw;
         }
+        // LDS bank spreading (fast path only): a lane's operand read starts at bank (48 x + klo_g + 4 c) mod 64 (x = its frame row),
+        // so two mel groups served in the same 16-lane slice of a ds_read_b128 -- {0,3,5,6}, {1,2,4,7}, {8,11,13,14}, {9,10,12,15}
+        // -- collide when their window starts agree mod 16.  A window may start up to 12 bins early as long as its band still
+        // ends inside the MEL_BMAX steps: pick the cheapest shifts that make the four residues distinct.
+        if (mel_S <= MEL_BMAX && std::getenv("UITK_PACK_NO_BANK_SPREAD") == nullptr) {
+            static const int svc[4][4] = {{0, 3, 5, 6}, {1, 2, 4, 7}, {8, 11, 13, 14}, {9, 10, 12, 15}};
+            for (const auto& sg : svc) {
+                int best = -1, best_cost = 1 << 30;
+                for (int code = 0; code < 256; ++code) {
+                    int res[4], cost = 0; bool ok = true;
+                    for (int i = 0; i < 4 && ok; ++i) {
+                        const int g = sg[i], sh = 4 * ((code >> (2 * i)) & 3), k = grp_klo[g] - sh;
+                        if (k < 0 || (first[g] >= 0 && last[g] - k + 1 > MEL_BMAX)) ok = false;
+                        res[i] = ((k % 16) + 16) % 16; cost += sh;
+                    }
+                    for (int i = 0; i < 4 && ok; ++i)
+                        for (int j = i + 1; j < 4; ++j) if (res[i] == res[j]) ok = false;
+                    if (ok && cost < best_cost) { best = code; best_cost = cost; }
+                }
+                if (best >= 0)
+                    for (int i = 0; i < 4; ++i) grp_klo[sg[i]] -= 4 * ((best >> (2 * i)) & 3);
+            }
+            int S = 4;
+            for (int g = 0; g < 16; ++g) { const int span = first[g] < 0 ? 0 : last[g] - grp_klo[g] + 1; if (span > S) S = (span + 3) & ~3; }
+            mel_S = S;
+        }
     }
     ImageHeader h{};
     h.magic = IMAGE_MAGIC; h.precision = prec; h.depth = depth; h.outputdim = C; h.mel_steps = mel_S;
