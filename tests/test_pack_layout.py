@@ -80,6 +80,10 @@ def test_front_end_filterbank_table_reconstructs_fb(kind):
     tab = np.frombuffer(img, np.float32, S * 64, off + 256).reshape(S // 4, 64, 4)
     assert S % 4 == 0 and np.all(klo % 4 == 0) and np.all(klo >= 0) and np.all(klo + max(S, 52) <= 272)
     assert np.all(klo.reshape(16, 4) == klo.reshape(16, 4)[:, :1])          # one window per 4-mel group
+    if S <= 52:
+        # LDS bank spreading: the four mel groups served in one 16-lane slice of a ds_read_b128 start on distinct residues mod 16
+        for sg in ([0, 3, 5, 6], [1, 2, 4, 7], [8, 11, 13, 14], [9, 10, 12, 15]):
+            assert len({int(klo[4 * g]) % 16 for g in sg}) == 4, (kind, [int(klo[4 * g]) for g in sg])
     assert (S <= 52) == (kind != "dense")
     rec = np.zeros_like(fb)
     for st in range(S):
