@@ -40,14 +40,56 @@ namespace uitk {
 typedef float c32 __attribute__((ext_vector_type(2)));       // complex: (re, im), 8-byte aligned
 typedef float f4v __attribute__((ext_vector_type(4)));
 
+// Packed complex arithmetic.  A c32 lives in a 64-bit VGPR pair; v_pk_{mul,fma,add}_f32 take per-source half selects
+// (op_sel / op_sel_hi) and per-half negation (neg_lo / neg_hi), so a complex multiply is TWO instructions and a
+// multiplication by -i or a conjugation rides on the add that consumes it.  The compiler does not form these modifiers for
+// f32 pairs (it emits 4 scalar mul/fma per complex multiply and v_mov + v_xor per swizzle: 406 VALU instructions in the FFT
+// phase against 300 this way), hence inline asm.  FE_PK_ASM=0 restores the plain C++ forms (same arithmetic, bit for bit:
+// products and sums are formed in the same order, fma where the scalar form contracts to fma).
+#ifndef FE_PK_ASM
+#define FE_PK_ASM 1
+#endif
+#if FE_PK_ASM
+__device__ __forceinline__ c32 cmul(c32 a, c32 w) {          // a * w = (a.x w.x - a.y w.y, a.x w.y + a.y w.x)
+    c32 t, r;
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel:[0,0] op_sel_hi:[0,1]" : "=v"(t) : "v"(a), "v"(w));                       // (a.x w.x, a.x w.y)
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[1,0,0]" : "=v"(r) : "v"(a), "v"(w), "v"(t));   // (-a.y w.y, a.y w.x) + t
+    return r;
+}
+__device__ __forceinline__ c32 add_mi(c32 s, c32 t) {        // s + (-i) t = (s.x + t.y, s.y - t.x)
+    c32 r;
+    asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_hi:[0,1]" : "=v"(r) : "v"(s), "v"(t));
+    return r;
+}
+__device__ __forceinline__ c32 sub_mi(c32 s, c32 t) {        // s - (-i) t = (s.x - t.y, s.y + t.x)
+    c32 r;
+    asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1]" : "=v"(r) : "v"(s), "v"(t));
+    return r;
+}
+__device__ __forceinline__ c32 add_conj(c32 a, c32 b) {      // a + conj(b)
+    c32 r;
+    asm("v_pk_add_f32 %0, %1, %2 neg_hi:[0,1]" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ c32 sub_conj(c32 a, c32 b) {      // a - conj(b)
+    c32 r;
+    asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1]" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+#else
 __device__ __forceinline__ c32 cmul(c32 a, c32 w) { return c32{a.x * w.x - a.y * w.y, a.x * w.y + a.y * w.x}; }
-__device__ __forceinline__ c32 mul_mi(c32 a) { return c32{a.y, -a.x}; }   // a * (-i)
+__device__ __forceinline__ c32 add_mi(c32 s, c32 t) { return c32{s.x + t.y, s.y - t.x}; }
+__device__ __forceinline__ c32 sub_mi(c32 s, c32 t) { return c32{s.x - t.y, s.y + t.x}; }
+__device__ __forceinline__ c32 add_conj(c32 a, c32 b) { return c32{a.x + b.x, a.y - b.y}; }
+__device__ __forceinline__ c32 sub_conj(c32 a, c32 b) { return c32{a.x - b.x, a.y + b.y}; }
+#endif
 
-// forward 4-point DFT (W4 = -i) in place
+// forward 4-point DFT (W4 = -i) in place; CMI: the third input is still to be multiplied by -i (folded into its adds)
+template <bool CMI = false>
 __device__ __forceinline__ void dft4(c32& a, c32& b, c32& c, c32& d) {
-    const c32 s0 = a + c, s1 = a - c, s2 = b + d, s3 = mul_mi(b - d);
+    const c32 s0 = CMI ? add_mi(a, c) : a + c, s1 = CMI ? sub_mi(a, c) : a - c, s2 = b + d, t = b - d;
     a = s0 + s2; c = s0 - s2;
-    b = s1 + s3; d = s1 - s3;
+    b = add_mi(s1, t); d = sub_mi(s1, t);
 }
 
 // forward 16-point DFT in place, natural order in.  OUTPUT ORDER: Y[k] is left in v[FPOS(k)] (no reorder copy).
@@ -61,18 +103,23 @@ __device__ __forceinline__ void fft16(c32 (&v)[16]) {
     v[4 + 2] = cmul(v[4 + 2], c32{H, -H});     // W^2
     v[4 + 3] = cmul(v[4 + 3], c32{S1, -C1});   // W^3
     v[8 + 1] = cmul(v[8 + 1], c32{H, -H});     // W^2
-    v[8 + 2] = mul_mi(v[8 + 2]);               // W^4 = -i
+    //                                            W^4 = -i on v[8 + 2]: folded into the k1 = 2 butterfly below
     v[8 + 3] = cmul(v[8 + 3], c32{-H, -H});    // W^6
     v[12 + 1] = cmul(v[12 + 1], c32{S1, -C1}); // W^3
     v[12 + 2] = cmul(v[12 + 2], c32{-H, -H});  // W^6
     v[12 + 3] = cmul(v[12 + 3], c32{-C1, S1}); // W^9
-#pragma unroll
-    for (int k1 = 0; k1 < 4; ++k1) dft4(v[4 * k1 + 0], v[4 * k1 + 1], v[4 * k1 + 2], v[4 * k1 + 3]);
+    dft4(v[0], v[1], v[2], v[3]);
+    dft4(v[4], v[5], v[6], v[7]);
+    dft4<true>(v[8], v[9], v[10], v[11]);
+    dft4(v[12], v[13], v[14], v[15]);
 }
 
 #ifndef FE_LDS_TABLES
 #define FE_LDS_TABLES 0      // mask of constant tables kept in LDS instead of per-lane VGPRs (1 window, 2 W256, 4 W512); 0 measured fastest
 #endif
+#ifndef FE_ABLATE
+#define FE_ABLATE 0          // timing-only ablation builds (tools/ab): 1 no sample loads, 2 no mel MFMAs, 4 no log, 8 no stores,
+#endif                       // 16 no FFT phase, 32 no split/power; results are wrong by construction -- never set in the product build
 constexpr int FE_WAVES = 4;
 #ifndef FE_OCC
 #define FE_OCC 2             // workgroups per CU the register allocation aims at
@@ -136,7 +183,7 @@ __global__ __launch_bounds__(FE_WAVES * 64, FE_OCC) void mel_frontend_kernel(Fro
         const int i = tid;                                               // 256 threads
         if (FE_LDS_TABLES & 1) Wwin[i] = *(const c32*)(a.window + 2 * i);
         if (FE_LDS_TABLES & 2) { const float2 t = a.tw256[(i & 15) * 16 + (i >> 4)]; Wtw[i] = c32{t.x, t.y}; }   // source is [p][k1]
-        if ((FE_LDS_TABLES & 4) && i < 128) { const float2 u = a.tw512[i]; Wpw[i] = c32{u.x, u.y}; }
+        if ((FE_LDS_TABLES & 4) && i < 128) { const float2 u = a.tw512[i]; Wpw[i] = c32{-u.y, -u.x}; }
     }
     __syncthreads();
     c32 win_[16], tw_[16], pw_[8];                                       // per-lane VGPR constants
@@ -150,18 +197,23 @@ __global__ __launch_bounds__(FE_WAVES * 64, FE_OCC) void mel_frontend_kernel(Fro
     }
     if (!(FE_LDS_TABLES & 4)) {
 #pragma unroll
-        for (int j = 0; j < 8; ++j) { const float2 t = a.tw512[p + 16 * j]; pw_[j] = c32{t.x, t.y}; }
+        for (int j = 0; j < 8; ++j) { const float2 t = a.tw512[p + 16 * j]; pw_[j] = c32{-t.y, -t.x}; }   // -i conj(w), w = (cos, sin)(2 pi k/512)
     }
 #define WIN(m1) ((FE_LDS_TABLES & 1) ? Wwin[16 * (m1) + p] : win_[m1])
 #define TW(k1) ((FE_LDS_TABLES & 2) ? Wtw[16 * (k1) + p] : tw_[k1])
 #define PW(j) ((FE_LDS_TABLES & 4) ? Wpw[p + 16 * (j)] : pw_[j])
 
     // "full" passes are (clip b, column k): frames 16k..16k+15; the nF % 16 leftover frames of a clip are bundled,
-    // per_tail clips at a time, into "tail" passes (for 1 s clips: 6 full passes per clip + one tail pass per 3 clips)
+    // per_tail clips at a time, into "tail" passes (for 1 s clips: 6 full passes per clip + one tail pass per 3 clips).
+    // A workgroup walks pass = blockIdx.x + i * gridDim.x as the pair (cb, ck), pass = cb * max(full, 1) + ck: full passes
+    // first (cb < B), then tail passes.  The two kinds run SPECIALISED loop bodies: a wave's instruction stream -- scalar
+    // bookkeeping included -- is its critical path (two waves per SIMD: measured 1.37x from the second wave, nothing from a
+    // third), so the full-pass body carries no tail / dead-slot logic, forms its addresses as uniform base + lane-invariant
+    // 32-bit offset, and needs no 64-bit arithmetic per lane.
     const int full = a.nF >> 4, rem = a.nF & 15;
     const int per_tail = rem ? 16 / rem : 1;
-    const int64_t nfull = a.B * (int64_t)full;
-    const int64_t npass = nfull + (rem ? (a.B + per_tail - 1) / per_tail : 0);
+    const int B = (int)a.B;
+    const int ntail = rem ? (B + per_tail - 1) / per_tail : 0;
     // per-lane (clip offset, frame) of the 16 slots of a tail pass: slot = 4*wave+q in the FFT phase, 4q+r in the mel phase
     const int tslot = 4 * wave + q;
     const int t_cl = rem ? tslot / rem : 0, t_fr = rem ? tslot - t_cl * rem : 0;
@@ -170,46 +222,50 @@ __global__ __launch_bounds__(FE_WAVES * 64, FE_OCC) void mel_frontend_kernel(Fro
     for (int r = 0; r < 4; ++r) { m_cl[r] = rem ? (4 * wave + r) / rem : 0; m_fr[r] = rem ? (4 * wave + r) - m_cl[r] * rem : 0; }
     const int T = (int)a.T;
     const bool pair_ok = (T & 1) == 0;                   // pair loads need every row to start pair-aligned
+    constexpr int ES = I16 ? 2 : 4;                      // bytes per sample
     float lmax = -INFINITY;
-    int it = 0;
     // mel phase lane map (v_mfma_f32_4x4x1, 16 blocks): lane = 4*group + x; as A operand x = frame row of this wave's
     // quad, as B operand / result x = mel within the group, i.e. result column = mel `lane`
     const float bn_sc = PATCH ? a.bn_sc[lane] : 0.f, bn_sh = PATCH ? a.bn_sh[lane] : 0.f;   // init_bn scale/shift of mel `lane`
-    // raw (unwindowed) sample pairs of this lane's frame for a pass: z[m1] = (x[32 m1 + 2p], x[32 m1 + 2p + 1])
-    // (clip, column) of a full pass are tracked incrementally by the pass loop: a 64-bit division costs ~130 scalar
-    // instructions per use
-    auto load_pass = [&](int64_t pass, int pb_, int pk_, c32 (&raw)[16]) {
-        int b, f;
-        if (pass < nfull) {
-            b = pb_;
-            f = 16 * pk_ + 4 * wave + q;
-        } else {
-            const int64_t cb = (pass - nfull) * per_tail;
-            if (4 * wave >= per_tail * rem) return;                       // fully dead quad of a tail pass (uniform)
-            b = (int)cb + t_cl; f = 16 * full + t_fr;
-            if (t_cl >= per_tail || b >= a.B) { b = (int)cb; f = 16 * full; }    // dead slot: any valid frame
+    // raw (unwindowed) sample pairs of a lane's frame: z[m1] = (x[32 m1 + 2p], x[32 m1 + 2p + 1]); `row` = the clip's first
+    // sample (uniform for a full pass), su + sl = index of the lane's first sample (su uniform, sl >= 0 lane-invariant)
+    auto load_frame = [&](const char* row, int su, int sl, c32 (&raw)[16]) {
+        if (FE_ABLATE & 1) {
+#pragma unroll
+            for (int m1 = 0; m1 < 16; ++m1) raw[m1] = c32{(float)(lane + m1) * 1e-3f, (float)(su & 7)};
+            return;
         }
-        const int64_t row_off = (int64_t)b * a.T;
-        const int s0 = f * a.hop - 256 + 2 * p;
+        const int s0 = su + sl;
         if (pair_ok && s0 >= 0 && s0 + 32 * 15 + 1 < T) {                 // interior frame: no reflection, pair loads
+            const char* src = row + (int64_t)su * ES + (unsigned)(sl * ES);    // scalar base + 32-bit lane offset
             if (I16) {
-                const int16_t* src = (const int16_t*)a.pcm + row_off + s0;
 #pragma unroll
                 for (int m1 = 0; m1 < 16; ++m1) {
-                    const short2 s2 = *(const short2*)(src + 32 * m1);
+                    const short2 s2 = *(const short2*)(src + 32 * ES * m1);
                     raw[m1] = c32{(float)s2.x, (float)s2.y} * (1.0f / 32768.0f);
                 }
             } else {
-                const float* src = (const float*)a.pcm + row_off + s0;
 #pragma unroll
-                for (int m1 = 0; m1 < 16; ++m1) raw[m1] = *(const c32*)(src + 32 * m1);
+                for (int m1 = 0; m1 < 16; ++m1) raw[m1] = *(const c32*)(src + 32 * ES * m1);
             }
         } else {
+            const int64_t row_off = (row - (const char*)a.pcm) / ES;
 #pragma unroll
             for (int m1 = 0; m1 < 16; ++m1)
                 raw[m1] = c32{load_sample<I16>(a.pcm, row_off, T, s0 + 32 * m1),
                               load_sample<I16>(a.pcm, row_off, T, s0 + 32 * m1 + 1)};
         }
+    };
+    const int sl_full = (4 * wave + q) * a.hop + 2 * p;                   // lane part of a full pass's first-sample index
+    auto load_full = [&](int b, int k, c32 (&raw)[16]) {
+        load_frame((const char*)a.pcm + (int64_t)b * a.T * ES, 16 * k * a.hop - 256, sl_full, raw);
+    };
+    auto load_tail = [&](int t, c32 (&raw)[16]) {
+        if (4 * wave >= per_tail * rem) return;                           // fully dead quad of a tail pass (uniform)
+        const int cb0 = t * per_tail;
+        int b = cb0 + t_cl, f = 16 * full + t_fr;
+        if (t_cl >= per_tail || b >= B) { b = cb0; f = 16 * full; }       // dead slot: any valid frame
+        load_frame((const char*)a.pcm + (int64_t)b * a.T * ES, f * a.hop - 256, 2 * p, raw);
     };
     unsigned long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tlast = 0;
     if constexpr (TIMING) tlast = fe_stamp();
@@ -217,6 +273,64 @@ __global__ __launch_bounds__(FE_WAVES * 64, FE_OCC) void mel_frontend_kernel(Fro
     const int nst = a.mel_steps;
     const int klo_g = ((const int*)a.mel_b)[lane];       // first bin (multiple of 4) of this lane's 4-mel group
     typedef float f4a __attribute__((ext_vector_type(4)));
+    float* Pq = (float*)E + q * FE_PSTRIDE;              // this frame's power row (wave-private, over its own Z row)
+    const float* Ar = (const float*)E + (lane & 3) * FE_PSTRIDE + klo_g;     // mel A[row = frame lane&3][k = step] of block lane>>2
+    const float* Bl = Blds + lane * 4;
+    // lane part of the patch-major operand address (single-crop clips): [token pf*6 + k][mel-in-patch][frame-in-patch]
+    const unsigned st_lane = (unsigned)(((((lane >> 4) * 6 * 16 + (lane & 15)) * 16) + 4 * wave) * 2);
+    c32 v[16];
+
+    // -------------------------------------------------------------------------------- FFT phase of one pass (VALU + LDS)
+    auto fft_phase = [&]() {
+#pragma unroll
+        for (int m1 = 0; m1 < 16; ++m1) v[m1] = v[m1] * WIN(m1);
+        fft16(v);                                        // over m1 -> k1 (at FPOS), for m2 = p
+#pragma unroll
+        for (int k1 = 0; k1 < 16; ++k1) {                // twiddle + transpose write E[q][k1][m2 = p]
+            const c32 y = k1 == 0 ? v[FPOS(0)] : cmul(v[FPOS(k1)], TW(k1));
+            E[(q * 16 + k1) * FE_ROW + p] = y;
+        }
+        FSTAMP(1);                                       // window + FFT-1 + twiddle + transpose write
+        __builtin_amdgcn_wave_barrier();
+        asm volatile("" ::: "memory");
+#pragma unroll
+        for (int m2 = 0; m2 < 16; ++m2) v[m2] = E[(q * 16 + p) * FE_ROW + m2];   // lane k1 = p gathers its row
+        fft16(v);                                        // over m2 -> Z[k1 + 16 k2], k1 = p, k2 at FPOS
+        __builtin_amdgcn_wave_barrier();
+        asm volatile("" ::: "memory");
+        c32* Z = E;                                      // natural order Z[q][k], frame stride 272 (bank offset 32)
+#pragma unroll
+        for (int k2 = 0; k2 < 16; ++k2) Z[q * FE_ZROW + 16 * k2 + p] = v[FPOS(k2)];
+        __builtin_amdgcn_wave_barrier();
+        asm volatile("" ::: "memory");
+        FSTAMP(2);                                       // transpose read + FFT-2 + Z write
+        if (FE_ABLATE & 32) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { Pq[p + 16 * j] = v[j].x; Pq[256 - p - 16 * j] = v[j].y; }
+            return;
+        }
+        c32 za[8], zb[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int k = p + 16 * j;
+            za[j] = Z[q * FE_ZROW + k];
+            zb[j] = Z[q * FE_ZROW + ((256 - k) & 255)];
+        }
+        const c32 z128 = Z[q * FE_ZROW + 128];
+        __builtin_amdgcn_wave_barrier();                 // every Z value is in registers: the power row may overwrite the Z row
+        asm volatile("" ::: "memory");
+        // power spectrum of bins k and 256-k into the wave's own tile P[frame q][bin]
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int k = p + 16 * j;
+            const c32 A = add_conj(za[j], zb[j]), Bm = sub_conj(za[j], zb[j]);   // Z[k] +- conj Z[256-k]
+            const c32 Tw = cmul(Bm, PW(j));                                         // -i e^{-2 pi i k/512} (Z[k] - conj Z[256-k])
+            const c32 X = A + Tw, Y = A - Tw;                                        // 2 X[k], 2 conj X[256-k]
+            Pq[k] = X.x * X.x + X.y * X.y;                       // 4 |X[k]|^2: the 1/4 lives in the filterbank operand (pack.cpp)
+            Pq[256 - k] = Y.x * Y.x + Y.y * Y.y;                 // k = 0 writes bin 256 (Nyquist)
+        }
+        if (p == 0) Pq[128] = 4.0f * (z128.x * z128.x + z128.y * z128.y);
+    };
 
     // ---- mel phase of one pass (matrix pipe): mel[frame][m] = sum_k P[frame][k] fb[k][m] for the wave's OWN four frames,
     // as 16 independent 4x4 blocks (one per 4-mel group, each walking its own bin band) of v_mfma_f32_4x4x1: no power
@@ -224,15 +338,11 @@ __global__ __launch_bounds__(FE_WAVES * 64, FE_OCC) void mel_frontend_kernel(Fro
     // lane's power row at its group's band, B = ds_read_b128 of the lane's filterbank column.  One straight-line block of
     // MEL_BMAX steps (steps past the band multiply zero B operands by finite pad columns), so the reads of later steps fly
     // under the MFMAs of earlier ones; the next pass's sample loads are already in flight behind it.
-    auto mel_phase = [&](int64_t passp, int pb_, int pk_) {
-        const bool is_tail = passp >= nfull;             // uniform
-        const int b = is_tail ? (int)((passp - nfull) * per_tail) : pb_;   // (first) clip of the pass
-        const int k0 = is_tail ? full : pk_;
-        const int fbase = 16 * k0 + 4 * wave;            // first frame of this wave's quad in a full pass
-        const float* Ar = (const float*)E + (lane & 3) * FE_PSTRIDE + klo_g;     // A[row = frame lane&3][k = step] of block lane>>2
-        const float* Bl = Blds + lane * 4;
+    auto mel_mfma = [&]() -> f4v {
         f4v acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
-        if (nst <= MEL_BMAX) {
+        if (FE_ABLATE & 2) {
+            acc0 = *(const f4v*)Ar; acc1 = *(const f4v*)Bl;
+        } else if (nst <= MEL_BMAX) {
             // operand reads run MEL_AHEAD groups (of four steps) ahead of their MFMAs, so that the LDS latency is covered by
             // the MFMAs of the groups in between; the sched_barriers pin that order (the scheduler would otherwise sink
             // every read to just before its use and expose the latency once per group)
@@ -260,115 +370,108 @@ __global__ __launch_bounds__(FE_WAVES * 64, FE_OCC) void mel_frontend_kernel(Fro
                 acc1 = __builtin_amdgcn_mfma_f32_4x4x1f32(A4[3], B4[3], acc1, 0, 0, 0);
             }
         }
-        const f4v acc = acc0 + acc1;                     // D[frame slot 4*wave + r][mel lane]
-        FSTAMP(5);                                       // mel MFMAs
-        float db[4];
-        int fb[4], ff[4];                                // clip / frame of this lane's 4 rows; fb < 0 = dead slot
+        return acc0 + acc1;                              // D[frame slot 4*wave + r][mel lane]
+    };
+    // 10 log10(max(P, 1e-10)) = (10 log10 2) * v_log_f32: the operand is never denormal, so the library log10's
+    // denormal scaling and split-constant multiply (14 instructions per value) buy nothing; |error| <= 2e-5 dB
+    auto to_db = [&](float pw) { return (FE_ABLATE & 4) ? pw : 3.0102999566398120f * __builtin_amdgcn_logf(fmaxf(pw, 1e-10f)); };
+    // 16-bit operands of the encoder's patch embed: init_bn applied here (y = sc*dB + sh, uit.py:310-313); the top_db
+    // clamp commutes with this monotone map and with rounding, so the encoder applies it on y.
+    // Layout [clip-crop][token pf*6+pt][mel-in-patch][frame-in-patch].
+    auto store_elems = [&](const float (&db)[4], const int (&fb)[4], const int (&ff)[4]) {    // generic: any crop rule, dead slots
+        const int pf = lane >> 4, mp = lane & 15;
+        unsigned short* out = (unsigned short*)a.mel;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            db[r] = 10.0f * __log10f(fmaxf(acc[r], 1e-10f));
-            if (!is_tail) { fb[r] = b; ff[r] = fbase + r; }
-            else { fb[r] = (m_cl[r] < per_tail && b + m_cl[r] < a.B) ? b + m_cl[r] : -1; ff[r] = 16 * full + m_fr[r]; }
-            if (fb[r] >= 0) lmax = fmaxf(lmax, db[r]);                                // every frame counts for the top_db amax
+            const int f = ff[r];
+            const int64_t bb = fb[r];
+            if (bb < 0) continue;
+            const unsigned short y = to_op16(db[r] * bn_sc + bn_sh, a.op_bf16);
+            if (a.ncrops == 1) {
+                if (f < 16 * a.nt) out[(((bb * 24 + pf * 6 + (f >> 4)) * 16 + mp) * 16) + (f & 15)] = y;
+                continue;
+            }
+            // long clips: crops start every target_length frames, not patch aligned; a frame belongs to its regular crop
+            // and/or the re-cropped tail (models/uit.py:474-480)
+            const int cr0 = f / a.tl, t0 = f - cr0 * a.tl;
+            if (cr0 < a.ncrops - 1 && t0 < 96)
+                out[(((bb * a.ncrops + cr0) * 24 + pf * 6 + (t0 >> 4)) * 16 + mp) * 16 + (t0 & 15)] = y;
+            const int t1 = f - (a.nF - a.tl);
+            if (t1 >= 0 && t1 < 96)
+                out[(((bb * a.ncrops + a.ncrops - 1) * 24 + pf * 6 + (t1 >> 4)) * 16 + mp) * 16 + (t1 & 15)] = y;
+        }
+    };
+    // results of a full pass (clip b, column k): every slot live, frames 16k + 4*wave + r
+    auto finish_full = [&](int b, int k, f4v acc) {
+        float db[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) db[r] = to_db(acc[r]);
+        lmax = fmaxf(fmaxf(lmax, fmaxf(db[0], db[1])), fmaxf(db[2], db[3]));      // every frame counts for the top_db amax
+        if (!PATCH) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) a.mel[((int64_t)b * a.nF + 16 * k + 4 * wave + r) * 64 + lane] = db[r];
+        } else if (a.ncrops == 1) {
+            // lane = (mel, frames 4*wave .. 4*wave+3 of time patch k): 8 contiguous bytes at uniform base + lane offset
+            if (k < a.nt && (!(FE_ABLATE & 8) || db[0] == 12345.f)) {
+                typedef _Float16 h4v __attribute__((ext_vector_type(4)));
+                typedef __bf16 b4v __attribute__((ext_vector_type(4)));
+                char* dst = (char*)a.mel + ((int64_t)b * 24 + k) * 512 + st_lane;
+                float y[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) y[r] = db[r] * bn_sc + bn_sh;
+                if (a.op_bf16) {                         // uniform; two v_cvt_pk_* either way (RNE, = to_op16)
+                    *(b4v*)dst = b4v{(__bf16)y[0], (__bf16)y[1], (__bf16)y[2], (__bf16)y[3]};
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) y[r] = __builtin_amdgcn_fmed3f(y[r], -65504.0f, 65504.0f);   // see to_op16
+                    *(h4v*)dst = h4v{(_Float16)y[0], (_Float16)y[1], (_Float16)y[2], (_Float16)y[3]};
+                }
+            }
+        } else {
+            int fb[4], ff[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { fb[r] = b; ff[r] = 16 * k + 4 * wave + r; }
+            store_elems(db, fb, ff);
+        }
+    };
+    // results of tail pass t: slot 4*wave + r = (clip t*per_tail + m_cl[r], frame 16*full + m_fr[r]) or dead
+    auto finish_tail = [&](int t, f4v acc) {
+        float db[4];
+        int fb[4], ff[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            db[r] = to_db(acc[r]);
+            const int b = t * per_tail + m_cl[r];
+            fb[r] = (m_cl[r] < per_tail && b < B) ? b : -1;
+            ff[r] = 16 * full + m_fr[r];
+            if (fb[r] >= 0) lmax = fmaxf(lmax, db[r]);
         }
         if (!PATCH) {
 #pragma unroll
             for (int r = 0; r < 4; ++r)
                 if (fb[r] >= 0) a.mel[((int64_t)fb[r] * a.nF + ff[r]) * 64 + lane] = db[r];
         } else {
-            // 16-bit operands of the encoder's patch embed: init_bn applied here (y = sc*dB + sh, uit.py:310-313);
-            // the top_db clamp commutes with this monotone map and with rounding, so the encoder applies it on y.
-            // Layout [clip-crop][token pf*6+pt][mel-in-patch][frame-in-patch].
-            const int pf = lane >> 4, mp = lane & 15;
-            unsigned short y[4];
-#pragma unroll
-            for (int r = 0; r < 4; ++r) y[r] = to_op16(db[r] * bn_sc + bn_sh, a.op_bf16);
-            unsigned short* out = (unsigned short*)a.mel;
-            if (a.ncrops == 1) {
-                // lane = (mel, frames 4*wave .. 4*wave+3 of time patch k0): 8 contiguous bytes per lane
-                if (!is_tail && k0 < a.nt) {
-                    typedef unsigned short us4 __attribute__((ext_vector_type(4)));
-                    *(us4*)(out + (((int64_t)b * 24 + pf * 6 + k0) * 16 + mp) * 16 + 4 * wave) = us4{y[0], y[1], y[2], y[3]};
-                }
-            } else {
-                // long clips: crops start every target_length frames, not patch aligned -> per-element stores; a frame
-                // belongs to its regular crop and/or the re-cropped tail (models/uit.py:474-480)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int f = ff[r];
-                    const int64_t bb = fb[r];
-                    if (bb < 0) continue;
-                    const int cr0 = f / a.tl, t0 = f - cr0 * a.tl;
-                    if (cr0 < a.ncrops - 1 && t0 < 96)
-                        out[(((bb * a.ncrops + cr0) * 24 + pf * 6 + (t0 >> 4)) * 16 + mp) * 16 + (t0 & 15)] = y[r];
-                    const int t1 = f - (a.nF - a.tl);
-                    if (t1 >= 0 && t1 < 96)
-                        out[(((bb * a.ncrops + a.ncrops - 1) * 24 + pf * 6 + (t1 >> 4)) * 16 + mp) * 16 + (t1 & 15)] = y[r];
-                }
-            }
+            store_elems(db, fb, ff);
         }
-        FSTAMP(7);                                       // log + bn + stores
     };
 
-    float* Pq = (float*)E + q * FE_PSTRIDE;              // this frame's power row (wave-private, over its own Z row)
-    c32 v[16];
-    const unsigned fdiv = full > 0 ? (unsigned)full : 1u;
-    const int gb = (int)(gridDim.x / fdiv), gk = (int)(gridDim.x % fdiv);             // the pass stride as (clips, columns)
-    int cb = (int)(blockIdx.x / fdiv), ck = (int)(blockIdx.x % fdiv);                 // (clip, column) of the current pass
-    if ((int64_t)blockIdx.x < npass) load_pass(blockIdx.x, cb, ck, v);
-    for (int64_t pass = blockIdx.x; pass < npass; pass += gridDim.x, ++it) {
-        const bool is_tail = pass >= nfull;              // uniform
-        const bool quad_live = !is_tail || 4 * wave < per_tail * rem;        // uniform per wave: skip fully dead quads
-        FSTAMP(0);                                       // pass bookkeeping
-        // -------------------------------------------------------------------------------- FFT phase
-        if (quad_live) {
+    const int fdiv = full > 0 ? full : 1;
+    const int G = (int)gridDim.x;
+    const int gb = G / fdiv, gk = G % fdiv;                                           // the pass stride as (clips, columns)
+    int cb = (int)blockIdx.x / fdiv, ck = (int)blockIdx.x % fdiv;                     // (clip, column) of the current pass
+    const int Bf = full > 0 ? B : 0;                                                  // passes with cb >= Bf are tail passes
+    auto tail_index = [&](int b_, int k_) { return (b_ - Bf) * fdiv + k_; };
+    if (cb < Bf) load_full(cb, ck, v);
+    else if (tail_index(cb, ck) < ntail) load_tail(tail_index(cb, ck), v);
+    while (cb < Bf) {                                                                  // ---------------- full passes
+        FSTAMP(0);
+        if (FE_ABLATE & 16) {
+            c32 sacc = v[0];
 #pragma unroll
-            for (int m1 = 0; m1 < 16; ++m1) v[m1] = v[m1] * WIN(m1);
-            fft16(v);                                    // over m1 -> k1 (at FPOS), for m2 = p
-#pragma unroll
-            for (int k1 = 0; k1 < 16; ++k1) {            // twiddle + transpose write E[q][k1][m2 = p]
-                const c32 y = k1 == 0 ? v[FPOS(0)] : cmul(v[FPOS(k1)], TW(k1));
-                E[(q * 16 + k1) * FE_ROW + p] = y;
-            }
-            FSTAMP(1);                                   // window + FFT-1 + twiddle + transpose write
-            __builtin_amdgcn_wave_barrier();
-            asm volatile("" ::: "memory");
-#pragma unroll
-            for (int m2 = 0; m2 < 16; ++m2) v[m2] = E[(q * 16 + p) * FE_ROW + m2];   // lane k1 = p gathers its row
-            fft16(v);                                    // over m2 -> Z[k1 + 16 k2], k1 = p, k2 at FPOS
-            __builtin_amdgcn_wave_barrier();
-            asm volatile("" ::: "memory");
-            c32* Z = E;                                  // natural order Z[q][k], frame stride 272 (bank offset 32)
-#pragma unroll
-            for (int k2 = 0; k2 < 16; ++k2) Z[q * FE_ZROW + 16 * k2 + p] = v[FPOS(k2)];
-            __builtin_amdgcn_wave_barrier();
-            asm volatile("" ::: "memory");
-            FSTAMP(2);                                   // transpose read + FFT-2 + Z write
-            c32 za[8], zb[8];
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const int k = p + 16 * j;
-                za[j] = Z[q * FE_ZROW + k];
-                zb[j] = Z[q * FE_ZROW + ((256 - k) & 255)];
-            }
-            const c32 z128 = Z[q * FE_ZROW + 128];
-            __builtin_amdgcn_wave_barrier();             // every Z value is in registers: the power row may overwrite the Z row
-            asm volatile("" ::: "memory");
-            // power spectrum of bins k and 256-k into the workgroup tile P[frame 4*wave+q][bin]
-            float* prow = Pq;
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const int k = p + 16 * j;
-                const float Ar = za[j].x + zb[j].x, Ai = za[j].y - zb[j].y;
-                const float Br = za[j].x - zb[j].x, Bi = za[j].y + zb[j].y;
-                const c32 cs = PW(j);
-                const float c = cs.x, s = cs.y;
-                const float Tr = c * Bi - s * Br, Ti = -s * Bi - c * Br;
-                const float xr = Ar + Tr, xi = Ai + Ti, yr = Ar - Tr, yi = Ti - Ai;
-                prow[k] = xr * xr + xi * xi;                     // 4 |X[k]|^2: the 1/4 lives in the filterbank operand (pack.cpp)
-                prow[256 - k] = yr * yr + yi * yi;               // k = 0 writes bin 256 (Nyquist)
-            }
-            if (p == 0) prow[128] = 4.0f * (z128.x * z128.x + z128.y * z128.y);
+            for (int m1 = 1; m1 < 16; ++m1) sacc += v[m1];
+            Pq[p] = sacc.x + sacc.y;
+        } else {
+            fft_phase();
         }
         FSTAMP(3);                                       // Z read + split + power write
         __builtin_amdgcn_wave_barrier();                 // the power rows are wave-private: LDS ops of one wave complete in
@@ -376,11 +479,28 @@ __global__ __launch_bounds__(FE_WAVES * 64, FE_OCC) void mel_frontend_kernel(Fro
         // the sample registers are free again: issue the NEXT pass's loads now, their HBM latency hides under this pass's
         // mel MFMAs, log and stores
         int nb = cb + gb, nk = ck + gk;
-        if (nk >= full) { nk -= full; ++nb; }
-        if (pass + gridDim.x < npass) load_pass(pass + gridDim.x, nb, nk, v);
+        if (nk >= fdiv) { nk -= fdiv; ++nb; }
+        if (nb < Bf) load_full(nb, nk, v);
+        else if (tail_index(nb, nk) < ntail) load_tail(tail_index(nb, nk), v);
         FSTAMP(4);                                       // next pass's load issue
-        mel_phase(pass, cb, ck);
+        const f4v acc = mel_mfma();
+        FSTAMP(5);                                       // mel MFMAs
+        finish_full(cb, ck, acc);
+        FSTAMP(7);                                       // log + bn + stores
         cb = nb; ck = nk;
+    }
+    for (int t = tail_index(cb, ck); t < ntail; t += G) {                              // ---------------- tail passes
+        FSTAMP(0);
+        if (4 * wave < per_tail * rem) fft_phase();      // uniform per wave: fully dead quads skip the FFT
+        FSTAMP(3);
+        __builtin_amdgcn_wave_barrier();
+        asm volatile("" ::: "memory");
+        if (t + G < ntail) load_tail(t + G, v);
+        FSTAMP(4);
+        const f4v acc = mel_mfma();
+        FSTAMP(5);
+        finish_tail(t, acc);
+        FSTAMP(7);
     }
     FSTAMP(6);                                                            // (accumulates log + stores of all passes? no: tail only)
     if constexpr (TIMING) {
