@@ -117,9 +117,16 @@ __device__ __forceinline__ void fft16(c32 (&v)[16]) {
 #ifndef FE_LDS_TABLES
 #define FE_LDS_TABLES 0      // mask of constant tables kept in LDS instead of per-lane VGPRs (1 window, 2 W256, 4 W512); 0 measured fastest
 #endif
+#ifndef FE_B_REGS
+#define FE_B_REGS 0          // 1: the banded filterbank operand (MEL_BMAX floats per lane) lives in VGPRs instead of LDS
+#endif
+#ifndef FE_DOUBLE_BUF
+#define FE_DOUBLE_BUF 0      // 1: two sample register sets, next pass's loads issued a whole pass ahead (needs a table in LDS to fit 256 VGPRs)
+#endif
 #ifndef FE_ABLATE
 #define FE_ABLATE 0          // timing-only ablation builds (tools/ab): 1 no sample loads, 2 no mel MFMAs, 4 no log, 8 no stores,
-#endif                       // 16 no FFT phase, 32 no split/power; results are wrong by construction -- never set in the product build
+#endif                       // 16 no FFT phase, 32 no split/power, 64 no transpose through LDS, 128 no Z round trip through LDS,
+                             // 256 mel operands from registers; results are wrong by construction -- never set in the product build
 constexpr int FE_WAVES = 4;
 #ifndef FE_OCC
 #define FE_OCC 2             // workgroups per CU the register allocation aims at
@@ -199,9 +206,6 @@ __global__ __launch_bounds__(FE_WAVES * 64, FE_OCC) void mel_frontend_kernel(Fro
 #pragma unroll
         for (int j = 0; j < 8; ++j) { const float2 t = a.tw512[p + 16 * j]; pw_[j] = c32{-t.y, -t.x}; }   // -i conj(w), w = (cos, sin)(2 pi k/512)
     }
-#define WIN(m1) ((FE_LDS_TABLES & 1) ? Wwin[16 * (m1) + p] : win_[m1])
-#define TW(k1) ((FE_LDS_TABLES & 2) ? Wtw[16 * (k1) + p] : tw_[k1])
-#define PW(j) ((FE_LDS_TABLES & 4) ? Wpw[p + 16 * (j)] : pw_[j])
 
     // "full" passes are (clip b, column k): frames 16k..16k+15; the nF % 16 leftover frames of a clip are bundled,
     // per_tail clips at a time, into "tail" passes (for 1 s clips: 6 full passes per clip + one tail pass per 3 clips).
@@ -281,26 +285,53 @@ __global__ __launch_bounds__(FE_WAVES * 64, FE_OCC) void mel_frontend_kernel(Fro
     c32 v[16];
 
     // -------------------------------------------------------------------------------- FFT phase of one pass (VALU + LDS)
-    auto fft_phase = [&]() {
+    // LDS-resident tables (FE_LDS_TABLES) are read AHEAD of their use, at points where their registers are free and other work
+    // covers the LDS latency (sched_barriers pin the issue points; left alone the scheduler sinks every read to just before
+    // its use, i.e. into the wave's dependent chain): the window behind the mel MFMAs of the previous pass, W256 before the
+    // first 16-point FFT, W512 before the second.
+    c32 wn[16];
+    auto prefetch_window = [&]() {
+        if (!(FE_LDS_TABLES & 1)) return;
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int m1 = 0; m1 < 16; ++m1) v[m1] = v[m1] * WIN(m1);
+        for (int m1 = 0; m1 < 16; ++m1) wn[m1] = Wwin[16 * m1 + p];
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    prefetch_window();
+    auto fft_phase = [&](c32 (&v)[16]) {
+#pragma unroll
+        for (int m1 = 0; m1 < 16; ++m1) v[m1] = v[m1] * ((FE_LDS_TABLES & 1) ? wn[m1] : win_[m1]);
+        c32 twl[16], pwl[8];
+        if (FE_LDS_TABLES & 2) {
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int k1 = 1; k1 < 16; ++k1) twl[k1] = Wtw[16 * k1 + p];
+            __builtin_amdgcn_sched_barrier(0);
+        }
         fft16(v);                                        // over m1 -> k1 (at FPOS), for m2 = p
 #pragma unroll
         for (int k1 = 0; k1 < 16; ++k1) {                // twiddle + transpose write E[q][k1][m2 = p]
-            const c32 y = k1 == 0 ? v[FPOS(0)] : cmul(v[FPOS(k1)], TW(k1));
+            const c32 y = k1 == 0 ? v[FPOS(0)] : cmul(v[FPOS(k1)], (FE_LDS_TABLES & 2) ? twl[k1] : tw_[k1]);
+            if (FE_ABLATE & 64) v[FPOS(k1)] = y; else
             E[(q * 16 + k1) * FE_ROW + p] = y;
         }
         FSTAMP(1);                                       // window + FFT-1 + twiddle + transpose write
+        if (FE_LDS_TABLES & 4) {
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) pwl[j] = Wpw[p + 16 * j];
+            __builtin_amdgcn_sched_barrier(0);
+        }
         __builtin_amdgcn_wave_barrier();
         asm volatile("" ::: "memory");
 #pragma unroll
-        for (int m2 = 0; m2 < 16; ++m2) v[m2] = E[(q * 16 + p) * FE_ROW + m2];   // lane k1 = p gathers its row
+        for (int m2 = 0; m2 < 16; ++m2) if (!(FE_ABLATE & 64)) v[m2] = E[(q * 16 + p) * FE_ROW + m2];   // lane k1 = p gathers its row
         fft16(v);                                        // over m2 -> Z[k1 + 16 k2], k1 = p, k2 at FPOS
         __builtin_amdgcn_wave_barrier();
         asm volatile("" ::: "memory");
         c32* Z = E;                                      // natural order Z[q][k], frame stride 272 (bank offset 32)
 #pragma unroll
-        for (int k2 = 0; k2 < 16; ++k2) Z[q * FE_ZROW + 16 * k2 + p] = v[FPOS(k2)];
+        for (int k2 = 0; k2 < 16; ++k2) if (!(FE_ABLATE & 128)) Z[q * FE_ZROW + 16 * k2 + p] = v[FPOS(k2)];
         __builtin_amdgcn_wave_barrier();
         asm volatile("" ::: "memory");
         FSTAMP(2);                                       // transpose read + FFT-2 + Z write
@@ -313,10 +344,11 @@ __global__ __launch_bounds__(FE_WAVES * 64, FE_OCC) void mel_frontend_kernel(Fro
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             const int k = p + 16 * j;
+            if (FE_ABLATE & 128) { za[j] = v[j]; zb[j] = v[15 - j]; continue; }
             za[j] = Z[q * FE_ZROW + k];
             zb[j] = Z[q * FE_ZROW + ((256 - k) & 255)];
         }
-        const c32 z128 = Z[q * FE_ZROW + 128];
+        const c32 z128 = (FE_ABLATE & 128) ? v[8] : Z[q * FE_ZROW + 128];
         __builtin_amdgcn_wave_barrier();                 // every Z value is in registers: the power row may overwrite the Z row
         asm volatile("" ::: "memory");
         // power spectrum of bins k and 256-k into the wave's own tile P[frame q][bin]
@@ -324,7 +356,7 @@ __global__ __launch_bounds__(FE_WAVES * 64, FE_OCC) void mel_frontend_kernel(Fro
         for (int j = 0; j < 8; ++j) {
             const int k = p + 16 * j;
             const c32 A = add_conj(za[j], zb[j]), Bm = sub_conj(za[j], zb[j]);   // Z[k] +- conj Z[256-k]
-            const c32 Tw = cmul(Bm, PW(j));                                         // -i e^{-2 pi i k/512} (Z[k] - conj Z[256-k])
+            const c32 Tw = cmul(Bm, (FE_LDS_TABLES & 4) ? pwl[j] : pw_[j]);                                         // -i e^{-2 pi i k/512} (Z[k] - conj Z[256-k])
             const c32 X = A + Tw, Y = A - Tw;                                        // 2 X[k], 2 conj X[256-k]
             Pq[k] = X.x * X.x + X.y * X.y;                       // 4 |X[k]|^2: the 1/4 lives in the filterbank operand (pack.cpp)
             Pq[256 - k] = Y.x * Y.x + Y.y * Y.y;                 // k = 0 writes bin 256 (Nyquist)
@@ -338,6 +370,11 @@ __global__ __launch_bounds__(FE_WAVES * 64, FE_OCC) void mel_frontend_kernel(Fro
     // lane's power row at its group's band, B = ds_read_b128 of the lane's filterbank column.  One straight-line block of
     // MEL_BMAX steps (steps past the band multiply zero B operands by finite pad columns), so the reads of later steps fly
     // under the MFMAs of earlier ones; the next pass's sample loads are already in flight behind it.
+    float Breg[FE_B_REGS ? MEL_BMAX : 1];
+    if (FE_B_REGS) {
+#pragma unroll
+        for (int i = 0; i < MEL_BMAX; ++i) Breg[i] = i < nst ? a.mel_b[64 + (i >> 2) * 256 + lane * 4 + (i & 3)] : 0.f;
+    }
     auto mel_mfma = [&]() -> f4v {
         f4v acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
         if (FE_ABLATE & 2) {
@@ -349,11 +386,19 @@ __global__ __launch_bounds__(FE_WAVES * 64, FE_OCC) void mel_frontend_kernel(Fro
             constexpr int NG = MEL_BMAX / 4, MEL_AHEAD = 6;
             f4a A4[NG], B4[NG];
 #pragma unroll
-            for (int c = 0; c < MEL_AHEAD; ++c) { A4[c] = *(const f4a*)(Ar + 4 * c); B4[c] = *(const f4a*)(Bl + 256 * c); }
+            for (int c = 0; c < MEL_AHEAD; ++c) { A4[c] = *(const f4a*)(Ar + 4 * c); if (!FE_B_REGS) B4[c] = *(const f4a*)(Bl + 256 * c); }
+            if (FE_B_REGS) {
+#pragma unroll
+                for (int c = 0; c < NG; ++c) B4[c] = f4a{Breg[4 * c], Breg[4 * c + 1], Breg[4 * c + 2], Breg[4 * c + 3]};
+            }
+            if (FE_ABLATE & 256) {
+#pragma unroll
+                for (int c = MEL_AHEAD; c < NG; ++c) { A4[c] = A4[c - MEL_AHEAD] + 1.f; B4[c] = B4[c - MEL_AHEAD]; }
+            }
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int c = 0; c < NG; ++c) {
-                if (c + MEL_AHEAD < NG) { A4[c + MEL_AHEAD] = *(const f4a*)(Ar + 4 * (c + MEL_AHEAD)); B4[c + MEL_AHEAD] = *(const f4a*)(Bl + 256 * (c + MEL_AHEAD)); }
+                if (!(FE_ABLATE & 256) && c + MEL_AHEAD < NG) { A4[c + MEL_AHEAD] = *(const f4a*)(Ar + 4 * (c + MEL_AHEAD)); if (!FE_B_REGS) B4[c + MEL_AHEAD] = *(const f4a*)(Bl + 256 * (c + MEL_AHEAD)); }
                 acc0 = __builtin_amdgcn_mfma_f32_4x4x1f32(A4[c][0], B4[c][0], acc0, 0, 0, 0);
                 acc1 = __builtin_amdgcn_mfma_f32_4x4x1f32(A4[c][1], B4[c][1], acc1, 0, 0, 0);
                 acc0 = __builtin_amdgcn_mfma_f32_4x4x1f32(A4[c][2], B4[c][2], acc0, 0, 0, 0);
@@ -463,41 +508,63 @@ __global__ __launch_bounds__(FE_WAVES * 64, FE_OCC) void mel_frontend_kernel(Fro
     auto tail_index = [&](int b_, int k_) { return (b_ - Bf) * fdiv + k_; };
     if (cb < Bf) load_full(cb, ck, v);
     else if (tail_index(cb, ck) < ntail) load_tail(tail_index(cb, ck), v);
-    while (cb < Bf) {                                                                  // ---------------- full passes
+    // One full pass: samples in vc.  FE_DOUBLE_BUF: the NEXT pass's loads are issued into vn at the top, a whole pass
+    // ahead of their use (issued behind the FFT phase into the same registers they had ~0.7 us -- the mel phase and the
+    // epilogue -- to land, less than the HBM latency under load: ablation "no sample loads" -12 %); otherwise vn is vc.
+    auto full_pass = [&](c32 (&vc)[16], c32 (&vn)[16]) {
         FSTAMP(0);
+        int nb = cb + gb, nk = ck + gk;
+        if (nk >= fdiv) { nk -= fdiv; ++nb; }
+        auto issue_next = [&]() {
+            if (nb < Bf) load_full(nb, nk, vn);
+            else if (tail_index(nb, nk) < ntail) load_tail(tail_index(nb, nk), vn);
+        };
+        if (FE_DOUBLE_BUF) issue_next();
         if (FE_ABLATE & 16) {
-            c32 sacc = v[0];
+            c32 sacc = vc[0];
 #pragma unroll
-            for (int m1 = 1; m1 < 16; ++m1) sacc += v[m1];
+            for (int m1 = 1; m1 < 16; ++m1) sacc += vc[m1];
             Pq[p] = sacc.x + sacc.y;
         } else {
-            fft_phase();
+            fft_phase(vc);
         }
         FSTAMP(3);                                       // Z read + split + power write
         __builtin_amdgcn_wave_barrier();                 // the power rows are wave-private: LDS ops of one wave complete in
         asm volatile("" ::: "memory");                   // order, so the mel phase below needs no workgroup barrier
-        // the sample registers are free again: issue the NEXT pass's loads now, their HBM latency hides under this pass's
-        // mel MFMAs, log and stores
-        int nb = cb + gb, nk = ck + gk;
-        if (nk >= fdiv) { nk -= fdiv; ++nb; }
-        if (nb < Bf) load_full(nb, nk, v);
-        else if (tail_index(nb, nk) < ntail) load_tail(tail_index(nb, nk), v);
+        if (!FE_DOUBLE_BUF) issue_next();                // the sample registers are free again
         FSTAMP(4);                                       // next pass's load issue
         const f4v acc = mel_mfma();
+        prefetch_window();
         FSTAMP(5);                                       // mel MFMAs
         finish_full(cb, ck, acc);
         FSTAMP(7);                                       // log + bn + stores
         cb = nb; ck = nk;
+    };
+#if FE_DOUBLE_BUF
+    c32 v2[16];
+    for (;;) {                                                                         // ---------------- full passes
+        if (!(cb < Bf)) break;
+        full_pass(v, v2);
+        if (!(cb < Bf)) {
+#pragma unroll
+            for (int m1 = 0; m1 < 16; ++m1) v[m1] = v2[m1];                           // the first tail pass's samples
+            break;
+        }
+        full_pass(v2, v);
     }
+#else
+    while (cb < Bf) full_pass(v, v);                                                   // ---------------- full passes
+#endif
     for (int t = tail_index(cb, ck); t < ntail; t += G) {                              // ---------------- tail passes
         FSTAMP(0);
-        if (4 * wave < per_tail * rem) fft_phase();      // uniform per wave: fully dead quads skip the FFT
+        if (4 * wave < per_tail * rem) fft_phase(v);     // uniform per wave: fully dead quads skip the FFT
         FSTAMP(3);
         __builtin_amdgcn_wave_barrier();
         asm volatile("" ::: "memory");
         if (t + G < ntail) load_tail(t + G, v);
         FSTAMP(4);
         const f4v acc = mel_mfma();
+        prefetch_window();
         FSTAMP(5);
         finish_tail(t, acc);
         FSTAMP(7);
