@@ -51,9 +51,12 @@ typedef float f4v __attribute__((ext_vector_type(4)));
 #endif
 #if FE_PK_ASM
 __device__ __forceinline__ c32 cmul(c32 a, c32 w) {          // a * w = (a.x w.x - a.y w.y, a.x w.y + a.y w.x)
-    c32 t, r;
-    asm("v_pk_mul_f32 %0, %1, %2 op_sel:[0,0] op_sel_hi:[0,1]" : "=v"(t) : "v"(a), "v"(w));                       // (a.x w.x, a.x w.y)
-    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[1,0,0]" : "=v"(r) : "v"(a), "v"(w), "v"(t));   // (-a.y w.y, a.y w.x) + t
+    // one asm block: the compiler's hazard recogniser pads every inline-asm VGPR write that the next VALU instruction reads
+    // with an s_nop (it cannot see that the writer has no dst_sel); a full 64-bit v_pk_*_f32 result needs none
+    c32 r;
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel:[0,0] op_sel_hi:[0,1]\n\t"                                               // (a.x w.x, a.x w.y)
+        "v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[1,0,0]"                              // + (-a.y w.y, a.y w.x)
+        : "=&v"(r) : "v"(a), "v"(w));
     return r;
 }
 __device__ __forceinline__ c32 add_mi(c32 s, c32 t) {        // s + (-i) t = (s.x + t.y, s.y - t.x)
