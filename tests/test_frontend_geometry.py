@@ -49,6 +49,78 @@ def kernel_store_map(B, nF, tl, ncrops, nt):
     return dest, seen
 
 
+def kernel_walk(B, nF, tl, ncrops, nt, G):
+    """Mirror of the round-2 pass loop: G persistent workgroups walk pass = wg + i*G as the pair (cb, ck), full passes first
+    (specialised body: uniform byte base ((b*24 + k)*512) + lane-invariant byte offset st_lane), then tail passes through
+    tail_index (generic per-element stores).  Returns (dest map in ELEMENT indices, amax set, list of visited passes)."""
+    full, rem = nF >> 4, nF & 15
+    per_tail = 16 // rem if rem else 1
+    ntail = (B + per_tail - 1) // per_tail if rem else 0
+    fdiv = full if full > 0 else 1
+    Bf = B if full > 0 else 0
+    gb, gk = G // fdiv, G % fdiv
+    dest, seen, visited = {}, set(), []
+
+    def store_elems(b, f, mel, val):
+        pf, mp = mel >> 4, mel & 15
+        if ncrops == 1:
+            if f < 16 * nt:
+                d = (((b * 24 + pf * 6 + (f >> 4)) * 16 + mp) * 16) + (f & 15)
+                assert d not in dest
+                dest[d] = val
+            return
+        cr0, t0 = f // tl, f % tl
+        if cr0 < ncrops - 1 and t0 < 96:
+            d = (((b * ncrops + cr0) * 24 + pf * 6 + (t0 >> 4)) * 16 + mp) * 16 + (t0 & 15)
+            assert d not in dest
+            dest[d] = val
+        t1 = f - (nF - tl)
+        if 0 <= t1 < 96:
+            d = (((b * ncrops + ncrops - 1) * 24 + pf * 6 + (t1 >> 4)) * 16 + mp) * 16 + (t1 & 15)
+            assert d not in dest
+            dest[d] = val
+
+    for wg in range(G):
+        cb, ck = wg // fdiv, wg % fdiv
+        while cb < Bf:                                                     # full passes
+            visited.append(cb * fdiv + ck)
+            for wave in range(4):
+                for lane in range(64):
+                    st_lane = ((((lane >> 4) * 6 * 16 + (lane & 15)) * 16) + 4 * wave) * 2       # bytes
+                    for r in range(4):
+                        f = 16 * ck + 4 * wave + r
+                        if lane == 0:
+                            seen.add((cb, f))
+                        if ncrops == 1:
+                            if ck < nt:
+                                byte = (cb * 24 + ck) * 512 + st_lane + 2 * r
+                                assert byte % 2 == 0 and byte // 2 not in dest
+                                dest[byte // 2] = (cb, f, lane)
+                        else:
+                            store_elems(cb, f, lane, (cb, f, lane))
+            nb, nk = cb + gb, ck + gk
+            if nk >= fdiv:
+                nk -= fdiv
+                nb += 1
+            cb, ck = nb, nk
+        t = (cb - Bf) * fdiv + ck                                          # tail passes
+        while t < ntail:
+            visited.append(Bf * fdiv + t)
+            for wave in range(4):
+                for r in range(4):
+                    slot = 4 * wave + r
+                    cl, fr = slot // rem, slot % rem
+                    b = t * per_tail + cl
+                    if cl >= per_tail or b >= B:
+                        continue
+                    f = 16 * full + fr
+                    seen.add((b, f))
+                    for mel in range(64):
+                        store_elems(b, f, mel, (b, f, mel))
+            t += G
+    return dest, seen, visited
+
+
 def reference_expectation(B, nF, tl):
     """What the encoder must find: per the reference, crops = split(tl) with a short tail replaced by the last tl frames;
     each crop's first (min(frames, tl) // 16) * 16 frames form the patches."""
@@ -75,6 +147,21 @@ def test_every_patch_element_comes_from_the_right_frame(B, T, hop, tl):
     got, seen = kernel_store_map(B, nF, tl, ncrops, nt)
     assert seen == {(b, f) for b in range(B) for f in range(nF)}        # every frame of every clip feeds the amax, once
     assert got == want                                                   # and every operand is written once, from the right source
+
+
+@pytest.mark.parametrize("G", [1, 5, 512])
+@pytest.mark.parametrize("B,T,hop,tl", [(5, 16000, 160, 102), (3, 16384, 160, 102), (2, 160000, 160, 102), (4, 8000, 160, 102),
+                                        (7, 16000, 128, 102), (3, 4099, 160, 102), (6, 15360, 160, 96), (9, 2400, 160, 102)])
+def test_persistent_walk_visits_every_pass_once_and_stores_like_the_reference(B, T, hop, tl, G):
+    """The specialised full / tail loops of round 2 (uniform base + lane-invariant offset; (cb, ck) stepping; tail_index)."""
+    nF = 1 + T // hop
+    ncrops, nt, want = reference_expectation(B, nF, tl)
+    got, seen, visited = kernel_walk(B, nF, tl, ncrops, nt, G)
+    full, rem = nF >> 4, nF & 15
+    npass = B * full + ((B + 16 // rem - 1) // (16 // rem) if rem else 0)
+    assert sorted(visited) == list(range(npass))
+    assert seen == {(b, f) for b in range(B) for f in range(nF)}
+    assert got == want
 
 
 def test_front_end_tables_and_split_algebra_reproduce_the_oracle_mel():
