@@ -40,9 +40,13 @@ typedef enum uitk_in_dtype {
 typedef enum uitk_precision {
     UITK_PREC_F16 = 0,  /* fp16 MFMA operands, fp32 accumulate/residual/LN/softmax (default: meets 1e-3) */
     UITK_PREC_BF16 = 1, /* bf16 MFMA operands, same structure (same MFMA rate, ~8x the operand rounding) */
-    UITK_PREC_FP8 = 2   /* BASELINE config #5: qkv / fc1 / fc2 weights AND their input activations as OCP e4m3 with MX block
+    UITK_PREC_FP8 = 2,  /* BASELINE config #5: qkv / fc1 / fc2 weights AND their input activations as OCP e4m3 with MX block
                            scales on v_mfma_scale_f32_16x16x128_f8f6f4 (2x the f16 MFMA rate); patch embed, attention
                            internals, proj and the head stay f16.  Far outside the 1e-3 gate: a measured throughput mode */
+    UITK_PREC_F16X2 = 3 /* parity-margin mode: every weight of the path as TWO fp16 terms (W = hi + lo, 22 significant bits,
+                           two MFMAs per fragment), activations fp16 as in UITK_PREC_F16.  Removes the weight-rounding term
+                           that dominates the fp16 error at trained-checkpoint magnitudes at ~1.7x the
+                           encoder time; uit_* family (BNeckAttention, mean pooling) only */
 } uitk_precision;
 
 typedef enum uitk_eval_avg { UITK_AVG_MEAN = 0, UITK_AVG_MAX = 1 } uitk_eval_avg; /* models/uit.py:483-488 */

@@ -134,6 +134,59 @@ def test_fp8_weight_stream_reconstructs_the_folded_weights():
                 assert np.all(mx / 2.0 ** e <= 448.0) and np.all(mx / 2.0 ** e > 224.0)
 
 
+def test_f16x2_weight_stream_holds_hi_plus_lo_of_every_block_weight():
+    """precision='f16x2': 28 stages per block (uitk_dev.h), every stage holding the hi AND the lo fragments of its rows.  Decoding the
+    universal fragment order (lane (c, g), element j <-> W[16 ft + c][32 s + 16 (j >> 2) + 4 g + (j & 3)]) must give hi + lo = the
+    folded fp64 weight to 2^-21 of its magnitude (two fp16 terms), and hi must be an fp16 rounding of it (within one ulp: fc2's hi is
+    rounded structurally)."""
+    import struct
+    from mfma_emu import HDR_FMT, HDR_FIELDS
+    m, sd = _model("uit_xxxs", 12, "f16x2")
+    img = m.packed_image()
+    h = dict(zip(HDR_FIELDS, struct.unpack_from(HDR_FMT, img, 0)))
+    assert h["precision"] == 3
+    STAGE, FRAG, PE_ST, BLKX = 16384, 1024, 8, 28
+    assert h["off_bias"] - h["off_wstream"] >= (PE_ST + 4 * BLKX + 4) * STAGE
+
+    def frag(stage, f):                                   # -> [16 rows][32 k] of one fragment
+        raw = np.frombuffer(img, np.float16, 512, h["off_wstream"] + stage * STAGE + f * FRAG).reshape(64, 8).astype(np.float64)
+        out = np.zeros((16, 32))
+        for lane in range(64):
+            c, g = lane & 15, lane >> 4
+            for j in range(8):
+                out[c, 16 * (j >> 2) + 4 * g + (j & 3)] = raw[lane, j]
+        return out
+
+    g = lambda k: np.asarray(sd[k], np.float64)
+    scale = (128 // 2) ** -0.5 * 1.4426950408889634
+    for b in (0, 3):
+        p = f"blocks.{b}."
+        Wq = g(p + "attn.qkv.weight") * g(p + "norm1.weight")[None]
+        Wq[:32] *= scale
+        Wp = g(p + "attn.proj.weight"); Wp = Wp - Wp.mean(0, keepdims=True)
+        W1 = g(p + "mlp.fc1.weight") * g(p + "norm2.weight")[None]
+        W2 = g(p + "mlp.fc2.weight"); W2 = W2 - W2.mean(0, keepdims=True)
+        st = PE_ST + b * BLKX
+
+        def check(want, stage, f_hi, f_lo):
+            hi, lo = frag(stage, f_hi), frag(stage, f_lo)
+            # lo is often an fp16 subnormal (|W| ~ 4e-3 -> lo ~ 1e-6): absolute resolution 2^-24, still 60x below hi's rounding step
+            assert np.all(np.abs(hi + lo - want) <= np.abs(want) * 2.0 ** -21 + 2.0 ** -25), (stage, f_hi)
+            assert np.all(np.abs(hi - want) <= np.abs(want) * 2.0 ** -10 + 2.0 ** -24)          # hi: an fp16 neighbour of W
+
+        for t in range(6):                                 # qkv row tiles: stages 0..2, half t & 1: hi s0..3, lo s0..3
+            for s in range(4):
+                check(Wq[16 * t:16 * t + 16, 32 * s:32 * s + 32], st + t // 2, (t & 1) * 8 + s, (t & 1) * 8 + 4 + s)
+        for ft in range(8):                                # proj: K = 32, one k-step
+            check(Wp[16 * ft:16 * ft + 16, :32], st + 3, ft, 8 + ft)
+        for ch in (0, 5, 11):
+            for i in range(2):
+                for s in range(4):
+                    check(W1[32 * ch + 16 * i:32 * ch + 16 * i + 16, 32 * s:32 * s + 32], st + 4 + 2 * ch, i * 8 + s, i * 8 + 4 + s)
+            for ft in range(8):
+                check(W2[16 * ft:16 * ft + 16, 32 * ch:32 * ch + 32], st + 5 + 2 * ch, ft, 8 + ft)
+
+
 def test_structured_rounding_preserves_group_sums_of_the_conv_weights():
     """pack.cpp round_structured: the packed patch-embed weights are 16-bit neighbours of the exact (column-centred) conv
     weights -- never more than one step away -- and inside every group of 16 frame-columns of a mel row the SUMMED rounding

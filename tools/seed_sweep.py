@@ -29,17 +29,18 @@ for name in ("uit_xs", "uit_xxs", "uit_xxxs"):
             e = np.array(errs)
             print(f"{name:9s} scale {scale:.0f} {prec}: max|dlogit| {e[:,0].max():.2e} (median {np.median(e[:,0]):.2e})  "
                   f"max|dprob| {e[:,1].max():.2e}  |logit|max {e[:,2].max():.1f}", flush=True)
-# trained-checkpoint magnitudes (synth_weights.make_trained_like_state_dict): logits beyond -10
-for name in ("uit_xs", "uit_xxs", "uit_xxxs"):
+# trained-checkpoint magnitudes (synth_weights.make_trained_like_state_dict): logits beyond -10; f16 and the split-weight mode
+import itertools
+for name, tprec in itertools.product(("uit_xs", "uit_xxs", "uit_xxxs"), ("f16", "f16x2")):
     errs = []
     for seed in range(200, 200 + nseeds):
         sd = make_trained_like_state_dict(name, seed)
-        m = getattr(models, name)(outputdim=537, target_length=102)
+        m = getattr(models, name)(outputdim=537, target_length=102, precision=tprec)
         m.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()}); m = m.cuda().eval()
         p, l = m(torch.from_numpy(x).cuda(), return_logits=True)
         r = Oracle(sd).forward(x); wp, wl = r["probs"], r["logits"]
         errs.append((float(np.abs(l.cpu().numpy().reshape(wl.shape) - wl).max()), float(np.abs(p.cpu().numpy() - wp).max()),
                      float(np.abs(wl).max())))
     e = np.array(errs)
-    print(f"{name:9s} trained-like f16: max|dlogit| {e[:,0].max():.2e} (median {np.median(e[:,0]):.2e}, per seed "
+    print(f"{name:9s} trained-like {tprec}: max|dlogit| {e[:,0].max():.2e} (median {np.median(e[:,0]):.2e}, per seed "
           f"{' '.join('%.1e' % v for v in e[:,0])})  max|dprob| {e[:,1].max():.2e}  |logit|max {e[:,2].max():.1f}", flush=True)

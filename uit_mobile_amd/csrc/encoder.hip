@@ -283,7 +283,7 @@ __device__ constexpr int TI[7] = {0, 0, 1, 1, 1, 2, 2};
 // Attention of one block on 16x16x16 MFMAs (K = head_dim 16 exactly) + the proj linear into the residual stream R.
 //   Qh/Kh[h][ct]: q, k of head h as C/D tiles packed to 16 bits (feature-major);  Vh[ct][h]: V token-major (A operand of P.V)
 //   tvalid / pmask: see the kernel;  proj: the eight 1 KiB proj fragments (K = 32 = (head, d));  bias: this block's bias table
-template <class OP, bool SHORT>
+template <class OP, bool SHORT, bool X2 = false>
 __device__ __forceinline__ void attention_proj(f4 (&R)[8][3], const typename OP::v4 (&Qh)[2][3], const typename OP::v4 (&Kh)[2][3],
                                                const typename OP::v4 (&Vh)[3][2], const bool (&tvalid)[7], const u2 (&pmask)[7],
                                                const char* proj, const float* bias, int lane, int g) {
@@ -395,6 +395,14 @@ __device__ __forceinline__ void attention_proj(f4 (&R)[8][3], const typename OP:
 #pragma unroll
         for (int ct = 0; ct < 3; ++ct) R[ft][ct] = OP::mfma32(A[ft], OX[ct], add4s(R[ft][ct], bp));
     }
+    if constexpr (X2) {                                   // precision f16x2: the low-order proj fragments follow the high-order ones
+#pragma unroll
+        for (int ft = 0; ft < 8; ++ft) A[ft] = *(const v8*)(proj + (8 + ft) * FRAG_BYTES + lane * 16);
+#pragma unroll
+        for (int ft = 0; ft < 8; ++ft)
+#pragma unroll
+            for (int ct = 0; ct < 3; ++ct) R[ft][ct] = OP::mfma32(A[ft], OX[ct], R[ft][ct]);
+    }
 }
 
 // ---- precision fp8 (BASELINE config #5): OCP e4m3 operands of v_mfma_scale_f32_16x16x128_f8f6f4 ---------------------
@@ -480,7 +488,7 @@ __device__ __forceinline__ unsigned long long stamp() {
 // column 0 = the cls token, columns 1..24 = the patch tokens, columns 25..47 dead (masked as keys, never read as outputs).
 template <int PREC, int WAVES, bool SHORT, bool TIMING, int ABL = 0, int ATT = 0, int ACT = 0, int POOL = 0>
 __global__ __launch_bounds__(WAVES * 64, 2) void uit_encoder_kernel(EncoderArgs a) {
-    constexpr int OPC = PREC == 2 ? 0 : PREC;              // precision fp8: patch embed, attention, proj and head stay f16
+    constexpr int OPC = PREC >= 2 ? 0 : PREC;              // precision fp8: patch embed, attention, proj and head stay f16; f16x2: fp16 operands
     using OP = Op<OPC>;
     using v8 = typename OP::v8;
     using v4 = typename OP::v4;
@@ -754,6 +762,108 @@ __global__ __launch_bounds__(WAVES * 64, 2) void uit_encoder_kernel(EncoderArgs 
                     const v8i A = lds_frag8(slot + ft * FRAG8_BYTES, lane);
 #pragma unroll
                     for (int ct = 0; ct < 3; ++ct) R[ft][ct] = mfma8_wa_sel(ft, A, HX8[ct], R[ft][ct], s2[2 * q + (ft >> 2)]);
+                }
+            }
+        }
+#pragma unroll
+        for (int ft = 0; ft < 8; ++ft) {
+            const f4 b2 = *(const f4*)(bias + BIAS_FC2 + 16 * ft + 4 * g);
+#pragma unroll
+            for (int ct = 0; ct < 3; ++ct) R[ft][ct] = add4s(R[ft][ct], b2);
+        }
+        if (a.dbg != nullptr) {
+            dbg_store(blk + 1);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+      } else if constexpr (PREC == 3) {
+        // ================= precision f16x2: W = hi + lo, 28 ring stages per block (uitk_dev.h) =================
+        // Every stage carries the hi and the lo fragments of the rows it covers; an accumulator takes the hi chain, then the lo
+        // chain, and is finished (packed / ReLU'd) inside the stage.  Activations are the fp16 operands of precision f16.
+        static_assert(ATT == 0 && POOL == 0, "precision f16x2: uit_* family only");
+        const int tb = PE_STAGES + blk * BLOCK_STAGES_X2;
+        const float* bias = (const float*)(breg + (blk & 1) * BIAS_FLOATS * 4);
+        v8 X[4][3];
+        layernorm_to_operand<OPC>(R, 1e-6f, X);
+        v4 Qh[2][3], Kh[2][3], Vh[3][2];
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {                             // stage 0: q h0, q h1; stage 1: k h0, k h1
+            ring_step<WAVES>(a.wstream, ring, tb + half, wave, lane);
+            if (half == 0 && blk + 1 < a.depth) bias_issue<WAVES>(a.bias, breg, blk + 1, wave, lane);
+            const char* slot = ring + ((tb + half) & (RING_SLOTS - 1)) * STAGE_BYTES;
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                v8 A[8];
+#pragma unroll
+                for (int f = 0; f < 8; ++f) A[f] = lds_frag<OPC>(slot, 8 * i + f, lane);
+                const f4 bq = *(const f4*)(bias + BIAS_QKV + 16 * (2 * half + i) + 4 * g);
+#pragma unroll
+                for (int ct = 0; ct < 3; ++ct) {
+                    f4 acc = bq;
+#pragma unroll
+                    for (int s = 0; s < 8; ++s) acc = OP::mfma32(A[s], X[s & 3][ct], acc);
+                    if (half == 0) Qh[i][ct] = OP::pack4(acc); else Kh[i][ct] = OP::pack4(acc);
+                }
+            }
+        }
+        ring_step<WAVES>(a.wstream, ring, tb + 2, wave, lane);             // stage 2: V (weights as the B operand: V token-major)
+        {
+            const char* slot = ring + ((tb + 2) & (RING_SLOTS - 1)) * STAGE_BYTES;
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                v8 Bw[8];
+#pragma unroll
+                for (int f = 0; f < 8; ++f) Bw[f] = lds_frag<OPC>(slot, 8 * h + f, lane);
+                const f4 bv = splat(bias[BIAS_QKV + 64 + 16 * h + c]);
+#pragma unroll
+                for (int ct = 0; ct < 3; ++ct) {
+                    f4 acc = bv;
+#pragma unroll
+                    for (int s = 0; s < 8; ++s) acc = OP::mfma32(X[s & 3][ct], Bw[s], acc);
+                    Vh[ct][h] = OP::pack4(acc);
+                }
+            }
+        }
+        ring_step<WAVES>(a.wstream, ring, tb + 3, wave, lane);             // stage 3: attention + proj (hi, lo)
+        attention_proj<OP, PERKEY, true>(R, Qh, Kh, Vh, tvalid, pmask, ring + ((tb + 3) & (RING_SLOTS - 1)) * STAGE_BYTES, bias, lane, g);
+        layernorm_to_operand<OPC>(R, 1e-6f, X);
+#pragma unroll 1
+        for (int ch = 0; ch < 12; ++ch) {
+            v8 HX[3];
+            ring_step<WAVES>(a.wstream, ring, tb + 4 + 2 * ch, wave, lane);     // fc1 rows 32ch .. 32ch+31
+            {
+                const char* slot = ring + ((tb + 4 + 2 * ch) & (RING_SLOTS - 1)) * STAGE_BYTES;
+                f4 H[2][3];
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    v8 A[8];
+#pragma unroll
+                    for (int f = 0; f < 8; ++f) A[f] = lds_frag<OPC>(slot, 8 * i + f, lane);
+                    const f4 b1 = *(const f4*)(bias + BIAS_FC1 + 32 * ch + 16 * i + 4 * g);
+#pragma unroll
+                    for (int ct = 0; ct < 3; ++ct) {
+                        H[i][ct] = b1;
+#pragma unroll
+                        for (int s = 0; s < 8; ++s) H[i][ct] = OP::mfma32(A[s], X[s & 3][ct], H[i][ct]);
+                    }
+                }
+#pragma unroll
+                for (int ct = 0; ct < 3; ++ct) {
+                    if constexpr (ACT == 1) HX[ct] = OP::pack8(gelu4(H[0][ct]), gelu4(H[1][ct]));
+                    else HX[ct] = OP::relu_pack8(H[0][ct], H[1][ct]);
+                }
+            }
+            ring_step<WAVES>(a.wstream, ring, tb + 5 + 2 * ch, wave, lane);     // fc2 k-step ch
+            {
+                const char* slot = ring + ((tb + 5 + 2 * ch) & (RING_SLOTS - 1)) * STAGE_BYTES;
+#pragma unroll
+                for (int half = 0; half < 2; ++half) {
+                    v8 A2[8];
+#pragma unroll
+                    for (int ft = 0; ft < 8; ++ft) A2[ft] = lds_frag<OPC>(slot, 8 * half + ft, lane);
+#pragma unroll
+                    for (int ft = 0; ft < 8; ++ft)
+#pragma unroll
+                        for (int ct = 0; ct < 3; ++ct) R[ft][ct] = OP::mfma32(A2[ft], HX[ct], R[ft][ct]);
                 }
             }
         }
@@ -1427,6 +1537,8 @@ hipError_t launch_encoder(const EncoderArgs& a, int precision, int waves, int sc
         return precision == 0 ? UITK_VARIANT(0, false) : UITK_VARIANT(1, false);
 #undef UITK_VARIANT
     }
+    if (precision == 3)                                   // f16x2: split weights (hi + lo), 8-wave workgroups
+        return a.nt < GT ? launch_enc<3, 8, true>(a, stream) : launch_enc<3, 8, false>(a, stream);
     if (precision == 2) {                                 // fp8 weights / activations on the MX-scaled 16x16x128 MFMA
         if (waves == 4) return a.nt < GT ? launch_enc<2, 4, true>(a, stream) : launch_enc<2, 4, false>(a, stream);
         return a.nt < GT ? launch_enc<2, 8, true>(a, stream) : launch_enc<2, 8, false>(a, stream);

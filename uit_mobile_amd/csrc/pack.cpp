@@ -179,7 +179,8 @@ int validate_config(const uitk_config* c, const char** why) {
     if (c->depth < 1 || c->depth > 64) return bad("depth out of range");
     if (c->outputdim < 1 || c->outputdim > 65536) return bad("outputdim out of range");
     if (c->eval_avg != UITK_AVG_MEAN && c->eval_avg != UITK_AVG_MAX) return bad("unknown eval_avg");
-    if (c->precision != UITK_PREC_F16 && c->precision != UITK_PREC_BF16 && c->precision != UITK_PREC_FP8) return bad("unknown precision");
+    if (c->precision != UITK_PREC_F16 && c->precision != UITK_PREC_BF16 && c->precision != UITK_PREC_FP8 && c->precision != UITK_PREC_F16X2) return bad("unknown precision");
+    if (c->precision == UITK_PREC_F16X2 && (c->attention_full || c->act_gelu || c->pooling)) return bad("precision f16x2 is built for the uit_* family (BNeckAttention, ReLU, mean pooling) only");
     if ((c->attention_full != 0 && c->attention_full != 1) || (c->act_gelu != 0 && c->act_gelu != 1)) return bad("attention_full / act_gelu must be 0 or 1");
     if ((c->attention_full || c->act_gelu || c->pooling) && c->precision == UITK_PREC_FP8) return bad("precision fp8 is built for the uit_* family (BNeckAttention, ReLU, mean pooling) only");
     if (c->pooling < 0 || c->pooling > 2) return bad("pooling must be 0 (mean), 1 (dm) or 2 (token)");
@@ -199,7 +200,7 @@ static void pack_frag(uint16_t* dst, int prec, const std::function<double(int, i
 }
 
 int pack_image(const uitk_config* c, const uitk_weights* w, std::vector<char>* out, ImageHeader* hdr_out) {
-    const int prec = c->precision, depth = c->depth, C = c->outputdim;
+    const int prec = c->precision == UITK_PREC_F16X2 ? UITK_PREC_F16 : c->precision, depth = c->depth, C = c->outputdim;
     const int ntiles = (C + 15) / 16;
     const int nb = c->n_fft / 2 + 1;
     // ---- mel filterbank as banded B operands of v_mfma_f32_4x4x1 (16 independent 4x4 blocks): block g owns mels
@@ -260,12 +261,13 @@ int pack_image(const uitk_config* c, const uitk_weights* w, std::vector<char>* o
         }
     }
     ImageHeader h{};
-    h.magic = IMAGE_MAGIC; h.precision = prec; h.depth = depth; h.outputdim = C; h.mel_steps = mel_S;
+    h.magic = IMAGE_MAGIC; h.precision = c->precision; h.depth = depth; h.outputdim = C; h.mel_steps = mel_S;
     size_t o = align_up(sizeof(ImageHeader), 256);
     auto take = [&](size_t bytes) { size_t r = o; o = align_up(o + bytes, 256); return r; };
     const bool full = c->attention_full != 0;
     const int inner = full ? DIM : INNER;                                // qkv = Linear(dim, 3 * inner), proj = Linear(inner, dim)
-    const int blk_stages = full ? BLOCK_STAGES_ATT : (prec == UITK_PREC_FP8 ? BLOCK_STAGES_FP8 : BLOCK_STAGES);
+    const bool x2 = c->precision == UITK_PREC_F16X2;                     // split weights: operand type fp16 (prec 0 for every conversion)
+    const int blk_stages = full ? BLOCK_STAGES_ATT : (prec == UITK_PREC_FP8 ? BLOCK_STAGES_FP8 : x2 ? BLOCK_STAGES_X2 : BLOCK_STAGES);
     const int b_proj = full ? BIASF_PROJ : BIAS_PROJ, b_fc1 = full ? BIASF_FC1 : BIAS_FC1, b_fc2 = full ? BIASF_FC2 : BIAS_FC2;
     h.off_wstream = take((size_t)(PE_STAGES + depth * blk_stages + TAIL_STAGES) * STAGE_BYTES);
     h.off_bias = take((size_t)depth * BIAS_FLOATS * 4);
@@ -433,6 +435,30 @@ int pack_image(const uitk_config* c, const uitk_weights* w, std::vector<char>* o
             for (int ch = 0; ch < 12; ++ch) {
                 for (int f = 0; f < 8; ++f) pack_frag(frag_ptr(st + 8 + ch, f), prec, Wfc1, 2 * ch + f / 4, f % 4);
                 for (int ft = 0; ft < 8; ++ft) pack_frag(frag_ptr(st + 8 + ch, 8 + ft), prec, Wfc2, ft, ch);
+            }
+            continue;
+        }
+        if (x2) {
+            // precision f16x2 (uitk_dev.h): lo = W - value(hi), hi as the single-term modes round it (fc2: structured)
+            auto lo_of = [&](const std::function<double(int, int)>& W) {
+                return [&W, prec](int r, int k) { const double v = W(r, k); return v - op16_value(cvt(v, prec), prec); };
+            };
+            const std::function<double(int, int)> fq = Wqkv, fp = Wproj, f1 = Wfc1, f2x = Wfc2_exact, f2h = Wfc2;
+            const std::function<double(int, int)> lq = lo_of(fq), lp = lo_of(fp), l1 = lo_of(f1);
+            const std::function<double(int, int)> l2 = [&](int r, int k) { return f2x(r, k) - f2h(r, k); };
+            for (int t = 0; t < 6; ++t)                                  // qkv row tiles 0..5 -> stages 0, 1, 2, half t & 1
+                for (int s = 0; s < 4; ++s) {
+                    pack_frag(frag_ptr(st + t / 2, (t & 1) * 8 + s), prec, fq, t, s);
+                    pack_frag(frag_ptr(st + t / 2, (t & 1) * 8 + 4 + s), prec, lq, t, s);
+                }
+            for (int ft = 0; ft < 8; ++ft) { pack_frag(frag_ptr(st + 3, ft), prec, fp, ft, 0); pack_frag(frag_ptr(st + 3, 8 + ft), prec, lp, ft, 0); }
+            for (int ch = 0; ch < 12; ++ch) {
+                for (int i = 0; i < 2; ++i)
+                    for (int s = 0; s < 4; ++s) {
+                        pack_frag(frag_ptr(st + 4 + 2 * ch, i * 8 + s), prec, f1, 2 * ch + i, s);
+                        pack_frag(frag_ptr(st + 4 + 2 * ch, i * 8 + 4 + s), prec, l1, 2 * ch + i, s);
+                    }
+                for (int ft = 0; ft < 8; ++ft) { pack_frag(frag_ptr(st + 5 + 2 * ch, ft), prec, f2h, ft, ch); pack_frag(frag_ptr(st + 5 + 2 * ch, 8 + ft), prec, l2, ft, ch); }
             }
             continue;
         }

@@ -41,6 +41,11 @@ constexpr int TAIL_STAGES = 4;          // zero stages after the last block: the
 constexpr int BLOCK_STAGES_ATT = 20;
 constexpr int BIASF_QKV = 0, BIASF_PROJ = 384, BIASF_FC1 = 512, BIASF_FC2 = 896;
 constexpr int BLOCK_STAGES_FP8 = 8;
+// ---- precision f16x2 (W = hi + lo, both fp16): 28 stages per block; every stage holds the hi AND the lo fragments of the rows
+// it covers, so that an accumulator chain (4 or 8 hi MFMAs + as many lo MFMAs) completes inside one stage:
+//   0: q h0, q h1 (per row tile: hi s0..3, lo s0..3)   1: k h0, k h1   2: v h0, v h1 (B operand)   3: proj ft 0..7 hi, then lo
+//   4 + 2ch: fc1 row tiles 2ch, 2ch+1 (hi s0..3, lo s0..3 each)        5 + 2ch: fc2 k-step ch, ft 0..7 hi, then lo
+constexpr int BLOCK_STAGES_X2 = 28;
 constexpr int FRAG8_BYTES = 2048;
 constexpr int FP8_QKV_SCALES = 6 * FRAG8_BYTES;                 // 2 dwords per lane: bytes = tiles 0..3 | 4, 5
 constexpr int FP8_MLP_SCALES = 8 * FRAG_BYTES;                  // stage 1: 6 dwords per lane for fc1 tiles, then 6 for fc2 (q*8 + ft)

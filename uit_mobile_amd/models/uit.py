@@ -160,10 +160,10 @@ class UITBase(nn.Module):
         if not qkv_bias: unsupported.append("qkv_bias must be True")
         if unsupported:
             raise NotImplementedError("uit_mobile_amd implements the uit_xs/xxs/xxxs family only: " + "; ".join(unsupported))
-        if precision not in ('f16', 'bf16', 'fp8'):
+        if precision not in ('f16', 'bf16', 'fp8', 'f16x2'):
             raise ValueError(f"Unknown precision ({precision})")
-        if precision == 'fp8' and (self.attention_full or self.act_gelu or pooling != 'mean'):
-            raise NotImplementedError("precision='fp8' is built for the uit_* family (BNeckAttention + ReLU, mean pooling) only")
+        if precision in ('fp8', 'f16x2') and (self.attention_full or self.act_gelu or pooling != 'mean'):
+            raise NotImplementedError(f"precision='{precision}' is built for the uit_* family (BNeckAttention + ReLU, mean pooling) only")
         if pooling != 'mean' and precision != 'f16':
             raise NotImplementedError("pooling='dm' / 'token' are built for precision='f16'")
 
@@ -229,7 +229,7 @@ class UITBase(nn.Module):
                            n_mels=self.n_mels, n_fft=self.n_fft, hop_size=self.hop_size, win_size=self.win_size,
                            patch_size=self.patch_size, center=int(bool(self.center)),
                            eval_avg={'mean': _lib.AVG_MEAN, 'max': _lib.AVG_MAX}.get(self.eval_avg, -1),
-                           precision={'f16': _lib.PREC_F16, 'bf16': _lib.PREC_BF16, 'fp8': _lib.PREC_FP8}[self.precision], top_db=120.0,
+                           precision={'f16': _lib.PREC_F16, 'bf16': _lib.PREC_BF16, 'fp8': _lib.PREC_FP8, 'f16x2': _lib.PREC_F16X2}[self.precision], top_db=120.0,
                            attention_full=int(self.attention_full), act_gelu=int(self.act_gelu),
                            pooling={'mean': 0, 'dm': 1, 'token': 2}[self.pooling])
 
