@@ -79,8 +79,22 @@ def test_other_factories_match_reference_layout(name, depth, gelu):
     assert m.depth == depth and m.attention_full and m.act_gelu == gelu and m.pooling == "mean"
     img = m.eval().packed_image()                   # host-only packing of the 20-stage layout works without a GPU
     assert len(img) > (8 + 20 * depth) * 16384
+    for prec in ("fp8", "f16x2"):                   # built for the uit_* family only
+        with pytest.raises(NotImplementedError):
+            getattr(models, name)(outputdim=537, target_length=102, precision=prec)
+
+
+def test_precision_kwarg_surface():
+    """precision is this package's own kwarg: 'f16' (default, parity), 'f16x2' (split weights), 'bf16' / 'fp8' (measured modes);
+    anything else is a ValueError like the reference's unknown-eval_avg; non-mean pooling is f16 only."""
+    for prec, stages in (("f16", 14), ("bf16", 14), ("fp8", 8), ("f16x2", 28)):
+        m = models.uit_xxxs(outputdim=537, target_length=102, precision=prec).eval()
+        assert m.precision == prec
+        assert len(m.packed_image()) > (8 + stages * 4 + 4) * 16384
+    with pytest.raises(ValueError):
+        models.uit_xxxs(outputdim=537, target_length=102, precision="int8")
     with pytest.raises(NotImplementedError):
-        getattr(models, name)(outputdim=537, target_length=102, precision="fp8")
+        models.uit_xxxs(outputdim=537, target_length=102, precision="f16x2", pooling="token")
 
 
 def test_strict_load_and_pos_embed_resize():
