@@ -75,12 +75,13 @@ def test_oracle_reproduces_readme(golden, name, clip):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("precision", ["f16", "f16x2"])
 @pytest.mark.parametrize("name,clip", sorted(KNOWN))
-def test_hip_path_reproduces_readme(golden, name, clip):
+def test_hip_path_reproduces_readme(golden, name, clip, precision):
     import torch
     from uit_mobile_amd import models
     sd = _ckpt(name)
-    m = models.PRETRAINED_CHECKPOINTS[name]["model"](**models.PRETRAINED_CHECKPOINTS[name]["model_kwargs"])
+    m = models.PRETRAINED_CHECKPOINTS[name]["model"](precision=precision, **models.PRETRAINED_CHECKPOINTS[name]["model_kwargs"])
     m.load_state_dict(sd, strict=True)
     m = m.to("cuda").eval()
     pcm = golden("samples_uit_xs")[f"{clip}_pcm"]
