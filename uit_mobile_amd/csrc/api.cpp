@@ -42,6 +42,7 @@ struct uitk_model {
     int enc_sched = 0, enc_stagger = 0, enc_stagger_mode = 1, enc_ablate = 0;   // tuning knobs (UITK_ENC_SCHED, UITK_ENC_STAGGER)
     int split_pe = 0;             // UITK_SPLIT_PE=1: patch embed on split weights (W = hi + lo); measured no better than the
                                   // structured rounding of pack.cpp, +1.6 % encoder time: off by default
+    int bn_nonneg = 0;            // every init_bn scale >= 0 (decided once from the packed table): the encoder's clamp fast path
     int fe_wg_per_cu = 0;         // persistent front-end workgroups per CU (0 = the kernel's occupancy target; UITK_FE_WG_PER_CU)
     int device = 0;
     int64_t fe_B = 0, fe_T = 0;   // shape of the latest uitk_frontend call (uitk_encode must match it)
@@ -87,6 +88,12 @@ int uitk_create(const uitk_config* cfg, const uitk_weights* w, uitk_model** out)
         return fail(UITK_ERR_NO_DEVICE, "libuitk is built for gfx950 only, found " + arch);
     }
     m->n_cu = prop.multiProcessorCount;
+    {
+        const float* sc = (const float*)(img.data() + m->hdr.off_bn_sc);
+        m->bn_nonneg = 1;
+        for (int i = 0; i < NMEL; ++i) if (!(sc[i] >= 0.f)) m->bn_nonneg = 0;
+        if (const char* e = std::getenv("UITK_ENC_GENERIC_CLAMP")) if (std::atoi(e)) m->bn_nonneg = 0;     // A/B and tests of the generic path
+    }
     if (const char* e = std::getenv("UITK_ENC_WAVES")) m->enc_waves = std::atoi(e) == 4 ? 4 : 8;
     if (const char* e = std::getenv("UITK_ENC_SCHED")) m->enc_sched = std::atoi(e) != 0;
     if (const char* e = std::getenv("UITK_ENC_STAGGER")) m->enc_stagger = std::atoi(e);
@@ -240,6 +247,7 @@ int uitk_encode(uitk_model* m, int64_t B, int64_t T, float* probs, float* logits
     a.probs = nc > 1 ? m->rowprobs : probs;
     a.logits = logits; a.dbg = m->dbg;
     a.timing = m->timing; a.ablate = m->enc_ablate;
+    a.bn_nonneg = m->bn_nonneg;
     a.split_pe = m->split_pe || m->cfg.precision == UITK_PREC_F16X2;     // f16x2: the patch embed runs on its split weights too
     a.attention_full = m->cfg.attention_full; a.act_gelu = m->cfg.act_gelu; a.pooling = m->cfg.pooling;
     a.stagger = m->enc_stagger; a.stagger_group = m->n_cu; a.stagger_mode = m->enc_stagger_mode;

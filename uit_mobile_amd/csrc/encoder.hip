@@ -121,6 +121,10 @@ constexpr int LDS_ZBUF = 2 * 16 * DIM * 2;                    // 8 KiB: up to 16
 constexpr int LDS_PELO = PE_HI_STAGES * STAGE_BYTES;          // 64 KiB: low-order patch-embed weights (prologue only; 8-wave workgroups)
 constexpr int ENC_LDS = LDS_RING + LDS_BIAS + LDS_ZBUF;       // 80 KiB (4-wave workgroups: two per CU)
 constexpr int ENC_LDS_SPLIT_PE = ENC_LDS + LDS_PELO;          // 144 KiB (8-wave workgroups: one per CU anyway, by registers)
+constexpr int PEB_STRIDE = DIM + 4;                           // padded row of the LDS copy of the pos/bias table: lane (token c, g) reads
+                                                              // 16 B at bank 4 (c + g + 4 ft) mod 64 -> conflict-free per 16-lane slice
+constexpr int LDS_PEB = (NTOK + 1) * PEB_STRIDE * 4;          // 13 200 B
+constexpr int ENC_LDS_W8 = ENC_LDS_SPLIT_PE + LDS_PEB;        // 8-wave workgroups: 160 656 B of the CU's 163 840
 
 #define GPTR(p) ((const __attribute__((address_space(1))) void*)(p))
 #define LPTR(p) ((__attribute__((address_space(3))) void*)(p))
@@ -542,6 +546,21 @@ __global__ __launch_bounds__(WAVES * 64, 2) void uit_encoder_kernel(EncoderArgs 
                                                  LPTR(pelo + i * STAGE_BYTES + piece * FRAG_BYTES), 16, 0, 0);
             }
     }
+    // the conv-bias + positional table (25 x 128 f32) goes to LDS by DMA as well (8-wave workgroups): 24 per-lane global loads of
+    // sixteen cache lines each were a quarter of the prologue's trip through the CU's vector-memory address path
+    constexpr bool PEB_LDS = WAVES == 8;
+    float* peb = (float*)(smem + ENC_LDS_SPLIT_PE);
+    if constexpr (PEB_LDS) {
+#pragma unroll
+        for (int i = 0; i < (NTOK + 1 + WAVES - 1) / WAVES; ++i) {
+            const int row = wave + WAVES * i;                               // uniform
+            if (row <= NTOK) {
+#pragma unroll
+                for (int hf = 0; hf < 2; ++hf)
+                    __builtin_amdgcn_global_load_lds(GPTR(a.pe_bias + row * DIM + 64 * hf + lane), LPTR(peb + row * PEB_STRIDE + 64 * hf), 4, 0, 0);
+            }
+        }
+    }
     TSTAMP(12);                                                           // weight-stream kick
 
     // ---- rows (clip-crops) of this wave, token maps
@@ -581,10 +600,12 @@ __global__ __launch_bounds__(WAVES * 64, 2) void uit_encoder_kernel(EncoderArgs 
     }
     // accumulator init (conv bias + positional embeddings) rides the same memory round trip
     f4 R[8][3];
+    if constexpr (!PEB_LDS) {
 #pragma unroll
-    for (int ct = 0; ct < 3; ++ct)
+        for (int ct = 0; ct < 3; ++ct)
 #pragma unroll
-        for (int ft = 0; ft < 8; ++ft) R[ft][ct] = *(const f4*)(a.pe_bias + (patch_[ct] ? tk_[ct] : NTOK) * DIM + 16 * ft + 4 * g);   // row 24: cls
+            for (int ft = 0; ft < 8; ++ft) R[ft][ct] = *(const f4*)(a.pe_bias + (patch_[ct] ? tk_[ct] : NTOK) * DIM + 16 * ft + 4 * g);   // row 24: cls
+    }
     // init_bn scale / shift of mel bin `lane`: two coalesced dword loads per wave; the 24 (token tile, k-step) clamp
     // thresholds of a lane are then handed out through a wave-private 512-byte LDS table (zbuf is idle until the head)
     const float my_sc = a.bn_sc[lane], my_sh = a.bn_sh[lane];
@@ -606,6 +627,30 @@ __global__ __launch_bounds__(WAVES * 64, 2) void uit_encoder_kernel(EncoderArgs 
         __builtin_amdgcn_wave_barrier();                                  // same-wave LDS ops complete in order
         asm volatile("" ::: "memory");
     }
+    if (OPC == 0 && a.bn_nonneg) {
+        // every init_bn scale is >= 0 (decided on the host from the packed table): the clamp is ONE v_pk_max_f16 per register
+        // against a per-(tile, k-step) threshold pair -- written as asm because the compiler canonicalises both inputs of an
+        // fp16 max first (3 instructions per register) and the generic path below computes max AND min and selects
+        typedef unsigned u4v __attribute__((ext_vector_type(4)));
+        typedef _Float16 h2v __attribute__((ext_vector_type(2)));
+#pragma unroll
+        for (int ct = 0; ct < 3; ++ct) {
+            const bool live = patch_[ct] && pt_[ct] < a.nt;               // cls / dead columns carry no patch: operand 0
+            const float* trow = clamp_tab + 16 * pf_[ct] + 8 * (g >> 1);
+            const f4 th_lo = *(const f4*)trow, th_hi = *(const f4*)(trow + 4);
+#pragma unroll
+            for (int s = 0; s < 8; ++s) {
+                const float th = s < 4 ? th_lo[s & 3] : th_hi[s & 3];
+                const _Float16 hth = (_Float16)th;
+                const unsigned t2 = __builtin_bit_cast(unsigned, h2v{hth, hth});
+                u4v x = __builtin_bit_cast(u4v, XB[ct][s]);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) asm("v_pk_max_f16 %0, %1, %2" : "=v"(x[i]) : "v"(x[i]), "v"(t2));
+                if constexpr (PERKEY) { if (!live) x = u4v{0u, 0u, 0u, 0u}; }
+                XB[ct][s] = __builtin_bit_cast(v8, x);
+            }
+        }
+    } else {
 #pragma unroll
     for (int ct = 0; ct < 3; ++ct) {
         const bool live = patch_[ct] && pt_[ct] < a.nt;                   // cls / dead columns carry no patch: operand 0
@@ -620,11 +665,18 @@ __global__ __launch_bounds__(WAVES * 64, 2) void uit_encoder_kernel(EncoderArgs 
             XB[ct][s] = live ? y : OP::zero8();
         }
     }
+    }
     TSTAMP(14);                                                           // clamp (+ its init_bn table loads)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                      // patch-embed weights landed ...
     __builtin_amdgcn_s_barrier();                                         // ... for every wave
     asm volatile("" ::: "memory");
     TSTAMP(9);                                                            // barrier: slowest wave of the workgroup
+    if constexpr (PEB_LDS) {
+#pragma unroll
+        for (int ct = 0; ct < 3; ++ct)
+#pragma unroll
+            for (int ft = 0; ft < 8; ++ft) R[ft][ct] = *(const f4*)(peb + (patch_[ct] ? tk_[ct] : NTOK) * PEB_STRIDE + 16 * ft + 4 * g);   // row 24: cls
+    }
 
     // ---- patch embed: 64 LDS-resident fragments (ft = f/8, s = f%8) x 3 token tiles; accumulators start from the
     // conv bias + positional embeddings table
@@ -1491,14 +1543,14 @@ static hipError_t launch_enc(const EncoderArgs& a, hipStream_t stream) {
     const unsigned long long bit = 1ull << (dev & 63);
     if (!(attr_done.load(std::memory_order_acquire) & bit)) {
         hipError_t e = hipFuncSetAttribute((const void*)uit_encoder_kernel<PREC, WAVES, SHORT, TIMING, ABL, ATT, ACT, POOL>,
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, WAVES == 8 ? ENC_LDS_SPLIT_PE : ENC_LDS);
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, WAVES == 8 ? ENC_LDS_W8 : ENC_LDS);
         if (e != hipSuccess) return e;
         attr_done.fetch_or(bit, std::memory_order_release);
     }
     const int per_wg = POOL == 2 ? WAVES : 2 * WAVES;     // clip rows per workgroup (pooling 'token': one clip per wave)
     const int grid = (a.rows + per_wg - 1) / per_wg;
     hipLaunchKernelGGL((uit_encoder_kernel<PREC, WAVES, SHORT, TIMING, ABL, ATT, ACT, POOL>), dim3(grid), dim3(WAVES * 64),
-                       WAVES == 8 ? ENC_LDS_SPLIT_PE : ENC_LDS, stream, a);
+                       WAVES == 8 ? ENC_LDS_W8 : ENC_LDS, stream, a);
     return hipGetLastError();
 }
 

@@ -98,6 +98,7 @@ struct EncoderArgs {
     int act_gelu;           // MLP activation: 0 = ReLU, 1 = exact (erf) GELU
     int pooling;            // 0 = mean over the tokens, 1 = 'dm' (per time patch: mean over frequency patches -> head -> sigmoid; mean over
                             // time), 2 = 'token' (a cls token in column 0 of a ONE-clip wave; its row feeds the head)
+    int bn_nonneg;          // 1 = every init_bn scale w/sqrt(var+eps) is >= 0 (the usual case): the top_db clamp is a plain max
     int split_pe;           // 1 = patch embed on split weights (W = hi + lo, 8-wave workgroups only); 0 = high-order term only
     int ablate;             // timing experiments (builds with -DUITK_ABLATION_BUILDS only): ABL template value
     int stagger;            // 0 = off, else shader cycles to delay every other workgroup generation
