@@ -123,8 +123,8 @@ constexpr int ENC_LDS = LDS_RING + LDS_BIAS + LDS_ZBUF;       // 80 KiB (4-wave 
 constexpr int ENC_LDS_SPLIT_PE = ENC_LDS + LDS_PELO;          // 144 KiB (8-wave workgroups: one per CU anyway, by registers)
 constexpr int PEB_STRIDE = DIM + 4;                           // padded row of the LDS copy of the pos/bias table: lane (token c, g) reads
                                                               // 16 B at bank 4 (c + g + 4 ft) mod 64 -> conflict-free per 16-lane slice
-constexpr int LDS_PEB = (NTOK + 1) * PEB_STRIDE * 4;          // 13 200 B
-constexpr int ENC_LDS_W8 = ENC_LDS_SPLIT_PE + LDS_PEB;        // 8-wave workgroups: 160 656 B of the CU's 163 840
+constexpr int LDS_PEB = (NTOK + 1 + 4) * PEB_STRIDE * 4;      // 15 312 B: 25 table rows + the 4 rows of final-norm / head-norm parameters
+constexpr int ENC_LDS_W8 = ENC_LDS_SPLIT_PE + LDS_PEB;        // 8-wave workgroups: 162 768 B of the CU's 163 840
 
 #define GPTR(p) ((const __attribute__((address_space(1))) void*)(p))
 #define LPTR(p) ((__attribute__((address_space(3))) void*)(p))
@@ -560,7 +560,17 @@ __global__ __launch_bounds__(WAVES * 64, 2) void uit_encoder_kernel(EncoderArgs 
                     __builtin_amdgcn_global_load_lds(GPTR(a.pe_bias + row * DIM + 64 * hf + lane), LPTR(peb + row * PEB_STRIDE + 64 * hf), 4, 0, 0);
             }
         }
+        if (wave < 4) {                                                     // norm.w, norm.b, head_ln.w, head_ln.b: rows 25..28 (epilogue)
+#pragma unroll
+            for (int hf = 0; hf < 2; ++hf)
+                __builtin_amdgcn_global_load_lds(GPTR(a.fin + wave * DIM + 64 * hf + lane), LPTR(peb + (NTOK + 1 + wave) * PEB_STRIDE + 64 * hf), 4, 0, 0);
+        }
     }
+    // final-norm / head-norm parameter row i (0 norm.w, 1 norm.b, 2 head_ln.w, 3 head_ln.b): LDS copy or global
+    auto fin4 = [&](int i, int ft) -> f4 {
+        if constexpr (PEB_LDS) return *(const f4*)(peb + (NTOK + 1 + i) * PEB_STRIDE + 16 * ft + 4 * g);
+        else return *(const f4*)(a.fin + i * DIM + 16 * ft + 4 * g);
+    };
     TSTAMP(12);                                                           // weight-stream kick
 
     // ---- rows (clip-crops) of this wave, token maps
@@ -1430,8 +1440,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void uit_encoder_kernel(EncoderArgs 
         f4 acc = splat(0.f);
 #pragma unroll
         for (int ft = 0; ft < 8; ++ft) {
-            const f4 gw = *(const f4*)(a.fin + 0 * DIM + 16 * ft + 4 * g);
-            const f4 gb = *(const f4*)(a.fin + 1 * DIM + 16 * ft + 4 * g);
+            const f4 gw = fin4(0, ft), gb = fin4(1, ft);
             pooled[ft] = pooled[ft] * splat(inv_ntok) * gw + gb;
             acc = acc + pooled[ft];
         }
@@ -1443,8 +1452,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void uit_encoder_kernel(EncoderArgs 
         const int slot_clip = 2 * wave + (c >= 8 ? 1 : 0);
 #pragma unroll
         for (int ft = 0; ft < 8; ++ft) {
-            const f4 gw = *(const f4*)(a.fin + 2 * DIM + 16 * ft + 4 * g);
-            const f4 gb = *(const f4*)(a.fin + 3 * DIM + 16 * ft + 4 * g);
+            const f4 gw = fin4(2, ft), gb = fin4(3, ft);
             const f4 z = (pooled[ft] - splat(mean)) * splat(rstd) * gw + gb;
             if ((c & 7) == 0) {                           // split operand: z = hi + lo (two 16-bit terms)
                 const v4 zh = OP::pack4(z);
