@@ -183,7 +183,16 @@ __device__ __forceinline__ f4 add4s(f4 a, f4 b) {
 #endif
 }
 __device__ __forceinline__ float hsum(f4 x) { return (x[0] + x[1]) + (x[2] + x[3]); }
-__device__ __forceinline__ float hmax(f4 x) { return fmaxf(fmaxf(x[0], x[1]), fmaxf(x[2], x[3])); }
+// Maxima as plain v_max_f32 / v_max3_f32 (asm): for fmaxf on MFMA results or lane-swapped bits the compiler first canonicalises
+// every input with a v_max_f32 x, x, x (sNaN quieting that llvm.maxnum asks for) -- 56 extra VALU instructions per block in the
+// softmax alone.  The hardware maximum needs no canonical inputs and the scores are never NaN.
+__device__ __forceinline__ float vmax(float a, float b) { float r; asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+__device__ __forceinline__ float vmax3(float a, float b, float c) { float r; asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; }
+__device__ __forceinline__ float hmax(f4 x) {
+    float r;
+    asm("v_max3_f32 %0, %1, %2, %3\n\tv_max_f32 %0, %0, %4" : "=&v"(r) : "v"(x[0]), "v"(x[1]), "v"(x[2]), "v"(x[3]));
+    return r;
+}
 
 // Reductions over the 4 lane groups g (lanes c, c+16, c+32, c+48) with the gfx950 VALU swaps (no LDS crossbar):
 // v_permlane16_swap(v, v): {rows 0,0,2,2 | rows 1,1,3,3}; v_permlane32_swap(v, v): {lo,lo | hi,hi}.
@@ -195,9 +204,9 @@ __device__ __forceinline__ float xsum(float v) {
 }
 __device__ __forceinline__ float xmax(float v) {
     auto a = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
-    v = fmaxf(__uint_as_float(a[0]), __uint_as_float(a[1]));
+    v = vmax(__uint_as_float(a[0]), __uint_as_float(a[1]));
     auto b = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
-    return fmaxf(__uint_as_float(b[0]), __uint_as_float(b[1]));
+    return vmax(__uint_as_float(b[0]), __uint_as_float(b[1]));
 }
 
 // x + (x moved by a DPP row operation within each 16-lane row): quad_perm / row_half_mirror / row_mirror (pure VALU)
@@ -318,9 +327,9 @@ __device__ __forceinline__ void attention_proj(f4 (&R)[8][3], const typename OP:
         }
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
-        mx[h][0] = xmax(fmaxf(tm[h][0], tm[h][1]));
-        mx[h][1] = xmax(fmaxf(fmaxf(tm[h][2], tm[h][3]), tm[h][4]));
-        mx[h][2] = xmax(fmaxf(tm[h][5], tm[h][6]));
+        mx[h][0] = xmax(vmax(tm[h][0], tm[h][1]));
+        mx[h][1] = xmax(vmax3(tm[h][2], tm[h][3], tm[h][4]));
+        mx[h][2] = xmax(vmax(tm[h][5], tm[h][6]));
     }
     f4 Lsum[2][3];
 #pragma unroll
@@ -364,9 +373,9 @@ __device__ __forceinline__ void attention_proj(f4 (&R)[8][3], const typename OP:
             }
         }
         float mx[3];
-        mx[0] = xmax(fmaxf(tm[0], tm[1]));
-        mx[1] = xmax(fmaxf(fmaxf(tm[2], tm[3]), tm[4]));
-        mx[2] = xmax(fmaxf(tm[5], tm[6]));
+        mx[0] = xmax(vmax(tm[0], tm[1]));
+        mx[1] = xmax(vmax3(tm[2], tm[3], tm[4]));
+        mx[2] = xmax(vmax(tm[5], tm[6]));
         // P = 2^(S - max), converted, masked on the packed bits; row sums by a ones-row MFMA (sums exactly the
         // rounded probabilities that multiply V; every output row holds the column sum => no cross-lane step)
         f4 Lsum[3];
@@ -996,9 +1005,9 @@ __global__ __launch_bounds__(WAVES * 64, 2) void uit_encoder_kernel(EncoderArgs 
                     tm[i] = tvalid[i] ? hmax(S[i]) : -INFINITY;
                 }
             }
-            mx[0] = xmax(fmaxf(tm[0], tm[1]));
-            mx[1] = xmax(fmaxf(fmaxf(tm[2], tm[3]), tm[4]));
-            mx[2] = xmax(fmaxf(tm[5], tm[6]));
+            mx[0] = xmax(vmax(tm[0], tm[1]));
+            mx[1] = xmax(vmax3(tm[2], tm[3], tm[4]));
+            mx[2] = xmax(vmax(tm[5], tm[6]));
             // v_h token-major (operand roles swapped: tokens are the rows)
             ring_step<WAVES>(a.wstream, ring, tb + 3 * h + 2, wave, lane);
             v4 Vp[3][4];
