@@ -454,7 +454,8 @@ __global__ __launch_bounds__(FE_WAVES * 64, FE_OCC) void mel_frontend_kernel(Fro
         float db[4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) db[r] = to_db(acc[r]);
-        lmax = fmaxf(fmaxf(lmax, fmaxf(db[0], db[1])), fmaxf(db[2], db[3]));      // every frame counts for the top_db amax
+        // every frame counts for the top_db amax (two v_max3_f32; fmaxf would canonicalise each input with a v_max x, x first)
+        asm("v_max3_f32 %0, %0, %1, %2\n\tv_max3_f32 %0, %0, %3, %4" : "+v"(lmax) : "v"(db[0]), "v"(db[1]), "v"(db[2]), "v"(db[3]));
         if (!PATCH) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) a.mel[((int64_t)b * a.nF + 16 * k + 4 * wave + r) * 64 + lane] = db[r];
