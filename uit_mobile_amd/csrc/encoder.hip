@@ -536,6 +536,43 @@ __global__ __launch_bounds__(WAVES * 64, 2) void uit_encoder_kernel(EncoderArgs 
 
     unsigned long long tacc[ENC_TIMING_SLOTS] = {}, tlast = 0;
     if constexpr (TIMING) tlast = stamp();
+    // ---- rows (clip-crops) of this wave, token maps
+    constexpr bool TOK = POOL == 2;
+    constexpr bool PERKEY = SHORT || TOK;                   // softmax maxima with per-key masks (padding / dead columns exist)
+    const int r0 = TOK ? blockIdx.x * WAVES + wave : (blockIdx.x * WAVES + wave) * 2;
+    const int row_lo = r0 < a.rows ? r0 : a.rows - 1, row_hi = TOK ? row_lo : (r0 + 1 < a.rows ? r0 + 1 : a.rows - 1);
+    int clip_[3], tk_[3], pf_[3], pt_[3];
+    bool patch_[3];                                         // the column holds a patch token (TOK: not the cls token, not dead)
+#pragma unroll
+    for (int ct = 0; ct < 3; ++ct) {
+        const int col = 16 * ct + c;
+        if constexpr (TOK) {
+            clip_[ct] = 0;
+            patch_[ct] = col >= 1 && col <= NTOK;
+            tk_[ct] = patch_[ct] ? col - 1 : 0;                              // patch index (clamped for cls / dead columns)
+            pf_[ct] = tk_[ct] / GT;
+            pt_[ct] = patch_[ct] ? tk_[ct] - GT * pf_[ct] : (col == 0 ? 0 : 99);   // cls: always valid; dead: never
+        } else {
+            clip_[ct] = col >= NTOK ? 1 : 0;
+            patch_[ct] = true;
+            tk_[ct] = col - NTOK * clip_[ct];
+            pf_[ct] = tk_[ct] / GT;
+            pt_[ct] = tk_[ct] - GT * pf_[ct];
+        }
+    }
+    // ---- issue ALL patch loads now (3 token tiles x 8 k-steps x 16 B per lane).  The front-end wrote each token's
+    // 256 operands contiguously in k-slot order ((s,g,j) <-> mel 2s+(g>>1), frame 8(g&1)+j = offset 32s+8g+j),
+    // already init_bn-normalised and converted, so a wave-instruction reads sixteen 64-byte runs and one HBM round
+    // trip covers the whole patch embed.
+    v8 XB[3][8];
+#pragma unroll
+    for (int ct = 0; ct < 3; ++ct) {
+        const unsigned short* src = a.mel + ((int64_t)(clip_[ct] ? row_hi : row_lo) * NTOK + tk_[ct]) * 256 + 8 * g;
+#pragma unroll
+        for (int s = 0; s < 8; ++s) { if constexpr (ABL & 256) XB[ct][s] = OP::zero8(); else XB[ct][s] = *(const v8*)(src + 32 * s); }
+    }
+    // The patch operands come from HBM (the slowest trip of the prologue): their loads are issued FIRST, the L2-resident weight /
+    // table DMAs behind them.
     // ---- kick the weight stream: block-0 biases + the whole patch-embed weight set (4 stages = the whole ring)
     if (a.depth > 0) bias_issue<WAVES>(a.bias, breg, 0, wave, lane);
 #pragma unroll
@@ -582,41 +619,6 @@ __global__ __launch_bounds__(WAVES * 64, 2) void uit_encoder_kernel(EncoderArgs 
     };
     TSTAMP(12);                                                           // weight-stream kick
 
-    // ---- rows (clip-crops) of this wave, token maps
-    constexpr bool TOK = POOL == 2;
-    constexpr bool PERKEY = SHORT || TOK;                   // softmax maxima with per-key masks (padding / dead columns exist)
-    const int r0 = TOK ? blockIdx.x * WAVES + wave : (blockIdx.x * WAVES + wave) * 2;
-    const int row_lo = r0 < a.rows ? r0 : a.rows - 1, row_hi = TOK ? row_lo : (r0 + 1 < a.rows ? r0 + 1 : a.rows - 1);
-    int clip_[3], tk_[3], pf_[3], pt_[3];
-    bool patch_[3];                                         // the column holds a patch token (TOK: not the cls token, not dead)
-#pragma unroll
-    for (int ct = 0; ct < 3; ++ct) {
-        const int col = 16 * ct + c;
-        if constexpr (TOK) {
-            clip_[ct] = 0;
-            patch_[ct] = col >= 1 && col <= NTOK;
-            tk_[ct] = patch_[ct] ? col - 1 : 0;                              // patch index (clamped for cls / dead columns)
-            pf_[ct] = tk_[ct] / GT;
-            pt_[ct] = patch_[ct] ? tk_[ct] - GT * pf_[ct] : (col == 0 ? 0 : 99);   // cls: always valid; dead: never
-        } else {
-            clip_[ct] = col >= NTOK ? 1 : 0;
-            patch_[ct] = true;
-            tk_[ct] = col - NTOK * clip_[ct];
-            pf_[ct] = tk_[ct] / GT;
-            pt_[ct] = tk_[ct] - GT * pf_[ct];
-        }
-    }
-    // ---- issue ALL patch loads now (3 token tiles x 8 k-steps x 16 B per lane).  The front-end wrote each token's
-    // 256 operands contiguously in k-slot order ((s,g,j) <-> mel 2s+(g>>1), frame 8(g&1)+j = offset 32s+8g+j),
-    // already init_bn-normalised and converted, so a wave-instruction reads sixteen 64-byte runs and one HBM round
-    // trip covers the whole patch embed.
-    v8 XB[3][8];
-#pragma unroll
-    for (int ct = 0; ct < 3; ++ct) {
-        const unsigned short* src = a.mel + ((int64_t)(clip_[ct] ? row_hi : row_lo) * NTOK + tk_[ct]) * 256 + 8 * g;
-#pragma unroll
-        for (int s = 0; s < 8; ++s) { if constexpr (ABL & 256) XB[ct][s] = OP::zero8(); else XB[ct][s] = *(const v8*)(src + 32 * s); }
-    }
     // accumulator init (conv bias + positional embeddings) rides the same memory round trip
     f4 R[8][3];
     if constexpr (!PEB_LDS) {

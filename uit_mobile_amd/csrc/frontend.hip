@@ -178,24 +178,32 @@ __global__ __launch_bounds__(FE_WAVES * 64, FE_OCC) void mel_frontend_kernel(Fro
     if (blockIdx.x == 0 && tid < AMAX_SLOTS) ((unsigned*)a.amax_rearm)[tid] = 0xFF800000u;   // arm the NEXT launch's slots with -inf
     c32* E = (c32*)(smem + wave * FE_WAVE_LDS);          // [4][16][17] transpose tile, then Z[4][272]
     float* Blds = (float*)(smem + FE_WAVES * FE_WAVE_LDS);
-    // the power rows overlay the Z rows; their pad columns (bins 257..271, multiplied by zero filterbank operands) only have
-    // to be finite: stale FFT values are, uninitialised LDS need not be
-    for (int i = tid; i < FE_WAVES * FE_WAVE_LDS / 4; i += FE_WAVES * 64) ((float*)smem)[i] = 0.f;
-    // filterbank operands: the whole banded table if it fits (HTK: 52 steps), zero-padded to MEL_BMAX steps
-    for (int i = tid; i < MEL_BMAX * 64; i += FE_WAVES * 64) Blds[i] = (i >> 8) * 4 < a.mel_steps ? a.mel_b[64 + i] : 0.f;
     // per-lane constants: window pairs, W256^(p*k1), (cos, sin)(2 pi k / 512).  Each table lives either in VGPRs (default) or
     // in LDS (FE_LDS_TABLES mask: 1 window, 2 W256, 4 W512; b64 reads, conflict-free across p, broadcast across the wave's
     // four frames) -- the LDS forms free 32 / 32 / 16 VGPRs for a higher occupancy target (FE_OCC)
     c32* Wwin = (c32*)(smem + FE_WAVES * FE_WAVE_LDS + FE_B_LDS);       // window[(2m, 2m+1)], m = 16 m1 + p
     c32* Wtw = Wwin + 256;                                               // W256^(p*k1) at [k1][p]
     c32* Wpw = Wtw + 256;                                                // (cos, sin)(2 pi k / 512), k < 128
-    if (FE_LDS_TABLES) {
-        const int i = tid;                                               // 256 threads
-        if (FE_LDS_TABLES & 1) Wwin[i] = *(const c32*)(a.window + 2 * i);
-        if (FE_LDS_TABLES & 2) { const float2 t = a.tw256[(i & 15) * 16 + (i >> 4)]; Wtw[i] = c32{t.x, t.y}; }   // source is [p][k1]
-        if ((FE_LDS_TABLES & 4) && i < 128) { const float2 u = a.tw512[i]; Wpw[i] = c32{-u.y, -u.x}; }
-    }
-    __syncthreads();
+    // LDS set-up of the workgroup, run AFTER the first pass's sample loads and the per-lane constant loads have been issued, so
+    // that the kernel start pays one memory round trip, not three in a row (the fixed cost of a launch was 16 us)
+    auto lds_setup = [&]() {
+        // the power rows overlay the Z rows; their pad columns (bins 257..271, multiplied by zero filterbank operands) only have
+        // to be finite: stale FFT values are, uninitialised LDS need not be
+        for (int i = tid; i < FE_WAVES * FE_WAVE_LDS / 4; i += FE_WAVES * 64) ((float*)smem)[i] = 0.f;
+        // filterbank operands: the whole banded table if it fits (HTK: 52 steps), zero-padded to MEL_BMAX steps
+#pragma unroll
+        for (int j = 0; j < (MEL_BMAX * 64 + FE_WAVES * 64 - 1) / (FE_WAVES * 64); ++j) {
+            const int i = tid + j * FE_WAVES * 64;
+            if (i < MEL_BMAX * 64) Blds[i] = (i >> 8) * 4 < a.mel_steps ? a.mel_b[64 + i] : 0.f;
+        }
+        if (FE_LDS_TABLES) {
+            const int i = tid;                                           // 256 threads
+            if (FE_LDS_TABLES & 1) Wwin[i] = *(const c32*)(a.window + 2 * i);
+            if (FE_LDS_TABLES & 2) { const float2 t = a.tw256[(i & 15) * 16 + (i >> 4)]; Wtw[i] = c32{t.x, t.y}; }   // source is [p][k1]
+            if ((FE_LDS_TABLES & 4) && i < 128) { const float2 u = a.tw512[i]; Wpw[i] = c32{-u.y, -u.x}; }
+        }
+        __syncthreads();
+    };
     c32 win_[16], tw_[16], pw_[8];                                       // per-lane VGPR constants
     if (!(FE_LDS_TABLES & 1)) {
 #pragma unroll
@@ -300,7 +308,6 @@ __global__ __launch_bounds__(FE_WAVES * 64, FE_OCC) void mel_frontend_kernel(Fro
         for (int m1 = 0; m1 < 16; ++m1) wn[m1] = Wwin[16 * m1 + p];
         __builtin_amdgcn_sched_barrier(0);
     };
-    prefetch_window();
     auto fft_phase = [&](c32 (&v)[16]) {
 #pragma unroll
         for (int m1 = 0; m1 < 16; ++m1) v[m1] = v[m1] * ((FE_LDS_TABLES & 1) ? wn[m1] : win_[m1]);
@@ -512,6 +519,8 @@ __global__ __launch_bounds__(FE_WAVES * 64, FE_OCC) void mel_frontend_kernel(Fro
     auto tail_index = [&](int b_, int k_) { return (b_ - Bf) * fdiv + k_; };
     if (cb < Bf) load_full(cb, ck, v);
     else if (tail_index(cb, ck) < ntail) load_tail(tail_index(cb, ck), v);
+    lds_setup();
+    prefetch_window();
     // One full pass: samples in vc.  FE_DOUBLE_BUF: the NEXT pass's loads are issued into vn at the top, a whole pass
     // ahead of their use (issued behind the FFT phase into the same registers they had ~0.7 us -- the mel phase and the
     // epilogue -- to land, less than the HBM latency under load: ablation "no sample loads" -12 %); otherwise vn is vc.
