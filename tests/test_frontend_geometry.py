@@ -49,16 +49,18 @@ def kernel_store_map(B, nF, tl, ncrops, nt):
     return dest, seen
 
 
-def kernel_walk(B, nF, tl, ncrops, nt, G):
-    """Mirror of the round-2 pass loop: G persistent workgroups walk pass = wg + i*G as the pair (cb, ck), full passes first
-    (specialised body: uniform byte base ((b*24 + k)*512) + lane-invariant byte offset st_lane), then tail passes through
-    tail_index (generic per-element stores).  Returns (dest map in ELEMENT indices, amax set, list of visited passes)."""
+def kernel_walk(B, nF, tl, ncrops, nt, G, static_pct=88):
+    """Mirror of the round-2 pass loop.  Passes: idx = column * B + clip for the full passes (column-major), then the tail passes.
+    Workgroup wg takes idx = wg + r G for its first Rs rounds and the rest is drawn one pass at a time from a counter (here: handed
+    out round-robin, any order must do).  In round r wave w transforms frame quad (w + r) & 3 of a full pass; full-pass stores are
+    uniform byte base ((b*24 + k)*512 + 8 wq) + lane-invariant byte offset.  Returns (dest map in ELEMENT indices, amax set,
+    visited passes)."""
     full, rem = nF >> 4, nF & 15
     per_tail = 16 // rem if rem else 1
     ntail = (B + per_tail - 1) // per_tail if rem else 0
-    fdiv = full if full > 0 else 1
-    Bf = B if full > 0 else 0
-    gb, gk = G // fdiv, G % fdiv
+    nfull, npass = B * full, B * full + ntail
+    Rs = max(1, npass * static_pct // 100 // G)
+    pstatic = Rs * G
     dest, seen, visited = {}, set(), []
 
     def store_elems(b, f, mel, val):
@@ -80,32 +82,27 @@ def kernel_walk(B, nF, tl, ncrops, nt, G):
             assert d not in dest
             dest[d] = val
 
-    for wg in range(G):
-        cb, ck = wg // fdiv, wg % fdiv
-        while cb < Bf:                                                     # full passes
-            visited.append(cb * fdiv + ck)
+    def do_pass(idx, rnd):
+        visited.append(idx)
+        if idx < nfull:
+            ck, cb = idx // B, idx % B
             for wave in range(4):
+                wq = (wave + rnd) & 3
                 for lane in range(64):
-                    st_lane = ((((lane >> 4) * 6 * 16 + (lane & 15)) * 16) + 4 * wave) * 2       # bytes
+                    st_lane = (((lane >> 4) * 6 * 16 + (lane & 15)) * 16) * 2                    # bytes
                     for r in range(4):
-                        f = 16 * ck + 4 * wave + r
+                        f = 16 * ck + 4 * wq + r
                         if lane == 0:
                             seen.add((cb, f))
                         if ncrops == 1:
                             if ck < nt:
-                                byte = (cb * 24 + ck) * 512 + st_lane + 2 * r
-                                assert byte % 2 == 0 and byte // 2 not in dest
+                                byte = (cb * 24 + ck) * 512 + 8 * wq + st_lane + 2 * r
+                                assert byte // 2 not in dest
                                 dest[byte // 2] = (cb, f, lane)
                         else:
                             store_elems(cb, f, lane, (cb, f, lane))
-            nb, nk = cb + gb, ck + gk
-            if nk >= fdiv:
-                nk -= fdiv
-                nb += 1
-            cb, ck = nb, nk
-        t = (cb - Bf) * fdiv + ck                                          # tail passes
-        while t < ntail:
-            visited.append(Bf * fdiv + t)
+        else:
+            t = idx - nfull
             for wave in range(4):
                 for r in range(4):
                     slot = 4 * wave + r
@@ -117,7 +114,18 @@ def kernel_walk(B, nF, tl, ncrops, nt, G):
                     seen.add((b, f))
                     for mel in range(64):
                         store_elems(b, f, mel, (b, f, mel))
-            t += G
+
+    rounds = {wg: 0 for wg in range(G)}
+    for wg in range(G):                                                    # static rounds
+        for r in range(Rs):
+            idx = wg + r * G
+            if idx < npass:
+                do_pass(idx, r)
+                rounds[wg] = r + 1
+    for k, idx in enumerate(range(pstatic, npass)):                        # drawn passes: whoever asks first
+        wg = (7 * k) % G
+        do_pass(idx, rounds[wg])
+        rounds[wg] += 1
     return dest, seen, visited
 
 

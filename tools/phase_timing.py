@@ -42,3 +42,13 @@ for waves, B in (("8", 8192),):
     fn = ["pass setup+load issue", "load wait+window+FFT1+tw+Ewrite", "Eread+FFT2+Zwrite", "Zread+split+P", "barrier", "mel MFMA", "tail", "log+store"]
     print(f"   frontend per-pass cycles (median over {len(fr)} waves, {npass:.1f} passes/WG): "
           + "  ".join(f"{n}={v:.0f}" for n, v in zip(fn, np.median(fr, 0) / npass)) + f"  total/pass {np.median(fr.sum(1)) / npass:.0f}")
+    tot = fr.sum(1)                                      # per-wave lifetime in the pass loops (static pass assignment: the kernel
+    pw = tot.reshape(-1, 4).max(1)                       # ends with its slowest workgroup)
+    print(f"   frontend workgroup lifetimes (cycles): median {np.median(pw):.0f}  p90 {np.percentile(pw, 90):.0f}  max {pw.max():.0f}  "
+          f"min {pw.min():.0f}  -> slowest / median = {pw.max() / np.median(pw):.3f}")
+    wv = tot.reshape(-1, 4)
+    print("   frontend lifetime by wave index (median): " + "  ".join(f"w{i}={np.median(wv[:, i]):.0f}" for i in range(4))
+          + "   by blockIdx % 8 (XCD, median of workgroup max): " + "  ".join(f"{np.median(pw[i::8]):.0f}" for i in range(8)))
+    order = np.argsort(pw)
+    print("   slowest workgroups (blockIdx): " + " ".join(str(int(i)) for i in order[-12:]) + "   fastest: " + " ".join(str(int(i)) for i in order[:12]))
+

@@ -123,8 +123,11 @@ __device__ __forceinline__ void fft16(c32 (&v)[16]) {
 #ifndef FE_B_REGS
 #define FE_B_REGS 0          // 1: the banded filterbank operand (MEL_BMAX floats per lane) lives in VGPRs instead of LDS
 #endif
-#ifndef FE_DOUBLE_BUF
-#define FE_DOUBLE_BUF 0      // 1: two sample register sets, next pass's loads issued a whole pass ahead (needs a table in LDS to fit 256 VGPRs)
+#ifndef FE_DYNAMIC
+#define FE_DYNAMIC 1         // 1: the last (100 - FE_STATIC_PCT) % of the passes are drawn from a global counter, 0: static split only
+#endif
+#ifndef FE_STATIC_PCT
+#define FE_STATIC_PCT 88
 #endif
 #ifndef FE_ABLATE
 #define FE_ABLATE 0          // timing-only ablation builds (tools/ab): 1 no sample loads, 2 no mel MFMAs, 4 no log, 8 no stores,
@@ -271,9 +274,12 @@ __global__ __launch_bounds__(FE_WAVES * 64, FE_OCC) void mel_frontend_kernel(Fro
                               load_sample<I16>(a.pcm, row_off, T, s0 + 32 * m1 + 1)};
         }
     };
-    const int sl_full = (4 * wave + q) * a.hop + 2 * p;                   // lane part of a full pass's first-sample index
-    auto load_full = [&](int b, int k, c32 (&raw)[16]) {
-        load_frame((const char*)a.pcm + (int64_t)b * a.T * ES, 16 * k * a.hop - 256, sl_full, raw);
+    // full pass (clip b, column k): this wave transforms frame quad wq (frames 16k + 4wq .. +3).  The quad a wave takes rotates
+    // from pass to pass: quad 0 of column 0 takes the reflect-padding slow path, and pinned to wave 0 it made that wave 3.5 %
+    // slower than its three siblings (the workgroup ends with its slowest wave).
+    const int sl_full = q * a.hop + 2 * p;                                // lane part of a full pass's first-sample index
+    auto load_full = [&](int b, int k, int wq, c32 (&raw)[16]) {
+        load_frame((const char*)a.pcm + (int64_t)b * a.T * ES, (16 * k + 4 * wq) * a.hop - 256, sl_full, raw);
     };
     auto load_tail = [&](int t, c32 (&raw)[16]) {
         if (4 * wave >= per_tail * rem) return;                           // fully dead quad of a tail pass (uniform)
@@ -292,7 +298,7 @@ __global__ __launch_bounds__(FE_WAVES * 64, FE_OCC) void mel_frontend_kernel(Fro
     const float* Ar = (const float*)E + (lane & 3) * FE_PSTRIDE + klo_g;     // mel A[row = frame lane&3][k = step] of block lane>>2
     const float* Bl = Blds + lane * 4;
     // lane part of the patch-major operand address (single-crop clips): [token pf*6 + k][mel-in-patch][frame-in-patch]
-    const unsigned st_lane = (unsigned)(((((lane >> 4) * 6 * 16 + (lane & 15)) * 16) + 4 * wave) * 2);
+    const unsigned st_lane = (unsigned)((((lane >> 4) * 6 * 16 + (lane & 15)) * 16) * 2);       // + 8 wq (uniform) for frame quad wq
     c32 v[16];
 
     // -------------------------------------------------------------------------------- FFT phase of one pass (VALU + LDS)
@@ -457,7 +463,7 @@ __global__ __launch_bounds__(FE_WAVES * 64, FE_OCC) void mel_frontend_kernel(Fro
         }
     };
     // results of a full pass (clip b, column k): every slot live, frames 16k + 4*wave + r
-    auto finish_full = [&](int b, int k, f4v acc) {
+    auto finish_full = [&](int b, int k, int wq, f4v acc) {
         float db[4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) db[r] = to_db(acc[r]);
@@ -465,13 +471,13 @@ __global__ __launch_bounds__(FE_WAVES * 64, FE_OCC) void mel_frontend_kernel(Fro
         asm("v_max3_f32 %0, %0, %1, %2\n\tv_max3_f32 %0, %0, %3, %4" : "+v"(lmax) : "v"(db[0]), "v"(db[1]), "v"(db[2]), "v"(db[3]));
         if (!PATCH) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) a.mel[((int64_t)b * a.nF + 16 * k + 4 * wave + r) * 64 + lane] = db[r];
+            for (int r = 0; r < 4; ++r) a.mel[((int64_t)b * a.nF + 16 * k + 4 * wq + r) * 64 + lane] = db[r];
         } else if (a.ncrops == 1) {
             // lane = (mel, frames 4*wave .. 4*wave+3 of time patch k): 8 contiguous bytes at uniform base + lane offset
             if (k < a.nt && (!(FE_ABLATE & 8) || db[0] == 12345.f)) {
                 typedef _Float16 h4v __attribute__((ext_vector_type(4)));
                 typedef __bf16 b4v __attribute__((ext_vector_type(4)));
-                char* dst = (char*)a.mel + ((int64_t)b * 24 + k) * 512 + st_lane;
+                char* dst = (char*)a.mel + ((int64_t)b * 24 + k) * 512 + 8 * wq + st_lane;
                 float y[4];
 #pragma unroll
                 for (int r = 0; r < 4; ++r) y[r] = db[r] * bn_sc + bn_sh;
@@ -486,7 +492,7 @@ __global__ __launch_bounds__(FE_WAVES * 64, FE_OCC) void mel_frontend_kernel(Fro
         } else {
             int fb[4], ff[4];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) { fb[r] = b; ff[r] = 16 * k + 4 * wave + r; }
+            for (int r = 0; r < 4; ++r) { fb[r] = b; ff[r] = 16 * k + 4 * wq + r; }
             store_elems(db, fb, ff);
         }
     };
@@ -511,76 +517,77 @@ __global__ __launch_bounds__(FE_WAVES * 64, FE_OCC) void mel_frontend_kernel(Fro
         }
     };
 
-    const int fdiv = full > 0 ? full : 1;
+    // Passes: idx = column * B + clip for the full passes (column-major: every workgroup meets every column), then the tail
+    // passes.  A workgroup takes idx = blockIdx + r G for its first Rs rounds (static) and then draws the remaining ~12 % of the
+    // passes one at a time from a global counter: with a purely static split the workgroup launched first on a CU finished 10 %
+    // ahead of its sibling (oldest-first instruction arbitration) and the kernel ended with the slowest workgroup
+    // (tools/phase_timing.py: slowest / median lifetime 1.10).  The draw for pass n+1 is issued at the top of pass n by one
+    // lane, handed to the four waves through an LDS mailbox behind the FFT phase (one workgroup barrier per dynamic pass),
+    // and its sample loads go out right after -- the same software pipeline as in the static rounds.
     const int G = (int)gridDim.x;
-    const int gb = G / fdiv, gk = G % fdiv;                                           // the pass stride as (clips, columns)
-    int cb = (int)blockIdx.x / fdiv, ck = (int)blockIdx.x % fdiv;                     // (clip, column) of the current pass
-    const int Bf = full > 0 ? B : 0;                                                  // passes with cb >= Bf are tail passes
-    auto tail_index = [&](int b_, int k_) { return (b_ - Bf) * fdiv + k_; };
-    if (cb < Bf) load_full(cb, ck, v);
-    else if (tail_index(cb, ck) < ntail) load_tail(tail_index(cb, ck), v);
+    const int nfull = B * full, npass = nfull + ntail;
+    const int gk = G / B, gb = G % B;                                                 // the static stride as (columns, clips)
+    int Rs = (npass + G - 1) / G;                                                     // all rounds static ...
+    if (FE_DYNAMIC && a.work_ctr != nullptr) {                                        // ... or the first FE_STATIC_PCT % of them
+        Rs = (int)((int64_t)npass * FE_STATIC_PCT / 100 / G);
+        if (Rs < 1) Rs = 1;
+    }
+    const bool dynamic = FE_DYNAMIC && a.work_ctr != nullptr;
+    const int pstatic = Rs * G;                                                       // first dynamically drawn pass
+    if (dynamic && blockIdx.x == 0 && tid == 0) *a.work_ctr_rearm = 0;               // the NEXT launch's counter
+    volatile int* mbox = (volatile int*)(smem + FE_LDS);                              // [2] mailbox of drawn pass indices
+    int idx = (int)blockIdx.x, rnd = 0, par = 0;
+    int ck = idx / B, cb = idx - ck * B;                                              // (column, clip) of a full pass
+    auto issue_loads = [&](int i, int k_, int b_, int rot, c32 (&dst)[16]) {
+        if (i < nfull) load_full(b_, k_, (wave + rot) & 3, dst);
+        else if (i < npass) load_tail(i - nfull, dst);
+    };
+    issue_loads(idx, ck, cb, 0, v);
     lds_setup();
     prefetch_window();
-    // One full pass: samples in vc.  FE_DOUBLE_BUF: the NEXT pass's loads are issued into vn at the top, a whole pass
-    // ahead of their use (issued behind the FFT phase into the same registers they had ~0.7 us -- the mel phase and the
-    // epilogue -- to land, less than the HBM latency under load: ablation "no sample loads" -12 %); otherwise vn is vc.
-    auto full_pass = [&](c32 (&vc)[16], c32 (&vn)[16]) {
+    while (idx < npass) {
         FSTAMP(0);
-        int nb = cb + gb, nk = ck + gk;
-        if (nk >= fdiv) { nk -= fdiv; ++nb; }
-        auto issue_next = [&]() {
-            if (nb < Bf) load_full(nb, nk, vn);
-            else if (tail_index(nb, nk) < ntail) load_tail(tail_index(nb, nk), vn);
-        };
-        if (FE_DOUBLE_BUF) issue_next();
-        if (FE_ABLATE & 16) {
-            c32 sacc = vc[0];
+        const bool next_drawn = dynamic && rnd + 1 >= Rs;                             // uniform
+        int drawn = 0;
+        if (next_drawn && tid == 0) drawn = atomicAdd(a.work_ctr, 1);                 // in flight under the FFT phase
+        const bool is_full = idx < nfull;                                             // uniform
+        const int wq = (wave + rnd) & 3;
+        if (is_full) {
+            if (FE_ABLATE & 16) {
+                c32 sacc = v[0];
 #pragma unroll
-            for (int m1 = 1; m1 < 16; ++m1) sacc += vc[m1];
-            Pq[p] = sacc.x + sacc.y;
-        } else {
-            fft_phase(vc);
+                for (int m1 = 1; m1 < 16; ++m1) sacc += v[m1];
+                Pq[p] = sacc.x + sacc.y;
+            } else {
+                fft_phase(v);
+            }
+        } else if (4 * wave < per_tail * rem) {
+            fft_phase(v);                                // uniform per wave: fully dead quads of a tail pass skip the FFT
         }
         FSTAMP(3);                                       // Z read + split + power write
         __builtin_amdgcn_wave_barrier();                 // the power rows are wave-private: LDS ops of one wave complete in
         asm volatile("" ::: "memory");                   // order, so the mel phase below needs no workgroup barrier
-        if (!FE_DOUBLE_BUF) issue_next();                // the sample registers are free again
+        // the sample registers are free again: the NEXT pass's loads go out now, their latency hides under this pass's mel
+        // MFMAs, log and stores
+        int nidx, nk, nb;
+        if (next_drawn) {
+            if (tid == 0) mbox[par] = pstatic + drawn;
+            __syncthreads();
+            nidx = __builtin_amdgcn_readfirstlane(mbox[par]);
+            par ^= 1;
+            nk = nidx / B; nb = nidx - nk * B;
+        } else {
+            nidx = idx + G; nb = cb + gb; nk = ck + gk;
+            if (nb >= B) { nb -= B; ++nk; }
+        }
+        issue_loads(nidx, nk, nb, rnd + 1, v);
         FSTAMP(4);                                       // next pass's load issue
         const f4v acc = mel_mfma();
         prefetch_window();
         FSTAMP(5);                                       // mel MFMAs
-        finish_full(cb, ck, acc);
+        if (is_full) finish_full(cb, ck, wq, acc); else finish_tail(idx - nfull, acc);
         FSTAMP(7);                                       // log + bn + stores
-        cb = nb; ck = nk;
-    };
-#if FE_DOUBLE_BUF
-    c32 v2[16];
-    for (;;) {                                                                         // ---------------- full passes
-        if (!(cb < Bf)) break;
-        full_pass(v, v2);
-        if (!(cb < Bf)) {
-#pragma unroll
-            for (int m1 = 0; m1 < 16; ++m1) v[m1] = v2[m1];                           // the first tail pass's samples
-            break;
-        }
-        full_pass(v2, v);
-    }
-#else
-    while (cb < Bf) full_pass(v, v);                                                   // ---------------- full passes
-#endif
-    for (int t = tail_index(cb, ck); t < ntail; t += G) {                              // ---------------- tail passes
-        FSTAMP(0);
-        if (4 * wave < per_tail * rem) fft_phase(v);     // uniform per wave: fully dead quads skip the FFT
-        FSTAMP(3);
-        __builtin_amdgcn_wave_barrier();
-        asm volatile("" ::: "memory");
-        if (t + G < ntail) load_tail(t + G, v);
-        FSTAMP(4);
-        const f4v acc = mel_mfma();
-        prefetch_window();
-        FSTAMP(5);
-        finish_tail(t, acc);
-        FSTAMP(7);
+        idx = nidx; cb = nb; ck = nk; ++rnd;
     }
     FSTAMP(6);                                                            // (accumulates log + stores of all passes? no: tail only)
     if constexpr (TIMING) {
@@ -625,11 +632,11 @@ static hipError_t launch_fe(const FrontendArgs& a, int grid, hipStream_t stream)
     if (hipError_t e = hipGetDevice(&dev); e != hipSuccess) return e;
     const unsigned long long bit = 1ull << (dev & 63);
     if (!(attr_done.load(std::memory_order_acquire) & bit)) {
-        hipError_t e = hipFuncSetAttribute((const void*)mel_frontend_kernel<I16, PATCH, TIMING>, hipFuncAttributeMaxDynamicSharedMemorySize, FE_LDS);
+        hipError_t e = hipFuncSetAttribute((const void*)mel_frontend_kernel<I16, PATCH, TIMING>, hipFuncAttributeMaxDynamicSharedMemorySize, FE_LDS + 16);
         if (e != hipSuccess) return e;
         attr_done.fetch_or(bit, std::memory_order_release);
     }
-    hipLaunchKernelGGL((mel_frontend_kernel<I16, PATCH, TIMING>), dim3(grid), dim3(FE_WAVES * 64), FE_LDS, stream, a);
+    hipLaunchKernelGGL((mel_frontend_kernel<I16, PATCH, TIMING>), dim3(grid), dim3(FE_WAVES * 64), FE_LDS + 16, stream, a);     // + the 2-entry mailbox of drawn pass indices
     return hipGetLastError();
 }
 
