@@ -172,6 +172,20 @@ def test_persistent_walk_visits_every_pass_once_and_stores_like_the_reference(B,
     assert got == want
 
 
+@pytest.mark.parametrize("npass,G,pm", [(51883, 512, 590), (51883, 512, 500), (1000, 512, 590), (513, 512, 590), (7, 2, 590), (9, 4, 999)])
+def test_asymmetric_static_split_covers_every_pass_once(npass, G, pm):
+    """a.asym_pm: the first-dispatched half of the grid (blockIdx < G/2) walks its own pool [0, nA) with stride G/2, the other half
+    the pool [nA, npass): every pass exactly once, for any share."""
+    S, nA = G // 2, npass * pm // 1000
+    seen = []
+    for wg in range(G):
+        idx, end = (wg, nA) if wg < S else (nA + wg - S, npass)
+        while idx < end:
+            seen.append(idx)
+            idx += S
+    assert sorted(seen) == list(range(npass))
+
+
 def test_front_end_tables_and_split_algebra_reproduce_the_oracle_mel():
     """The kernel's arithmetic, restated with numpy on the PACKED tables (window, W256 twiddles as [p][k1], W512 as
     (cos, sin), banded filterbank x 1/4): 256-point complex FFT of the even/odd-packed frame as 16x16 Cooley-Tukey,

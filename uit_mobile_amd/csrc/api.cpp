@@ -43,6 +43,7 @@ struct uitk_model {
     int split_pe = 0;             // UITK_SPLIT_PE=1: patch embed on split weights (W = hi + lo); measured no better than the
                                   // structured rounding of pack.cpp, +1.6 % encoder time: off by default
     int bn_nonneg = 0;            // every init_bn scale >= 0 (decided once from the packed table): the encoder's clamp fast path
+    int fe_asym_pm = -1;          // UITK_FE_ASYM=<per-mille>: share of the first-dispatched workgroups (-1 = launch_frontend decides: 590 / 500)
     int fe_static = 0;            // UITK_FE_STATIC=1: purely static pass split in the front-end (A/B of the dynamic remainder)
     int fe_wg_per_cu = 0;         // persistent front-end workgroups per CU (0 = the kernel's occupancy target; UITK_FE_WG_PER_CU)
     int device = 0;
@@ -102,15 +103,16 @@ int uitk_create(const uitk_config* cfg, const uitk_weights* w, uitk_model** out)
     if (const char* e = std::getenv("UITK_ENC_ABLATE")) m->enc_ablate = std::atoi(e);
     if (const char* e = std::getenv("UITK_FE_WG_PER_CU")) m->fe_wg_per_cu = std::atoi(e);
     if (const char* e = std::getenv("UITK_FE_STATIC")) m->fe_static = std::atoi(e) != 0;
+    if (const char* e = std::getenv("UITK_FE_ASYM")) m->fe_asym_pm = std::atoi(e);
     if (const char* e = std::getenv("UITK_SPLIT_PE")) m->split_pe = std::atoi(e) != 0;
-    if (hipMalloc((void**)&m->image, img.size()) != hipSuccess || hipMalloc((void**)&m->amax, 2 * AMAX_SLOTS * 4 + 16) != hipSuccess) {      // + the two pass counters of the front-end
+    if (hipMalloc((void**)&m->image, img.size()) != hipSuccess || hipMalloc((void**)&m->amax, 2 * AMAX_SLOTS * 4 + 2 * 16 * 4) != hipSuccess) {      // + two sets of (up to 16) pass counters of the front-end
         uitk_destroy(m); return fail(UITK_ERR_HIP, "hipMalloc failed for the parameter image");
     }
     float armed[2 * AMAX_SLOTS];
     for (float& v : armed) v = -INFINITY;                                       // both amax slot sets start armed (-inf)
     if (hipMemcpy(m->image, img.data(), img.size(), hipMemcpyHostToDevice) != hipSuccess ||
         hipMemcpy(m->amax, armed, sizeof armed, hipMemcpyHostToDevice) != hipSuccess ||
-        hipMemset(m->amax + 2 * AMAX_SLOTS, 0, 16) != hipSuccess) {
+        hipMemset(m->amax + 2 * AMAX_SLOTS, 0, 2 * 16 * 4) != hipSuccess) {
         uitk_destroy(m); return fail(UITK_ERR_HIP, "parameter upload failed");
     }
     *out = m;
@@ -204,8 +206,9 @@ static int run_frontend(uitk_model* m, const void* pcm, int in_dtype, int64_t B,
     // no memset per call: this launch fills one set of slots and re-arms (0xFFFFFFFF) the other for the next launch
     m->amax_cur ^= 1;
     a.mel = mel_out; a.amax = m->amax + m->amax_cur * AMAX_SLOTS; a.amax_rearm = m->amax + (m->amax_cur ^ 1) * AMAX_SLOTS;
-    a.work_ctr = (int*)(m->amax + 2 * AMAX_SLOTS) + m->amax_cur; a.work_ctr_rearm = (int*)(m->amax + 2 * AMAX_SLOTS) + (m->amax_cur ^ 1);
+    a.work_ctr = (int*)(m->amax + 2 * AMAX_SLOTS) + 16 * m->amax_cur; a.work_ctr_rearm = (int*)(m->amax + 2 * AMAX_SLOTS) + 16 * (m->amax_cur ^ 1);
     if (m->fe_static) a.work_ctr = nullptr;
+    a.asym_pm = m->fe_asym_pm;
     a.bn_sc = (const float*)(m->image + h.off_bn_sc); a.bn_sh = (const float*)(m->image + h.off_bn_sh);
     a.op_bf16 = m->cfg.precision == UITK_PREC_BF16;
     a.timing = m->timing_fe;

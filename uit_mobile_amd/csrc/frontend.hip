@@ -124,7 +124,15 @@ __device__ __forceinline__ void fft16(c32 (&v)[16]) {
 #define FE_B_REGS 0          // 1: the banded filterbank operand (MEL_BMAX floats per lane) lives in VGPRs instead of LDS
 #endif
 #ifndef FE_DYNAMIC
-#define FE_DYNAMIC 1         // 1: the last (100 - FE_STATIC_PCT) % of the passes are drawn from a global counter, 0: static split only
+#define FE_DYNAMIC 0         // 1: the last (100 - FE_STATIC_PCT) % of the passes are drawn from global counters (measured: a drawn pass costs
+                             // ~1.9x a static one -- the returning atomic sits in the wave's in-order memory queue -- so the balance it buys
+                             // is lost again; kept as an experiment), 0: static split (asymmetric when the grid is two workgroups per CU)
+#endif
+#ifndef FE_ALT_PRIO
+#define FE_ALT_PRIO 0        // experiments: 1 = sibling workgroups swap issue priority every pass, 2 = the younger sibling has priority
+#endif
+#ifndef FE_CTRS
+#define FE_CTRS 8            // counters (= shares) of the dynamic remainder, one per XCD; <= 16
 #endif
 #ifndef FE_STATIC_PCT
 #define FE_STATIC_PCT 88
@@ -267,11 +275,16 @@ __global__ __launch_bounds__(FE_WAVES * 64, FE_OCC) void mel_frontend_kernel(Fro
                 for (int m1 = 0; m1 < 16; ++m1) raw[m1] = *(const c32*)(src + 32 * ES * m1);
             }
         } else {
+            // slow path (first / last frames of a clip: reflect padding).  The index is made opaque to the optimiser: left alone it
+            // splits the reflection arithmetic into a uniform and a lane part and hoists ~250 scalar instructions (and 40 SGPR
+            // spills) of it above this branch, into every pass of the drawn-pass loop.
+            int s0v = s0;
+            asm volatile("" : "+v"(s0v));
             const int64_t row_off = (row - (const char*)a.pcm) / ES;
 #pragma unroll
             for (int m1 = 0; m1 < 16; ++m1)
-                raw[m1] = c32{load_sample<I16>(a.pcm, row_off, T, s0 + 32 * m1),
-                              load_sample<I16>(a.pcm, row_off, T, s0 + 32 * m1 + 1)};
+                raw[m1] = c32{load_sample<I16>(a.pcm, row_off, T, s0v + 32 * m1),
+                              load_sample<I16>(a.pcm, row_off, T, s0v + 32 * m1 + 1)};
         }
     };
     // full pass (clip b, column k): this wave transforms frame quad wq (frames 16k + 4wq .. +3).  The quad a wave takes rotates
@@ -526,7 +539,15 @@ __global__ __launch_bounds__(FE_WAVES * 64, FE_OCC) void mel_frontend_kernel(Fro
     // and its sample loads go out right after -- the same software pipeline as in the static rounds.
     const int G = (int)gridDim.x;
     const int nfull = B * full, npass = nfull + ntail;
-    const int gk = G / B, gb = G % B;                                                 // the static stride as (columns, clips)
+    // Asymmetric static split (a.asym_pm, set by the host when the grid is exactly two workgroups per CU): the workgroups
+    // dispatched first (blockIdx < G/2, one per CU) are the older waves of their SIMDs, the instruction arbiter serves the oldest
+    // wave first, and with equal shares they finished 10 % ahead of their siblings while the kernel ended with the slowest
+    // workgroup (tools/phase_timing.py).  They get a pool of asym_pm / 1000 of the passes to themselves (590: measured optimum,
+    // same-box A/B 500 / 550 / 570 / 590 / 620 -> 0.336 / 0.332 / 0.327 / 0.324 / 0.333 ms).
+    const bool asym = a.asym_pm != 500 && a.asym_pm > 0 && !(FE_DYNAMIC && a.work_ctr != nullptr) && (G & 1) == 0 && G >= 2;
+    const int stride = asym ? G / 2 : G;
+    const int nA = asym ? (int)((int64_t)npass * a.asym_pm / 1000) : 0;
+    const int gk = stride / B, gb = stride % B;                                       // the static stride as (columns, clips)
     int Rs = (npass + G - 1) / G;                                                     // all rounds static ...
     if (FE_DYNAMIC && a.work_ctr != nullptr) {                                        // ... or the first FE_STATIC_PCT % of them
         Rs = (int)((int64_t)npass * FE_STATIC_PCT / 100 / G);
@@ -534,22 +555,48 @@ __global__ __launch_bounds__(FE_WAVES * 64, FE_OCC) void mel_frontend_kernel(Fro
     }
     const bool dynamic = FE_DYNAMIC && a.work_ctr != nullptr;
     const int pstatic = Rs * G;                                                       // first dynamically drawn pass
-    if (dynamic && blockIdx.x == 0 && tid == 0) *a.work_ctr_rearm = 0;               // the NEXT launch's counter
+    // A draw is a device-scope atomic with ~2-3 us of latency: it is issued TWO passes ahead of the pass it names (at the top of
+    // round r for round r + 2) and held in a register of thread 0 across one pass, so that nothing ever waits for it (drawn one
+    // pass ahead a dynamic pass cost 1.85x a static one; several counters with a retry loop, whose exit depends on the
+    // returned value, were worse still).
+    // Draws on ONE address serialise at ~10 ns each (measured: 26 k draws stretch the kernel by 0.12 ms), slower than the last
+    // workgroups consume passes -- so the drawn passes are split into FE_CTRS contiguous shares with a counter each, and a
+    // workgroup draws from the share of blockIdx % FE_CTRS (its XCD) only: balance inside each XCD's 64 workgroups, no retry.
+    const int dshare = (npass - pstatic + FE_CTRS - 1) / FE_CTRS;
+    const int home = (int)blockIdx.x % FE_CTRS;
+    const int dlo = pstatic + home * dshare, dhi = dlo + dshare < npass ? dlo + dshare : npass;
+    if (dynamic && blockIdx.x == 0 && tid < FE_CTRS) a.work_ctr_rearm[tid] = 0;      // the NEXT launch's counters
+#ifdef FE_DYN_TEST
+    auto draw = [&]() { if (FE_DYN_TEST & 1) return npass; const int i = dlo + atomicAdd(a.work_ctr + home, 1); return i < dhi ? i : npass; };   // 1: no atomic
+#else
+    auto draw = [&]() { const int i = dlo + atomicAdd(a.work_ctr + home, 1); return i < dhi ? i : npass; };
+#endif
+    int pend_prev = 0, pend_cur = 0;                                                  // thread 0: draws for rounds rnd + 1 / rnd + 2
+    if (dynamic && Rs <= 1 && tid == 0) pend_prev = draw();
     volatile int* mbox = (volatile int*)(smem + FE_LDS);                              // [2] mailbox of drawn pass indices
     int idx = (int)blockIdx.x, rnd = 0, par = 0;
+    int iend = npass;                                                                 // end of this workgroup's pool
+    if (asym) { if ((int)blockIdx.x < stride) iend = nA; else idx = nA + (int)blockIdx.x - stride; }
     int ck = idx / B, cb = idx - ck * B;                                              // (column, clip) of a full pass
     auto issue_loads = [&](int i, int k_, int b_, int rot, c32 (&dst)[16]) {
         if (i < nfull) load_full(b_, k_, (wave + rot) & 3, dst);
-        else if (i < npass) load_tail(i - nfull, dst);
+        else if (i < iend) load_tail(i - nfull, dst);
     };
-    issue_loads(idx, ck, cb, 0, v);
+    if (idx < iend) issue_loads(idx, ck, cb, 0, v);
     lds_setup();
     prefetch_window();
-    while (idx < npass) {
+#if FE_ALT_PRIO
+    const int slot_par = (int)(__builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 4) & 1u);      // hardware wave slot parity: which sibling
+#endif
+    while (idx < iend) {
+#if FE_ALT_PRIO == 1
+        if ((rnd + slot_par) & 1) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0);   // siblings swap priority every pass
+#elif FE_ALT_PRIO == 2
+        if (slot_par) __builtin_amdgcn_s_setprio(1);                                                    // the younger sibling always ahead
+#endif
         FSTAMP(0);
         const bool next_drawn = dynamic && rnd + 1 >= Rs;                             // uniform
-        int drawn = 0;
-        if (next_drawn && tid == 0) drawn = atomicAdd(a.work_ctr, 1);                 // in flight under the FFT phase
+        if (dynamic && rnd + 2 >= Rs && tid == 0) pend_cur = draw();                  // names round rnd + 2
         const bool is_full = idx < nfull;                                             // uniform
         const int wq = (wave + rnd) & 3;
         if (is_full) {
@@ -571,16 +618,21 @@ __global__ __launch_bounds__(FE_WAVES * 64, FE_OCC) void mel_frontend_kernel(Fro
         // MFMAs, log and stores
         int nidx, nk, nb;
         if (next_drawn) {
-            if (tid == 0) mbox[par] = pstatic + drawn;
-            __syncthreads();
+            if (tid == 0) mbox[par] = pend_prev;
+            // LDS visibility + barrier only: __syncthreads() also waits for vmcnt(0), i.e. for the draw issued at the top of
+            // THIS pass (2-3 us of atomic latency per dynamic pass: they cost twice a static pass that way)
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
             nidx = __builtin_amdgcn_readfirstlane(mbox[par]);
             par ^= 1;
-            nk = nidx / B; nb = nidx - nk * B;
+#ifdef FE_DYN_TEST
+            if (FE_DYN_TEST & 2) nidx = idx + G;           // experiment: the draw is made but ignored (the static successor is used)
+#endif
+            nk = __builtin_amdgcn_readfirstlane(nidx / B); nb = nidx - nk * B;       // (the quotient is formed on the VALU)
         } else {
-            nidx = idx + G; nb = cb + gb; nk = ck + gk;
+            nidx = idx + stride; nb = cb + gb; nk = ck + gk;
             if (nb >= B) { nb -= B; ++nk; }
         }
-        issue_loads(nidx, nk, nb, rnd + 1, v);
+        if (nidx < iend) issue_loads(nidx, nk, nb, rnd + 1, v);
         FSTAMP(4);                                       // next pass's load issue
         const f4v acc = mel_mfma();
         prefetch_window();
@@ -588,6 +640,7 @@ __global__ __launch_bounds__(FE_WAVES * 64, FE_OCC) void mel_frontend_kernel(Fro
         if (is_full) finish_full(cb, ck, wq, acc); else finish_tail(idx - nfull, acc);
         FSTAMP(7);                                       // log + bn + stores
         idx = nidx; cb = nb; ck = nk; ++rnd;
+        pend_prev = pend_cur;
     }
     FSTAMP(6);                                                            // (accumulates log + stores of all passes? no: tail only)
     if constexpr (TIMING) {
@@ -646,9 +699,11 @@ hipError_t launch_frontend(const FrontendArgs& a, int in_i16, int patch_layout, 
     const int64_t resident = (int64_t)n_cu * (wg_per_cu > 0 ? wg_per_cu : FE_OCC);       // persistent workgroups
     int grid = (int)(npass < resident ? npass : resident);
     if (grid < 1) grid = 1;
-    if (a.timing != nullptr && patch_layout && !in_i16) return launch_fe<false, true, true>(a, grid, stream);
-    if (patch_layout) return in_i16 ? launch_fe<true, true>(a, grid, stream) : launch_fe<false, true>(a, grid, stream);
-    return in_i16 ? launch_fe<true, false>(a, grid, stream) : launch_fe<false, false>(a, grid, stream);
+    FrontendArgs a2 = a;
+    if (a2.asym_pm < 0) a2.asym_pm = (npass >= resident && (wg_per_cu <= 0 ? FE_OCC : wg_per_cu) == 2) ? 590 : 500;     // -1 = decide here
+    if (a.timing != nullptr && patch_layout && !in_i16) return launch_fe<false, true, true>(a2, grid, stream);
+    if (patch_layout) return in_i16 ? launch_fe<true, true>(a2, grid, stream) : launch_fe<false, true>(a2, grid, stream);
+    return in_i16 ? launch_fe<true, false>(a2, grid, stream) : launch_fe<false, false>(a2, grid, stream);
 }
 
 hipError_t launch_mel_export(const float* mel, const float* amax, float top_db, int64_t B, int nF, float* out,

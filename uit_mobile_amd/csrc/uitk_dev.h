@@ -72,8 +72,9 @@ struct FrontendArgs {
     int ncrops, tl, nt;     // crop plan (models/uit.py:468-481): crops per clip, target_length, valid time patches
     float* amax;            // [AMAX_SLOTS] filled by this launch (pre-armed with 0xFFFFFFFF)
     float* amax_rearm;      // [AMAX_SLOTS] the other set: re-armed by this launch for the next one
-    int* work_ctr;          // pass counter of this launch's dynamic remainder (0 at launch), or null = static split only
-    int* work_ctr_rearm;    // the other launch parity's counter: zeroed by this launch
+    int asym_pm;            // per-mille share of the passes for the first-dispatched half of the grid (500 = symmetric, -1 = launch decides)
+    int* work_ctr;          // [<= 16] pass counters of this launch's dynamic remainder (0 at launch), or null = static split only
+    int* work_ctr_rearm;    // the other launch parity's counters: zeroed by this launch
 };
 
 struct EncoderArgs {
