@@ -36,6 +36,11 @@ for waves, B in (("8", 8192),):
     for tag, sl in (("first-round WGs", slice(0, half)), ("second-round WGs", slice(half, nw))):
         fx = np.median(raw[sl, 8:], 0)
         print(f"   {tag}: " + "  ".join(f"{n}={v:.0f}" for n, v in zip(names2, fx)))
+    life = raw.sum(1).reshape(-1, 8).max(1)              # encoder workgroup lifetime = its slowest wave (stamped phases only)
+    half_wg = len(life) // 2
+    print(f"   encoder workgroup lifetimes (cycles): median {np.median(life):.0f}  p10 {np.percentile(life, 10):.0f}  p90 {np.percentile(life, 90):.0f}  "
+          f"max {life.max():.0f}  -> slowest / median = {life.max() / np.median(life):.3f};  first-round median {np.median(life[:half_wg]):.0f}, "
+          f"second-round {np.median(life[half_wg:]):.0f};  by blockIdx % 8: " + " ".join(f"{np.median(life[i::8]):.0f}" for i in range(8)))
     fr = fbuf.cpu().numpy().astype(np.float64)
     fr = fr[fr.sum(1) > 0]
     npass = B * 7 / 512.0
