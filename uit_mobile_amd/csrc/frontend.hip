@@ -7,9 +7,10 @@
 // (max(x, amax-120)) needs the amax of the WHOLE call, so it is applied by the consumer (encoder prologue).
 //
 // Mapping (wave64; a workgroup = 4 waves walks "passes" = (clip, 16-frame column); each wave owns 4 of the 16 frames
-// from the sample loads to the stored operands -- the waves of a workgroup never exchange data and there is no
-// workgroup barrier in the pass loop; a clip's leftover frames are bundled into "tail" passes whose fully dead
-// quads skip the FFT):
+// -- a frame quad that rotates from pass to pass -- from the sample loads to the stored operands: the waves of a
+// workgroup never exchange data and there is no workgroup barrier in the pass loop; a clip's leftover frames are
+// bundled into "tail" passes whose fully dead quads skip the FFT; passes are split statically over the persistent grid,
+// the workgroups dispatched first taking the larger share (see the pass loop)):
 //   FFT phase, per wave, 4 frames x 16 lanes:
 //     * the 512 real samples of a frame are packed as 256 complex z[m] = x[2m] + i x[2m+1]; the 256-point complex
 //       FFT is a 16x16 Cooley-Tukey: lane p holds z[16*m1 + p] (m1 = 0..15), does a 16-point FFT in registers,
