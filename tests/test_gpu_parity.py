@@ -415,6 +415,26 @@ def test_full_size_properties(name, B, seed):
     assert np.abs(l[idx] - ref["logits"]).max() < TOL
 
 
+def test_pass_distribution_does_not_change_results(monkeypatch):
+    """The front-end's work distribution (asymmetric static split of the persistent grid) decides WHO transforms a
+    frame, never how: symmetric split, the default (59 % to the first-dispatched workgroups at this size) and an extreme share
+    give bit-identical probabilities and mel; so does the generic top_db clamp path of the encoder against its plain-max path."""
+    pcm = synth_pcm_i16(8192, 16000, seed=9)
+    pcm[3] = 0
+    x = torch.from_numpy(pcm).cuda()
+    outs = []
+    for env in ({}, {"UITK_FE_ASYM": "500"}, {"UITK_FE_ASYM": "900"}, {"UITK_ENC_GENERIC_CLAMP": "1"}):
+        for k in ("UITK_FE_ASYM", "UITK_ENC_GENERIC_CLAMP"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        m, _ = build("uit_xxxs", 31)                       # the knobs are read when the handle is created
+        with torch.no_grad():
+            outs.append((m(x).cpu().numpy(), m.melspec_db(x[:64]).cpu().numpy()))
+    for p, mel in outs[1:]:
+        assert np.array_equal(p, outs[0][0]) and np.array_equal(mel, outs[0][1])
+
+
 def test_errors_map_to_exceptions():
     m, _ = build("uit_xxxs", 1)
     with pytest.raises(ValueError):
