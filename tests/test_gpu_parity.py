@@ -120,6 +120,22 @@ def test_f16x2_split_weights_cut_the_error_at_trained_magnitudes(golden, name):
     assert np.abs(centred(toks.cpu().numpy()[:, 0]) - centred(g["stages"][:, 0])).max() < 2e-2
 
 
+def test_precision_margin_recommends_by_checkpoint(golden):
+    """UITBase.precision_margin: the f16 / f16x2 logit difference (= fp16's weight-rounding term) decides which parity precision a
+    checkpoint needs: init-scale weights -> 'f16'; the worst trained-like seed of the sweep (f16 error 1.1e-3 at |logit| 14) -> 'f16x2'."""
+    x = torch.from_numpy(synth_pcm_i16(24, 16000, seed=3)).cuda()
+    m, _ = build("uit_xs", 13)
+    r = m.precision_margin(x)
+    assert r["recommended"] == "f16" and r["max_abs_logit_diff"] < 3e-4 and m.precision == "f16"
+    m, _ = build_trained("uit_xs", 205)
+    r = m.precision_margin(x)
+    print("precision_margin, trained-like seed 205:", r)
+    assert r["recommended"] == "f16x2" and r["max_abs_logit"] > 10.0
+    m, _ = build("uit_xs", 13, prec="fp8")
+    with pytest.raises(ValueError):
+        m.precision_margin(x)
+
+
 def test_f16x2_golden_sizes(golden):
     """The split-weight mode through the other shapes of the path: init-scale XS (silence + tone batch), a short trained-like clip
     (masked tokens), and the reference's two-crop sample clip."""

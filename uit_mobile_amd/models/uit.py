@@ -396,6 +396,27 @@ class UITBase(nn.Module):
                                      ctypes.c_void_p(out.data_ptr()), stream), "uitk_mel_db")
         return out
 
+    def precision_margin(self, x, gate=1e-3):
+        """Which parity precision does THIS checkpoint need?  Runs `x` through precision 'f16' and 'f16x2' (same kernels, the latter
+        with every weight as two fp16 terms) and returns the largest logit difference: that difference is the weight-rounding term
+        of the fp16 path -- 90 % of its error at trained-checkpoint magnitudes.  'f16x2' is recommended when it
+        exceeds 0.6 * gate.  No reference, no CPU: two forward passes on the device."""
+        if self.precision not in ('f16', 'f16x2'):
+            raise ValueError("precision_margin compares the two parity precisions 'f16' and 'f16x2'")
+        keep, out = self.precision, {}
+        try:
+            for prec in ('f16', 'f16x2'):
+                self.precision = prec
+                self.refresh()
+                with torch.no_grad():
+                    out[prec] = self.forward(x, return_logits=True)[1].float().clone()
+        finally:
+            self.precision = keep
+            self.refresh()
+        d = float((out['f16'] - out['f16x2']).abs().max())
+        return {'max_abs_logit_diff': d, 'max_abs_logit': float(out['f16x2'].abs().max()),
+                'recommended': 'f16x2' if d > 0.6 * gate else 'f16'}
+
     def debug_tokens(self, x):
         """(probs, tokens[B, ncrops, depth+1, 24, 128]): residual stream after patch-embed and after each block."""
         x, _ = self._prep_input(x)
