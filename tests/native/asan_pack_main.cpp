@@ -13,8 +13,8 @@ int main() {
     const float* p = pool.data();
     int fails = 0;
     for (int full = 0; full < 2; ++full)
-        for (int prec = 0; prec < 3; ++prec) {
-            if (full && prec == 2) continue;
+        for (int prec = 0; prec < 4; ++prec) {                 // f16, bf16, fp8, f16x2 (the last two: uit_* family only)
+            if (full && prec >= 2) continue;
             for (int depth : {1, 4}) {
                 uitk_config c{};
                 c.depth = depth; c.embed_dim = 128; c.num_heads = 2; c.mlp_hidden = 384; c.outputdim = 537; c.target_length = 102;
