@@ -23,6 +23,41 @@ HDR_FIELDS = (["magic", "precision", "depth", "outputdim", "mel_steps"] + [f"mel
 FRAG, STAGE = 1024, 16384
 PE_HI_STAGES, PE_STAGES, BLOCK_STAGES, BIAS_FLOATS = 4, 8, 14, 1024     # PE: 4 stages of weights + 4 of their low-order terms
 BIAS_QKV, BIAS_PROJ, BIAS_FC1, BIAS_FC2 = 0, 96, 224, 608
+# precision f16l6 (uitk_dev.h): stage sizes of the variable-size stream, fragment6, row-scale table
+FRAG6, L6_QK, L6_VP, L6_M, L6_MB, L6_SCALES = 1536, 16384, 16384 + 8 * 1024, 16384 + 2 * 1536, 16384 + 10 * 1536, 736
+L6_BLOCK = L6_QK + L6_VP + 9 * L6_M + 3 * L6_MB
+
+
+def l6_mlp_offset(ch):
+    return L6_QK + L6_VP + ch * L6_M + (ch // 4) * (L6_MB - L6_M)
+
+
+def q_e2m3(v):
+    """OCP fp6 e2m3 grid (round to nearest even, saturating at 7.5)."""
+    a = np.abs(v).astype(np.float64)
+    e = np.clip(np.floor(np.log2(np.maximum(a, 1e-30))), 0, 2)
+    step = np.where(a < 1.0, 0.125, np.exp2(e - 3))
+    return (np.sign(v) * np.minimum(np.round(a / step) * step, 7.5)).astype(np.float32)
+
+
+def q_e2m1(v):
+    """OCP fp4 e2m1 grid: 0 .5 1 1.5 2 3 4 6."""
+    a = np.abs(v).astype(np.float64)
+    e = np.clip(np.floor(np.log2(np.maximum(a, 1e-30))), 0, 2)
+    step = np.where(a < 1.0, 0.5, np.exp2(e - 1))
+    return (np.sign(v) * np.minimum(np.round(a / step) * step, 6.0)).astype(np.float32)
+
+
+def mfma128(A, B, Cc):
+    """v_mfma_scale_f32_16x16x128_f8f6f4 with fp6 / fp4 operands (tools/probe/mx6_layout.hip): A, B [64 lanes][32 fields], already scaled;
+    D[m][n] = sum_g sum_i A[(m, g)][i] B[(n, g)][i]."""
+    Am = np.zeros((16, 128), np.float64)
+    Bm = np.zeros((128, 16), np.float64)
+    k = 32 * G_[:, None] + np.arange(32)[None]
+    Am[C_[:, None], k] = A
+    Bm[k, C_[:, None]] = B
+    D = (Am @ Bm).astype(np.float32)
+    return Cc + D[4 * G_[:, None] + np.arange(4)[None], C_[:, None]]
 
 
 def parse_header(img):
@@ -71,7 +106,8 @@ class EncoderEmu:
         self.img = img
         self.h = parse_header(img)
         assert self.h["magic"] == 0x4B544955
-        self.prec = self.h["precision"]
+        self.l6 = self.h["precision"] == 4                                # f16 operands + MX-fp6 low-order weight term
+        self.prec = 0 if self.l6 else self.h["precision"]
         self.depth = self.h["depth"]
         self.C = self.h["outputdim"]
 
@@ -81,6 +117,33 @@ class EncoderEmu:
     def frag(self, stage, f):
         off = self.h["off_wstream"] + stage * STAGE + f * FRAG
         return to_f32(np.frombuffer(self.img, np.uint16, 512, off).reshape(64, 8), self.prec)
+
+    def l6_frag(self, blk, stage_off, f):
+        off = self.h["off_wstream"] + PE_STAGES * STAGE + blk * L6_BLOCK + stage_off + f * FRAG
+        return to_f32(np.frombuffer(self.img, np.uint16, 512, off).reshape(64, 8), 0)
+
+    def l6_frag6(self, blk, byte_off, frag_index):
+        """fragment6 at byte_off inside block blk -> [64 lanes][32 fields] values, row scale (bias-table byte frag_index) applied"""
+        off = self.h["off_wstream"] + PE_STAGES * STAGE + blk * L6_BLOCK + byte_off
+        lo = np.frombuffer(self.img, np.uint32, 256, off).reshape(64, 4)
+        hi = np.frombuffer(self.img, np.uint32, 128, off + 1024).reshape(64, 2)
+        w = np.concatenate([lo, hi], 1).astype(np.uint64)
+        bits = np.zeros((64, 32), np.uint32)
+        for i in range(32):
+            b = 6 * i
+            v = w[:, b >> 5] >> np.uint64(b & 31)
+            if (b & 31) > 26:
+                v = v | (w[:, (b >> 5) + 1] << np.uint64(32 - (b & 31)))
+            bits[:, i] = (v & np.uint64(63)).astype(np.uint32)
+        e, m = (bits >> 3) & 3, bits & 7
+        val = np.where(e == 0, m / 8.0, np.exp2(e.astype(np.float64) - 1) * (1 + m / 8.0)) * np.where(bits & 32, -1.0, 1.0)
+        sc = np.frombuffer(self.img, np.uint8, 16 * 4, self.h["off_bias"] + (blk * BIAS_FLOATS + L6_SCALES + (frag_index >> 2) * 16) * 4).reshape(16, 4)
+        return (val * np.exp2(sc[C_, frag_index & 3].astype(np.float64) - 127)[:, None]).astype(np.float64)
+
+    @staticmethod
+    def x6(X, ct):
+        """fp6 copy of a token tile's four k-step operands (v_cvt_scalef32_pk32_fp6_f16, scale 2): field i = 8 s + j"""
+        return 2.0 * q_e2m3(np.concatenate([X[s][ct] for s in range(4)], 1) / 2.0)
 
     def head_frag(self, ot, s, term=0):
         off = self.h["off_head_w"] + ((ot * 4 + s) * 2 + term) * FRAG
@@ -130,9 +193,11 @@ class EncoderEmu:
         R = [[pe_bias[tk[ct][:, None], 16 * ft + 4 * G_[:, None] + r4].copy() for ct in range(3)] for ft in range(8)]
         for i in range(PE_HI_STAGES):
             for f in range(16):
-                A = self.frag(i, f)             # high-order term only: the low-order stages are used with UITK_SPLIT_PE=1 only
+                A = self.frag(i, f)             # high-order term; the low-order stages are used with UITK_SPLIT_PE=1 and by f16x2 / f16l6
                 for ct in range(3):
                     R[2 * i + f // 8][ct] = mfma32(A, XB[f % 8][ct], R[2 * i + f // 8][ct])
+                    if self.l6:
+                        R[2 * i + f // 8][ct] = mfma32(self.frag(PE_HI_STAGES + i, f), XB[f % 8][ct], R[2 * i + f // 8][ct])
         stages = np.zeros((2, self.depth + 1, 24, 128), np.float32)
 
         def dump(st):
@@ -152,16 +217,18 @@ class EncoderEmu:
             tb = PE_STAGES + blk * BLOCK_STAGES
             bias = self._f32(h["off_bias"] + blk * BIAS_FLOATS * 4, BIAS_FLOATS)
             X = self.layernorm_to_operand(R, 1e-6)
+            l6 = self.l6
+            fr = (lambda st, f: self.l6_frag(blk, 0 if st == 0 else L6_QK if st == 1 else l6_mlp_offset(st - 2), f)) if l6 else (lambda st, f: self.frag(tb + st, f))
             QK = [[np.repeat(bias[BIAS_QKV + 16 * ft + 4 * G_[:, None] + r4], 1, 0).copy() for _ in range(3)] for ft in range(4)]
             for f in range(16):
-                A = self.frag(tb, f)
+                A = fr(0, f)
                 for ct in range(3):
                     QK[f // 4][ct] = mfma32(A, X[f % 4][ct], QK[f // 4][ct])
             Qh = [[self.pack4(QK[hh][ct]) for ct in range(3)] for hh in range(2)]
             Kh = [[self.pack4(QK[2 + hh][ct]) for ct in range(3)] for hh in range(2)]
             V = [[np.repeat(bias[BIAS_QKV + 64 + 16 * hh + C_][:, None], 4, 1) for hh in range(2)] for _ in range(3)]
             for f in range(8):
-                Bw = self.frag(tb + 1, f)
+                Bw = fr(1, f)
                 for ct in range(3):
                     V[ct][f // 4] = mfma32(X[f % 4][ct], Bw, V[ct][f // 4])
             Vh = [[self.pack4(V[ct][hh]) for hh in range(2)] for ct in range(3)]
@@ -189,23 +256,38 @@ class EncoderEmu:
                     O[hh][it] = acc[it] / Ls[it][:, :1]
             OX = [self.pack8(O[0][ct], O[1][ct]) for ct in range(3)]
             for ft in range(8):
-                A = self.frag(tb + 1, 8 + ft)
+                A = fr(1, 8 + ft)
                 bp = bias[BIAS_PROJ + 16 * ft + 4 * G_[:, None] + r4]
                 for ct in range(3):
                     R[ft][ct] = mfma32(A, OX[ct], R[ft][ct] + bp)
+                    if l6:
+                        R[ft][ct] = mfma32(fr(1, 16 + ft), OX[ct], R[ft][ct])       # proj: full fp16 low-order fragment
             X = self.layernorm_to_operand(R, 1e-6)
+            HX4 = [[None] * 4 for _ in range(3)]
             for ch in range(12):
-                t = tb + 2 + ch
                 Hh = [[bias[BIAS_FC1 + 32 * ch + 16 * j + 4 * G_[:, None] + r4].copy() for _ in range(3)] for j in range(2)]
                 for f in range(8):
-                    A = self.frag(t, f)
+                    A = fr(2 + ch, f)
                     for ct in range(3):
                         Hh[f // 4][ct] = mfma32(A, X[f % 4][ct], Hh[f // 4][ct])
+                if l6:
+                    for i in range(2):
+                        W6 = self.l6_frag6(blk, l6_mlp_offset(ch) + STAGE + i * FRAG6, 2 * ch + i)
+                        for ct in range(3):
+                            Hh[i][ct] = mfma128(W6, self.x6(X, ct), Hh[i][ct])
                 HX = [self.pack8(np.maximum(Hh[0][ct], 0), np.maximum(Hh[1][ct], 0)) for ct in range(3)]
                 for ft in range(8):
-                    A = self.frag(t, 8 + ft)
+                    A = fr(2 + ch, 8 + ft)
                     for ct in range(3):
                         R[ft][ct] = mfma32(A, HX[ct], R[ft][ct])
+                if l6:
+                    for ct in range(3):
+                        HX4[ct][ch & 3] = 2.0 * q_e2m1(HX[ct] / 2.0)                   # v_cvt_scalef32_pk_fp4_f16, scale 2
+                    if (ch & 3) == 3:
+                        for ft in range(8):
+                            W6 = self.l6_frag6(blk, l6_mlp_offset(ch) + L6_M + ft * FRAG6, 24 + 8 * (ch // 4) + ft)
+                            for ct in range(3):
+                                R[ft][ct] = mfma128(W6, np.concatenate(HX4[ct], 1), R[ft][ct])
             for ft in range(8):
                 b2 = bias[BIAS_FC2 + 16 * ft + 4 * G_[:, None] + r4]
                 for ct in range(3):

@@ -195,3 +195,42 @@ def test_load_pretrained_filters_by_shape_and_resizes_pos_embed():
     assert torch.equal(m.time_pos_embed, ck["time_pos_embed"][..., :6])   # 10 -> 6 entries
     with pytest.raises(AssertionError):
         load_pretrained(m, {"unrelated": torch.zeros(1)})
+
+
+def test_uploaded_image_is_invalidated_by_hooks_not_by_a_per_call_scan(monkeypatch):
+    """The (pointer, version) walk over all 163 tensors is off the hot path (round 3): a cached handle is returned without
+    touching the parameters; load_state_dict, .to()/.float() (= _apply) and refresh() drop the handles.  UITK_CHECK_WEIGHTS=1
+    keeps the old per-call scan as a debug mode."""
+    from uit_mobile_amd.models import uit as U
+    m = models.uit_xxxs(outputdim=537, target_length=102).eval()
+
+    class H:                                            # stand-in for _Handle
+        ptr = 1234
+
+    m._handles[0] = (H(), m._stamp())
+    calls = []
+    monkeypatch.setattr(m, "_stamp", lambda: calls.append(1) or ())
+    dev = torch.device("cuda", 0)
+    assert m._handle(dev) == 1234 and calls == []                       # hot path: dict lookup only
+    m.float()                                                           # _apply hook
+    assert m._handles == {}
+    m._handles[0] = (H(), ())
+    m.load_state_dict(m.state_dict())
+    assert m._handles == {}
+    m._handles[0] = (H(), ())
+    m.refresh()
+    assert m._handles == {}
+    m._handles[0] = (H(), ())
+    monkeypatch.setattr(U, "_CHECK_WEIGHTS", True)
+    assert m._handle(dev) == 1234 and calls == [1]                      # debug mode: the scan runs (and matches)
+
+
+def test_parity_precision_is_part_of_the_interface():
+    """precision='f16l6' (f16 operands + MX-fp6 low-order weight term) packs without a GPU; it is a uit_* family mode."""
+    m = models.uit_xxxs(outputdim=537, target_length=102, precision="f16l6").eval()
+    img = m.packed_image()
+    assert len(img) > len(models.uit_xxxs(outputdim=537, target_length=102, precision="f16").eval().packed_image())
+    with pytest.raises(NotImplementedError):
+        models.audio_transformer_h128_d4_m3(outputdim=537, target_length=102, precision="f16l6")
+    with pytest.raises(ValueError):
+        models.uit_xxxs(precision="f16l7")

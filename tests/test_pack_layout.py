@@ -216,3 +216,27 @@ def test_structured_rounding_preserves_group_sums_of_the_conv_weights():
     gs = lambda A: (A - W).reshape(128, 16, 16).sum(-1)                    # summed error per (row, mel row)
     assert np.sqrt((gs(Q) ** 2).mean()) < 0.25 * np.sqrt((gs(rtn) ** 2).mean())
     assert np.sqrt(((Q - W) ** 2).mean()) < 1.1 * np.sqrt(((rtn - W) ** 2).mean())
+
+
+@pytest.mark.parametrize("seed", [205, 207])
+def test_emulated_f16l6_low_order_term_cuts_the_weight_rounding_error(seed):
+    """precision f16l6 (round 3): the packed fragment6 stream (e2m3 fields, row scales in the bias table, variable-size stages), the
+    fp6 / fp4 activation copies and the K = 128 MFMA lane map (tools/probe/mx6_layout.hip), executed by the emulator on a
+    trained-like checkpoint, must be CLOSER to the oracle than the same emulation of precision f16 -- i.e. the low-order term is
+    applied to the right rows / columns / scales (a misplaced correction adds error instead of removing it)."""
+    from synth_weights import make_trained_like_state_dict
+    sd = make_trained_like_state_dict("uit_xxxs", seed)
+    pcm = synth_pcm_i16(2, 16000, seed=7)
+    o = Oracle(sd)
+    ref = o.forward(pcm, want_stages=True)
+    mel_raw, amax = o.melspec_db(pcm)
+    mel2 = np.ascontiguousarray(mel_raw.transpose(0, 2, 1))
+    err = {}
+    for prec in ("f16", "f16l6"):
+        m = models.uit_xxxs(outputdim=537, target_length=102, precision=prec)
+        m.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()}, strict=True)
+        logits, stages = EncoderEmu(m.eval().packed_image()).run_wave(mel2, amax - 120.0, nt=6)
+        err[prec] = float(np.abs(logits - ref["logits"][:, 0]).max())
+        assert np.abs(stages.mean(-1)).max() < 1e-3
+    print(seed, err)
+    assert err["f16l6"] < 0.6 * err["f16"] and err["f16l6"] < 4e-4

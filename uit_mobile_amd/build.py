@@ -18,7 +18,7 @@ SOURCES = ["api.cpp", "pack.cpp", "frontend.hip", "encoder.hip", "epilogue.hip"]
 HEADERS = ["uitk_dev.h", "pack.h", "../../include/uitk.h"]
 # -fno-slp-vectorize: the kernels write their packed math explicitly (float2 / ext_vector types); the SLP vectoriser's
 # own packing costs more v_mov than it saves (same-box A/B: front-end -4 %)
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-fno-slp-vectorize", "-Wall", "-Wno-unused-result"]
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-fno-slp-vectorize", "-Wall", "-Wno-unused-result", "-Wno-inline-asm"]
 
 
 def hipcc():

@@ -256,7 +256,7 @@ int uitk_encode(uitk_model* m, int64_t B, int64_t T, float* probs, float* logits
     a.logits = logits; a.dbg = m->dbg;
     a.timing = m->timing; a.ablate = m->enc_ablate;
     a.bn_nonneg = m->bn_nonneg;
-    a.split_pe = m->split_pe || m->cfg.precision == UITK_PREC_F16X2;     // f16x2: the patch embed runs on its split weights too
+    a.split_pe = m->split_pe || m->cfg.precision == UITK_PREC_F16X2 || m->cfg.precision == UITK_PREC_F16L6;     // f16x2 / f16l6: the patch embed runs on its split weights too
     a.attention_full = m->cfg.attention_full; a.act_gelu = m->cfg.act_gelu; a.pooling = m->cfg.pooling;
     a.stagger = m->enc_stagger; a.stagger_group = m->n_cu; a.stagger_mode = m->enc_stagger_mode;
     HIP_TRY(launch_encoder(a, m->cfg.precision, m->enc_waves, m->enc_sched, s));

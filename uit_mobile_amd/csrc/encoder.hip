@@ -482,6 +482,86 @@ __device__ __forceinline__ float gelu1(float x) {
 }
 __device__ __forceinline__ f4 gelu4(f4 x) { return f4{gelu1(x[0]), gelu1(x[1]), gelu1(x[2]), gelu1(x[3])}; }
 
+// ---- precision f16l6 (round 3): the low-order weight term W - f16(W) as MX-fp6 (e2m3) operands of v_mfma_scale_f32_16x16x128_f8f6f4
+// against fp6 / fp4 copies of the activations: one MFMA at the cost of one f16 k-step covers K = 128 (tools/probe/mx6_layout.hip:
+// operand field order, row scales, conversion order and rounding, cycles per instruction).
+typedef _Float16 h32 __attribute__((ext_vector_type(32)));
+typedef _Float16 h16v __attribute__((ext_vector_type(16)));
+typedef _Float16 h2v __attribute__((ext_vector_type(2)));
+typedef unsigned u6 __attribute__((ext_vector_type(6)));
+typedef unsigned u4 __attribute__((ext_vector_type(4)));
+constexpr int E8M0_TWO = 128;                                       // activations are converted with scale 2: e2m3 covers +-15, e2m1 +-12
+__device__ __forceinline__ v8i pad6(u6 x) { return v8i{(int)x[0], (int)x[1], (int)x[2], (int)x[3], (int)x[4], (int)x[5], 0, 0}; }
+__device__ __forceinline__ v8i pad4(u4 x) { return v8i{(int)x[0], (int)x[1], (int)x[2], (int)x[3], 0, 0, 0, 0}; }
+__device__ __forceinline__ u6 lds_frag6(const char* base, int lane) {                 // ds_read_b128 + ds_read_b64, both lane-linear
+    typedef unsigned u2x __attribute__((ext_vector_type(2)));
+    const u4 lo = *(const u4*)(base + lane * 16);
+    const u2x hi = *(const u2x*)(base + 1024 + lane * 8);
+    return u6{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1]};
+}
+// the four k-step operands of a token tile (32 halves per lane) -> their fp6 copy (values / 2, saturating at +-7.5)
+__device__ __forceinline__ u6 operand_to_fp6(h8 x0, h8 x1, h8 x2, h8 x3, float scale = 2.0f) {
+    const h16v a = __builtin_shufflevector(x0, x1, 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15);
+    const h16v b = __builtin_shufflevector(x2, x3, 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15);
+    const h32 x = __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18, 19, 20, 21, 22, 23, 24, 25, 26, 27, 28, 29, 30, 31);
+    return __builtin_amdgcn_cvt_scalef32_pk32_fp6_f16(x, scale);
+}
+// eight halves (one MLP chunk's hidden operand of a lane) -> one dword of eight e2m1 fields (values / 2, saturating at +-6)
+__device__ __forceinline__ unsigned operand_to_fp4(h8 x) {
+    unsigned w = 0;
+    w = __builtin_amdgcn_cvt_scalef32_pk_fp4_f16(w, h2v{x[0], x[1]}, 2.0f, 0);
+    w = __builtin_amdgcn_cvt_scalef32_pk_fp4_f16(w, h2v{x[2], x[3]}, 2.0f, 1);
+    w = __builtin_amdgcn_cvt_scalef32_pk_fp4_f16(w, h2v{x[4], x[5]}, 2.0f, 2);
+    w = __builtin_amdgcn_cvt_scalef32_pk_fp4_f16(w, h2v{x[6], x[7]}, 2.0f, 3);
+    return w;
+}
+// D = Wlo . X + C; WSEL = byte of the row-scale dword that belongs to this fragment6
+template <int WSEL> __device__ __forceinline__ f4 mfma6_wa(u6 w, u6 x, f4 c, int wscale) {      // fp6 weights as A, fp6 activations as B
+    return __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(pad6(w), pad6(x), c, 2, 2, WSEL, wscale, 0, E8M0_TWO);
+}
+template <int WSEL> __device__ __forceinline__ f4 mfma6_wb(u6 x, u6 w, f4 c, int wscale) {      // fp6 activations as A, fp6 weights as B
+    return __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(pad6(x), pad6(w), c, 2, 2, 0, E8M0_TWO, WSEL, wscale);
+}
+template <int WSEL> __device__ __forceinline__ f4 mfma64_wa(u6 w, u4 x, f4 c, int wscale) {     // fp6 weights as A, fp4 activations as B
+    return __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(pad6(w), pad4(x), c, 2, 4, WSEL, wscale, 0, E8M0_TWO);
+}
+__device__ __forceinline__ f4 mfma6_wa_sel(int sel, u6 w, u6 x, f4 c, int wscale) {
+    switch (sel & 3) { case 0: return mfma6_wa<0>(w, x, c, wscale); case 1: return mfma6_wa<1>(w, x, c, wscale);
+                       case 2: return mfma6_wa<2>(w, x, c, wscale); default: return mfma6_wa<3>(w, x, c, wscale); }
+}
+__device__ __forceinline__ f4 mfma64_wa_sel(int sel, u6 w, u4 x, f4 c, int wscale) {
+    switch (sel & 3) { case 0: return mfma64_wa<0>(w, x, c, wscale); case 1: return mfma64_wa<1>(w, x, c, wscale);
+                       case 2: return mfma64_wa<2>(w, x, c, wscale); default: return mfma64_wa<3>(w, x, c, wscale); }
+}
+// Weight ring of precision f16l6: four 32 KiB slots, stages of four sizes (uitk_dev.h).  KIND 0 QK, 1 VP, 2 M, 3 MB.  Every wave issues
+// the same number of 1 KiB LDS-DMAs for a given kind (a tail of fewer than 8 pieces is fetched by the waves modulo its length, i.e.
+// some pieces twice), so the counted vmcnt is static per call site.
+template <int KIND> constexpr int l6_dma_count() { return KIND == 0 ? 2 : KIND == 1 ? 3 : KIND == 2 ? 3 : 5; }
+template <int KIND>
+__device__ __forceinline__ void l6_issue(const char* src, char* dst, int wave, int lane) {
+    // Scalar-base form of the LDS-DMA, written out: uniform 64-bit base (SGPR pair) + ONE 32-bit lane offset.  The builtin selects the
+    // 64-bit per-lane address form for dwordx4, i.e. a register pair per distinct piece held across the whole block loop -- registers
+    // this mode does not have (a spill reload inside the loop drains the counted vmcnt).
+    const unsigned lane16 = (unsigned)lane * 16u;
+    auto piece = [&](int p) {
+        const char* gsrc = src + (size_t)(unsigned)(p * FRAG_BYTES);
+        const unsigned ldst = (unsigned)(uintptr_t)LPTR(dst + p * FRAG_BYTES);
+        asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(ldst), "v"(lane16), "s"(gsrc) : "memory", "m0");
+    };
+    piece(wave * 2); piece(wave * 2 + 1);                            // the sixteen f16 fragments
+    if constexpr (KIND == 1) piece(16 + wave);                       // 8 low-order f16 fragments of proj
+    if constexpr (KIND >= 2) piece(16 + (wave >= 6 ? wave - 6 : wave >= 3 ? wave - 3 : wave));      // 2 fragment6 of fc1 = 3 KiB
+    if constexpr (KIND == 3) { piece(19 + wave); piece(27 + (wave & 3)); }                          // 8 fragment6 of fc2's k-group = 12 KiB
+}
+// issue the stage two ahead, wait for this wave's share of the current one (OUTSTANDING = DMAs of the two younger stages), barrier
+template <int KIND_ISSUE, int OUTSTANDING>
+__device__ __forceinline__ void l6_step(const char* src, char* dst, int wave, int lane) {
+    l6_issue<KIND_ISSUE>(src, dst, wave, lane);
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(OUTSTANDING) : "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+}
+
 // In-kernel stamps (diagnostic build only, TIMING = true): one asm statement = s_memtime + lgkmcnt(0), fenced.
 __device__ __forceinline__ unsigned long long stamp() {
     unsigned long long t;
@@ -506,9 +586,13 @@ __global__ __launch_bounds__(WAVES * 64, 2) void uit_encoder_kernel(EncoderArgs 
     using v8 = typename OP::v8;
     using v4 = typename OP::v4;
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    // precision f16l6: four 32 KiB ring slots (the low-order patch-embed weights use the upper half of the ring during the prologue)
+    constexpr bool L6 = PREC == 4;
+    constexpr int RING_BYTES = L6 ? 4 * L6_SLOT_BYTES : LDS_RING;
+    static_assert(!L6 || (WAVES == 8 && RING_BYTES + LDS_BIAS + LDS_ZBUF + LDS_PEB <= ENC_LDS_W8), "f16l6: 8-wave workgroups, LDS budget");
     char* ring = smem;
-    char* breg = smem + LDS_RING;
-    char* zbuf = smem + LDS_RING + LDS_BIAS;
+    char* breg = smem + RING_BYTES;
+    char* zbuf = smem + RING_BYTES + LDS_BIAS;
 
     const int tid = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -520,7 +604,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void uit_encoder_kernel(EncoderArgs 
     if (a.stagger > 0) {
         bool delay;
         if (a.stagger_mode == 2) {
-            unsigned* flag = (unsigned*)(smem + LDS_RING + LDS_BIAS);
+            unsigned* flag = (unsigned*)zbuf;
             if (tid == 0) *flag = __builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 4) & 1u;   // WAVE_ID parity
             __syncthreads();
             delay = *flag != 0;
@@ -580,7 +664,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void uit_encoder_kernel(EncoderArgs 
     // split patch embed (W = hi + lo): the low-order fragments go to their own 64 KiB behind the ring; 8-wave workgroups only
     // (a 4-wave workgroup shares its CU's LDS with a second one and runs the single-term patch embed)
     constexpr bool SPLIT_PE = WAVES == 8;
-    char* pelo = smem + ENC_LDS;
+    char* pelo = L6 ? ring + PE_HI_STAGES * STAGE_BYTES : smem + ENC_LDS;
     if (SPLIT_PE && a.split_pe) {
         constexpr int PER_WAVE = STAGE_FRAGS / WAVES;
 #pragma unroll
@@ -595,7 +679,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void uit_encoder_kernel(EncoderArgs 
     // the conv-bias + positional table (25 x 128 f32) goes to LDS by DMA as well (8-wave workgroups): 24 per-lane global loads of
     // sixteen cache lines each were a quarter of the prologue's trip through the CU's vector-memory address path
     constexpr bool PEB_LDS = WAVES == 8;
-    float* peb = (float*)(smem + ENC_LDS_SPLIT_PE);
+    float* peb = (float*)(smem + (L6 ? RING_BYTES + LDS_BIAS + LDS_ZBUF : ENC_LDS_SPLIT_PE));
     if constexpr (PEB_LDS) {
 #pragma unroll
         for (int i = 0; i < (NTOK + 1 + WAVES - 1) / WAVES; ++i) {
@@ -722,15 +806,23 @@ __global__ __launch_bounds__(WAVES * 64, 2) void uit_encoder_kernel(EncoderArgs 
     TSTAMP(10);                                                           // patch-embed MFMAs
     __builtin_amdgcn_s_barrier();                                         // every wave is done with the PE weights
     asm volatile("" ::: "memory");
+    if constexpr (L6) {
+        const char* w0 = a.wstream + (size_t)PE_STAGES * STAGE_BYTES;
+        l6_issue<0>(w0, ring, wave, lane);
+        l6_issue<1>(w0 + L6_QK_BYTES, ring + L6_SLOT_BYTES, wave, lane);
+    } else {
 #pragma unroll
-    for (int i = 0; i < PREFETCH; ++i) ring_issue<WAVES>(a.wstream, ring, PE_STAGES + i, wave, lane);
+        for (int i = 0; i < PREFETCH; ++i) ring_issue<WAVES>(a.wstream, ring, PE_STAGES + i, wave, lane);
+    }
 
-    auto dbg_store = [&](int stage) {
+    auto dbg_store = [&](int stage) {                      // (debug path: recomputes its token map instead of keeping it live)
 #pragma unroll
         for (int ct = 0; ct < 3; ++ct) {
-            const int row = r0 + clip_[ct];
+            const int col = 16 * ct + (threadIdx.x & 15);
+            const int dclip = (!TOK && col >= NTOK) ? 1 : 0, dtk = TOK ? (col >= 1 && col <= NTOK ? col - 1 : 0) : col - NTOK * dclip;
+            const int row = r0 + dclip;
             if (row < a.rows) {
-                float* dst = a.dbg + (((int64_t)row * (a.depth + 1) + stage) * NTOK + tk_[ct]) * DIM + 4 * g;
+                float* dst = a.dbg + (((int64_t)row * (a.depth + 1) + stage) * NTOK + dtk) * DIM + 4 * (int)((threadIdx.x & 63) >> 4);
 #pragma unroll
                 for (int ft = 0; ft < 8; ++ft) *(f4*)(dst + 16 * ft) = R[ft][ct];
             }
@@ -937,6 +1029,179 @@ __global__ __launch_bounds__(WAVES * 64, 2) void uit_encoder_kernel(EncoderArgs 
                     for (int ft = 0; ft < 8; ++ft)
 #pragma unroll
                         for (int ct = 0; ct < 3; ++ct) R[ft][ct] = OP::mfma32(A2[ft], HX[ct], R[ft][ct]);
+                }
+            }
+        }
+#pragma unroll
+        for (int ft = 0; ft < 8; ++ft) {
+            const f4 b2 = *(const f4*)(bias + BIAS_FC2 + 16 * ft + 4 * g);
+#pragma unroll
+            for (int ct = 0; ct < 3; ++ct) R[ft][ct] = add4s(R[ft][ct], b2);
+        }
+        if (a.dbg != nullptr) {
+            dbg_store(blk + 1);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+      } else if constexpr (PREC == 4) {
+        // ================= precision f16l6: the f16 block + the low-order weight term on the MX-fp6 MFMA (uitk_dev.h) =================
+        // Stage k of block blk lives in ring slot (2 blk + k) & 3 (14 stages per block); at step k the stage k + 2 is issued.
+        static_assert(ATT == 0 && POOL == 0 && ACT == 0, "precision f16l6: uit_* family only");
+        const char* wblk = a.wstream + (size_t)PE_STAGES * STAGE_BYTES + (size_t)blk * L6_BLOCK_BYTES;
+        const int sb = 2 * (blk & 1);
+        auto slot_of = [&](int k) -> char* { return ring + ((sb + k) & 3) * L6_SLOT_BYTES; };
+        const float* bias = (const float*)(breg + (blk & 1) * BIAS_FLOATS * 4);
+        const int* sct = (const int*)(bias + L6_SCALES) + c;              // row-scale dwords [quad][row = c]
+        v8 X[4][3];
+        layernorm_to_operand<OPC>(R, 1e-6f, X);
+        // ===== stage QK (issue MLP stage 0; younger stages VP + M).  qkv keeps single fp16 weights: its rounding is the smallest of the
+        // four weight terms and the stage has no register room for a second operand set
+        l6_step<2, l6_dma_count<1>() + l6_dma_count<2>()>(wblk + l6_mlp_offset(0), slot_of(2), wave, lane);
+        if (blk + 1 < a.depth) bias_issue<WAVES>(a.bias, breg, blk + 1, wave, lane);
+        v4 Qh[2][3], Kh[2][3];
+        {
+            const char* slot = slot_of(0);
+            v8 A[16];
+#pragma unroll
+            for (int f = 0; f < 8; ++f) A[f] = lds_frag<OPC>(slot, f, lane);
+#pragma unroll
+            for (int ft = 0; ft < 4; ++ft) {
+                if (ft == 1) {
+#pragma unroll
+                    for (int f = 8; f < 16; ++f) A[f] = lds_frag<OPC>(slot, f, lane);
+                }
+                const f4 bq = *(const f4*)(bias + BIAS_QKV + 16 * ft + 4 * g);
+#pragma unroll
+                for (int ct = 0; ct < 3; ++ct) {
+                    f4 acc = bq;
+#pragma unroll
+                    for (int s = 0; s < 4; ++s) acc = OP::mfma32(A[ft * 4 + s], X[s][ct], acc);
+                    if (ft < 2) Qh[ft][ct] = OP::pack4(acc); else Kh[ft - 2][ct] = OP::pack4(acc);
+                }
+            }
+        }
+        // ===== stage VP (issue MLP stage 1; younger stages M + M); proj on split fp16 weights (K = 32: 24 more MFMAs)
+        l6_step<2, 2 * l6_dma_count<2>()>(wblk + l6_mlp_offset(1), slot_of(3), wave, lane);
+        {
+            const char* slot = slot_of(1);
+            v4 Vh[3][2];
+            {
+                v8 Bw[8];
+#pragma unroll
+                for (int f = 0; f < 8; ++f) Bw[f] = lds_frag<OPC>(slot, f, lane);
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const f4 bv = splat(bias[BIAS_QKV + 64 + 16 * h + c]);
+#pragma unroll
+                    for (int ct = 0; ct < 3; ++ct) {
+                        f4 acc = bv;
+#pragma unroll
+                        for (int s = 0; s < 4; ++s) acc = OP::mfma32(X[s][ct], Bw[h * 4 + s], acc);
+                        Vh[ct][h] = OP::pack4(acc);
+                    }
+                }
+            }
+            if constexpr (PERKEY) {
+                attention_proj<OP, PERKEY, true>(R, Qh, Kh, Vh, tvalid, pmask, slot + 8 * FRAG_BYTES, bias, lane, g);
+            } else {
+                // full clips: a lane's four keys of a tile are all valid or all foreign, so the probability masks follow from tvalid --
+                // rebuilt per block (14 selects) instead of living in 14 registers through the MLP loop, which has none to spare
+                u2 pm[7];
+                unsigned ones = ~0u;
+                asm volatile("" : "+v"(ones));                        // (keeps the selects inside the block loop: hoisted, they are 14 live registers again)
+#pragma unroll
+                for (int i = 0; i < 7; ++i) pm[i] = tvalid[i] ? u2{ones, ones} : u2{0u, 0u};
+                attention_proj<OP, PERKEY, true>(R, Qh, Kh, Vh, tvalid, pm, slot + 8 * FRAG_BYTES, bias, lane, g);
+            }
+        }
+        // ===== MLP: 12 stages in three k-groups of four.  fc1: four fp16 k-steps + ONE fp6 MFMA per accumulator; fc2: the fp16 k-step of
+        // the chunk, and at the last stage of a group (MB) the group's low-order term on the fp4 copy of its 128 hidden activations.
+        // fc2 runs in its own chunk's stage (not under the next chunk's fragment reads as in precision f16): carrying its fragments
+        // across the barrier costs 44 registers this mode does not have -- any spill inside the loop would drain the counted vmcnt.
+        layernorm_to_operand<OPC>(R, 1e-6f, X);
+        u4 HX4[3];
+#pragma unroll 1
+        for (int q = 0; q < 3; ++q) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int ch = 4 * q + j;
+                // ring step: stage ch + 2 of the MLP, or the next block's QK / VP
+                if (j == 0) l6_step<2, 2 * l6_dma_count<2>()>(wblk + l6_mlp_offset(ch + 2), slot_of(ch + 4), wave, lane);
+                else if (j == 1) l6_step<3, l6_dma_count<2>() + l6_dma_count<3>()>(wblk + l6_mlp_offset(ch + 2), slot_of(ch + 4), wave, lane);
+                else if (j == 2) {
+                    if (q < 2) l6_step<2, l6_dma_count<3>() + l6_dma_count<2>()>(wblk + l6_mlp_offset(ch + 2), slot_of(ch + 4), wave, lane);
+                    else l6_step<0, l6_dma_count<3>() + l6_dma_count<0>()>(wblk + L6_BLOCK_BYTES, slot_of(ch + 4), wave, lane);
+                } else {
+                    if (q < 2) l6_step<2, 2 * l6_dma_count<2>()>(wblk + l6_mlp_offset(ch + 2), slot_of(ch + 4), wave, lane);
+                    else l6_step<1, l6_dma_count<0>() + l6_dma_count<1>()>(wblk + L6_BLOCK_BYTES + L6_QK_BYTES, slot_of(ch + 4), wave, lane);
+                }
+                const char* slot = slot_of(ch + 2);
+                v8 HX[3];
+                {
+                    v8 A[8];
+#pragma unroll
+                    for (int f = 0; f < 8; ++f) A[f] = lds_frag<OPC>(slot, f, lane);
+                    const u6 W6a = lds_frag6(slot + STAGE_BYTES, lane), W6b = lds_frag6(slot + STAGE_BYTES + FRAG6_BYTES, lane);
+                    const int s1 = sct[(2 * q + (j >> 1)) * 16];      // row scales of fc1 tiles 4 (2q + j/2) .. +3
+                    // fp6 copy of the LayerNorm operand, converted per chunk (3 instructions in MFMA shadows) instead of held in 18
+                    // registers; the laundered scale keeps the conversions from being hoisted out of the loop again
+                    float two = 2.0f;
+                    asm volatile("" : "+s"(two));
+                    u6 X6[3];
+#pragma unroll
+                    for (int ct = 0; ct < 3; ++ct) X6[ct] = operand_to_fp6(X[0][ct], X[1][ct], X[2][ct], X[3][ct], two);
+                    const f4 b10 = *(const f4*)(bias + BIAS_FC1 + 32 * ch + 4 * g), b11 = *(const f4*)(bias + BIAS_FC1 + 32 * ch + 16 + 4 * g);
+                    // one fc1 row tile at a time: its three accumulators are packed (ReLU on the packed halves) before the next tile's
+                    // start, so only 12 accumulator registers are live
+                    v4 P0[3], P1[3];
+                    {
+                        f4 H[3];
+#pragma unroll
+                        for (int ct = 0; ct < 3; ++ct) {
+                            H[ct] = b10;
+#pragma unroll
+                            for (int s = 0; s < 4; ++s) H[ct] = OP::mfma32(A[s], X[s][ct], H[ct]);
+                            H[ct] = mfma6_wa_sel(2 * j, W6a, X6[ct], H[ct], s1);
+                        }
+#pragma unroll
+                        for (int ct = 0; ct < 3; ++ct) { P0[ct] = __builtin_elementwise_max(OP::pack4(H[ct]), v4{0, 0, 0, 0}); asm volatile("" : "+v"(P0[ct])); }
+                    }
+                    {
+                        f4 H[3];
+#pragma unroll
+                        for (int ct = 0; ct < 3; ++ct) {
+                            H[ct] = b11;
+#pragma unroll
+                            for (int s = 0; s < 4; ++s) H[ct] = OP::mfma32(A[4 + s], X[s][ct], H[ct]);
+                            H[ct] = mfma6_wa_sel(2 * j + 1, W6b, X6[ct], H[ct], s1);
+                        }
+#pragma unroll
+                        for (int ct = 0; ct < 3; ++ct) P1[ct] = __builtin_elementwise_max(OP::pack4(H[ct]), v4{0, 0, 0, 0});
+                    }
+#pragma unroll
+                    for (int ct = 0; ct < 3; ++ct) {
+                        HX[ct] = __builtin_shufflevector(P0[ct], P1[ct], 0, 1, 2, 3, 4, 5, 6, 7);
+                        unsigned w4 = operand_to_fp4(HX[ct]);
+                        asm volatile("" : "+v"(w4));                  // convert HERE: the scheduler must not keep four chunks of f16 operands alive instead
+                        HX4[ct][j] = w4;
+                    }
+                }
+                {
+                    v8 A2[8];
+#pragma unroll
+                    for (int f = 0; f < 8; ++f) A2[f] = lds_frag<OPC>(slot, 8 + f, lane);
+#pragma unroll
+                    for (int ft = 0; ft < 8; ++ft)
+#pragma unroll
+                        for (int ct = 0; ct < 3; ++ct) R[ft][ct] = OP::mfma32(A2[ft], HX[ct], R[ft][ct]);
+                }
+                if (j == 3) {                                         // fc2 low-order term of k-group q
+                    const int s2a = sct[(6 + 2 * q) * 16], s2b = sct[(7 + 2 * q) * 16];
+#pragma unroll
+                    for (int ft = 0; ft < 8; ++ft) {
+                        const u6 W6 = lds_frag6(slot + L6_M_BYTES + ft * FRAG6_BYTES, lane);
+#pragma unroll
+                        for (int ct = 0; ct < 3; ++ct) R[ft][ct] = mfma64_wa_sel(ft, W6, HX4[ct], R[ft][ct], ft < 4 ? s2a : s2b);
+                    }
                 }
             }
         }
@@ -1608,6 +1873,8 @@ hipError_t launch_encoder(const EncoderArgs& a, int precision, int waves, int sc
         return precision == 0 ? UITK_VARIANT(0, false) : UITK_VARIANT(1, false);
 #undef UITK_VARIANT
     }
+    if (precision == 4)                                   // f16l6: f16 + low-order fp6 weight term, 8-wave workgroups
+        return a.nt < GT ? launch_enc<4, 8, true>(a, stream) : launch_enc<4, 8, false>(a, stream);
     if (precision == 3)                                   // f16x2: split weights (hi + lo), 8-wave workgroups
         return a.nt < GT ? launch_enc<3, 8, true>(a, stream) : launch_enc<3, 8, false>(a, stream);
     if (precision == 2) {                                 // fp8 weights / activations on the MX-scaled 16x16x128 MFMA

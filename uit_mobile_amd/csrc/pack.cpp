@@ -163,6 +163,56 @@ static void pack_frag8(uint8_t* dst, uint8_t* scales, const std::function<double
         }
 }
 
+// OCP fp6 e2m3: 1-2-3, bias 1, max 7.5, no inf/nan, subnormal step 1/8; round-to-nearest-even, saturating
+static uint8_t f32_to_e2m3(double x) {
+    const uint8_t s = std::signbit(x) ? 0x20 : 0;
+    double a = std::fabs(x);
+    if (!(a == a)) return 0;
+    if (a >= 7.5) return (uint8_t)(s | 0x1f);
+    int E = 0;                                                         // exponent of the leading bit, 0 for [0, 2)
+    if (a >= 4.0) E = 2; else if (a >= 2.0) E = 1;
+    double r = std::nearbyint(a / std::ldexp(1.0, E - 3));             // units of the last mantissa bit (ties to even)
+    if (r >= 16.0) { r = 8.0; E += 1; }
+    if (r < 8.0) return (uint8_t)(s | (uint8_t)r);                     // subnormal: exponent field 0, value r / 8
+    return (uint8_t)(s | ((E + 1) << 3) | ((int)r - 8));
+}
+
+// one 1536-byte fragment6 (uitk_dev.h) of rows 16*tile .. +15, k = kbase + [0, 128) from an accessor W(row, k) -> double; ONE MX
+// scale per row (the smallest power of two that brings the row's maximum inside e2m3's 7.5): scales[row] = E8M0 byte
+static void pack_frag6(uint8_t* dst, uint8_t* scales, const std::function<double(int, int)>& W, int tile, int kbase) {
+    double v[64][32];
+    double mx[16] = {};
+    for (int l = 0; l < 64; ++l)
+        for (int i = 0; i < 32; ++i) {
+            v[l][i] = W(16 * tile + (l & 15), kbase + 32 * (i >> 3) + 16 * ((i & 7) >> 2) + 4 * (l >> 4) + (i & 3));
+            mx[l & 15] = std::fmax(mx[l & 15], std::fabs(v[l][i]));
+        }
+    int ex[16];
+    for (int row = 0; row < 16; ++row) {
+        int e = -126;
+        if (mx[row] > 0.0) {
+            e = (int)std::ceil(std::log2(mx[row] / 7.5));
+            while (mx[row] / std::ldexp(1.0, e) > 7.5) ++e;
+            while (mx[row] / std::ldexp(1.0, e - 1) <= 7.5) --e;
+        }
+        if (e < -126) e = -126;
+        if (e > 126) e = 126;
+        ex[row] = e; scales[row] = (uint8_t)(127 + e);
+    }
+    std::memset(dst, 0, FRAG6_BYTES);
+    for (int l = 0; l < 64; ++l) {
+        uint32_t w[6] = {};
+        for (int i = 0; i < 32; ++i) {
+            const uint32_t q = f32_to_e2m3(v[l][i] / std::ldexp(1.0, ex[l & 15]));
+            const int bit = 6 * i;
+            w[bit >> 5] |= q << (bit & 31);
+            if ((bit & 31) > 26) w[(bit >> 5) + 1] |= q >> (32 - (bit & 31));
+        }
+        std::memcpy(dst + l * 16, w, 16);                              // lane-linear 1 KiB part: dwords 0..3
+        std::memcpy(dst + 1024 + l * 8, w + 4, 8);                     // lane-linear 512-byte part: dwords 4, 5
+    }
+}
+
 static size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
 int validate_config(const uitk_config* c, const char** why) {
@@ -179,8 +229,8 @@ int validate_config(const uitk_config* c, const char** why) {
     if (c->depth < 1 || c->depth > 64) return bad("depth out of range");
     if (c->outputdim < 1 || c->outputdim > 65536) return bad("outputdim out of range");
     if (c->eval_avg != UITK_AVG_MEAN && c->eval_avg != UITK_AVG_MAX) return bad("unknown eval_avg");
-    if (c->precision != UITK_PREC_F16 && c->precision != UITK_PREC_BF16 && c->precision != UITK_PREC_FP8 && c->precision != UITK_PREC_F16X2) return bad("unknown precision");
-    if (c->precision == UITK_PREC_F16X2 && (c->attention_full || c->act_gelu || c->pooling)) return bad("precision f16x2 is built for the uit_* family (BNeckAttention, ReLU, mean pooling) only");
+    if (c->precision != UITK_PREC_F16 && c->precision != UITK_PREC_BF16 && c->precision != UITK_PREC_FP8 && c->precision != UITK_PREC_F16X2 && c->precision != UITK_PREC_F16L6) return bad("unknown precision");
+    if ((c->precision == UITK_PREC_F16X2 || c->precision == UITK_PREC_F16L6) && (c->attention_full || c->act_gelu || c->pooling)) return bad("precision f16x2 / f16l6 are built for the uit_* family (BNeckAttention, ReLU, mean pooling) only");
     if ((c->attention_full != 0 && c->attention_full != 1) || (c->act_gelu != 0 && c->act_gelu != 1)) return bad("attention_full / act_gelu must be 0 or 1");
     if ((c->attention_full || c->act_gelu || c->pooling) && c->precision == UITK_PREC_FP8) return bad("precision fp8 is built for the uit_* family (BNeckAttention, ReLU, mean pooling) only");
     if (c->pooling < 0 || c->pooling > 2) return bad("pooling must be 0 (mean), 1 (dm) or 2 (token)");
@@ -200,7 +250,8 @@ static void pack_frag(uint16_t* dst, int prec, const std::function<double(int, i
 }
 
 int pack_image(const uitk_config* c, const uitk_weights* w, std::vector<char>* out, ImageHeader* hdr_out) {
-    const int prec = c->precision == UITK_PREC_F16X2 ? UITK_PREC_F16 : c->precision, depth = c->depth, C = c->outputdim;
+    const bool l6 = c->precision == UITK_PREC_F16L6;                     // f16 operands + fp6 low-order weight term
+    const int prec = (c->precision == UITK_PREC_F16X2 || l6) ? UITK_PREC_F16 : c->precision, depth = c->depth, C = c->outputdim;
     const int ntiles = (C + 15) / 16;
     const int nb = c->n_fft / 2 + 1;
     // ---- mel filterbank as banded B operands of v_mfma_f32_4x4x1 (16 independent 4x4 blocks): block g owns mels
@@ -269,7 +320,8 @@ int pack_image(const uitk_config* c, const uitk_weights* w, std::vector<char>* o
     const bool x2 = c->precision == UITK_PREC_F16X2;                     // split weights: operand type fp16 (prec 0 for every conversion)
     const int blk_stages = full ? BLOCK_STAGES_ATT : (prec == UITK_PREC_FP8 ? BLOCK_STAGES_FP8 : x2 ? BLOCK_STAGES_X2 : BLOCK_STAGES);
     const int b_proj = full ? BIASF_PROJ : BIAS_PROJ, b_fc1 = full ? BIASF_FC1 : BIAS_FC1, b_fc2 = full ? BIASF_FC2 : BIAS_FC2;
-    h.off_wstream = take((size_t)(PE_STAGES + depth * blk_stages + TAIL_STAGES) * STAGE_BYTES);
+    h.off_wstream = take(l6 ? (size_t)PE_STAGES * STAGE_BYTES + (size_t)depth * L6_BLOCK_BYTES + L6_TAIL_BYTES
+                            : (size_t)(PE_STAGES + depth * blk_stages + TAIL_STAGES) * STAGE_BYTES);
     h.off_bias = take((size_t)depth * BIAS_FLOATS * 4);
     h.off_bn_sc = take(NMEL * 4); h.off_bn_sh = take(NMEL * 4);
     h.off_pe_bias = take((NTOK + 1) * DIM * 4);                       // + the cls row (pooling 'token')
@@ -435,6 +487,35 @@ int pack_image(const uitk_config* c, const uitk_weights* w, std::vector<char>* o
             for (int ch = 0; ch < 12; ++ch) {
                 for (int f = 0; f < 8; ++f) pack_frag(frag_ptr(st + 8 + ch, f), prec, Wfc1, 2 * ch + f / 4, f % 4);
                 for (int ft = 0; ft < 8; ++ft) pack_frag(frag_ptr(st + 8 + ch, 8 + ft), prec, Wfc2, ft, ch);
+            }
+            continue;
+        }
+        if (l6) {
+            // precision f16l6 (uitk_dev.h): the f16 stages of precision f16 + the low-order term lo = W - value(hi) of fc1 / fc2 as
+            // fragment6 and of proj as full fp16 fragments (qkv keeps single weights); row scales into the bias table
+            auto lo_of = [&](const std::function<double(int, int)>& W) {
+                return [&W, prec](int r, int k) { const double v = W(r, k); return v - op16_value(cvt(v, prec), prec); };
+            };
+            const std::function<double(int, int)> fq = Wqkv, fp = Wproj, f1 = Wfc1, f2x = Wfc2_exact, f2h = Wfc2;
+            const std::function<double(int, int)> lp = lo_of(fp), l1 = lo_of(f1);
+            const std::function<double(int, int)> l2 = [&](int r, int k) { return f2x(r, k) - f2h(r, k); };
+            uint8_t* blk_base = (uint8_t*)(img + h.off_wstream) + (size_t)PE_STAGES * STAGE_BYTES + (size_t)b * L6_BLOCK_BYTES;
+            uint8_t* sc_tab = (uint8_t*)(bb + L6_SCALES);                 // [quad][row][4 fragments]
+            uint8_t sc[16];
+            auto put_scales = [&](int frag_index) { for (int row = 0; row < 16; ++row) sc_tab[((frag_index >> 2) * 16 + row) * 4 + (frag_index & 3)] = sc[row]; };
+            auto f16frag = [&](uint8_t* stage, int f) { return (uint16_t*)(stage + (size_t)f * FRAG_BYTES); };
+            uint8_t* sqk = blk_base;
+            for (int f = 0; f < 16; ++f) pack_frag(f16frag(sqk, f), prec, fq, f / 4, f % 4);
+            uint8_t* svp = blk_base + L6_QK_BYTES;
+            for (int f = 0; f < 8; ++f) pack_frag(f16frag(svp, f), prec, fq, 4 + f / 4, f % 4);
+            for (int ft = 0; ft < 8; ++ft) { pack_frag(f16frag(svp, 8 + ft), prec, fp, ft, 0); pack_frag(f16frag(svp, 16 + ft), prec, lp, ft, 0); }
+            for (int ch = 0; ch < 12; ++ch) {
+                uint8_t* sm = blk_base + l6_mlp_offset(ch);
+                for (int f = 0; f < 8; ++f) pack_frag(f16frag(sm, f), prec, f1, 2 * ch + f / 4, f % 4);
+                for (int ft = 0; ft < 8; ++ft) pack_frag(f16frag(sm, 8 + ft), prec, f2h, ft, ch);
+                for (int i = 0; i < 2; ++i) { pack_frag6(sm + STAGE_BYTES + i * FRAG6_BYTES, sc, l1, 2 * ch + i, 0); put_scales(2 * ch + i); }
+                if ((ch & 3) == 3)
+                    for (int ft = 0; ft < 8; ++ft) { pack_frag6(sm + L6_M_BYTES + ft * FRAG6_BYTES, sc, l2, ft, 128 * (ch / 4)); put_scales(24 + 8 * (ch / 4) + ft); }
             }
             continue;
         }

@@ -46,6 +46,30 @@ constexpr int BLOCK_STAGES_FP8 = 8;
 //   0: q h0, q h1 (per row tile: hi s0..3, lo s0..3)   1: k h0, k h1   2: v h0, v h1 (B operand)   3: proj ft 0..7 hi, then lo
 //   4 + 2ch: fc1 row tiles 2ch, 2ch+1 (hi s0..3, lo s0..3 each)        5 + 2ch: fc2 k-step ch, ft 0..7 hi, then lo
 constexpr int BLOCK_STAGES_X2 = 28;
+// ---- precision f16l6 (W = f16 hi + MX-fp6 lo; round 3): the 14 stages of precision f16, the MLP / proj stages followed by the
+// low-order fragments of the rows they cover, in a ring of four 32 KiB slots (stage sizes differ; every DMA is static per call site).
+// A "fragment6" is the 1536-byte A operand of one v_mfma_scale_f32_16x16x128_f8f6f4 with e2m3 data: lane l = (row c = l&15,
+// g = l>>4) holds 32 six-bit fields, field i at bits [6i, 6i+6) of its 192 bits; field i <-> k = kbase + 32 (i>>3) + 16 ((i&7)>>2)
+// + 4 g + (i&3): the order v_cvt_scalef32_pk32_fp6_f16 gives the 32 halves of a lane's four k-step operands (and four
+// v_cvt_scalef32_pk_fp4_f16 per chunk give the hidden activations of four MLP chunks) -- tools/probe/mx6_layout.hip.  Stored as a
+// lane-linear 1 KiB part (dwords 0..3 of every lane) followed by a lane-linear 512-byte part (dwords 4, 5).  One E8M0 scale per
+// ROW of a fragment6 (all four lane groups use it), four fragments per dword, in the block's bias table (L6_SCALES).
+//   QK : 16 f16 fragments (qkv keeps single fp16 weights)                                         16 KiB
+//   VP : 8 V + 8 proj f16 fragments | 8 proj low-order f16 fragments                              24 KiB
+//   M  : 8 fc1 + 8 fc2 f16 fragments | fragment6 of the two fc1 row tiles                         19 KiB
+//   MB : M | fragment6 ft = 0..7 of fc2's hidden k-group q (every fourth MLP stage)               31 KiB
+constexpr int FRAG6_BYTES = 1536;
+constexpr int L6_SLOT_BYTES = 32768;
+constexpr int L6_QK_BYTES = STAGE_BYTES;
+constexpr int L6_VP_BYTES = STAGE_BYTES + 8 * FRAG_BYTES;
+constexpr int L6_M_BYTES = STAGE_BYTES + 2 * FRAG6_BYTES;
+constexpr int L6_MB_BYTES = L6_M_BYTES + 8 * FRAG6_BYTES;
+constexpr int L6_BLOCK_BYTES = L6_QK_BYTES + L6_VP_BYTES + 9 * L6_M_BYTES + 3 * L6_MB_BYTES;
+constexpr int L6_TAIL_BYTES = L6_QK_BYTES + L6_VP_BYTES;         // two dummy stages: the prefetch of the last block never branches
+// byte offset of MLP stage ch (0..11) inside a block
+constexpr int l6_mlp_offset(int ch) { return L6_QK_BYTES + L6_VP_BYTES + ch * L6_M_BYTES + (ch / 4) * (L6_MB_BYTES - L6_M_BYTES); }
+constexpr int L6_SCALES = 736;          // bias-table dwords [736, 928): [quad][row] of E8M0 bytes; quads 0..5: fc1 row tiles 4 quad ..;
+                                        // quads 6..11: fc2 fragment6 8 q + ft = 4 (quad - 6) ..
 constexpr int FRAG8_BYTES = 2048;
 constexpr int FP8_QKV_SCALES = 6 * FRAG8_BYTES;                 // 2 dwords per lane: bytes = tiles 0..3 | 4, 5
 constexpr int FP8_MLP_SCALES = 8 * FRAG_BYTES;                  // stage 1: 6 dwords per lane for fc1 tiles, then 6 for fc2 (q*8 + ft)

@@ -21,7 +21,11 @@ import numpy as np
 import torch
 import torch.nn as nn
 
+import os
+
 from .. import _lib
+
+_CHECK_WEIGHTS = os.environ.get('UITK_CHECK_WEIGHTS', '0') == '1'   # debug: re-scan every tensor's (pointer, version) on every call
 
 __all__ = ["UITBase", "uit_xs", "uit_xxs", "uit_xxxs", "PRETRAINED_CHECKPOINTS",
            "audio_transformer_h128_d4_m3", "audio_transformer_h128_d4_m3_relu",
@@ -160,9 +164,9 @@ class UITBase(nn.Module):
         if not qkv_bias: unsupported.append("qkv_bias must be True")
         if unsupported:
             raise NotImplementedError("uit_mobile_amd implements the uit_xs/xxs/xxxs family only: " + "; ".join(unsupported))
-        if precision not in ('f16', 'bf16', 'fp8', 'f16x2'):
+        if precision not in ('f16', 'bf16', 'fp8', 'f16x2', 'f16l6'):
             raise ValueError(f"Unknown precision ({precision})")
-        if precision in ('fp8', 'f16x2') and (self.attention_full or self.act_gelu or pooling != 'mean'):
+        if precision in ('fp8', 'f16x2', 'f16l6') and (self.attention_full or self.act_gelu or pooling != 'mean'):
             raise NotImplementedError(f"precision='{precision}' is built for the uit_* family (BNeckAttention + ReLU, mean pooling) only")
         if pooling != 'mean' and precision != 'f16':
             raise NotImplementedError("pooling='dm' / 'token' are built for precision='f16'")
@@ -214,14 +218,22 @@ class UITBase(nn.Module):
 
     # ------------------------------------------------------------------ C-ABI plumbing
     def _stamp(self):
-        """Identity of the weights the uploaded image was packed from: (storage pointer, version counter) per tensor, so
-        in-place edits, re-assigned `.data` and dtype/device round trips all invalidate the handle.  Edits that change
-        neither (e.g. writes through a raw numpy view) need an explicit `refresh()`."""
+        """Identity of the weights the uploaded image was packed from: (storage pointer, version counter) per tensor.  A walk over
+        all 163 tensors (0.3 ms of Python), so it is NOT on the hot path: handles are invalidated by the hooks below
+        (`load_state_dict`, `_apply` = .to / .cuda / .half / .float, `refresh()`); the scan runs on every call only with
+        UITK_CHECK_WEIGHTS=1 (debug: also catches in-place edits such as `p.data.mul_()` that no hook sees)."""
         return tuple((t.data_ptr(), int(t._version)) for t in list(self.parameters()) + list(self.buffers()))
 
     def refresh(self):
-        """Drop the uploaded parameter images: the next call re-packs the current weights."""
+        """Drop the uploaded parameter images: the next call re-packs the current weights.  Call it after editing a parameter
+        in place (`p.data.mul_()`, a numpy view): only load_state_dict / .to() / .cuda() invalidate the images by themselves."""
         self._handles.clear()
+
+    def _apply(self, fn, *args, **kwargs):
+        out = super()._apply(fn, *args, **kwargs)
+        if hasattr(self, '_handles'):
+            self._handles.clear()
+        return out
 
     def _config(self):
         return _lib.Config(depth=self.depth, embed_dim=self.embed_dim, num_heads=self.num_heads,
@@ -229,7 +241,7 @@ class UITBase(nn.Module):
                            n_mels=self.n_mels, n_fft=self.n_fft, hop_size=self.hop_size, win_size=self.win_size,
                            patch_size=self.patch_size, center=int(bool(self.center)),
                            eval_avg={'mean': _lib.AVG_MEAN, 'max': _lib.AVG_MAX}.get(self.eval_avg, -1),
-                           precision={'f16': _lib.PREC_F16, 'bf16': _lib.PREC_BF16, 'fp8': _lib.PREC_FP8, 'f16x2': _lib.PREC_F16X2}[self.precision], top_db=120.0,
+                           precision={'f16': _lib.PREC_F16, 'bf16': _lib.PREC_BF16, 'fp8': _lib.PREC_FP8, 'f16x2': _lib.PREC_F16X2, 'f16l6': _lib.PREC_F16L6}[self.precision], top_db=120.0,
                            attention_full=int(self.attention_full), act_gelu=int(self.act_gelu),
                            pooling={'mean': 0, 'dm': 1, 'token': 2}[self.pooling])
 
@@ -278,9 +290,9 @@ class UITBase(nn.Module):
         if self.eval_avg not in ('mean', 'max'):
             raise ValueError(f'Unknown Eval average function ({self.eval_avg})')      # uit.py:488
         idx = device.index if device.index is not None else torch.cuda.current_device()
-        stamp = self._stamp()
         h = self._handles.get(idx)
-        if h is not None and h[1] == stamp:
+        stamp = self._stamp() if (_CHECK_WEIGHTS or h is None) else None
+        if h is not None and (stamp is None or h[1] == stamp):
             return h[0].ptr
         L = _lib.load()
         cfg = self._config()

@@ -9,7 +9,8 @@ collectives, both on torch.distributed's "nccl" backend (= RCCL on ROCm):
     result does not depend on R;
   * one all-gather of the [B/R, outputdim] fp32 outputs into [B, outputdim] on every rank (what evaluate.py's
     metric accumulation consumes): RCCL's all_gather_into_tensor, or -- selectable -- a copy-engine fan-out into IPC-mapped
-    peer buffers (PeerGather) that uses no CU.
+    peer buffers (PeerGather) that uses no CU.  The payload can be cut before it crosses xGMI: float16 probabilities, the
+    first n classes only, or the device-side top-k only (ShardedUiT).
 Nothing else crosses GPUs; there is no collective inside either kernel.
 """
 import torch
@@ -104,19 +105,34 @@ def amax_allreduce_host(slots, group=None):
     return slots
 
 
+class PeerGatherUnavailable(RuntimeError):
+    """The IPC precondition of PeerGather does not hold on this node (raised on EVERY rank, so callers can fall back together)."""
+
+
 class PeerGather:
     """Copy-engine all-gather over xGMI: every rank copies its [rows, C] block straight INTO
     every peer's output buffer with device-to-device copies (hipMemcpyPeerAsync through IPC-mapped buffers), so no RCCL
-    gather kernel competes for the CUs that the two persistent HIP kernels hold.  Completion fence: a 4-byte all-reduce
-    enqueued behind the copies -- a rank's contribution is stream-ordered after its own copies, so when the all-reduce has
-    completed on a rank, every peer's block has landed in that rank's buffer.
+    gather kernel competes for the CUs that the two persistent HIP kernels hold.
 
-    Buffers are allocated once (`nbuf` of them, rotated per call: a result stays valid until `nbuf` further gathers) and
-    exchanged once through torch's IPC handles (hipIpcGetMemHandle / dmabuf; needs HSA_ENABLE_IPC_MODE_LEGACY=0 on this
-    driver).  All ranks must live on one node and see the same device numbering."""
+    Fences (one 4-byte all-reduce per gather, enqueued on the copy stream BEHIND the copies and behind everything the caller's
+    stream held when gather_async was called):
+      * arrival: when the fence of gather s has completed on a rank, every peer's block of gather s has landed in that rank's
+        buffer (a rank contributes only after its own copies);
+      * consumption: the copies of gather s+1 wait for the fence of gather s, and a rank contributes to that fence only after
+        the work its caller had enqueued before gather_async(s) -- so a peer overwrites buffer b only after this rank has
+        finished every read of b that was enqueued before its LATEST-BUT-ONE gather_async call.
+    Contract: `nbuf` buffers rotate; the reads of a result must be enqueued on the current stream before the (nbuf-1)-th
+    following gather_async call.  nbuf = 3 (default) covers the pipelined pattern "wait handle N after enqueuing gather N+1";
+    nbuf = 2 is enough when every result is waited and consumed before the next gather.
 
-    def __init__(self, rows, cols, device, group=None, dtype=torch.float32, nbuf=2):
+    Buffers are allocated once and exchanged once through torch's IPC handles (hipIpcGetMemHandle / dmabuf; this driver needs
+    HSA_ENABLE_IPC_MODE_LEGACY=0).  The precondition is CHECKED: if any rank cannot export or map a buffer, every rank raises
+    PeerGatherUnavailable (ShardedUiT then falls back to the RCCL gather with a warning).  All ranks must live on one node."""
+
+    def __init__(self, rows, cols, device, group=None, dtype=torch.float32, nbuf=3):
         from torch.multiprocessing.reductions import reduce_tensor
+        if nbuf < 2:
+            raise ValueError("PeerGather needs nbuf >= 2")
         self.group, self.rows, self.cols = group, rows, cols
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
@@ -125,33 +141,56 @@ class PeerGather:
         self.fence = torch.zeros(1, device=self.device, dtype=torch.int32)
         self.copy_stream = torch.cuda.Stream(self.device)
         self.step = 0
+        self._last_fence = None                     # work handle of the previous gather's fence (device backends)
         self.peers = [[None] * nbuf for _ in range(self.world)]
         if self.world > 1:
-            mine = [reduce_tensor(t) for t in self.out]
+            import os
+            err = None
+            if os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "") != "0":
+                err = "HSA_ENABLE_IPC_MODE_LEGACY=0 is not set (the host driver only supports dmabuf IPC)"
+            mine = None
+            if err is None:
+                try:
+                    mine = [reduce_tensor(t) for t in self.out]
+                except Exception as e:              # hipIpcGetMemHandle refused
+                    err = f"cannot export the output buffers: {e}"
             everyone = [None] * self.world
-            dist.all_gather_object(everyone, mine, group=group)
-            for r, handles in enumerate(everyone):
-                if r != self.rank:
-                    self.peers[r] = [fn(*args) for fn, args in handles]     # peer buffers mapped into this process
+            dist.all_gather_object(everyone, (mine, err), group=group)
+            if all(e is None for _, e in everyone):
+                try:
+                    for r, (handles, _) in enumerate(everyone):
+                        if r != self.rank:
+                            self.peers[r] = [fn(*args) for fn, args in handles]     # peer buffers mapped into this process
+                except Exception as e:              # hipIpcOpenMemHandle refused
+                    err = f"cannot map a peer's buffers: {e}"
+            verdict = [None] * self.world
+            dist.all_gather_object(verdict, err, group=group)                       # every rank takes the same decision
+            bad = [(r, e) for r, e in enumerate(verdict) if e is not None] + [(r, e) for r, (_, e) in enumerate(everyone) if e is not None]
+            if bad:
+                raise PeerGatherUnavailable("PeerGather precondition failed: " + "; ".join(f"rank {r}: {e}" for r, e in sorted(set(bad))))
             self._keep = everyone
 
     def gather_async(self, local):
-        """Enqueue the fan-out of `local` [rows, C] (ready on the current stream) on the copy stream; returns a GatherHandle
-        whose wait() makes the current stream wait for the fence and returns this rank's full [world*rows, C] buffer."""
+        """Enqueue the fan-out of `local` [rows, C] (ready on the current stream) on the copy stream; returns a handle whose
+        wait() makes the current stream wait for the arrival fence and returns this rank's full [world*rows, C] buffer."""
         b = self.step % len(self.out)
         self.step += 1
         lo = self.rank * self.rows
         cur = torch.cuda.current_stream(self.device)
-        self.copy_stream.wait_stream(cur)
+        device_backend = self.world > 1 and _backend_is_device(self.group)
+        self.copy_stream.wait_stream(cur)           # `local` is ready; the caller's earlier reads of older results are ordered before our fence
         with torch.cuda.stream(self.copy_stream):
+            if device_backend and self._last_fence is not None:
+                self._last_fence.wait()             # consumption fence: the previous gather's all-reduce has completed on this stream
             self.out[b][lo:lo + self.rows].copy_(local, non_blocking=True)
             for r in range(self.world):
                 if r != self.rank:
                     self.peers[r][b][lo:lo + self.rows].copy_(local, non_blocking=True)   # device-to-device over xGMI
             work, done = None, None
             if self.world > 1:
-                if _backend_is_device(self.group):
+                if device_backend:
                     work = dist.all_reduce(self.fence, group=self.group, async_op=True)   # fence behind the copies
+                    self._last_fence = work
                 else:                                       # host-side backend (tests): drain the copies, then rendezvous
                     self.copy_stream.synchronize()
                     dist.barrier(group=self.group)
@@ -169,7 +208,7 @@ class _PeerHandle:
 
     def wait(self):
         if self.work is not None:
-            self.work.wait()
+            self.work.wait()                        # idempotent: PeerGather itself may wait on the same work for the next gather
             self.work = None
         if self.done is not None:
             torch.cuda.current_stream(self.out.device).wait_event(self.done)
@@ -181,14 +220,29 @@ class ShardedUiT:
     """model: any callable `model(x, amax_sync=fn) -> probs` (uit_mobile_amd.models.UITBase on a HIP device).
 
     gather: 'rccl' (default: torch.distributed all_gather_into_tensor on the nccl = RCCL backend) or 'peer' (PeerGather:
-    copy-engine fan-out, no collective kernel).  R-invariance: results do not depend on the rank count -- bit for bit -- as
-    long as every shard starts on an even row (rows-per-rank even): a clip's arithmetic depends on the PARITY of its row
-    within the call (the two clips of a wave are pooled in mirrored lane order), on nothing else."""
+    copy-engine fan-out, no collective kernel; falls back to 'rccl' with a warning when its IPC precondition fails).
+    What is gathered (the payload per clip decides the xGMI ingress per rank: fp32 [537] = 2 148 B):
+      * gather_dtype=None: the fp32 probabilities (bit-for-bit R-invariant);  torch.float16: converted before the collective
+        (1 074 B per clip; |error| <= 2.5e-4 on a probability, what evaluate.py's metrics see) and returned as float16;
+      * slice_classes=n: only the first n classes (evaluate.py:92 consumes `[..., :527]`);
+      * topk=k: only `output.topk(k)` (inference.py:57) computed on the device by uitk_topk BEFORE the collective -- 8 k bytes
+        per clip; the call then returns (values [B,k] float32, indices [B,k] int64).
+    R-invariance: results do not depend on the rank count -- bit for bit -- as long as every shard starts on an even row
+    (rows-per-rank even): a clip's arithmetic depends on the PARITY of its row within the call (the two clips of a wave are
+    pooled in mirrored lane order), on nothing else."""
 
-    def __init__(self, model, group=None, global_floor=True, gather="rccl"):
+    def __init__(self, model, group=None, global_floor=True, gather="rccl", gather_dtype=None, slice_classes=None, topk=None,
+                 topk_fn=None):
         if gather not in ("rccl", "peer"):
             raise ValueError(f"Unknown gather ({gather})")
+        if gather_dtype not in (None, torch.float32, torch.float16):
+            raise ValueError("gather_dtype must be None / torch.float32 / torch.float16")
+        if topk is not None and (gather_dtype is torch.float16 or slice_classes is not None):
+            raise ValueError("topk replaces the probability payload: do not combine it with gather_dtype / slice_classes")
         self.model, self.group, self.global_floor, self.gather = model, group, global_floor, gather
+        self.gather_dtype = None if gather_dtype is torch.float32 else gather_dtype
+        self.slice_classes, self.topk = slice_classes, topk
+        self._topk_fn = topk_fn                     # tests inject a host function; the product uses postprocess.topk (uitk_topk)
         self._peer = None
 
     def _amax_sync(self, slots):
@@ -197,13 +251,58 @@ class ShardedUiT:
             return amax_allreduce_host(slots, self.group)
         return amax_allreduce(slots, self.group)
 
+    def payload_bytes_per_clip(self, outputdim):
+        """bytes each rank RECEIVES per remote clip (sizing the xGMI ingress: DESIGN.md section 5)"""
+        if self.topk is not None:
+            return 8 * self.topk
+        n = outputdim if self.slice_classes is None else min(outputdim, self.slice_classes)
+        return n * (2 if self.gather_dtype is torch.float16 else 4)
+
+    def _payload(self, probs):
+        if self.topk is not None:
+            fn = self._topk_fn
+            if fn is None:
+                from .postprocess import topk as fn
+            vals, idx = fn(probs, self.topk)
+            # one [rows, 2k] int32 tensor: values bit-cast next to the indices -> ONE collective, 8 k bytes per clip
+            return torch.cat([vals.contiguous().view(torch.int32), idx.to(torch.int32)], 1)
+        if self.slice_classes is not None:
+            probs = probs[:, :self.slice_classes]
+        if self.gather_dtype is torch.float16:
+            probs = probs.to(torch.float16)
+        return probs.contiguous()
+
+    def _unpack(self, gathered):
+        if self.topk is None:
+            return gathered
+        k = self.topk
+        return gathered[:, :k].contiguous().view(torch.float32), gathered[:, k:].to(torch.int64)
+
     def __call__(self, local_x, async_gather=False):
         probs = self.model(local_x, amax_sync=self._amax_sync if self.global_floor else None)
-        if self.gather == "peer" and dist.is_available() and dist.is_initialized() and dist.get_world_size(self.group) > 1:
-            if self._peer is None or self._peer.rows != probs.shape[0] or self._peer.cols != probs.shape[1]:
-                self._peer = PeerGather(probs.shape[0], probs.shape[1], probs.device, self.group, probs.dtype)
-            h = self._peer.gather_async(probs)
-            return h if async_gather else h.wait()
-        if async_gather:
-            return gather_outputs_async(probs, self.group)      # -> GatherHandle, overlap with the next batch
-        return gather_outputs(probs, self.group)
+        send = self._payload(probs)
+        multi = dist.is_available() and dist.is_initialized() and dist.get_world_size(self.group) > 1
+        if self.gather == "peer" and multi:
+            if self._peer is None or self._peer.rows != send.shape[0] or self._peer.cols != send.shape[1] or self._peer.out[0].dtype != send.dtype:
+                try:
+                    self._peer = PeerGather(send.shape[0], send.shape[1], send.device, self.group, send.dtype)
+                except PeerGatherUnavailable as e:
+                    import warnings
+                    warnings.warn(f"{e} -- falling back to gather='rccl'")
+                    self.gather, self._peer = "rccl", None
+        if self.gather == "peer" and multi:
+            h = self._peer.gather_async(send)
+        else:
+            h = gather_outputs_async(send, self.group)      # -> GatherHandle, overlap with the next batch
+        h = _Unpacked(h, self._unpack) if self.topk is not None else h
+        return h if async_gather else h.wait()
+
+
+class _Unpacked:
+    """A gather handle whose wait() splits the packed top-k payload back into (values, indices)."""
+
+    def __init__(self, handle, fn):
+        self.handle, self.fn = handle, fn
+
+    def wait(self):
+        return self.fn(self.handle.wait())
