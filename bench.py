@@ -41,6 +41,13 @@ FRONTEND_ALG_FLOP = 1.34e6       # algorithmic fp32 work per clip, mel counted s
 # matrix pipe (v_mfma_f32_4x4x1, same FLOP rate as the VALU); log10 / init_bn / convert ~640.  x 101 frames (+5 % dead slots
 # of the bundled tail passes).
 FRONTEND_EXEC_FLOP = (10656 + 6656 + 640) * 101 * 1.05
+PARITY_NOTE = {
+    "f16l6": "the parity mode: inside the 1e-3 gate on all 36 trained-like sweep checkpoints (worst 6.6e-4) and every fixture",
+    "f16": "inside 1e-3 at init scale and up to |logit| ~ 12; 0.6 .. 1.1e-3 at |logit| 13-15 (single fp16 weights)",
+    "f16x2": "inside the 1e-3 gate with 2-3x the margin of f16 (every weight as two fp16 terms: the reference point of f16l6)",
+    "bf16": "outside the 1e-3 gate at trained magnitudes (measured: tests/test_gpu_parity.py)",
+    "fp8": "outside the 1e-3 gate (measured: tests/test_gpu_parity.py)",
+}
 PEAK_MFMA_TFLOPS = 2500.0        # dense bf16/f16, MI355X_MICROARCH.md chip table
 PEAK_MFMA_FP8_TFLOPS = 5000.0    # dense MX-scaled fp8 (v_mfma_scale_f32_16x16x128_f8f6f4), same table
 PEAK_HBM_GBS = 8000.0
@@ -65,6 +72,15 @@ def synth_batch(B, T, first_clip, device, i16):
         x = torch.where((idx % 8 == 3)[:, None], x * 0.001, x)
         out[lo:lo + n] = torch.clamp(torch.round(x * 32768.0), -32768, 32767).to(torch.int16)
     return out if i16 else out.float() / 32768.0
+
+
+def kernel_sources_sha16():
+    """identity of the kernel sources a PMC figure belongs to (csrc/*.hip + the layout header)"""
+    import hashlib
+    h = hashlib.sha256()
+    for f in ("encoder.hip", "frontend.hip", "epilogue.hip", "uitk_dev.h", "pack.cpp"):
+        h.update((ROOT / "uit_mobile_amd" / "csrc" / f).read_bytes())
+    return h.hexdigest()[:16]
 
 
 def cpu_model_string():
@@ -93,6 +109,56 @@ while True:
     if el >= {budget}: break
 print(n / el, n, el)
 """
+
+
+_PROC_LEG = """
+import sys, time
+sys.path[:0] = [{root!r}, {golden!r}]
+import numpy as np, torch
+torch.set_num_threads(1)
+from synth_weights import make_state_dict, synth_pcm_i16
+from oracle.torch_port import TorchPort
+tp = TorchPort(make_state_dict({model!r}, 13))
+x = torch.from_numpy(synth_pcm_i16({B}, {T}, seed=3 + {seed}).astype(np.float32) / 32768.0)
+tp.forward(x[:8])
+print("ready", flush=True)
+sys.stdin.readline()                      # all workers start together
+n, t0 = 0, time.perf_counter()
+while True:
+    tp.forward(x); n += {B}
+    el = time.perf_counter() - t0
+    if el >= {budget}: break
+print(n, el, flush=True)
+"""
+
+
+def cpu_process_parallel_leg(model_name, T, nproc, budget_s, batch=64):
+    """The fair many-core statement of the CPU path: `nproc` independent worker PROCESSES, one torch thread each (torch's
+    intra-op pool does not scale at these GEMM shapes: 64 threads measured 1.07x one thread), every worker looping the same
+    op-for-op port over its own batch; all released together, rate = clips of all workers / the slowest worker's time."""
+    import subprocess
+    procs = []
+    for i in range(nproc):
+        code = _PROC_LEG.format(root=str(ROOT), golden=str(ROOT / "tests" / "golden"), model=model_name, B=batch, T=T, seed=i,
+                                budget=budget_s)
+        procs.append(subprocess.Popen([sys.executable, "-c", code], stdin=subprocess.PIPE, stdout=subprocess.PIPE, text=True,
+                                      env=dict(os.environ, OMP_NUM_THREADS="1", MKL_NUM_THREADS="1")))
+    try:
+        for pr in procs:
+            if pr.stdout.readline().strip() != "ready":
+                raise RuntimeError("worker failed to start")
+        for pr in procs:
+            pr.stdin.write("go\n"); pr.stdin.flush()
+        res = [tuple(float(v) for v in pr.stdout.readline().split()) for pr in procs]
+        n, el = sum(r[0] for r in res), max(r[1] for r in res)
+        return {"impl": "torch_port", "batch": batch, "processes": nproc, "threads": 1, "clips_per_s": round(n / el, 1), "clips": int(n),
+                "seconds": round(el, 2)}
+    finally:
+        for pr in procs:
+            try:
+                pr.kill()
+            except Exception:
+                pass
 
 
 def cpu_baseline(model_name, sd, T, budget_s):
@@ -148,12 +214,24 @@ def cpu_baseline(model_name, sd, T, budget_s):
                 legs.append({"impl": impl, "batch": Bc, "threads": nt, "clips_per_s": round(rate, 1), "clips": int(n),
                              "seconds": round(el, 2)})
     torch.set_num_threads(best)
-    head = max((l for l in legs if l.get("impl") == "torch_port" and "clips_per_s" in l), key=lambda l: l["clips_per_s"])
-    return {"value": head["clips_per_s"], "unit": "clips/s", "cores": head["threads"], "kind": "port", "host_cpus": ncpu,
+    # headline: N single-thread worker processes (N = physical-core-sized, bounded so that the default bench run stays short)
+    nproc = max(1, min(ncpu // 2 if ncpu >= 16 else ncpu, 64))
+    head = None
+    try:
+        head = cpu_process_parallel_leg(model_name, T, nproc, max(budget_s / 4.0, 2.0))
+        legs.append(head)
+    except Exception as e:              # the baseline is reported, never required
+        legs.append({"impl": "torch_port", "processes": nproc, "error": str(e)[:80]})
+    if head is None:
+        head = max((l for l in legs if l.get("impl") == "torch_port" and "clips_per_s" in l), key=lambda l: l["clips_per_s"])
+        head = dict(head, processes=1)
+    cores = head.get("processes", 1) * head["threads"]
+    return {"value": head["clips_per_s"], "unit": "clips/s", "cores": cores, "kind": "port", "host_cpus": ncpu,
             "cpu_model": cpu_model_string(),
             "sample": f"{head['clips']} synthetic 1 s clips (batches of {head['batch']}) through oracle/torch_port.py "
                       f"(torch {torch.__version__} CPU fp32, same ATen ops as the reference), {head['seconds']} s, "
-                      f"{head['threads']} torch threads (best of a probe over 8..{ncpu}); all legs in `legs`",
+                      f"{head.get('processes', 1)} worker processes x {head['threads']} torch thread(s); the single-process legs "
+                      f"(1 thread / best-of-probe threads, B = 64 / 1024, torch port and C restatement) are in `legs`",
             "legs": legs}
 
 
@@ -164,11 +242,16 @@ def main():
     ap.add_argument("--warmup", type=int, default=50)
     ap.add_argument("--model", default="uit_xs", choices=list(GEMM_FLOP))
     ap.add_argument("--batch-per-gpu", type=int, default=8192)
-    ap.add_argument("--precision", default="f16", choices=["f16", "bf16", "fp8", "f16x2"])
+    ap.add_argument("--precision", default="f16l6", choices=["f16l6", "f16", "bf16", "fp8", "f16x2"],
+                    help="f16l6 (default) = THE parity mode: fp16 operands + the low-order weight term on the MX-fp6 MFMA (all 36 "
+                         "trained-like sweep checkpoints inside 1e-3 with margin); f16 = single fp16 weights (at the gate for |logit| >= 13)")
     ap.add_argument("--pcm16", action="store_true", help="feed int16 PCM instead of float32 waves")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-other-dtypes", action="store_true", help="skip the bf16 / fp8 sub-records (N=1 only)")
+    ap.add_argument("--no-other-dtypes", action="store_true", help="skip the f16 / bf16 / fp8 / f16x2 sub-records (N=1 only)")
+    ap.add_argument("--input-buffers", type=int, default=3,
+                    help="distinct synthetic input batches rotated step by step (>= 3: 3 x 524 MB of float32 waves cannot be served "
+                         "by the 256 MB Infinity Cache, so the front-end really reads its PCM from HBM)")
     ap.add_argument("--spinup-steps", type=int, default=120,
                     help="untimed set-up steps that bring the idle GPU's clocks up before the --warmup steps (0 = none)")
     ap.add_argument("--gather", default="rccl", choices=["rccl", "peer"],
@@ -210,7 +293,9 @@ def main():
         r.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()}, strict=True)
         reps.append(r.to(dev).eval())
     m = reps[0]
-    x = synth_batch(Bl, T, rank * Bl, dev, args.pcm16)
+    nbuf_in = max(1, args.input_buffers)
+    xs = [synth_batch(Bl, T, (rank + i * world) * Bl, dev, args.pcm16) for i in range(nbuf_in)]
+    x = xs[0]
     # HIP events on the launch stream (torch's current stream is the one handed to the C ABI), four per step:
     # around the front-end kernel and around the encoder kernel.
     n_ev = args.warmup + args.steps
@@ -226,7 +311,7 @@ def main():
         r = reps[n & 1]
         if rec:
             evs[n][0].record()
-        st = r.frontend(x)
+        st = r.frontend(xs[n % nbuf_in])
         if rec:
             evs[n][1].record()
         red = amax_allreduce_async(r.amax_tensor(dev)) if world > 1 else None
@@ -305,11 +390,22 @@ def main():
         achieved = Bl * GEMM_FLOP[args.model] / (enc * 1e-3) / 1e12
         # precision fp8 (config #5): qkv / fc1 / fc2 (94 % of the GEMM FLOPs) run on the MX fp8 MFMA -> priced against its peak
         peak = PEAK_MFMA_FP8_TFLOPS if args.precision == "fp8" else PEAK_MFMA_TFLOPS
-        traffic = None
+        # HBM bytes per encoder launch: measured with rocprofv3 --pmc (tools/prof.sh, separate passes, corrected as MI355X_MICROARCH.md
+        # prescribes) and committed with the hash of the kernel sources it was measured on; a figure measured on OTHER sources
+        # (or on another precision) is not quoted.
+        traffic, traffic_source = None, None
         pmc = ROOT / "profiles" / "pmc_latest.json"
         if pmc.exists():
             try:
-                traffic = json.loads(pmc.read_text()).get("encoder_hbm_bytes_per_launch")
+                rec_ = json.loads(pmc.read_text())
+                src_now = kernel_sources_sha16()
+                if rec_.get("kernel_sources_sha16") == src_now and rec_.get("precision", "f16") == args.precision:
+                    traffic = rec_.get("encoder_hbm_bytes_per_launch")
+                    traffic_source = f"profiles/pmc_latest.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, kernel sources {src_now})"
+                else:
+                    traffic_source = (f"not quoted: profiles/pmc_latest.json was measured on kernel sources "
+                                      f"{rec_.get('kernel_sources_sha16')} / precision {rec_.get('precision', 'f16')}, this run is "
+                                      f"{src_now} / {args.precision} (re-run tools/prof.sh)")
             except Exception:
                 traffic = None
         line = {
@@ -320,14 +416,14 @@ def main():
             "config": {"workload": f"{args.model} (UiT-XS family, seeded random-init weights), {Bl} synthetic "
                                    f"16 kHz x 1 s clips per GPU ({'int16 PCM' if args.pcm16 else 'float32 wave'} "
                                    f"resident in HBM), global batch {world * Bl}",
-                       "global_batch": world * Bl, "clip_samples": T,
+                       "global_batch": world * Bl, "clip_samples": T, "input_buffers": nbuf_in,
                        "setup": f"handles + workspace + RCCL communicator, then {args.spinup_steps} untimed steps of device "
                                 "spin-up (clock ramp) before the --warmup steps",
                        "parallelism": f"dp{world} (batch shards, in-place RCCL MAX all-reduce of the 64 amax slots + "
                                       f"{'copy-engine peer fan-out' if peer is not None else 'RCCL all-gather'} of [B,537])"},
             "roofline": {"bound": "mfma", "kernel": "uit_encoder_kernel", "achieved": round(achieved, 2),
                          "peak": peak, "unit": "TFLOP/s", "frac": round(achieved / peak, 5),
-                         "traffic": traffic, "launch_ms": round(enc, 4),
+                         "traffic": traffic, "traffic_source": traffic_source, "launch_ms": round(enc, 4),
                          "algorithmic_flops_per_launch": Bl * GEMM_FLOP[args.model],
                          # the WHOLE step (front-end + encoder + gaps) against the same peak: GEMM FLOPs / ms_per_step / peak
                          "step_frac": round(Bl * GEMM_FLOP[args.model] / (ms * 1e-3) / 1e12 / peak, 5)},
@@ -345,7 +441,7 @@ def main():
             # the metric's own label says bf16 (BASELINE configs #2-#4) and config #5 says fp8: both are on record next to the
             # parity dtype.  Same workload, same pipeline, 100 timed steps after 40 warm-up steps; NOT parity modes.
             line["other_dtypes"] = {}
-            for prec in ("bf16", "fp8", "f16x2"):
+            for prec in ("f16", "bf16", "fp8", "f16x2", "f16l6"):
                 if prec == args.precision:
                     continue
                 rr = []
@@ -370,8 +466,7 @@ def main():
                     torch.cuda.synchronize()
                     el2 = time.perf_counter() - t0
                 line["other_dtypes"][prec] = {"value": round(Bl * 100 / el2, 1), "unit": "clips/s", "ms_per_step": round(el2 * 10, 4),
-                                              "steps": 100, "parity": ("inside the 1e-3 gate with 2-3x the margin of f16 (split weights; tests/test_gpu_parity.py)" if prec == "f16x2"
-                                                                       else "outside the 1e-3 gate (measured: tests/test_gpu_parity.py)")}
+                                              "steps": 100, "parity": PARITY_NOTE[prec]}
                 del rr
         if world == 1 and args.from_host:
             from uit_mobile_amd.streaming import HostClipStreamer

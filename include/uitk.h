@@ -176,12 +176,20 @@ int uitk_mel_db(uitk_model* m, const void* pcm, int in_dtype, int64_t B, int64_t
  * patch-embed(+pos) and after every block (token = f*6+t as in uit.py:388).  NULL disables (default). */
 int uitk_set_debug_tokens(uitk_model* m, float* dev_buf);
 
-/* Diagnostics: device buffers receiving per-phase shader-cycle sums per wave -- encoder [waves][20] uint64 (0-7 per
- * block: LN1, ring wait QK, QK, ring wait VP, attention+proj, LN2, ring waits MLP, MLP; 8-11 once: load wait, prologue
- * barrier, patch embed, epilogue total; 12-14 prologue detail: stream kick, load issue, clamp; 15-19 epilogue detail:
- * final LN + pool, head LN + LDS hand-over, barrier, z reads, head tiles + stores), front-end [waves][8].  A non-NULL buffer selects a separate instrumented kernel build (slower; never use it to
- * time the product).  NULL (default) = normal kernels. */
+/* Diagnostics (lab builds): device buffers receiving per-phase shader-cycle sums per wave -- encoder [waves][20] uint64, front-end
+ * [waves][8] (tools/phase_timing.py).  The instrumented kernels are compiled only into -DUITK_LAB builds of the library
+ * (tools/mklib.sh); the product library returns UITK_ERR_UNSUPPORTED for a non-NULL buffer.  NULL (default) = normal kernels. */
 int uitk_set_timing_buffers(uitk_model* m, unsigned long long* enc_buf, unsigned long long* fe_buf);
+
+/* Explicit tuning / test options of a model handle (the library reads no environment variables).  None of them changes a result
+ * bit (tests/test_gpu_parity.py::test_pass_distribution_does_not_change_results).  Unknown name -> UITK_ERR_UNSUPPORTED.
+ *   "fe_asym_pm"        300..700: per-mille share of the front-end passes walked by the first-dispatched workgroups of every CU;
+ *                       -1 (default) = measured on this device by the next uitk_reserve (a few short launches)
+ *   "fe_wg_per_cu"      persistent front-end workgroups per CU (0 = default 2)
+ *   "enc_waves"         8 (default: one 8-wave encoder workgroup per CU) or 4 (two 4-wave workgroups per CU; f16 / bf16 / fp8)
+ *   "split_pe"          1 / 0: patch embed on split (hi + lo) weights; -1 = the precision's default (on for f16x2)
+ *   "enc_generic_clamp" 1 = use the generic top_db clamp path even when every init_bn scale is >= 0 (test of that path) */
+int uitk_set_option(uitk_model* m, const char* name, int value);
 
 /* ---- Step after the path: post-processing of the probability rows on the device, so that only
  * k winners (or class indices) cross PCIe instead of [B, outputdim].  Stateless: no model handle.  C <= 1024.

@@ -193,11 +193,9 @@ class EncoderEmu:
         R = [[pe_bias[tk[ct][:, None], 16 * ft + 4 * G_[:, None] + r4].copy() for ct in range(3)] for ft in range(8)]
         for i in range(PE_HI_STAGES):
             for f in range(16):
-                A = self.frag(i, f)             # high-order term; the low-order stages are used with UITK_SPLIT_PE=1 and by f16x2 / f16l6
+                A = self.frag(i, f)             # high-order term only: the low-order stages are used with option split_pe and by f16x2
                 for ct in range(3):
                     R[2 * i + f // 8][ct] = mfma32(A, XB[f % 8][ct], R[2 * i + f // 8][ct])
-                    if self.l6:
-                        R[2 * i + f // 8][ct] = mfma32(self.frag(PE_HI_STAGES + i, f), XB[f % 8][ct], R[2 * i + f // 8][ct])
         stages = np.zeros((2, self.depth + 1, 24, 128), np.float32)
 
         def dump(st):

@@ -120,6 +120,87 @@ def test_f16x2_split_weights_cut_the_error_at_trained_magnitudes(golden, name):
     assert np.abs(centred(toks.cpu().numpy()[:, 0]) - centred(g["stages"][:, 0])).max() < 2e-2
 
 
+SWEEP_SEEDS = list(range(200, 212))            # the 12 trained-like checkpoints per model of tools/seed_sweep.py (round 2: f16 worst 1.13e-3)
+
+
+@pytest.mark.parametrize("name", ["uit_xs", "uit_xxs", "uit_xxxs"])
+def test_parity_mode_all_sweep_seeds(name):
+    """THE parity statement of round 3: precision='f16l6' (fp16 operands + the low-order weight term of fc1 / fc2 on the MX-fp6 MFMA,
+    proj on split fp16 weights) holds 1e-3 on logits AND probabilities on ALL twelve trained-like checkpoints of every model
+    (|logit| up to 14.4), not on hand-picked seeds.  Measured worst: XS 6.6e-4, 2XS 4.9e-4, 3XS 4.5e-4 (precision f16 on the same
+    checkpoints: 1.13e-3 / 9.0e-4 / 9.0e-4, three XS seeds over the gate) -- asserted with margin at 8e-4."""
+    from bench import synth_batch
+    x = synth_batch(24, 16000, 0, "cpu", False).numpy()
+    xd = torch.from_numpy(x).cuda()
+    worst_l, worst_p, over = 0.0, 0.0, []
+    for seed in SWEEP_SEEDS:
+        m, sd = build_trained(name, seed, prec="f16l6")
+        with torch.no_grad():
+            p, l = m(xd, return_logits=True)
+        r = Oracle(sd).forward(x)
+        dl = float(np.abs(l.cpu().numpy().reshape(r["logits"].shape) - r["logits"]).max())
+        dp = float(np.abs(p.cpu().numpy() - r["probs"]).max())
+        worst_l, worst_p = max(worst_l, dl), max(worst_p, dp)
+        if dl >= TOL or dp >= TOL:
+            over.append((seed, dl, dp))
+        del m
+    print(f"f16l6 {name}: worst max|dlogit| {worst_l:.2e}, worst max|dprob| {worst_p:.2e} over {len(SWEEP_SEEDS)} checkpoints")
+    assert not over, over
+    assert worst_l < 8e-4 and worst_p < 2e-4
+
+
+@pytest.mark.parametrize("name", ["uit_xs", "uit_xxxs"])
+def test_parity_mode_fixtures_and_shapes(golden, name):
+    """precision='f16l6' against the fixtures of the imported reference: trained-like checkpoint (tighter than f16's own bound),
+    per-block centred tokens, and -- for the other shapes of the path -- init scale, a short (masked) clip and the two-crop sample."""
+    g = golden(f"trained_{name}")
+    m, _ = build_trained(name, g["seed"], prec="f16l6")
+    m1, _ = build_trained(name, g["seed"])
+    p, l = run(m, g["pcm"])
+    p1, l1 = run(m1, g["pcm"])
+    d, d1 = np.abs(l - g["logits"]).max(), np.abs(l1 - g["logits"]).max()
+    print(f"trained-like {name}: max|dlogit| f16l6 {d:.2e} vs f16 {d1:.2e}; max|dprob| {np.abs(p - g['probs']).max():.2e}")
+    assert d < 5e-4 and d < 0.85 * d1 and np.abs(p - g["probs"]).max() < 2.5e-4
+    _, toks = m.debug_tokens(torch.from_numpy(g["pcm"][:2]).cuda())
+    toks = toks.cpu().numpy()[:, 0]
+    assert np.abs(toks.mean(-1)).max() < 5e-3
+    assert np.abs(centred(toks) - centred(g["stages"][:, 0])).max() < 2e-2
+    if name == "uit_xs":
+        gi = golden("synth1s_uit_xs")
+        mi, _ = build("uit_xs", gi["seed"], prec="f16l6")
+        pi, li = run(mi, gi["pcm"])
+        assert np.abs(li - gi["logits"]).max() < 2.5e-4 and np.abs(pi - gi["probs"]).max() < 1e-4
+        gs, pcm = golden("trained_samples_uit_xs"), golden("samples_uit_xs")
+        ms, _ = build_trained("uit_xs", gs["seed"], prec="f16l6")
+        ps, ls = run(ms, pcm["water_000_pcm"][None])
+        assert ls.shape[1] == 2 and np.abs(ls[0] - gs["water_000_logits"]).max() < 6e-4 and np.abs(ps[0] - gs["water_000_probs"]).max() < 2.5e-4
+    else:
+        gs = golden("trained_short_uit_xxxs")
+        ms, _ = build_trained("uit_xxxs", gs["seed"], prec="f16l6")
+        ps, ls = run(ms, gs["pcm"])
+        assert np.abs(ls - gs["logits"]).max() < 6e-4 and np.abs(ps - gs["probs"]).max() < 2.5e-4
+
+
+def test_parity_mode_ragged_and_full_size():
+    """precision='f16l6' on ragged batch sizes (odd last wave, partial workgroup) against the oracle, and at the bench size:
+    permutation of the clips permutes the rows bit for bit (even offsets keep the row parity), a sampled subset matches the oracle."""
+    m, sd = build("uit_xxxs", 5, prec="f16l6")
+    o = Oracle(sd)
+    for B in (1, 3, 17, 33):
+        pcm = synth_pcm_i16(B, 16000, seed=40 + B)
+        p, l = run(m, pcm)
+        r = o.forward(pcm)
+        assert np.abs(p - r["probs"]).max() < TOL and np.abs(l - r["logits"]).max() < TOL
+    pcm = synth_pcm_i16(4096, 16000, seed=41)
+    p, _ = run(m, pcm)
+    perm = np.random.default_rng(3).permutation(2048) * 2
+    idx = np.stack([perm, perm + 1], 1).reshape(-1)                 # clip pairs move together: row parity is kept
+    p2, _ = run(m, pcm[idx])
+    assert np.array_equal(p2, p[idx])
+    sub = np.random.default_rng(4).choice(4096, 8, replace=False)
+    assert np.abs(p[sub] - o.forward(pcm[sub])["probs"]).max() < TOL
+
+
 def test_precision_margin_recommends_by_checkpoint(golden):
     """UITBase.precision_margin: the f16 / f16x2 logit difference (= fp16's weight-rounding term) decides which parity precision a
     checkpoint needs: init-scale weights -> 'f16'; the worst trained-like seed of the sweep (f16 error 1.1e-3 at |logit| 14) -> 'f16x2'."""
@@ -228,12 +309,13 @@ def test_golden_pooling_dm(golden):
             p = m(torch.from_numpy(pcm).cuda()).cpu().numpy()
         assert np.abs(p - o.forward(pcm)["probs"]).max() < TOL
     sd = make_trained_like_state_dict("uit_xs", int(g["xs_trained_seed"]))
-    m = models.uit_xs(outputdim=537, target_length=102, pooling="dm")
-    m.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()}, strict=True)
-    with torch.no_grad():
-        p = m.to("cuda").eval()(torch.from_numpy(g["pcm"]).cuda()).cpu().numpy()
-    print(f"pooling dm, trained-like uit_xs: max|dprob| {np.abs(p - g['xs_trained_probs']).max():.2e}")
-    assert np.abs(p - g["xs_trained_probs"]).max() < TOL
+    for prec in ("f16", "f16l6"):
+        m = models.uit_xs(outputdim=537, target_length=102, pooling="dm", precision=prec)
+        m.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()}, strict=True)
+        with torch.no_grad():
+            p = m.to("cuda").eval()(torch.from_numpy(g["pcm"]).cuda()).cpu().numpy()
+        print(f"pooling dm, trained-like uit_xs ({prec}): max|dprob| {np.abs(p - g['xs_trained_probs']).max():.2e}")
+        assert np.abs(p - g["xs_trained_probs"]).max() < TOL
     # and on the full-width-attention GELU factory, against the oracle
     sd = make_state_dict("audio_transformer_h128_d4_m3", 41, attention="full")
     m = models.audio_transformer_h128_d4_m3(outputdim=537, target_length=102, pooling="dm")
@@ -254,13 +336,16 @@ def test_golden_pooling_token(golden):
                                          ("h128", "audio_transformer_h128_d4_m3", False, "full", "gelu")):
         sd = dict((make_trained_like_state_dict if trained else make_state_dict)(name, int(g[f"{tag}_seed"]), attention=att))
         sd["cls_token"] = g[f"{tag}_cls_token"]
-        m = getattr(models, name)(outputdim=537, target_length=102, pooling="token")
+        # trained-checkpoint magnitudes run in the parity mode (precision f16l6; round 2 held plain f16 to its measured 1.5e-3 here);
+        # the full-width-attention factory has no f16l6 build and stays on f16 (init scale)
+        prec = "f16l6" if (trained and att == "bneck") else "f16"
+        m = getattr(models, name)(outputdim=537, target_length=102, pooling="token", precision=prec)
         m.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()}, strict=True)
         m = m.to("cuda").eval()
         p, l = run(m, g["pcm"])
         dl, dp = np.abs(l - g[f"{tag}_logits"]).max(), np.abs(p - g[f"{tag}_probs"]).max()
-        print(f"pooling token {name}: |logit|max {np.abs(g[f'{tag}_logits']).max():.1f} max|dlogit| {dl:.2e} max|dprob| {dp:.2e}")
-        assert dl < (1.5e-3 if trained else TOL) and dp < TOL
+        print(f"pooling token {name} ({prec}): |logit|max {np.abs(g[f'{tag}_logits']).max():.1f} max|dlogit| {dl:.2e} max|dprob| {dp:.2e}")
+        assert dl < TOL and dp < TOL
         if tag == "xxxs":
             p, l = run(m, g["xxxs_short_pcm"])
             assert np.abs(l - g["xxxs_short_logits"]).max() < TOL
@@ -431,24 +516,27 @@ def test_full_size_properties(name, B, seed):
     assert np.abs(l[idx] - ref["logits"]).max() < TOL
 
 
-def test_pass_distribution_does_not_change_results(monkeypatch):
+def test_pass_distribution_does_not_change_results():
     """The front-end's work distribution (asymmetric static split of the persistent grid) decides WHO transforms a
-    frame, never how: symmetric split, the default (59 % to the first-dispatched workgroups at this size) and an extreme share
-    give bit-identical probabilities and mel; so does the generic top_db clamp path of the encoder against its plain-max path."""
+    frame, never how: the calibrated default, a symmetric split and an extreme share give bit-identical probabilities and mel; so
+    does the generic top_db clamp path of the encoder against its plain-max path.  Options go through uitk_set_option (the library
+    reads no environment)."""
     pcm = synth_pcm_i16(8192, 16000, seed=9)
     pcm[3] = 0
     x = torch.from_numpy(pcm).cuda()
     outs = []
-    for env in ({}, {"UITK_FE_ASYM": "500"}, {"UITK_FE_ASYM": "900"}, {"UITK_ENC_GENERIC_CLAMP": "1"}):
-        for k in ("UITK_FE_ASYM", "UITK_ENC_GENERIC_CLAMP"):
-            monkeypatch.delenv(k, raising=False)
-        for k, v in env.items():
-            monkeypatch.setenv(k, v)
-        m, _ = build("uit_xxxs", 31)                       # the knobs are read when the handle is created
+    for opts in ({}, {"fe_asym_pm": 500}, {"fe_asym_pm": 700}, {"fe_asym_pm": 300}, {"enc_generic_clamp": 1}):
+        m, _ = build("uit_xxxs", 31)
+        for k, v in opts.items():
+            m.set_option(k, v)
         with torch.no_grad():
             outs.append((m(x).cpu().numpy(), m.melspec_db(x[:64]).cpu().numpy()))
     for p, mel in outs[1:]:
         assert np.array_equal(p, outs[0][0]) and np.array_equal(mel, outs[0][1])
+    m, _ = build("uit_xxxs", 31)
+    with pytest.raises(ValueError):                     # unknown option: UITK_ERR_UNSUPPORTED when the handle is created
+        m.set_option("no_such_option", 1)
+        m(x[:2])
 
 
 def test_errors_map_to_exceptions():
@@ -596,9 +684,11 @@ def test_rccl_collectives_accept_the_library_owned_amax_slots():
     assert res == (True, True, True)
 
 
-def _one_gpu_worker(rank, world, port, q, rows_per_rank):
-    """Two ranks sharing ONE GPU: gloo for the control plane (RCCL refuses two ranks on one device), the amax MAX all-reduce
-    staged through the host, the outputs gathered by PeerGather's device-to-device copies into IPC-mapped buffers."""
+def _one_gpu_worker(rank, world, port, q, rows_per_rank, mode):
+    """Several ranks sharing ONE GPU: gloo for the control plane (RCCL refuses two ranks on one device), the amax MAX all-reduce
+    staged through the host, the outputs gathered by PeerGather's device-to-device copies into IPC-mapped buffers.
+    mode: 'probs' (fp32 payload), 'f16' (float16 payload), 'topk' (device-side top-5 before the gather), 'pipelined' (two gathers in
+    flight, every handle waited after the next gather was enqueued: the pattern the consumption fence exists for)."""
     import os
     import torch.distributed as dist
     from uit_mobile_amd.sharded import ShardedUiT
@@ -606,44 +696,88 @@ def _one_gpu_worker(rank, world, port, q, rows_per_rank):
     torch.cuda.set_device(0)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
-        m, sd = build("uit_xxxs", 32)
-        pcm = synth_pcm_i16(world * rows_per_rank, 16000, seed=13)
+        m, sd = build("uit_xxxs", 32, prec="f16l6")
         lo = rank * rows_per_rank
-        sh = ShardedUiT(m, gather="peer")
+        kw = {"f16": dict(gather_dtype=torch.float16), "topk": dict(topk=5)}.get(mode, {})
+        sh = ShardedUiT(m, gather="peer", **kw)
         outs = []
-        for rep in range(3):                                   # repeated: the gather buffers rotate, the amax slot sets alternate
-            out = sh(torch.from_numpy(pcm[lo:lo + rows_per_rank]).cuda())
-            torch.cuda.synchronize()
-            outs.append(out.cpu().numpy())
+        if mode == "pipelined":
+            batches = [synth_pcm_i16(world * rows_per_rank, 16000, seed=13 + i) for i in range(5)]
+            prev = None
+            for pcm in batches:                                # handle n is waited after gather n+1 has been enqueued
+                h = sh(torch.from_numpy(pcm[lo:lo + rows_per_rank]).cuda(), async_gather=True)
+                if prev is not None:
+                    outs.append(prev.wait().clone().cpu().numpy())
+                prev = h
+            outs.append(prev.wait().clone().cpu().numpy())
+        else:
+            pcm = synth_pcm_i16(world * rows_per_rank, 16000, seed=13)
+            for rep in range(3):                               # repeated: the gather buffers rotate, the amax slot sets alternate
+                out = sh(torch.from_numpy(pcm[lo:lo + rows_per_rank]).cuda())
+                torch.cuda.synchronize()
+                outs.append(tuple(o.cpu().numpy() for o in out) if isinstance(out, tuple) else out.cpu().numpy())
         q.put((rank, outs))
-        dist.barrier()                                         # keep the IPC-mapped buffers alive until both ranks have read
+        dist.barrier()                                         # keep the IPC-mapped buffers alive until every rank has read
     finally:
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("rows_per_rank", [8, 6])
-def test_two_ranks_on_one_gpu_peer_gather_is_bitwise_the_single_rank_result(rows_per_rank):
-    """The N>1 data path on a 1-GPU box: 2 processes, batch shards, MAX all-reduce of the amax slots, copy-engine gather
-    through IPC-mapped peer buffers -> every rank holds the full [B, 537] output, bit for bit the single-rank result
-    (R-invariance; shards start on even rows) and within 1e-3 of the oracle."""
+def _run_ranks_on_one_gpu(world, rows_per_rank, mode):
     import torch.multiprocessing as mp
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_one_gpu_worker, args=(r, 2, 29900 + os.getpid() % 500, q, rows_per_rank)) for r in range(2)]
+    port = 29900 + (os.getpid() * 7 + world * 13 + rows_per_rank) % 500
+    procs = [ctx.Process(target=_one_gpu_worker, args=(r, world, port, q, rows_per_rank, mode)) for r in range(world)]
     for p in procs:
         p.start()
     res = dict(q.get(timeout=300) for _ in procs)
     for p in procs:
         p.join(timeout=60)
-    m, sd = build("uit_xxxs", 32)
-    pcm = synth_pcm_i16(2 * rows_per_rank, 16000, seed=13)
+    return res
+
+
+@pytest.mark.parametrize("world,rows_per_rank", [(2, 8), (2, 6), (4, 4)])
+def test_ranks_on_one_gpu_peer_gather_is_bitwise_the_single_rank_result(world, rows_per_rank):
+    """The N>1 data path on a 1-GPU box: 2 or 4 processes, batch shards, MAX all-reduce of the amax slots, copy-engine gather
+    through IPC-mapped peer buffers -> every rank holds the full [B, 537] output, bit for bit the single-rank result
+    (R-invariance; shards start on even rows) and within 1e-3 of the oracle.  Parity mode (f16l6)."""
+    res = _run_ranks_on_one_gpu(world, rows_per_rank, "probs")
+    m, sd = build("uit_xxxs", 32, prec="f16l6")
+    pcm = synth_pcm_i16(world * rows_per_rank, 16000, seed=13)
     single, _ = run(m, pcm)
     ref = Oracle(sd).forward(pcm)
-    for r in range(2):
+    for r in range(world):
         for out in res[r]:
-            assert out.shape == (2 * rows_per_rank, 537)
+            assert out.shape == (world * rows_per_rank, 537)
             assert np.array_equal(out, single)
             assert np.abs(out - ref["probs"]).max() < TOL
+
+
+@pytest.mark.parametrize("mode", ["f16", "topk", "pipelined"])
+def test_ranks_on_one_gpu_reduced_payloads_and_pipelined_gathers(mode):
+    """The payload cuts that de-risk the 8-GPU gather and the consumption fence of PeerGather, on two ranks
+    sharing the GPU: float16 probabilities (1 074 B per clip instead of 2 148; |error| <= 2.5e-4), the device-side top-5 gathered
+    instead of the probabilities (40 B per clip; equals torch.topk of the single-rank output), and five pipelined steps in which
+    every handle is waited only after the next gather has been enqueued (results must be those of the single-rank run)."""
+    world, rows = 2, 8
+    res = _run_ranks_on_one_gpu(world, rows, mode)
+    m, _ = build("uit_xxxs", 32, prec="f16l6")
+    if mode == "pipelined":
+        for i in range(5):
+            single, _ = run(m, synth_pcm_i16(world * rows, 16000, seed=13 + i))
+            for r in range(world):
+                assert np.array_equal(res[r][i], single), (r, i)
+        return
+    single, _ = run(m, synth_pcm_i16(world * rows, 16000, seed=13))
+    for r in range(world):
+        for out in res[r]:
+            if mode == "f16":
+                assert out.dtype == np.float16 and out.shape == single.shape
+                assert np.array_equal(out, single.astype(np.float16))
+            else:
+                v, i = out
+                tv, ti = torch.from_numpy(single).topk(5)
+                assert np.array_equal(v, tv.numpy()) and np.array_equal(i, ti.numpy())
 
 
 def test_host_clip_streamer_matches_direct_calls():

@@ -160,10 +160,11 @@ def main():
         mb = mel_bn_of(sd, x)
         exact = forward(sd, mb, depth)
         cal, frac = calibrate(sd, depth)
-        schemes = [Scheme("f16"), Scheme("x2"), Scheme("fp6"),
-                   Scheme("fp6/fp4 s2 row", fc2_act="fp4", h_scale=2.0, wblk=128),
-                   Scheme("fp6/fp4 s2 row mlp+proj = f16l6", fc2_act="fp4", h_scale=2.0, wblk=128, which=("fc1", "fc2", "proj")),
-                   Scheme("top32", cal, 32)]
+        kw = dict(fc2_act="fp4", h_scale=2.0, wblk=128)
+        schemes = [Scheme("f16"), Scheme("x2"), Scheme("fp6 all linears (fp6/fp4 s2 row)", **kw),
+                   Scheme("fp6 mlp+proj = f16l6", which=("fc1", "fc2", "proj"), **kw),
+                   Scheme("fp6 fc2+proj", which=("fc2", "proj"), **kw), Scheme("fp6 fc1+proj", which=("fc1", "proj"), **kw),
+                   Scheme("fp6 proj only", which=("proj",), **kw), Scheme("fp6 qkv+fc2+proj", which=("qkv", "fc2", "proj"), **kw)]
         line = []
         for s in schemes:
             e = float((forward(sd, mb, depth, s) - exact).abs().max())

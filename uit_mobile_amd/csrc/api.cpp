@@ -2,6 +2,7 @@
 // Host code only; the kernels live in frontend.hip / encoder.hip.  There is no CPU compute path here.
 #include <hip/hip_runtime.h>
 
+#include <cctype>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -38,14 +39,14 @@ struct uitk_model {
     unsigned long long* timing = nullptr;
     unsigned long long* timing_fe = nullptr;
     int n_cu = 256;
-    int enc_waves = 8;            // waves per encoder workgroup (8 = one WG per CU; 4 = two independent WGs per CU)
-    int enc_sched = 0, enc_stagger = 0, enc_stagger_mode = 1, enc_ablate = 0;   // tuning knobs (UITK_ENC_SCHED, UITK_ENC_STAGGER)
-    int split_pe = 0;             // UITK_SPLIT_PE=1: patch embed on split weights (W = hi + lo); measured no better than the
-                                  // structured rounding of pack.cpp, +1.6 % encoder time: off by default
+    int enc_waves = 8;            // option enc_waves: waves per encoder workgroup (8 = one WG per CU; 4 = two independent WGs per CU)
+    int split_pe_env = -1;        // option split_pe: patch embed on split weights (W = hi + lo); -1 = the precision's default (on for f16x2;
+                                  // off for f16: measured no better than the structured rounding of pack.cpp at +1.6 % encoder time)
+    int force_generic_clamp = 0;  // option enc_generic_clamp
+    int fe_calibrated = 0;        // the asymmetric front-end split has been measured on this device (uitk_reserve) or set explicitly
     int bn_nonneg = 0;            // every init_bn scale >= 0 (decided once from the packed table): the encoder's clamp fast path
-    int fe_asym_pm = -1;          // UITK_FE_ASYM=<per-mille>: share of the first-dispatched workgroups (-1 = launch_frontend decides: 590 / 500)
-    int fe_static = 0;            // UITK_FE_STATIC=1: purely static pass split in the front-end (A/B of the dynamic remainder)
-    int fe_wg_per_cu = 0;         // persistent front-end workgroups per CU (0 = the kernel's occupancy target; UITK_FE_WG_PER_CU)
+    int fe_asym_pm = -1;          // option fe_asym_pm: share of the first-dispatched front-end workgroups (-1 = not calibrated yet: 590)
+    int fe_wg_per_cu = 0;         // option fe_wg_per_cu: persistent front-end workgroups per CU (0 = the kernel's occupancy target)
     int device = 0;
     int64_t fe_B = 0, fe_T = 0;   // shape of the latest uitk_frontend call (uitk_encode must match it)
 };
@@ -94,25 +95,23 @@ int uitk_create(const uitk_config* cfg, const uitk_weights* w, uitk_model** out)
         const float* sc = (const float*)(img.data() + m->hdr.off_bn_sc);
         m->bn_nonneg = 1;
         for (int i = 0; i < NMEL; ++i) if (!(sc[i] >= 0.f)) m->bn_nonneg = 0;
-        if (const char* e = std::getenv("UITK_ENC_GENERIC_CLAMP")) if (std::atoi(e)) m->bn_nonneg = 0;     // A/B and tests of the generic path
     }
-    if (const char* e = std::getenv("UITK_ENC_WAVES")) m->enc_waves = std::atoi(e) == 4 ? 4 : 8;
-    if (const char* e = std::getenv("UITK_ENC_SCHED")) m->enc_sched = std::atoi(e) != 0;
-    if (const char* e = std::getenv("UITK_ENC_STAGGER")) m->enc_stagger = std::atoi(e);
-    if (const char* e = std::getenv("UITK_ENC_STAGGER_MODE")) m->enc_stagger_mode = std::atoi(e);
-    if (const char* e = std::getenv("UITK_ENC_ABLATE")) m->enc_ablate = std::atoi(e);
-    if (const char* e = std::getenv("UITK_FE_WG_PER_CU")) m->fe_wg_per_cu = std::atoi(e);
-    if (const char* e = std::getenv("UITK_FE_STATIC")) m->fe_static = std::atoi(e) != 0;
-    if (const char* e = std::getenv("UITK_FE_ASYM")) m->fe_asym_pm = std::atoi(e);
-    if (const char* e = std::getenv("UITK_SPLIT_PE")) m->split_pe = std::atoi(e) != 0;
-    if (hipMalloc((void**)&m->image, img.size()) != hipSuccess || hipMalloc((void**)&m->amax, 2 * AMAX_SLOTS * 4 + 2 * 16 * 4) != hipSuccess) {      // + two sets of (up to 16) pass counters of the front-end
+    // Tuning / test options are set explicitly through uitk_set_option (no environment is read here, except under -DUITK_LAB where
+    // the A/B scripts of tools/ drive a variant library by environment).
+#ifdef UITK_LAB
+    for (const char* name : {"enc_waves", "fe_wg_per_cu", "fe_asym_pm", "split_pe", "enc_generic_clamp"}) {
+        std::string env = "UITK_";
+        for (const char* c = name; *c; ++c) env += (char)std::toupper((unsigned char)*c);
+        if (const char* e = std::getenv(env.c_str())) (void)uitk_set_option(m, name, std::atoi(e));
+    }
+#endif
+    if (hipMalloc((void**)&m->image, img.size()) != hipSuccess || hipMalloc((void**)&m->amax, 2 * AMAX_SLOTS * 4) != hipSuccess) {
         uitk_destroy(m); return fail(UITK_ERR_HIP, "hipMalloc failed for the parameter image");
     }
     float armed[2 * AMAX_SLOTS];
     for (float& v : armed) v = -INFINITY;                                       // both amax slot sets start armed (-inf)
     if (hipMemcpy(m->image, img.data(), img.size(), hipMemcpyHostToDevice) != hipSuccess ||
-        hipMemcpy(m->amax, armed, sizeof armed, hipMemcpyHostToDevice) != hipSuccess ||
-        hipMemset(m->amax + 2 * AMAX_SLOTS, 0, 2 * 16 * 4) != hipSuccess) {
+        hipMemcpy(m->amax, armed, sizeof armed, hipMemcpyHostToDevice) != hipSuccess) {
         uitk_destroy(m); return fail(UITK_ERR_HIP, "parameter upload failed");
     }
     *out = m;
@@ -148,6 +147,8 @@ static int check_shape(const uitk_model* m, int64_t B, int64_t T) {
     return UITK_OK;
 }
 
+static int calibrate_frontend_split(uitk_model* m, int64_t B, int64_t T);
+
 int uitk_reserve(uitk_model* m, int64_t B, int64_t T) {
     if (int rc = check_shape(m, B, T)) return rc;
     const int nc = uitk_num_crops(m, T);
@@ -167,6 +168,49 @@ int uitk_reserve(uitk_model* m, int64_t B, int64_t T) {
         HIP_TRY(hipMalloc((void**)&m->rowprobs, rp_bytes));
         m->rowprobs_cap = rp_bytes;
     }
+    if (!m->fe_calibrated && m->fe_asym_pm < 0 && nc == 1) return calibrate_frontend_split(m, B, T);
+    return UITK_OK;
+}
+
+static int run_frontend(uitk_model* m, const void* pcm, int in_dtype, int64_t B, int64_t T, float* mel_out, int patch, hipStream_t s);
+
+// The asymmetric pass split of the front-end (frontend.hip: the first-dispatched workgroup of a CU is served first by the
+// instruction arbiter and gets a larger pool of passes) depends on dispatch order and arbitration, i.e. on the device: rounds 1-2
+// baked in 590 per mille from one box and saw +-8 % box-to-box spread.  Round 3: measured here, once per handle, on the first
+// uitk_reserve whose batch fills the persistent grid -- five candidate shares, a warm-up + five timed launches each on a zero batch
+// (the kernel has no data-dependent control flow), smallest minimum wins.  Results never depend on the split (bit-identical:
+// tests/test_gpu_parity.py::test_pass_distribution_does_not_change_results).
+static int calibrate_frontend_split(uitk_model* m, int64_t B, int64_t T) {
+    m->fe_calibrated = 1;
+    const int nF = uitk_num_frames(m, T), rem = nF & 15;
+    const int64_t Bc = B < 2048 ? B : 2048;
+    const int64_t npass = Bc * (int64_t)(nF >> 4) + (rem ? (Bc + 16 / rem - 1) / (16 / rem) : 0);
+    const int wg = m->fe_wg_per_cu > 0 ? m->fe_wg_per_cu : 2;
+    if (wg != 2 || npass < 4 * (int64_t)m->n_cu * wg) return UITK_OK;      // no asymmetric split at this size: nothing to measure
+    void* zero = nullptr;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (hipMalloc(&zero, (size_t)Bc * T * 4) != hipSuccess) { (void)hipGetLastError(); return UITK_OK; }   // calibration is optional
+    int best = 590; float best_ms = 1e30f;
+    if (hipMemset(zero, 0, (size_t)Bc * T * 4) == hipSuccess && hipEventCreate(&e0) == hipSuccess && hipEventCreate(&e1) == hipSuccess) {
+        for (int cand : {500, 550, 590, 630, 670}) {
+            m->fe_asym_pm = cand;
+            float mn = 1e30f;
+            for (int rep = 0; rep < 6; ++rep) {
+                (void)hipEventRecord(e0, nullptr);
+                if (run_frontend(m, zero, UITK_IN_F32, Bc, T, m->mel, 1, nullptr) != UITK_OK) { mn = 1e30f; break; }
+                (void)hipEventRecord(e1, nullptr);
+                float ms = 0.f;
+                if (hipEventSynchronize(e1) != hipSuccess || hipEventElapsedTime(&ms, e0, e1) != hipSuccess) { mn = 1e30f; break; }
+                if (rep > 0 && ms < mn) mn = ms;
+            }
+            if (mn < best_ms) { best_ms = mn; best = cand; }
+        }
+    }
+    m->fe_asym_pm = best;
+    m->fe_B = 0; m->fe_T = 0;
+    if (e0) (void)hipEventDestroy(e0);
+    if (e1) (void)hipEventDestroy(e1);
+    (void)hipFree(zero);
     return UITK_OK;
 }
 
@@ -181,9 +225,35 @@ int uitk_set_debug_tokens(uitk_model* m, float* dev_buf) {
 
 int uitk_set_timing_buffers(uitk_model* m, unsigned long long* enc_buf, unsigned long long* fe_buf) {
     if (!m) return fail(UITK_ERR_INVALID_ARG, "null model");
+#ifndef UITK_LAB
+    if (enc_buf || fe_buf) return fail(UITK_ERR_UNSUPPORTED, "the instrumented kernels exist in -DUITK_LAB builds of the library only (tools/mklib.sh)");
+#else
     if ((enc_buf || fe_buf) && (m->cfg.precision != UITK_PREC_F16 || m->cfg.attention_full || m->cfg.act_gelu || m->cfg.pooling))
         return fail(UITK_ERR_UNSUPPORTED, "the instrumented kernel builds exist for precision f16, BNeckAttention + ReLU only");
+#endif
     m->timing = enc_buf; m->timing_fe = fe_buf;
+    return UITK_OK;
+}
+
+int uitk_set_option(uitk_model* m, const char* name, int value) {
+    if (!m || !name) return fail(UITK_ERR_INVALID_ARG, "null argument");
+    const std::string n = name;
+    if (n == "fe_asym_pm") {                  // per-mille share of the front-end passes for the first-dispatched workgroups; -1 = calibrate
+        if (value != -1 && (value < 300 || value > 700)) return fail(UITK_ERR_INVALID_ARG, "fe_asym_pm: -1 or 300..700");
+        m->fe_asym_pm = value; m->fe_calibrated = value != -1;
+    } else if (n == "fe_wg_per_cu") {         // persistent front-end workgroups per CU (0 = the kernel's occupancy target)
+        if (value < 0 || value > 4) return fail(UITK_ERR_INVALID_ARG, "fe_wg_per_cu: 0..4");
+        m->fe_wg_per_cu = value;
+    } else if (n == "enc_waves") {            // 8 = one encoder workgroup per CU (default), 4 = two independent workgroups per CU
+        if (value != 4 && value != 8) return fail(UITK_ERR_INVALID_ARG, "enc_waves: 4 or 8");
+        m->enc_waves = value;
+    } else if (n == "split_pe") {             // patch embed on split weights: 1 / 0 / -1 = the precision's default
+        m->split_pe_env = value < 0 ? -1 : (value != 0);
+    } else if (n == "enc_generic_clamp") {    // 1 = take the generic top_db clamp path even when every init_bn scale is >= 0 (tests)
+        m->force_generic_clamp = value != 0;
+    } else {
+        return fail(UITK_ERR_UNSUPPORTED, "unknown option: " + n);
+    }
     return UITK_OK;
 }
 
@@ -206,8 +276,6 @@ static int run_frontend(uitk_model* m, const void* pcm, int in_dtype, int64_t B,
     // no memset per call: this launch fills one set of slots and re-arms (0xFFFFFFFF) the other for the next launch
     m->amax_cur ^= 1;
     a.mel = mel_out; a.amax = m->amax + m->amax_cur * AMAX_SLOTS; a.amax_rearm = m->amax + (m->amax_cur ^ 1) * AMAX_SLOTS;
-    a.work_ctr = (int*)(m->amax + 2 * AMAX_SLOTS) + 16 * m->amax_cur; a.work_ctr_rearm = (int*)(m->amax + 2 * AMAX_SLOTS) + 16 * (m->amax_cur ^ 1);
-    if (m->fe_static) a.work_ctr = nullptr;
     a.asym_pm = m->fe_asym_pm;
     a.bn_sc = (const float*)(m->image + h.off_bn_sc); a.bn_sh = (const float*)(m->image + h.off_bn_sh);
     a.op_bf16 = m->cfg.precision == UITK_PREC_BF16;
@@ -254,12 +322,12 @@ int uitk_encode(uitk_model* m, int64_t B, int64_t T, float* probs, float* logits
     a.head_b = (const float*)(m->image + h.off_head_b);
     a.probs = nc > 1 ? m->rowprobs : probs;
     a.logits = logits; a.dbg = m->dbg;
-    a.timing = m->timing; a.ablate = m->enc_ablate;
-    a.bn_nonneg = m->bn_nonneg;
-    a.split_pe = m->split_pe || m->cfg.precision == UITK_PREC_F16X2 || m->cfg.precision == UITK_PREC_F16L6;     // f16x2 / f16l6: the patch embed runs on its split weights too
+    a.timing = m->timing;
+    a.bn_nonneg = m->bn_nonneg && !m->force_generic_clamp;
+    a.split_pe = m->split_pe_env >= 0 ? m->split_pe_env : m->cfg.precision == UITK_PREC_F16X2;     // f16x2: the patch embed runs on its split weights too
+    // (f16l6 keeps the structurally rounded single weights: same-box, worst sweep seeds 6.0e-4 / 5.1e-4 without vs 6.6e-4 / 4.8e-4 with, +1.2 % time)
     a.attention_full = m->cfg.attention_full; a.act_gelu = m->cfg.act_gelu; a.pooling = m->cfg.pooling;
-    a.stagger = m->enc_stagger; a.stagger_group = m->n_cu; a.stagger_mode = m->enc_stagger_mode;
-    HIP_TRY(launch_encoder(a, m->cfg.precision, m->enc_waves, m->enc_sched, s));
+    HIP_TRY(launch_encoder(a, m->cfg.precision, m->enc_waves, s));
     if (nc > 1) HIP_TRY(launch_crop_reduce(m->rowprobs, probs, B, nc, a.C, m->cfg.eval_avg, s));
     return UITK_OK;
 }

@@ -108,12 +108,8 @@ template <> struct Op<1> {   // bf16 operands
     static __device__ __forceinline__ v8 zero8() { return v8{(__bf16)0.f, (__bf16)0.f, (__bf16)0.f, (__bf16)0.f, (__bf16)0.f, (__bf16)0.f, (__bf16)0.f, (__bf16)0.f}; }
 };
 
-#ifndef UITK_RING_SLOTS
-#define UITK_RING_SLOTS 4
-#define UITK_PREFETCH 2
-#endif
-constexpr int RING_SLOTS = UITK_RING_SLOTS;   // power of two, >= PREFETCH + 2 (see ring_step)
-constexpr int PREFETCH = UITK_PREFETCH;       // stages in flight ahead of the one being consumed
+constexpr int RING_SLOTS = 4;                 // power of two, >= PREFETCH + 2 (see ring_step); 8 slots with 3-4 stages in flight measured +0.5-1 %
+constexpr int PREFETCH = 2;                   // stages in flight ahead of the one being consumed
 static_assert((RING_SLOTS & (RING_SLOTS - 1)) == 0 && RING_SLOTS >= PREFETCH + 2 && RING_SLOTS >= PE_HI_STAGES && PREFETCH <= TAIL_STAGES, "ring geometry");
 constexpr int LDS_RING = RING_SLOTS * STAGE_BYTES;            // 64 KiB
 constexpr int LDS_BIAS = 2 * BIAS_FLOATS * 4;                 // 8 KiB (double-buffered per block)
@@ -157,15 +153,29 @@ __device__ __forceinline__ void ring_step(const char* wstream, char* ring, int t
     asm volatile("" ::: "memory");
 }
 
-template <int WAVES>
+// scalar-base form of a 16-byte-per-lane LDS-DMA, written out: uniform 64-bit global base (SGPR pair) + ONE 32-bit lane offset, uniform
+// LDS address in M0.  The builtin selects the 64-bit per-lane address form, i.e. a register pair per distinct piece that stays live
+// (or is spilled and reloaded -- a vmem op the counted vmcnt scheme cannot see) across the whole block loop.
+__device__ __forceinline__ void dma_b128(const char* gsrc, unsigned lane16, char* ldst) {
+    const unsigned l = (unsigned)(uintptr_t)LPTR(ldst);
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(l), "v"(lane16), "s"(gsrc) : "memory", "m0");
+}
+__device__ __forceinline__ void dma_b32(const char* gsrc, unsigned lane4, char* ldst) {
+    const unsigned l = (unsigned)(uintptr_t)LPTR(ldst);
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dword %1, %2" ::"s"(l), "v"(lane4), "s"(gsrc) : "memory", "m0");
+}
+
+template <int WAVES, bool SCALAR_BASE = false>
 __device__ __forceinline__ void bias_issue(const float* bias, char* breg, int blk, int wave, int lane) {
     constexpr int PER_WAVE_BYTES = BIAS_FLOATS * 4 / WAVES;
     constexpr int N = PER_WAVE_BYTES / 256;                      // dword x 64 lanes = 256 B per instruction
     const char* src = (const char*)(bias + (size_t)blk * BIAS_FLOATS) + wave * PER_WAVE_BYTES;
     char* dst = breg + (blk & 1) * BIAS_FLOATS * 4 + wave * PER_WAVE_BYTES;
 #pragma unroll
-    for (int i = 0; i < N; ++i)
-        __builtin_amdgcn_global_load_lds(GPTR(src + i * 256 + lane * 4), LPTR(dst + i * 256), 4, 0, 0);
+    for (int i = 0; i < N; ++i) {
+        if constexpr (SCALAR_BASE) dma_b32(src + i * 256, (unsigned)lane * 4u, dst + i * 256);
+        else __builtin_amdgcn_global_load_lds(GPTR(src + i * 256 + lane * 4), LPTR(dst + i * 256), 4, 0, 0);
+    }
 }
 
 template <int PREC>
@@ -176,11 +186,7 @@ __device__ __forceinline__ typename Op<PREC>::v8 lds_frag(const char* slot, int 
 __device__ __forceinline__ f4 splat(float x) { return f4{x, x, x, x}; }
 // a + b as four scalar v_add_f32: beside MFMAs a v_pk_add_f32 pair costs more issue time than the scalar adds it replaces
 __device__ __forceinline__ f4 add4s(f4 a, f4 b) {
-#ifdef UITK_PK_BIAS
-    return a + b;
-#else
     return f4{a[0] + b[0], a[1] + b[1], a[2] + b[2], a[3] + b[3]};
-#endif
 }
 __device__ __forceinline__ float hsum(f4 x) { return (x[0] + x[1]) + (x[2] + x[3]); }
 // Maxima as plain v_max_f32 / v_max3_f32 (asm): for fmaxf on MFMA results or lane-swapped bits the compiler first canonicalises
@@ -270,21 +276,6 @@ __device__ __forceinline__ void layernorm_to_operand(const f4 (&R)[8][3], float 
     }
 }
 
-// Timing experiment (ABL & 64, f16): an MFMA with FILL plain VALU instructions pinned in its shadow -- prices a schedule
-// in which the LN/softmax arithmetic of another token stream is spread over the MLP's MFMA gaps.
-template <int FILL>
-__device__ __forceinline__ f4 mfma32_filled(h8 a, h8 b, f4 c, float& d0, float& d1, float& d2) {
-    if constexpr (FILL == 1)
-        asm volatile("v_mfma_f32_16x16x32_f16 %0, %2, %3, %0\n\tv_fma_f32 %1, %1, %1, %1" : "+v"(c), "+v"(d0) : "v"(a), "v"(b));
-    else if constexpr (FILL == 2)
-        asm volatile("v_mfma_f32_16x16x32_f16 %0, %3, %4, %0\n\tv_fma_f32 %1, %1, %1, %1\n\tv_fma_f32 %2, %2, %2, %2"
-                     : "+v"(c), "+v"(d0), "+v"(d1) : "v"(a), "v"(b));
-    else
-        asm volatile("v_mfma_f32_16x16x32_f16 %0, %4, %5, %0\n\tv_fma_f32 %1, %1, %1, %1\n\tv_fma_f32 %2, %2, %2, %2\n\tv_fma_f32 %3, %3, %3, %3"
-                     : "+v"(c), "+v"(d0), "+v"(d1), "+v"(d2) : "v"(a), "v"(b));
-    return c;
-}
-
 typedef unsigned u2 __attribute__((ext_vector_type(2)));
 typedef int v8i __attribute__((ext_vector_type(8)));
 
@@ -303,7 +294,6 @@ __device__ __forceinline__ void attention_proj(f4 (&R)[8][3], const typename OP:
     using v8 = typename OP::v8;
     using v4 = typename OP::v4;
     f4 O[2][3];
-#ifndef UITK_ATTN_HEADS_SEQUENTIAL
     // both heads advance together phase by phase (scores, maxima, exponentials, P.V): two independent dependency chains
     // in every phase for the scheduler to overlap
     f4 S[2][7];
@@ -352,49 +342,6 @@ __device__ __forceinline__ void attention_proj(f4 (&R)[8][3], const typename OP:
     for (int h = 0; h < 2; ++h)
 #pragma unroll
         for (int it = 0; it < 3; ++it) O[h][it] = O[h][it] * splat(__builtin_amdgcn_rcpf(Lsum[h][it][0]));
-#else
-#pragma unroll
-    for (int h = 0; h < 2; ++h) {
-        // S^T = K.Q^T in the log2 domain (0.125*log2(e) folded into Wq/bq by pack.cpp)
-        f4 S[7];
-        float tm[7];
-#pragma unroll
-        for (int i = 0; i < 7; ++i) {
-            S[i] = OP::mfma16(Kh[h][TJ[i]], Qh[h][TI[i]], splat(0.f));
-            if constexpr (SHORT) {
-                // padding tokens (time patch >= nt) of the query's own clip must not set the running max: a large score of
-                // one of them would underflow every valid probability (sum 0 -> rcp(0)).  Per-key select, short clips only.
-                f4 sv;
-#pragma unroll
-                for (int r = 0; r < 4; ++r) sv[r] = ((r < 2 ? pmask[i][0] : pmask[i][1]) >> (16 * (r & 1))) & 1u ? S[i][r] : -INFINITY;
-                tm[i] = hmax(sv);
-            } else {
-                tm[i] = tvalid[i] ? hmax(S[i]) : -INFINITY;
-            }
-        }
-        float mx[3];
-        mx[0] = xmax(vmax(tm[0], tm[1]));
-        mx[1] = xmax(vmax3(tm[2], tm[3], tm[4]));
-        mx[2] = xmax(vmax(tm[5], tm[6]));
-        // P = 2^(S - max), converted, masked on the packed bits; row sums by a ones-row MFMA (sums exactly the
-        // rounded probabilities that multiply V; every output row holds the column sum => no cross-lane step)
-        f4 Lsum[3];
-#pragma unroll
-        for (int it = 0; it < 3; ++it) { O[h][it] = splat(0.f); Lsum[it] = splat(0.f); }
-#pragma unroll
-        for (int i = 0; i < 7; ++i) {
-            f4 p;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) p[r] = __builtin_amdgcn_exp2f(S[i][r] - mx[TI[i]]);
-            const u2 bits = __builtin_bit_cast(u2, OP::pack4(p)) & pmask[i];
-            const v4 Pm = __builtin_bit_cast(v4, bits);
-            O[h][TI[i]] = OP::mfma16(Vh[TJ[i]][h], Pm, O[h][TI[i]]);
-            Lsum[TI[i]] = OP::mfma16(OP::ones4(), Pm, Lsum[TI[i]]);
-        }
-#pragma unroll
-        for (int it = 0; it < 3; ++it) O[h][it] = O[h][it] * splat(__builtin_amdgcn_rcpf(Lsum[it][0]));
-    }
-#endif
     // proj: K = 32 = (head, d); slots j<4 head 0, j>=4 head 1 (same universal k-order as pack_frag)
     v8 A[8];
 #pragma unroll
@@ -539,15 +486,8 @@ __device__ __forceinline__ f4 mfma64_wa_sel(int sel, u6 w, u4 x, f4 c, int wscal
 template <int KIND> constexpr int l6_dma_count() { return KIND == 0 ? 2 : KIND == 1 ? 3 : KIND == 2 ? 3 : 5; }
 template <int KIND>
 __device__ __forceinline__ void l6_issue(const char* src, char* dst, int wave, int lane) {
-    // Scalar-base form of the LDS-DMA, written out: uniform 64-bit base (SGPR pair) + ONE 32-bit lane offset.  The builtin selects the
-    // 64-bit per-lane address form for dwordx4, i.e. a register pair per distinct piece held across the whole block loop -- registers
-    // this mode does not have (a spill reload inside the loop drains the counted vmcnt).
     const unsigned lane16 = (unsigned)lane * 16u;
-    auto piece = [&](int p) {
-        const char* gsrc = src + (size_t)(unsigned)(p * FRAG_BYTES);
-        const unsigned ldst = (unsigned)(uintptr_t)LPTR(dst + p * FRAG_BYTES);
-        asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(ldst), "v"(lane16), "s"(gsrc) : "memory", "m0");
-    };
+    auto piece = [&](int p) { dma_b128(src + (size_t)(unsigned)(p * FRAG_BYTES), lane16, dst + p * FRAG_BYTES); };
     piece(wave * 2); piece(wave * 2 + 1);                            // the sixteen f16 fragments
     if constexpr (KIND == 1) piece(16 + wave);                       // 8 low-order f16 fragments of proj
     if constexpr (KIND >= 2) piece(16 + (wave >= 6 ? wave - 6 : wave >= 3 ? wave - 3 : wave));      // 2 fragment6 of fc1 = 3 KiB
@@ -562,6 +502,10 @@ __device__ __forceinline__ void l6_step(const char* src, char* dst, int wave, in
     asm volatile("" ::: "memory");
 }
 
+#if !defined(UITK_LAB) || !defined(L6_ABL)
+#undef L6_ABL
+#define L6_ABL 0      // -DUITK_LAB builds only (timing, wrong results; tools/mklib.sh): 1 = no fc1 low-order term, 2 = no fc2 low-order term,
+#endif                // 4 = no proj low-order term.  The product build (uit_mobile_amd/build.py) never defines UITK_LAB.
 // In-kernel stamps (diagnostic build only, TIMING = true): one asm statement = s_memtime + lgkmcnt(0), fenced.
 __device__ __forceinline__ unsigned long long stamp() {
     unsigned long long t;
@@ -572,14 +516,12 @@ __device__ __forceinline__ unsigned long long stamp() {
 }
 #define TSTAMP(slot) do { if constexpr (TIMING) { const unsigned long long _t = stamp(); tacc[slot] += _t - tlast; tlast = _t; } } while (0)
 
-// ABL: timing experiments only (wrong outputs; 64|128 = 1..3 filler VALU pinned behind every MLP MFMA): 1 skip attention, 2 skip LayerNorms, 4 MLP without ring steps
-// (no DMA, no barrier), 8 MLP without LDS fragment reads, 16 MLP without ReLU/convert, 32 MLP without bias reads.  The product kernel is ABL = 0.
 // SHORT: clips with fewer than 6 time patches (masked padding tokens; a separate instantiation keeps the full-clip kernel's
 // register allocation untouched).
 // ATT: 0 = BNeckAttention (the uit_* family), 1 = full-width Attention (2 heads x 64; 20 ring stages per block).  ACT: 0 ReLU, 1 GELU.
 // POOL: 0 = pooling 'mean', 1 = pooling 'dm' (models/uit.py:405-412), 2 = pooling 'token' (:389-392, 399-401): ONE clip per wave,
 // column 0 = the cls token, columns 1..24 = the patch tokens, columns 25..47 dead (masked as keys, never read as outputs).
-template <int PREC, int WAVES, bool SHORT, bool TIMING, int ABL = 0, int ATT = 0, int ACT = 0, int POOL = 0>
+template <int PREC, int WAVES, bool SHORT, bool TIMING, int ATT = 0, int ACT = 0, int POOL = 0>
 __global__ __launch_bounds__(WAVES * 64, 2) void uit_encoder_kernel(EncoderArgs a) {
     constexpr int OPC = PREC >= 2 ? 0 : PREC;              // precision fp8: patch embed, attention, proj and head stay f16; f16x2: fp16 operands
     using OP = Op<OPC>;
@@ -597,26 +539,6 @@ __global__ __launch_bounds__(WAVES * 64, 2) void uit_encoder_kernel(EncoderArgs 
     const int tid = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lane = tid & 63, c = lane & 15, g = lane >> 4;
-
-    // ---- optional stagger: delay one of the two workgroups sharing a CU so that they run out of phase (one in its
-    // MFMA-bound MLP while the other is in its VALU-bound LN/softmax).  Mode 1 keys on the workgroup generation,
-    // mode 2 on the hardware wave slot of wave 0 (HW_REG_HW_ID[3:0]); a pure speed knob, results do not depend on it.
-    if (a.stagger > 0) {
-        bool delay;
-        if (a.stagger_mode == 2) {
-            unsigned* flag = (unsigned*)zbuf;
-            if (tid == 0) *flag = __builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 4) & 1u;   // WAVE_ID parity
-            __syncthreads();
-            delay = *flag != 0;
-            __syncthreads();
-        } else {
-            delay = ((blockIdx.x / a.stagger_group) & 1) != 0;
-        }
-        if (delay) {
-            const uint64_t t0 = __builtin_amdgcn_s_memtime();
-            while (__builtin_amdgcn_s_memtime() - t0 < (uint64_t)a.stagger) __builtin_amdgcn_s_sleep(16);
-        }
-    }
 
     unsigned long long tacc[ENC_TIMING_SLOTS] = {}, tlast = 0;
     if constexpr (TIMING) tlast = stamp();
@@ -653,7 +575,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void uit_encoder_kernel(EncoderArgs 
     for (int ct = 0; ct < 3; ++ct) {
         const unsigned short* src = a.mel + ((int64_t)(clip_[ct] ? row_hi : row_lo) * NTOK + tk_[ct]) * 256 + 8 * g;
 #pragma unroll
-        for (int s = 0; s < 8; ++s) { if constexpr (ABL & 256) XB[ct][s] = OP::zero8(); else XB[ct][s] = *(const v8*)(src + 32 * s); }
+        for (int s = 0; s < 8; ++s) XB[ct][s] = *(const v8*)(src + 32 * s);
     }
     // The patch operands come from HBM (the slowest trip of the prologue): their loads are issued FIRST, the L2-resident weight /
     // table DMAs behind them.
@@ -856,7 +778,6 @@ __global__ __launch_bounds__(WAVES * 64, 2) void uit_encoder_kernel(EncoderArgs 
     }
 
     // ---- transformer blocks
-    float dmy0 = 1.0f, dmy1 = 0.5f, dmy2 = 0.25f;          // filler chains of the ABL & 192 timing experiment
 #pragma unroll 1
     for (int blk = 0; blk < a.depth; ++blk) {
       if constexpr (PREC == 2) {
@@ -1045,7 +966,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void uit_encoder_kernel(EncoderArgs 
       } else if constexpr (PREC == 4) {
         // ================= precision f16l6: the f16 block + the low-order weight term on the MX-fp6 MFMA (uitk_dev.h) =================
         // Stage k of block blk lives in ring slot (2 blk + k) & 3 (14 stages per block); at step k the stage k + 2 is issued.
-        static_assert(ATT == 0 && POOL == 0 && ACT == 0, "precision f16l6: uit_* family only");
+        static_assert(ATT == 0 && ACT == 0, "precision f16l6: BNeckAttention + ReLU (any pooling)");
         const char* wblk = a.wstream + (size_t)PE_STAGES * STAGE_BYTES + (size_t)blk * L6_BLOCK_BYTES;
         const int sb = 2 * (blk & 1);
         auto slot_of = [&](int k) -> char* { return ring + ((sb + k) & 3) * L6_SLOT_BYTES; };
@@ -1056,7 +977,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void uit_encoder_kernel(EncoderArgs 
         // ===== stage QK (issue MLP stage 0; younger stages VP + M).  qkv keeps single fp16 weights: its rounding is the smallest of the
         // four weight terms and the stage has no register room for a second operand set
         l6_step<2, l6_dma_count<1>() + l6_dma_count<2>()>(wblk + l6_mlp_offset(0), slot_of(2), wave, lane);
-        if (blk + 1 < a.depth) bias_issue<WAVES>(a.bias, breg, blk + 1, wave, lane);
+        if (blk + 1 < a.depth) bias_issue<WAVES, true>(a.bias, breg, blk + 1, wave, lane);
         v4 Qh[2][3], Kh[2][3];
         {
             const char* slot = slot_of(0);
@@ -1101,7 +1022,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void uit_encoder_kernel(EncoderArgs 
                 }
             }
             if constexpr (PERKEY) {
-                attention_proj<OP, PERKEY, true>(R, Qh, Kh, Vh, tvalid, pmask, slot + 8 * FRAG_BYTES, bias, lane, g);
+                attention_proj<OP, PERKEY, !(L6_ABL & 4)>(R, Qh, Kh, Vh, tvalid, pmask, slot + 8 * FRAG_BYTES, bias, lane, g);
             } else {
                 // full clips: a lane's four keys of a tile are all valid or all foreign, so the probability masks follow from tvalid --
                 // rebuilt per block (14 selects) instead of living in 14 registers through the MLP loop, which has none to spare
@@ -1110,7 +1031,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void uit_encoder_kernel(EncoderArgs 
                 asm volatile("" : "+v"(ones));                        // (keeps the selects inside the block loop: hoisted, they are 14 live registers again)
 #pragma unroll
                 for (int i = 0; i < 7; ++i) pm[i] = tvalid[i] ? u2{ones, ones} : u2{0u, 0u};
-                attention_proj<OP, PERKEY, true>(R, Qh, Kh, Vh, tvalid, pm, slot + 8 * FRAG_BYTES, bias, lane, g);
+                attention_proj<OP, PERKEY, !(L6_ABL & 4)>(R, Qh, Kh, Vh, tvalid, pm, slot + 8 * FRAG_BYTES, bias, lane, g);
             }
         }
         // ===== MLP: 12 stages in three k-groups of four.  fc1: four fp16 k-steps + ONE fp6 MFMA per accumulator; fc2: the fp16 k-step of
@@ -1119,6 +1040,15 @@ __global__ __launch_bounds__(WAVES * 64, 2) void uit_encoder_kernel(EncoderArgs 
         // across the barrier costs 44 registers this mode does not have -- any spill inside the loop would drain the counted vmcnt.
         layernorm_to_operand<OPC>(R, 1e-6f, X);
         u4 HX4[3];
+        // the fp6 copy of the LayerNorm operand is converted ONCE per block and held (18 registers): converting it per chunk instead
+        // (3 v_cvt_scalef32_pk32_fp6_f16 of ~16 issue cycles each) was measured at +5 % encoder time
+        u6 X6[3];
+#pragma unroll
+        for (int ct = 0; ct < 3; ++ct) X6[ct] = operand_to_fp6(X[0][ct], X[1][ct], X[2][ct], X[3][ct]);
+        // v_cvt_scalef32_pk32_fp6_f16 is a multi-pass VALU instruction whose 6-register result the matrix pipe may read too early: the
+        // compiler's hazard table pads a VALU -> MFMA operand dependency for single-pass producers only.  Measured: without these
+        // wait states the low-order term -- and so the last bits of the output -- differed from run to run (tools/l6_determinism.py).
+        asm volatile("s_nop 7\n\ts_nop 7" : "+v"(X6[0]), "+v"(X6[1]), "+v"(X6[2]));
 #pragma unroll 1
         for (int q = 0; q < 3; ++q) {
 #pragma unroll
@@ -1137,50 +1067,51 @@ __global__ __launch_bounds__(WAVES * 64, 2) void uit_encoder_kernel(EncoderArgs 
                 const char* slot = slot_of(ch + 2);
                 v8 HX[3];
                 {
-                    v8 A[8];
-#pragma unroll
-                    for (int f = 0; f < 8; ++f) A[f] = lds_frag<OPC>(slot, f, lane);
                     const u6 W6a = lds_frag6(slot + STAGE_BYTES, lane), W6b = lds_frag6(slot + STAGE_BYTES + FRAG6_BYTES, lane);
                     const int s1 = sct[(2 * q + (j >> 1)) * 16];      // row scales of fc1 tiles 4 (2q + j/2) .. +3
-                    // fp6 copy of the LayerNorm operand, converted per chunk (3 instructions in MFMA shadows) instead of held in 18
-                    // registers; the laundered scale keeps the conversions from being hoisted out of the loop again
-                    float two = 2.0f;
-                    asm volatile("" : "+s"(two));
-                    u6 X6[3];
-#pragma unroll
-                    for (int ct = 0; ct < 3; ++ct) X6[ct] = operand_to_fp6(X[0][ct], X[1][ct], X[2][ct], X[3][ct], two);
                     const f4 b10 = *(const f4*)(bias + BIAS_FC1 + 32 * ch + 4 * g), b11 = *(const f4*)(bias + BIAS_FC1 + 32 * ch + 16 + 4 * g);
-                    // one fc1 row tile at a time: its three accumulators are packed (ReLU on the packed halves) before the next tile's
-                    // start, so only 12 accumulator registers are live
-                    v4 P0[3], P1[3];
-                    {
-                        f4 H[3];
+                    // NT fc1 row tiles at a time (NT = 1: only 12 accumulator registers are live; the accumulators are packed, ReLU on the
+                    // packed halves, before the next tile starts).  Each chain starts with its low-order MFMA: that one needs no f16
+                    // fragment, so it and the fp6 conversions run while the fragment reads are still in flight.  The f16 k-steps are
+                    // written k-step-major so that the 3 NT chains interleave.
+#ifndef L6_NT
+#define L6_NT 1
+#endif
+                    constexpr int NT = L6_NT;
+                    v4 P[2][3];
 #pragma unroll
-                        for (int ct = 0; ct < 3; ++ct) {
-                            H[ct] = b10;
+                    for (int t0 = 0; t0 < 2; t0 += NT) {
+                        v8 A[8];                                      // this tile's f16 fragments (read per tile: 16 registers, not 32)
 #pragma unroll
-                            for (int s = 0; s < 4; ++s) H[ct] = OP::mfma32(A[s], X[s][ct], H[ct]);
-                            H[ct] = mfma6_wa_sel(2 * j, W6a, X6[ct], H[ct], s1);
-                        }
+                        for (int f = 4 * t0; f < 4 * (t0 + NT); ++f) A[f] = lds_frag<OPC>(slot, f, lane);
+                        f4 H[NT][3];
 #pragma unroll
-                        for (int ct = 0; ct < 3; ++ct) { P0[ct] = __builtin_elementwise_max(OP::pack4(H[ct]), v4{0, 0, 0, 0}); asm volatile("" : "+v"(P0[ct])); }
-                    }
-                    {
-                        f4 H[3];
+                        for (int tt = 0; tt < NT; ++tt)
 #pragma unroll
-                        for (int ct = 0; ct < 3; ++ct) {
-                            H[ct] = b11;
+                            for (int ct = 0; ct < 3; ++ct) {
+                                H[tt][ct] = t0 + tt == 0 ? b10 : b11;
+#if !(L6_ABL & 1)
+                                H[tt][ct] = mfma6_wa_sel(2 * j + t0 + tt, t0 + tt == 0 ? W6a : W6b, X6[ct], H[tt][ct], s1);
+#endif
+                            }
 #pragma unroll
-                            for (int s = 0; s < 4; ++s) H[ct] = OP::mfma32(A[4 + s], X[s][ct], H[ct]);
-                            H[ct] = mfma6_wa_sel(2 * j + 1, W6b, X6[ct], H[ct], s1);
-                        }
+                        for (int s = 0; s < 4; ++s)
 #pragma unroll
-                        for (int ct = 0; ct < 3; ++ct) P1[ct] = __builtin_elementwise_max(OP::pack4(H[ct]), v4{0, 0, 0, 0});
+                            for (int tt = 0; tt < NT; ++tt)
+#pragma unroll
+                                for (int ct = 0; ct < 3; ++ct) H[tt][ct] = OP::mfma32(A[(t0 + tt) * 4 + s], X[s][ct], H[tt][ct]);
+#pragma unroll
+                        for (int tt = 0; tt < NT; ++tt)
+#pragma unroll
+                            for (int ct = 0; ct < 3; ++ct) {
+                                P[t0 + tt][ct] = __builtin_elementwise_max(OP::pack4(H[tt][ct]), v4{0, 0, 0, 0});
+                                if (NT == 1 && t0 == 0) asm volatile("" : "+v"(P[0][ct]));
+                            }
                     }
 #pragma unroll
                     for (int ct = 0; ct < 3; ++ct) {
-                        HX[ct] = __builtin_shufflevector(P0[ct], P1[ct], 0, 1, 2, 3, 4, 5, 6, 7);
-                        unsigned w4 = operand_to_fp4(HX[ct]);
+                        HX[ct] = __builtin_shufflevector(P[0][ct], P[1][ct], 0, 1, 2, 3, 4, 5, 6, 7);
+                        unsigned w4 = (L6_ABL & 2) ? 0u : operand_to_fp4(HX[ct]);
                         asm volatile("" : "+v"(w4));                  // convert HERE: the scheduler must not keep four chunks of f16 operands alive instead
                         HX4[ct][j] = w4;
                     }
@@ -1194,7 +1125,10 @@ __global__ __launch_bounds__(WAVES * 64, 2) void uit_encoder_kernel(EncoderArgs 
 #pragma unroll
                         for (int ct = 0; ct < 3; ++ct) R[ft][ct] = OP::mfma32(A2[ft], HX[ct], R[ft][ct]);
                 }
-                if (j == 3) {                                         // fc2 low-order term of k-group q
+                if (j == 3 && !(L6_ABL & 2)) {                        // fc2 low-order term of k-group q
+                    // (same producer -> matrix-pipe hazard as after the fp6 conversion: v_cvt_scalef32_pk_fp4_f16 writes one byte of its
+                    // destination; the operand is normally long finished here -- 24 MFMAs lie in between -- the wait states make it certain)
+                    asm volatile("s_nop 7" : "+v"(HX4[0]), "+v"(HX4[1]), "+v"(HX4[2]));
                     const int s2a = sct[(6 + 2 * q) * 16], s2b = sct[(7 + 2 * q) * 16];
 #pragma unroll
                     for (int ft = 0; ft < 8; ++ft) {
@@ -1221,8 +1155,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void uit_encoder_kernel(EncoderArgs 
         const int tb = PE_STAGES + blk * BLK_ST;
         const float* bias = (const float*)(breg + (blk & 1) * BIAS_FLOATS * 4);
         v8 X[4][3];
-        if constexpr (!(ABL & 2)) layernorm_to_operand<OPC>(R, 1e-6f, X);
-        else { for (int s = 0; s < 4; ++s) for (int ct = 0; ct < 3; ++ct) X[s][ct] = OP::pack8(R[s][ct], R[s + 4][ct]); }
+        layernorm_to_operand<OPC>(R, 1e-6f, X);
         TSTAMP(0);                                                     // LN1
 
         if constexpr (ATT) {
@@ -1347,7 +1280,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void uit_encoder_kernel(EncoderArgs 
         TSTAMP(1);                                                     // ring wait QK
         if (blk + 1 < a.depth) bias_issue<WAVES>(a.bias, breg, blk + 1, wave, lane);
         v4 Qh[2][3], Kh[2][3];
-        if constexpr (!(ABL & 1)) {
+        {
             const char* slot = ring + (tb & (RING_SLOTS - 1)) * STAGE_BYTES;
             v8 A[16];
 #pragma unroll
@@ -1373,7 +1306,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void uit_encoder_kernel(EncoderArgs 
         // ===== stage VP: fragments 0..7 = V (h = f/4, s = f%4) used as the B operand; 8..15 = proj (ft = f-8)
         ring_step<WAVES>(a.wstream, ring, tb + 1, wave, lane);
         TSTAMP(3);                                                     // ring wait VP
-        if constexpr (!(ABL & 1)) {
+        {
             const char* slot = ring + ((tb + 1) & (RING_SLOTS - 1)) * STAGE_BYTES;
             v4 Vh[3][2];                       // V[token 16ct+4g+r][d = c] -> A operand of P.V (rows d, k = token)
             {
@@ -1399,44 +1332,37 @@ __global__ __launch_bounds__(WAVES * 64, 2) void uit_encoder_kernel(EncoderArgs 
 
         TSTAMP(4);                                                     // V + attention + proj
         // ===== MLP: 12 stages; stage ch = fc1 rows 32ch..32ch+31 (frags j*4+s) and fc2 k-step ch (frags 8+ft)
-        if constexpr (!(ABL & 2)) layernorm_to_operand<OPC>(R, 1e-6f, X);
+        layernorm_to_operand<OPC>(R, 1e-6f, X);
         TSTAMP(5);                                                     // LN2
         // Software-pipelined over the 12 stages: at stage ch the fc1 fragment reads are issued first, then the fc2
         // MFMAs of chunk ch-1 run from registers (A2/HX carried across the barrier) and cover the LDS latency; the
         // fc2 fragment reads of chunk ch fly under its fc1 MFMAs.
         v8 A2[8], HX[3];
-        auto mlp_mfma = [&](v8 a_, v8 b_, f4 c_) -> f4 {
-            if constexpr ((ABL & 192) != 0 && PREC == 0) return mfma32_filled<(ABL >> 6) & 3>(a_, b_, c_, dmy0, dmy1, dmy2);
-            else return OP::mfma32(a_, b_, c_);
-        };
         auto fc1_chunk = [&](const char* slot, int ch, const v8 (&A)[8]) {
-            f4 b10, b11;
-            if constexpr (ABL & 32) { b10 = splat(0.f); b11 = splat(0.f); }
-            else { b10 = *(const f4*)(bias + B_FC1 + 32 * ch + 4 * g); b11 = *(const f4*)(bias + B_FC1 + 32 * ch + 16 + 4 * g); }
+            const f4 b10 = *(const f4*)(bias + B_FC1 + 32 * ch + 4 * g), b11 = *(const f4*)(bias + B_FC1 + 32 * ch + 16 + 4 * g);
 #pragma unroll
-            for (int f = 0; f < 8; ++f) { if constexpr (!(ABL & 8)) A2[f] = lds_frag<OPC>(slot, 8 + f, lane); else A2[f] = A[f]; }   // fc2 fragments of this chunk
+            for (int f = 0; f < 8; ++f) A2[f] = lds_frag<OPC>(slot, 8 + f, lane);   // fc2 fragments of this chunk
             f4 H0[3], H1[3];
 #pragma unroll
             for (int ct = 0; ct < 3; ++ct) {
                 H0[ct] = b10;
 #pragma unroll
-                for (int s = 0; s < 4; ++s) H0[ct] = mlp_mfma(A[s], X[s][ct], H0[ct]);
+                for (int s = 0; s < 4; ++s) H0[ct] = OP::mfma32(A[s], X[s][ct], H0[ct]);
             }
 #pragma unroll
             for (int ct = 0; ct < 3; ++ct) {
                 H1[ct] = b11;
 #pragma unroll
-                for (int s = 0; s < 4; ++s) H1[ct] = mlp_mfma(A[4 + s], X[s][ct], H1[ct]);
+                for (int s = 0; s < 4; ++s) H1[ct] = OP::mfma32(A[4 + s], X[s][ct], H1[ct]);
             }
 #pragma unroll
             for (int ct = 0; ct < 3; ++ct) {
-                if constexpr (ABL & 16) { asm volatile("" :: "v"(H0[ct]), "v"(H1[ct])); if (ch == 0) HX[ct] = X[0][ct]; }
-                else if constexpr (ACT == 1) HX[ct] = OP::pack8(gelu4(H0[ct]), gelu4(H1[ct]));
+                if constexpr (ACT == 1) HX[ct] = OP::pack8(gelu4(H0[ct]), gelu4(H1[ct]));
                 else HX[ct] = OP::relu_pack8(H0[ct], H1[ct]);
             }
         };
         {   // chunk 0 (peeled: defines A2 / HX before the steady-state loop)
-            if constexpr (!(ABL & 4)) ring_step<WAVES>(a.wstream, ring, tb + MLP0, wave, lane);
+            ring_step<WAVES>(a.wstream, ring, tb + MLP0, wave, lane);
             TSTAMP(6);
             const char* slot = ring + ((tb + MLP0) & (RING_SLOTS - 1)) * STAGE_BYTES;
             v8 A[8];
@@ -1448,23 +1374,23 @@ __global__ __launch_bounds__(WAVES * 64, 2) void uit_encoder_kernel(EncoderArgs 
 #pragma unroll 1
         for (int ch = 1; ch < 12; ++ch) {
             const int t = tb + MLP0 + ch;
-            if constexpr (!(ABL & 4)) ring_step<WAVES>(a.wstream, ring, t, wave, lane);
+            ring_step<WAVES>(a.wstream, ring, t, wave, lane);
             TSTAMP(6);                                                 // ring wait MLP (sum of 12)
             const char* slot = ring + (t & (RING_SLOTS - 1)) * STAGE_BYTES;
             v8 A[8];
 #pragma unroll
-            for (int f = 0; f < 8; ++f) { if constexpr (ABL & 8) A[f] = A2[f]; else A[f] = lds_frag<OPC>(slot, f, lane); }   // fc1 fragments: in flight ...
+            for (int f = 0; f < 8; ++f) A[f] = lds_frag<OPC>(slot, f, lane);   // fc1 fragments: in flight ...
 #pragma unroll
             for (int ft = 0; ft < 8; ++ft)                                              // ... under chunk ch-1's fc2
 #pragma unroll
-                for (int ct = 0; ct < 3; ++ct) R[ft][ct] = mlp_mfma(A2[ft], HX[ct], R[ft][ct]);
+                for (int ct = 0; ct < 3; ++ct) R[ft][ct] = OP::mfma32(A2[ft], HX[ct], R[ft][ct]);
             fc1_chunk(slot, ch, A);
             TSTAMP(7);                                                 // MLP chunk compute (sum of 12)
         }
 #pragma unroll
         for (int ft = 0; ft < 8; ++ft)
 #pragma unroll
-            for (int ct = 0; ct < 3; ++ct) R[ft][ct] = mlp_mfma(A2[ft], HX[ct], R[ft][ct]);
+            for (int ct = 0; ct < 3; ++ct) R[ft][ct] = OP::mfma32(A2[ft], HX[ct], R[ft][ct]);
 #pragma unroll
         for (int ft = 0; ft < 8; ++ft) {
             const f4 b2 = *(const f4*)(bias + B_FC2 + 16 * ft + 4 * g);
@@ -1818,7 +1744,7 @@ __global__ void crop_reduce_kernel(const float* __restrict__ rp, float* __restri
     }
 }
 
-template <int PREC, int WAVES, bool SHORT, bool TIMING = false, int ABL = 0, int ATT = 0, int ACT = 0, int POOL = 0>
+template <int PREC, int WAVES, bool SHORT, bool TIMING = false, int ATT = 0, int ACT = 0, int POOL = 0>
 static hipError_t launch_enc(const EncoderArgs& a, hipStream_t stream) {
     // the attribute is per device: one bit per device, set once (see launch_fe)
     static std::atomic<unsigned long long> attr_done{0};
@@ -1826,49 +1752,44 @@ static hipError_t launch_enc(const EncoderArgs& a, hipStream_t stream) {
     if (hipError_t e = hipGetDevice(&dev); e != hipSuccess) return e;
     const unsigned long long bit = 1ull << (dev & 63);
     if (!(attr_done.load(std::memory_order_acquire) & bit)) {
-        hipError_t e = hipFuncSetAttribute((const void*)uit_encoder_kernel<PREC, WAVES, SHORT, TIMING, ABL, ATT, ACT, POOL>,
+        hipError_t e = hipFuncSetAttribute((const void*)uit_encoder_kernel<PREC, WAVES, SHORT, TIMING, ATT, ACT, POOL>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, WAVES == 8 ? ENC_LDS_W8 : ENC_LDS);
         if (e != hipSuccess) return e;
         attr_done.fetch_or(bit, std::memory_order_release);
     }
     const int per_wg = POOL == 2 ? WAVES : 2 * WAVES;     // clip rows per workgroup (pooling 'token': one clip per wave)
     const int grid = (a.rows + per_wg - 1) / per_wg;
-    hipLaunchKernelGGL((uit_encoder_kernel<PREC, WAVES, SHORT, TIMING, ABL, ATT, ACT, POOL>), dim3(grid), dim3(WAVES * 64),
+    hipLaunchKernelGGL((uit_encoder_kernel<PREC, WAVES, SHORT, TIMING, ATT, ACT, POOL>), dim3(grid), dim3(WAVES * 64),
                        WAVES == 8 ? ENC_LDS_W8 : ENC_LDS, stream, a);
     return hipGetLastError();
 }
 
-hipError_t launch_encoder(const EncoderArgs& a, int precision, int waves, int sched, hipStream_t stream) {
-#ifdef UITK_ABLATION_BUILDS
-    if (a.ablate == 3) return launch_enc<0, 8, false, false, 3>(a, stream);
-    if (a.ablate == 7) return launch_enc<0, 8, false, false, 7>(a, stream);
-    if (a.ablate == 15) return launch_enc<0, 8, false, false, 15>(a, stream);
-    if (a.ablate == 31) return launch_enc<0, 8, false, false, 31>(a, stream);
-    if (a.ablate == 47) return launch_enc<0, 8, false, false, 47>(a, stream);
-    if (a.ablate == 63) return launch_enc<0, 8, false, false, 63>(a, stream);
-    if (a.ablate == 64 + 3) return launch_enc<0, 8, false, false, 64 + 3>(a, stream);      // no LN/attention, 1 filler VALU per MLP MFMA
-    if (a.ablate == 128 + 3) return launch_enc<0, 8, false, false, 128 + 3>(a, stream);    // ... 2 fillers
-    if (a.ablate == 192 + 3) return launch_enc<0, 8, false, false, 192 + 3>(a, stream);    // ... 3 fillers
-    if (a.ablate == 128) return launch_enc<0, 8, false, false, 128>(a, stream);            // full kernel + 2 fillers per MLP MFMA
-    if (a.ablate == 512) { EncoderArgs b = a; b.depth = 0; return launch_enc<0, 8, false, false, 0>(b, stream); }     // prologue + epilogue only
-    if (a.ablate == 768) { EncoderArgs b = a; b.depth = 0; return launch_enc<0, 8, false, false, 256>(b, stream); }   // ... without the patch loads
-    if (a.ablate == 256) return launch_enc<0, 8, false, false, 256>(a, stream);                                       // full kernel without the patch loads
-#endif
-    if (a.timing != nullptr)                              // diagnostic build with in-kernel stamps (f16, full clips only)
+hipError_t launch_encoder(const EncoderArgs& a, int precision, int waves, hipStream_t stream) {
+#ifdef UITK_LAB
+    if (a.timing != nullptr) {                            // -DUITK_LAB: build with in-kernel stamps (f16, full clips only; tools/phase_timing.py)
+        if (a.nt < GT) return hipErrorInvalidValue;       // the instrumented build has no short-clip (masked padding) instantiation
         return waves == 4 ? launch_enc<0, 4, false, true>(a, stream) : launch_enc<0, 8, false, true>(a, stream);
-    (void)sched;
+    }
+#else
+    if (a.timing != nullptr) return hipErrorInvalidValue; // the product library carries no instrumented kernel
+#endif
+    if (a.pooling && precision == 4) {                    // pooling 'dm' / 'token' in the parity mode: BNeckAttention + ReLU only
+        if (a.attention_full || a.act_gelu) return hipErrorInvalidValue;
+        if (a.pooling == 2) return launch_enc<4, 8, true, false, 0, 0, 2>(a, stream);
+        return a.nt < GT ? launch_enc<4, 8, true, false, 0, 0, 1>(a, stream) : launch_enc<4, 8, false, false, 0, 0, 1>(a, stream);
+    }
     if (a.pooling) {                                      // pooling 'dm' / 'token' (f16, 8-wave workgroups), any attention / activation
         if (precision != 0 || a.timing != nullptr) return hipErrorInvalidValue;
-#define UITK_POOL(SH, PL) (a.attention_full ? (a.act_gelu ? launch_enc<0, 8, SH, false, 0, 1, 1, PL>(a, stream) : launch_enc<0, 8, SH, false, 0, 1, 0, PL>(a, stream)) \
-                                            : (a.act_gelu ? launch_enc<0, 8, SH, false, 0, 0, 1, PL>(a, stream) : launch_enc<0, 8, SH, false, 0, 0, 0, PL>(a, stream)))
+#define UITK_POOL(SH, PL) (a.attention_full ? (a.act_gelu ? launch_enc<0, 8, SH, false, 1, 1, PL>(a, stream) : launch_enc<0, 8, SH, false, 1, 0, PL>(a, stream)) \
+                                            : (a.act_gelu ? launch_enc<0, 8, SH, false, 0, 1, PL>(a, stream) : launch_enc<0, 8, SH, false, 0, 0, PL>(a, stream)))
         if (a.pooling == 2) return UITK_POOL(true, 2);     // per-key softmax masks always (dead columns)
         return a.nt < GT ? UITK_POOL(true, 1) : UITK_POOL(false, 1);
 #undef UITK_POOL
     }
     if (a.attention_full || a.act_gelu) {                 // SURVEY 8f-4 variants: f16 / bf16, 8-wave workgroups
         if (precision == 2 || a.timing != nullptr) return hipErrorInvalidValue;
-#define UITK_VARIANT(P, SH) (a.attention_full ? (a.act_gelu ? launch_enc<P, 8, SH, false, 0, 1, 1>(a, stream) : launch_enc<P, 8, SH, false, 0, 1, 0>(a, stream)) \
-                                               : launch_enc<P, 8, SH, false, 0, 0, 1>(a, stream))
+#define UITK_VARIANT(P, SH) (a.attention_full ? (a.act_gelu ? launch_enc<P, 8, SH, false, 1, 1>(a, stream) : launch_enc<P, 8, SH, false, 1, 0>(a, stream)) \
+                                               : launch_enc<P, 8, SH, false, 0, 1>(a, stream))
         if (a.nt < GT) return precision == 0 ? UITK_VARIANT(0, true) : UITK_VARIANT(1, true);
         return precision == 0 ? UITK_VARIANT(0, false) : UITK_VARIANT(1, false);
 #undef UITK_VARIANT

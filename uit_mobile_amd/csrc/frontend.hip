@@ -17,8 +17,8 @@
 //       multiplies by W256^(p*k1), transposes through a conflict-free padded LDS tile (row stride 17 complex),
 //       does the second 16-point FFT, and the real-FFT split X[k] = ((Z[k]+conj Z[256-k]) - i w^k (Z[k]-conj
 //       Z[256-k]))/2 pairs bins k and 256-k through LDS.  Complex values are float2 => v_pk_* math, b64 LDS ops.
-//     * window and both twiddle sets are per-lane VGPR constants (FE_LDS_TABLES moves any of them to LDS; with
-//       FE_OCC=3 that buys a third workgroup per CU -- measured equal, the kernel is VALU-issue bound).
+//     * window and both twiddle sets are per-lane VGPR constants (kept in LDS instead they buy a third workgroup per CU:
+//       measured +3 %, the kernel is VALU-issue bound -- DESIGN.md 4.1).
 //     * 4|X|^2 of a frame overwrites the start of its own (dead) Z row; the 1/4 lives in the filterbank operand.
 //   then the NEXT pass's sample loads are issued (the FFT registers are free), and behind them the mel phase:
 //     * mel[4 frames][64] = P[4][257] . fb[257][64] on the matrix pipe with the EXACT-fp32 v_mfma_f32_4x4x1_16b_f32
@@ -45,12 +45,8 @@ typedef float f4v __attribute__((ext_vector_type(4)));
 // (op_sel / op_sel_hi) and per-half negation (neg_lo / neg_hi), so a complex multiply is TWO instructions and a
 // multiplication by -i or a conjugation rides on the add that consumes it.  The compiler does not form these modifiers for
 // f32 pairs (it emits 4 scalar mul/fma per complex multiply and v_mov + v_xor per swizzle: 406 VALU instructions in the FFT
-// phase against 300 this way), hence inline asm.  FE_PK_ASM=0 restores the plain C++ forms (same arithmetic, bit for bit:
-// products and sums are formed in the same order, fma where the scalar form contracts to fma).
-#ifndef FE_PK_ASM
-#define FE_PK_ASM 1
-#endif
-#if FE_PK_ASM
+// phase against 300 this way), hence inline asm (same arithmetic as the plain C++ forms, bit for bit: products and sums are
+// formed in the same order, fma where the scalar form contracts to fma).
 __device__ __forceinline__ c32 cmul(c32 a, c32 w) {          // a * w = (a.x w.x - a.y w.y, a.x w.y + a.y w.x)
     // one asm block: the compiler's hazard recogniser pads every inline-asm VGPR write that the next VALU instruction reads
     // with an s_nop (it cannot see that the writer has no dst_sel); a full 64-bit v_pk_*_f32 result needs none
@@ -80,13 +76,6 @@ __device__ __forceinline__ c32 sub_conj(c32 a, c32 b) {      // a - conj(b)
     asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1]" : "=v"(r) : "v"(a), "v"(b));
     return r;
 }
-#else
-__device__ __forceinline__ c32 cmul(c32 a, c32 w) { return c32{a.x * w.x - a.y * w.y, a.x * w.y + a.y * w.x}; }
-__device__ __forceinline__ c32 add_mi(c32 s, c32 t) { return c32{s.x + t.y, s.y - t.x}; }
-__device__ __forceinline__ c32 sub_mi(c32 s, c32 t) { return c32{s.x - t.y, s.y + t.x}; }
-__device__ __forceinline__ c32 add_conj(c32 a, c32 b) { return c32{a.x + b.x, a.y - b.y}; }
-__device__ __forceinline__ c32 sub_conj(c32 a, c32 b) { return c32{a.x - b.x, a.y + b.y}; }
-#endif
 
 // forward 4-point DFT (W4 = -i) in place; CMI: the third input is still to be multiplied by -i (folded into its adds)
 template <bool CMI = false>
@@ -118,34 +107,8 @@ __device__ __forceinline__ void fft16(c32 (&v)[16]) {
     dft4(v[12], v[13], v[14], v[15]);
 }
 
-#ifndef FE_LDS_TABLES
-#define FE_LDS_TABLES 0      // mask of constant tables kept in LDS instead of per-lane VGPRs (1 window, 2 W256, 4 W512); 0 measured fastest
-#endif
-#ifndef FE_B_REGS
-#define FE_B_REGS 0          // 1: the banded filterbank operand (MEL_BMAX floats per lane) lives in VGPRs instead of LDS
-#endif
-#ifndef FE_DYNAMIC
-#define FE_DYNAMIC 0         // 1: the last (100 - FE_STATIC_PCT) % of the passes are drawn from global counters (measured: a drawn pass costs
-                             // ~1.9x a static one -- the returning atomic sits in the wave's in-order memory queue -- so the balance it buys
-                             // is lost again; kept as an experiment), 0: static split (asymmetric when the grid is two workgroups per CU)
-#endif
-#ifndef FE_ALT_PRIO
-#define FE_ALT_PRIO 0        // experiments: 1 = sibling workgroups swap issue priority every pass, 2 = the younger sibling has priority
-#endif
-#ifndef FE_CTRS
-#define FE_CTRS 8            // counters (= shares) of the dynamic remainder, one per XCD; <= 16
-#endif
-#ifndef FE_STATIC_PCT
-#define FE_STATIC_PCT 88
-#endif
-#ifndef FE_ABLATE
-#define FE_ABLATE 0          // timing-only ablation builds (tools/ab): 1 no sample loads, 2 no mel MFMAs, 4 no log, 8 no stores,
-#endif                       // 16 no FFT phase, 32 no split/power, 64 no transpose through LDS, 128 no Z round trip through LDS,
-                             // 256 mel operands from registers; results are wrong by construction -- never set in the product build
 constexpr int FE_WAVES = 4;
-#ifndef FE_OCC
-#define FE_OCC 2             // workgroups per CU the register allocation aims at
-#endif
+constexpr int FE_OCC = 2;                                // workgroups per CU the register allocation aims at (a third buys nothing: DESIGN.md 4.1)
 constexpr int FE_ROW = 17;                               // padded row stride (complex) of the transpose tile
 constexpr int FE_ZROW = 272;                             // per-frame stride (complex) of the natural-order Z tile
 constexpr int FE_WAVE_LDS = 4 * FE_ZROW * 8;             // 8704 B per wave: E[4][16][17] (8704 B) / Z[4][272]
@@ -154,8 +117,7 @@ constexpr int FE_PSTRIDE = 2 * FE_ZROW + 16;             // a frame's power row 
                                                          // of a wave hit disjoint banks), rows 16-byte aligned (b128 operand reads)
 static_assert(3 * 16 + MEL_PROW <= 2 * FE_ZROW && MEL_PROW % 4 == 0, "power row must fit inside its Z row");
 constexpr int FE_B_LDS = MEL_BMAX * 64 * 4;              // filterbank B operands [13][64 lanes][4 steps]: 13 KiB
-constexpr int FE_TAB_LDS = FE_LDS_TABLES ? (256 + 256 + 128) * 8 : 0;   // window pairs, W256^(p*k1) as [k1][p], (cos,sin)(2 pi k/512)
-constexpr int FE_LDS = FE_WAVES * FE_WAVE_LDS + FE_B_LDS + FE_TAB_LDS;    // 47 KiB: three workgroups per CU
+constexpr int FE_LDS = FE_WAVES * FE_WAVE_LDS + FE_B_LDS;                // 47 KiB
 
 template <bool I16>
 __device__ __forceinline__ float load_sample(const void* pcm, int64_t row_off, int T, int s) {
@@ -190,12 +152,7 @@ __global__ __launch_bounds__(FE_WAVES * 64, FE_OCC) void mel_frontend_kernel(Fro
     if (blockIdx.x == 0 && tid < AMAX_SLOTS) ((unsigned*)a.amax_rearm)[tid] = 0xFF800000u;   // arm the NEXT launch's slots with -inf
     c32* E = (c32*)(smem + wave * FE_WAVE_LDS);          // [4][16][17] transpose tile, then Z[4][272]
     float* Blds = (float*)(smem + FE_WAVES * FE_WAVE_LDS);
-    // per-lane constants: window pairs, W256^(p*k1), (cos, sin)(2 pi k / 512).  Each table lives either in VGPRs (default) or
-    // in LDS (FE_LDS_TABLES mask: 1 window, 2 W256, 4 W512; b64 reads, conflict-free across p, broadcast across the wave's
-    // four frames) -- the LDS forms free 32 / 32 / 16 VGPRs for a higher occupancy target (FE_OCC)
-    c32* Wwin = (c32*)(smem + FE_WAVES * FE_WAVE_LDS + FE_B_LDS);       // window[(2m, 2m+1)], m = 16 m1 + p
-    c32* Wtw = Wwin + 256;                                               // W256^(p*k1) at [k1][p]
-    c32* Wpw = Wtw + 256;                                                // (cos, sin)(2 pi k / 512), k < 128
+    // per-lane VGPR constants: window pairs, W256^(p*k1), (cos, sin)(2 pi k / 512)
     // LDS set-up of the workgroup, run AFTER the first pass's sample loads and the per-lane constant loads have been issued, so
     // that the kernel start pays one memory round trip, not three in a row (the fixed cost of a launch was 16 us)
     auto lds_setup = [&]() {
@@ -208,27 +165,15 @@ __global__ __launch_bounds__(FE_WAVES * 64, FE_OCC) void mel_frontend_kernel(Fro
             const int i = tid + j * FE_WAVES * 64;
             if (i < MEL_BMAX * 64) Blds[i] = (i >> 8) * 4 < a.mel_steps ? a.mel_b[64 + i] : 0.f;
         }
-        if (FE_LDS_TABLES) {
-            const int i = tid;                                           // 256 threads
-            if (FE_LDS_TABLES & 1) Wwin[i] = *(const c32*)(a.window + 2 * i);
-            if (FE_LDS_TABLES & 2) { const float2 t = a.tw256[(i & 15) * 16 + (i >> 4)]; Wtw[i] = c32{t.x, t.y}; }   // source is [p][k1]
-            if ((FE_LDS_TABLES & 4) && i < 128) { const float2 u = a.tw512[i]; Wpw[i] = c32{-u.y, -u.x}; }
-        }
         __syncthreads();
     };
     c32 win_[16], tw_[16], pw_[8];                                       // per-lane VGPR constants
-    if (!(FE_LDS_TABLES & 1)) {
 #pragma unroll
-        for (int m1 = 0; m1 < 16; ++m1) win_[m1] = *(const c32*)(a.window + 32 * m1 + 2 * p);
-    }
-    if (!(FE_LDS_TABLES & 2)) {
+    for (int m1 = 0; m1 < 16; ++m1) win_[m1] = *(const c32*)(a.window + 32 * m1 + 2 * p);
 #pragma unroll
-        for (int k1 = 0; k1 < 16; ++k1) { const float2 t = a.tw256[p * 16 + k1]; tw_[k1] = c32{t.x, t.y}; }
-    }
-    if (!(FE_LDS_TABLES & 4)) {
+    for (int k1 = 0; k1 < 16; ++k1) { const float2 t = a.tw256[p * 16 + k1]; tw_[k1] = c32{t.x, t.y}; }
 #pragma unroll
-        for (int j = 0; j < 8; ++j) { const float2 t = a.tw512[p + 16 * j]; pw_[j] = c32{-t.y, -t.x}; }   // -i conj(w), w = (cos, sin)(2 pi k/512)
-    }
+    for (int j = 0; j < 8; ++j) { const float2 t = a.tw512[p + 16 * j]; pw_[j] = c32{-t.y, -t.x}; }   // -i conj(w), w = (cos, sin)(2 pi k/512)
 
     // "full" passes are (clip b, column k): frames 16k..16k+15; the nF % 16 leftover frames of a clip are bundled,
     // per_tail clips at a time, into "tail" passes (for 1 s clips: 6 full passes per clip + one tail pass per 3 clips).
@@ -257,11 +202,6 @@ __global__ __launch_bounds__(FE_WAVES * 64, FE_OCC) void mel_frontend_kernel(Fro
     // raw (unwindowed) sample pairs of a lane's frame: z[m1] = (x[32 m1 + 2p], x[32 m1 + 2p + 1]); `row` = the clip's first
     // sample (uniform for a full pass), su + sl = index of the lane's first sample (su uniform, sl >= 0 lane-invariant)
     auto load_frame = [&](const char* row, int su, int sl, c32 (&raw)[16]) {
-        if (FE_ABLATE & 1) {
-#pragma unroll
-            for (int m1 = 0; m1 < 16; ++m1) raw[m1] = c32{(float)(lane + m1) * 1e-3f, (float)(su & 7)};
-            return;
-        }
         const int s0 = su + sl;
         if (pair_ok && s0 >= 0 && s0 + 32 * 15 + 1 < T) {                 // interior frame: no reflection, pair loads
             const char* src = row + (int64_t)su * ES + (unsigned)(sl * ES);    // scalar base + 32-bit lane offset
@@ -316,69 +256,37 @@ __global__ __launch_bounds__(FE_WAVES * 64, FE_OCC) void mel_frontend_kernel(Fro
     c32 v[16];
 
     // -------------------------------------------------------------------------------- FFT phase of one pass (VALU + LDS)
-    // LDS-resident tables (FE_LDS_TABLES) are read AHEAD of their use, at points where their registers are free and other work
-    // covers the LDS latency (sched_barriers pin the issue points; left alone the scheduler sinks every read to just before
-    // its use, i.e. into the wave's dependent chain): the window behind the mel MFMAs of the previous pass, W256 before the
-    // first 16-point FFT, W512 before the second.
-    c32 wn[16];
-    auto prefetch_window = [&]() {
-        if (!(FE_LDS_TABLES & 1)) return;
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int m1 = 0; m1 < 16; ++m1) wn[m1] = Wwin[16 * m1 + p];
-        __builtin_amdgcn_sched_barrier(0);
-    };
     auto fft_phase = [&](c32 (&v)[16]) {
 #pragma unroll
-        for (int m1 = 0; m1 < 16; ++m1) v[m1] = v[m1] * ((FE_LDS_TABLES & 1) ? wn[m1] : win_[m1]);
-        c32 twl[16], pwl[8];
-        if (FE_LDS_TABLES & 2) {
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int k1 = 1; k1 < 16; ++k1) twl[k1] = Wtw[16 * k1 + p];
-            __builtin_amdgcn_sched_barrier(0);
-        }
+        for (int m1 = 0; m1 < 16; ++m1) v[m1] = v[m1] * win_[m1];
         fft16(v);                                        // over m1 -> k1 (at FPOS), for m2 = p
 #pragma unroll
         for (int k1 = 0; k1 < 16; ++k1) {                // twiddle + transpose write E[q][k1][m2 = p]
-            const c32 y = k1 == 0 ? v[FPOS(0)] : cmul(v[FPOS(k1)], (FE_LDS_TABLES & 2) ? twl[k1] : tw_[k1]);
-            if (FE_ABLATE & 64) v[FPOS(k1)] = y; else
+            const c32 y = k1 == 0 ? v[FPOS(0)] : cmul(v[FPOS(k1)], tw_[k1]);
             E[(q * 16 + k1) * FE_ROW + p] = y;
         }
         FSTAMP(1);                                       // window + FFT-1 + twiddle + transpose write
-        if (FE_LDS_TABLES & 4) {
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int j = 0; j < 8; ++j) pwl[j] = Wpw[p + 16 * j];
-            __builtin_amdgcn_sched_barrier(0);
-        }
         __builtin_amdgcn_wave_barrier();
         asm volatile("" ::: "memory");
 #pragma unroll
-        for (int m2 = 0; m2 < 16; ++m2) if (!(FE_ABLATE & 64)) v[m2] = E[(q * 16 + p) * FE_ROW + m2];   // lane k1 = p gathers its row
+        for (int m2 = 0; m2 < 16; ++m2) v[m2] = E[(q * 16 + p) * FE_ROW + m2];   // lane k1 = p gathers its row
         fft16(v);                                        // over m2 -> Z[k1 + 16 k2], k1 = p, k2 at FPOS
         __builtin_amdgcn_wave_barrier();
         asm volatile("" ::: "memory");
         c32* Z = E;                                      // natural order Z[q][k], frame stride 272 (bank offset 32)
 #pragma unroll
-        for (int k2 = 0; k2 < 16; ++k2) if (!(FE_ABLATE & 128)) Z[q * FE_ZROW + 16 * k2 + p] = v[FPOS(k2)];
+        for (int k2 = 0; k2 < 16; ++k2) Z[q * FE_ZROW + 16 * k2 + p] = v[FPOS(k2)];
         __builtin_amdgcn_wave_barrier();
         asm volatile("" ::: "memory");
         FSTAMP(2);                                       // transpose read + FFT-2 + Z write
-        if (FE_ABLATE & 32) {
-#pragma unroll
-            for (int j = 0; j < 8; ++j) { Pq[p + 16 * j] = v[j].x; Pq[256 - p - 16 * j] = v[j].y; }
-            return;
-        }
         c32 za[8], zb[8];
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             const int k = p + 16 * j;
-            if (FE_ABLATE & 128) { za[j] = v[j]; zb[j] = v[15 - j]; continue; }
             za[j] = Z[q * FE_ZROW + k];
             zb[j] = Z[q * FE_ZROW + ((256 - k) & 255)];
         }
-        const c32 z128 = (FE_ABLATE & 128) ? v[8] : Z[q * FE_ZROW + 128];
+        const c32 z128 = Z[q * FE_ZROW + 128];
         __builtin_amdgcn_wave_barrier();                 // every Z value is in registers: the power row may overwrite the Z row
         asm volatile("" ::: "memory");
         // power spectrum of bins k and 256-k into the wave's own tile P[frame q][bin]
@@ -386,7 +294,7 @@ __global__ __launch_bounds__(FE_WAVES * 64, FE_OCC) void mel_frontend_kernel(Fro
         for (int j = 0; j < 8; ++j) {
             const int k = p + 16 * j;
             const c32 A = add_conj(za[j], zb[j]), Bm = sub_conj(za[j], zb[j]);   // Z[k] +- conj Z[256-k]
-            const c32 Tw = cmul(Bm, (FE_LDS_TABLES & 4) ? pwl[j] : pw_[j]);                                         // -i e^{-2 pi i k/512} (Z[k] - conj Z[256-k])
+            const c32 Tw = cmul(Bm, pw_[j]);                                         // -i e^{-2 pi i k/512} (Z[k] - conj Z[256-k])
             const c32 X = A + Tw, Y = A - Tw;                                        // 2 X[k], 2 conj X[256-k]
             Pq[k] = X.x * X.x + X.y * X.y;                       // 4 |X[k]|^2: the 1/4 lives in the filterbank operand (pack.cpp)
             Pq[256 - k] = Y.x * Y.x + Y.y * Y.y;                 // k = 0 writes bin 256 (Nyquist)
@@ -400,35 +308,20 @@ __global__ __launch_bounds__(FE_WAVES * 64, FE_OCC) void mel_frontend_kernel(Fro
     // lane's power row at its group's band, B = ds_read_b128 of the lane's filterbank column.  One straight-line block of
     // MEL_BMAX steps (steps past the band multiply zero B operands by finite pad columns), so the reads of later steps fly
     // under the MFMAs of earlier ones; the next pass's sample loads are already in flight behind it.
-    float Breg[FE_B_REGS ? MEL_BMAX : 1];
-    if (FE_B_REGS) {
-#pragma unroll
-        for (int i = 0; i < MEL_BMAX; ++i) Breg[i] = i < nst ? a.mel_b[64 + (i >> 2) * 256 + lane * 4 + (i & 3)] : 0.f;
-    }
     auto mel_mfma = [&]() -> f4v {
         f4v acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
-        if (FE_ABLATE & 2) {
-            acc0 = *(const f4v*)Ar; acc1 = *(const f4v*)Bl;
-        } else if (nst <= MEL_BMAX) {
+        if (nst <= MEL_BMAX) {
             // operand reads run MEL_AHEAD groups (of four steps) ahead of their MFMAs, so that the LDS latency is covered by
             // the MFMAs of the groups in between; the sched_barriers pin that order (the scheduler would otherwise sink
             // every read to just before its use and expose the latency once per group)
             constexpr int NG = MEL_BMAX / 4, MEL_AHEAD = 6;
             f4a A4[NG], B4[NG];
 #pragma unroll
-            for (int c = 0; c < MEL_AHEAD; ++c) { A4[c] = *(const f4a*)(Ar + 4 * c); if (!FE_B_REGS) B4[c] = *(const f4a*)(Bl + 256 * c); }
-            if (FE_B_REGS) {
-#pragma unroll
-                for (int c = 0; c < NG; ++c) B4[c] = f4a{Breg[4 * c], Breg[4 * c + 1], Breg[4 * c + 2], Breg[4 * c + 3]};
-            }
-            if (FE_ABLATE & 256) {
-#pragma unroll
-                for (int c = MEL_AHEAD; c < NG; ++c) { A4[c] = A4[c - MEL_AHEAD] + 1.f; B4[c] = B4[c - MEL_AHEAD]; }
-            }
+            for (int c = 0; c < MEL_AHEAD; ++c) { A4[c] = *(const f4a*)(Ar + 4 * c); B4[c] = *(const f4a*)(Bl + 256 * c); }
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int c = 0; c < NG; ++c) {
-                if (!(FE_ABLATE & 256) && c + MEL_AHEAD < NG) { A4[c + MEL_AHEAD] = *(const f4a*)(Ar + 4 * (c + MEL_AHEAD)); if (!FE_B_REGS) B4[c + MEL_AHEAD] = *(const f4a*)(Bl + 256 * (c + MEL_AHEAD)); }
+                if (c + MEL_AHEAD < NG) { A4[c + MEL_AHEAD] = *(const f4a*)(Ar + 4 * (c + MEL_AHEAD)); B4[c + MEL_AHEAD] = *(const f4a*)(Bl + 256 * (c + MEL_AHEAD)); }
                 acc0 = __builtin_amdgcn_mfma_f32_4x4x1f32(A4[c][0], B4[c][0], acc0, 0, 0, 0);
                 acc1 = __builtin_amdgcn_mfma_f32_4x4x1f32(A4[c][1], B4[c][1], acc1, 0, 0, 0);
                 acc0 = __builtin_amdgcn_mfma_f32_4x4x1f32(A4[c][2], B4[c][2], acc0, 0, 0, 0);
@@ -449,7 +342,7 @@ __global__ __launch_bounds__(FE_WAVES * 64, FE_OCC) void mel_frontend_kernel(Fro
     };
     // 10 log10(max(P, 1e-10)) = (10 log10 2) * v_log_f32: the operand is never denormal, so the library log10's
     // denormal scaling and split-constant multiply (14 instructions per value) buy nothing; |error| <= 2e-5 dB
-    auto to_db = [&](float pw) { return (FE_ABLATE & 4) ? pw : 3.0102999566398120f * __builtin_amdgcn_logf(fmaxf(pw, 1e-10f)); };
+    auto to_db = [&](float pw) { return 3.0102999566398120f * __builtin_amdgcn_logf(fmaxf(pw, 1e-10f)); };
     // 16-bit operands of the encoder's patch embed: init_bn applied here (y = sc*dB + sh, uit.py:310-313); the top_db
     // clamp commutes with this monotone map and with rounding, so the encoder applies it on y.
     // Layout [clip-crop][token pf*6+pt][mel-in-patch][frame-in-patch].
@@ -488,7 +381,7 @@ __global__ __launch_bounds__(FE_WAVES * 64, FE_OCC) void mel_frontend_kernel(Fro
             for (int r = 0; r < 4; ++r) a.mel[((int64_t)b * a.nF + 16 * k + 4 * wq + r) * 64 + lane] = db[r];
         } else if (a.ncrops == 1) {
             // lane = (mel, frames 4*wave .. 4*wave+3 of time patch k): 8 contiguous bytes at uniform base + lane offset
-            if (k < a.nt && (!(FE_ABLATE & 8) || db[0] == 12345.f)) {
+            if (k < a.nt) {
                 typedef _Float16 h4v __attribute__((ext_vector_type(4)));
                 typedef __bf16 b4v __attribute__((ext_vector_type(4)));
                 char* dst = (char*)a.mel + ((int64_t)b * 24 + k) * 512 + 8 * wq + st_lane;
@@ -532,50 +425,20 @@ __global__ __launch_bounds__(FE_WAVES * 64, FE_OCC) void mel_frontend_kernel(Fro
     };
 
     // Passes: idx = column * B + clip for the full passes (column-major: every workgroup meets every column), then the tail
-    // passes.  A workgroup takes idx = blockIdx + r G for its first Rs rounds (static) and then draws the remaining ~12 % of the
-    // passes one at a time from a global counter: with a purely static split the workgroup launched first on a CU finished 10 %
-    // ahead of its sibling (oldest-first instruction arbitration) and the kernel ended with the slowest workgroup
-    // (tools/phase_timing.py: slowest / median lifetime 1.10).  The draw for pass n+1 is issued at the top of pass n by one
-    // lane, handed to the four waves through an LDS mailbox behind the FFT phase (one workgroup barrier per dynamic pass),
-    // and its sample loads go out right after -- the same software pipeline as in the static rounds.
+    // passes, split STATICALLY over the persistent grid.
+    // Asymmetric split (a.asym_pm, chosen by the host when the grid is exactly two workgroups per CU): the workgroups dispatched
+    // first (blockIdx < G/2, one per CU) hold the older waves of their SIMDs, the instruction arbiter serves the oldest wave first,
+    // and with equal shares they finished 10 % ahead of their siblings while the kernel ended with the slowest workgroup (slowest /
+    // median lifetime 1.10 -> 1.03).  They get a pool of asym_pm / 1000 of the passes to themselves; the share is measured per
+    // device at uitk_reserve (api.cpp: calibrate_frontend_split).  Drawing the last passes from global counters instead was
+    // measured and removed: a drawn pass costs ~1.9x a static one.
     const int G = (int)gridDim.x;
     const int nfull = B * full, npass = nfull + ntail;
-    // Asymmetric static split (a.asym_pm, set by the host when the grid is exactly two workgroups per CU): the workgroups
-    // dispatched first (blockIdx < G/2, one per CU) are the older waves of their SIMDs, the instruction arbiter serves the oldest
-    // wave first, and with equal shares they finished 10 % ahead of their siblings while the kernel ended with the slowest
-    // workgroup (tools/phase_timing.py).  They get a pool of asym_pm / 1000 of the passes to themselves (590: measured optimum,
-    // same-box A/B 500 / 550 / 570 / 590 / 620 -> 0.336 / 0.332 / 0.327 / 0.324 / 0.333 ms).
-    const bool asym = a.asym_pm != 500 && a.asym_pm > 0 && !(FE_DYNAMIC && a.work_ctr != nullptr) && (G & 1) == 0 && G >= 2;
+    const bool asym = a.asym_pm != 500 && a.asym_pm > 0 && (G & 1) == 0 && G >= 2;
     const int stride = asym ? G / 2 : G;
     const int nA = asym ? (int)((int64_t)npass * a.asym_pm / 1000) : 0;
     const int gk = stride / B, gb = stride % B;                                       // the static stride as (columns, clips)
-    int Rs = (npass + G - 1) / G;                                                     // all rounds static ...
-    if (FE_DYNAMIC && a.work_ctr != nullptr) {                                        // ... or the first FE_STATIC_PCT % of them
-        Rs = (int)((int64_t)npass * FE_STATIC_PCT / 100 / G);
-        if (Rs < 1) Rs = 1;
-    }
-    const bool dynamic = FE_DYNAMIC && a.work_ctr != nullptr;
-    const int pstatic = Rs * G;                                                       // first dynamically drawn pass
-    // A draw is a device-scope atomic with ~2-3 us of latency: it is issued TWO passes ahead of the pass it names (at the top of
-    // round r for round r + 2) and held in a register of thread 0 across one pass, so that nothing ever waits for it (drawn one
-    // pass ahead a dynamic pass cost 1.85x a static one; several counters with a retry loop, whose exit depends on the
-    // returned value, were worse still).
-    // Draws on ONE address serialise at ~10 ns each (measured: 26 k draws stretch the kernel by 0.12 ms), slower than the last
-    // workgroups consume passes -- so the drawn passes are split into FE_CTRS contiguous shares with a counter each, and a
-    // workgroup draws from the share of blockIdx % FE_CTRS (its XCD) only: balance inside each XCD's 64 workgroups, no retry.
-    const int dshare = (npass - pstatic + FE_CTRS - 1) / FE_CTRS;
-    const int home = (int)blockIdx.x % FE_CTRS;
-    const int dlo = pstatic + home * dshare, dhi = dlo + dshare < npass ? dlo + dshare : npass;
-    if (dynamic && blockIdx.x == 0 && tid < FE_CTRS) a.work_ctr_rearm[tid] = 0;      // the NEXT launch's counters
-#ifdef FE_DYN_TEST
-    auto draw = [&]() { if (FE_DYN_TEST & 1) return npass; const int i = dlo + atomicAdd(a.work_ctr + home, 1); return i < dhi ? i : npass; };   // 1: no atomic
-#else
-    auto draw = [&]() { const int i = dlo + atomicAdd(a.work_ctr + home, 1); return i < dhi ? i : npass; };
-#endif
-    int pend_prev = 0, pend_cur = 0;                                                  // thread 0: draws for rounds rnd + 1 / rnd + 2
-    if (dynamic && Rs <= 1 && tid == 0) pend_prev = draw();
-    volatile int* mbox = (volatile int*)(smem + FE_LDS);                              // [2] mailbox of drawn pass indices
-    int idx = (int)blockIdx.x, rnd = 0, par = 0;
+    int idx = (int)blockIdx.x, rnd = 0;
     int iend = npass;                                                                 // end of this workgroup's pool
     if (asym) { if ((int)blockIdx.x < stride) iend = nA; else idx = nA + (int)blockIdx.x - stride; }
     int ck = idx / B, cb = idx - ck * B;                                              // (column, clip) of a full pass
@@ -585,30 +448,12 @@ __global__ __launch_bounds__(FE_WAVES * 64, FE_OCC) void mel_frontend_kernel(Fro
     };
     if (idx < iend) issue_loads(idx, ck, cb, 0, v);
     lds_setup();
-    prefetch_window();
-#if FE_ALT_PRIO
-    const int slot_par = (int)(__builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 4) & 1u);      // hardware wave slot parity: which sibling
-#endif
     while (idx < iend) {
-#if FE_ALT_PRIO == 1
-        if ((rnd + slot_par) & 1) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0);   // siblings swap priority every pass
-#elif FE_ALT_PRIO == 2
-        if (slot_par) __builtin_amdgcn_s_setprio(1);                                                    // the younger sibling always ahead
-#endif
         FSTAMP(0);
-        const bool next_drawn = dynamic && rnd + 1 >= Rs;                             // uniform
-        if (dynamic && rnd + 2 >= Rs && tid == 0) pend_cur = draw();                  // names round rnd + 2
         const bool is_full = idx < nfull;                                             // uniform
         const int wq = (wave + rnd) & 3;
         if (is_full) {
-            if (FE_ABLATE & 16) {
-                c32 sacc = v[0];
-#pragma unroll
-                for (int m1 = 1; m1 < 16; ++m1) sacc += v[m1];
-                Pq[p] = sacc.x + sacc.y;
-            } else {
-                fft_phase(v);
-            }
+            fft_phase(v);
         } else if (4 * wave < per_tail * rem) {
             fft_phase(v);                                // uniform per wave: fully dead quads of a tail pass skip the FFT
         }
@@ -617,31 +462,15 @@ __global__ __launch_bounds__(FE_WAVES * 64, FE_OCC) void mel_frontend_kernel(Fro
         asm volatile("" ::: "memory");                   // order, so the mel phase below needs no workgroup barrier
         // the sample registers are free again: the NEXT pass's loads go out now, their latency hides under this pass's mel
         // MFMAs, log and stores
-        int nidx, nk, nb;
-        if (next_drawn) {
-            if (tid == 0) mbox[par] = pend_prev;
-            // LDS visibility + barrier only: __syncthreads() also waits for vmcnt(0), i.e. for the draw issued at the top of
-            // THIS pass (2-3 us of atomic latency per dynamic pass: they cost twice a static pass that way)
-            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-            nidx = __builtin_amdgcn_readfirstlane(mbox[par]);
-            par ^= 1;
-#ifdef FE_DYN_TEST
-            if (FE_DYN_TEST & 2) nidx = idx + G;           // experiment: the draw is made but ignored (the static successor is used)
-#endif
-            nk = __builtin_amdgcn_readfirstlane(nidx / B); nb = nidx - nk * B;       // (the quotient is formed on the VALU)
-        } else {
-            nidx = idx + stride; nb = cb + gb; nk = ck + gk;
-            if (nb >= B) { nb -= B; ++nk; }
-        }
+        int nidx = idx + stride, nb = cb + gb, nk = ck + gk;
+        if (nb >= B) { nb -= B; ++nk; }
         if (nidx < iend) issue_loads(nidx, nk, nb, rnd + 1, v);
         FSTAMP(4);                                       // next pass's load issue
         const f4v acc = mel_mfma();
-        prefetch_window();
         FSTAMP(5);                                       // mel MFMAs
         if (is_full) finish_full(cb, ck, wq, acc); else finish_tail(idx - nfull, acc);
         FSTAMP(7);                                       // log + bn + stores
         idx = nidx; cb = nb; ck = nk; ++rnd;
-        pend_prev = pend_cur;
     }
     FSTAMP(6);                                                            // (accumulates log + stores of all passes? no: tail only)
     if constexpr (TIMING) {
@@ -686,11 +515,11 @@ static hipError_t launch_fe(const FrontendArgs& a, int grid, hipStream_t stream)
     if (hipError_t e = hipGetDevice(&dev); e != hipSuccess) return e;
     const unsigned long long bit = 1ull << (dev & 63);
     if (!(attr_done.load(std::memory_order_acquire) & bit)) {
-        hipError_t e = hipFuncSetAttribute((const void*)mel_frontend_kernel<I16, PATCH, TIMING>, hipFuncAttributeMaxDynamicSharedMemorySize, FE_LDS + 16);
+        hipError_t e = hipFuncSetAttribute((const void*)mel_frontend_kernel<I16, PATCH, TIMING>, hipFuncAttributeMaxDynamicSharedMemorySize, FE_LDS);
         if (e != hipSuccess) return e;
         attr_done.fetch_or(bit, std::memory_order_release);
     }
-    hipLaunchKernelGGL((mel_frontend_kernel<I16, PATCH, TIMING>), dim3(grid), dim3(FE_WAVES * 64), FE_LDS + 16, stream, a);     // + the 2-entry mailbox of drawn pass indices
+    hipLaunchKernelGGL((mel_frontend_kernel<I16, PATCH, TIMING>), dim3(grid), dim3(FE_WAVES * 64), FE_LDS, stream, a);
     return hipGetLastError();
 }
 
@@ -701,8 +530,15 @@ hipError_t launch_frontend(const FrontendArgs& a, int in_i16, int patch_layout, 
     int grid = (int)(npass < resident ? npass : resident);
     if (grid < 1) grid = 1;
     FrontendArgs a2 = a;
-    if (a2.asym_pm < 0) a2.asym_pm = (npass >= resident && (wg_per_cu <= 0 ? FE_OCC : wg_per_cu) == 2) ? 590 : 500;     // -1 = decide here
+    // the asymmetric split only applies to a full persistent grid of two workgroups per CU; -1 (not calibrated yet) = 590, the optimum
+    // measured on the boxes of rounds 2 and 3
+    const bool two_per_cu = npass >= resident && (wg_per_cu <= 0 ? FE_OCC : wg_per_cu) == 2;
+    if (!two_per_cu) a2.asym_pm = 500; else if (a2.asym_pm < 0) a2.asym_pm = 590;
+#ifdef UITK_LAB
     if (a.timing != nullptr && patch_layout && !in_i16) return launch_fe<false, true, true>(a2, grid, stream);
+#else
+    if (a.timing != nullptr) return hipErrorInvalidValue;
+#endif
     if (patch_layout) return in_i16 ? launch_fe<true, true>(a2, grid, stream) : launch_fe<false, true>(a2, grid, stream);
     return in_i16 ? launch_fe<true, false>(a2, grid, stream) : launch_fe<false, false>(a2, grid, stream);
 }

@@ -230,11 +230,12 @@ int validate_config(const uitk_config* c, const char** why) {
     if (c->outputdim < 1 || c->outputdim > 65536) return bad("outputdim out of range");
     if (c->eval_avg != UITK_AVG_MEAN && c->eval_avg != UITK_AVG_MAX) return bad("unknown eval_avg");
     if (c->precision != UITK_PREC_F16 && c->precision != UITK_PREC_BF16 && c->precision != UITK_PREC_FP8 && c->precision != UITK_PREC_F16X2 && c->precision != UITK_PREC_F16L6) return bad("unknown precision");
-    if ((c->precision == UITK_PREC_F16X2 || c->precision == UITK_PREC_F16L6) && (c->attention_full || c->act_gelu || c->pooling)) return bad("precision f16x2 / f16l6 are built for the uit_* family (BNeckAttention, ReLU, mean pooling) only");
+    if (c->precision == UITK_PREC_F16X2 && (c->attention_full || c->act_gelu || c->pooling)) return bad("precision f16x2 is built for the uit_* family (BNeckAttention, ReLU, mean pooling) only");
+    if (c->precision == UITK_PREC_F16L6 && (c->attention_full || c->act_gelu)) return bad("precision f16l6 is built for BNeckAttention + ReLU (any pooling)");
     if ((c->attention_full != 0 && c->attention_full != 1) || (c->act_gelu != 0 && c->act_gelu != 1)) return bad("attention_full / act_gelu must be 0 or 1");
     if ((c->attention_full || c->act_gelu || c->pooling) && c->precision == UITK_PREC_FP8) return bad("precision fp8 is built for the uit_* family (BNeckAttention, ReLU, mean pooling) only");
     if (c->pooling < 0 || c->pooling > 2) return bad("pooling must be 0 (mean), 1 (dm) or 2 (token)");
-    if (c->pooling && c->precision != UITK_PREC_F16) return bad("pooling 'dm' / 'token' are built for precision f16");
+    if (c->pooling && c->precision != UITK_PREC_F16 && c->precision != UITK_PREC_F16L6) return bad("pooling 'dm' / 'token' are built for precision f16 / f16l6");
     if (c->pooling == 1 && c->outputdim > 640) return bad("pooling 'dm' is built for outputdim <= 640");
     return UITK_OK;
 }
@@ -288,7 +289,11 @@ int pack_image(const uitk_config* c, const uitk_weights* w, std::vector<char>* o
         // so two mel groups served in the same 16-lane slice of a ds_read_b128 -- {0,3,5,6}, {1,2,4,7}, {8,11,13,14}, {9,10,12,15}
         // -- collide when their window starts agree mod 16.  A window may start up to 12 bins early as long as its band still
         // ends inside the MEL_BMAX steps: pick the cheapest shifts that make the four residues distinct.
-        if (mel_S <= MEL_BMAX && std::getenv("UITK_PACK_NO_BANK_SPREAD") == nullptr) {
+        bool bank_spread = true;
+#ifdef UITK_LAB
+        bank_spread = std::getenv("UITK_PACK_NO_BANK_SPREAD") == nullptr;      // lab A/B of the LDS bank spreading
+#endif
+        if (mel_S <= MEL_BMAX && bank_spread) {
             static const int svc[4][4] = {{0, 3, 5, 6}, {1, 2, 4, 7}, {8, 11, 13, 14}, {9, 10, 12, 15}};
             for (const auto& sg : svc) {
                 int best = -1, best_cost = 1 << 30;
@@ -406,7 +411,10 @@ int pack_image(const uitk_config* c, const uitk_weights* w, std::vector<char>* o
     }
     // conv weights: structured rounding, column groups = the 16 frames of one mel row of the patch (k = fi*16 + ti); the
     // low-order fragments hold the rounding residuals of the high-order ones (split patch embed, optional at run time)
-    const bool structured = std::getenv("UITK_PACK_RTN") == nullptr;       // experiments: UITK_PACK_RTN=1 -> plain round-to-nearest
+    bool structured = true;
+#ifdef UITK_LAB
+    structured = std::getenv("UITK_PACK_RTN") == nullptr;       // lab A/B: UITK_PACK_RTN=1 -> plain round-to-nearest
+#endif
     auto Wpe = [&](int r, int k) { return (double)w->pe_w[r * 256 + k] - pe_colmean[k]; };
     const std::vector<uint16_t> pe_q = round_structured(DIM, 256, Wpe, prec, structured ? 16 : 1);
     for (int i = 0; i < PE_HI_STAGES; ++i)

@@ -92,13 +92,11 @@ struct FrontendArgs {
     const float* bn_sc;     // [64] init_bn scale / shift (PATCH layout only)
     const float* bn_sh;
     int op_bf16;            // operand type of the PATCH layout: 0 = fp16, 1 = bf16
-    unsigned long long* timing;  // diagnostics: [waves][8] phase cycle sums (null = normal build)
+    unsigned long long* timing;  // -DUITK_LAB builds: [waves][8] phase cycle sums (null = off; the product build rejects non-null)
     int ncrops, tl, nt;     // crop plan (models/uit.py:468-481): crops per clip, target_length, valid time patches
     float* amax;            // [AMAX_SLOTS] filled by this launch (pre-armed with 0xFFFFFFFF)
     float* amax_rearm;      // [AMAX_SLOTS] the other set: re-armed by this launch for the next one
-    int asym_pm;            // per-mille share of the passes for the first-dispatched half of the grid (500 = symmetric, -1 = launch decides)
-    int* work_ctr;          // [<= 16] pass counters of this launch's dynamic remainder (0 at launch), or null = static split only
-    int* work_ctr_rearm;    // the other launch parity's counters: zeroed by this launch
+    int asym_pm;            // per-mille share of the passes for the first-dispatched half of the grid (500 = symmetric, -1 = not calibrated: 590)
 };
 
 struct EncoderArgs {
@@ -120,23 +118,19 @@ struct EncoderArgs {
     float* probs;           // [rows][C]
     float* logits;          // [rows][C] or null
     float* dbg;             // [rows][depth+1][24][128] or null
-    unsigned long long* timing;  // diagnostics: [waves][12] phase cycle sums (null = off, normal build)
+    unsigned long long* timing;  // -DUITK_LAB builds: [waves][ENC_TIMING_SLOTS] phase cycle sums (null = off; the product build rejects non-null)
     int attention_full;     // 0 = BNeckAttention, 1 = Attention (full width, 2 heads x 64)
     int act_gelu;           // MLP activation: 0 = ReLU, 1 = exact (erf) GELU
     int pooling;            // 0 = mean over the tokens, 1 = 'dm' (per time patch: mean over frequency patches -> head -> sigmoid; mean over
                             // time), 2 = 'token' (a cls token in column 0 of a ONE-clip wave; its row feeds the head)
     int bn_nonneg;          // 1 = every init_bn scale w/sqrt(var+eps) is >= 0 (the usual case): the top_db clamp is a plain max
     int split_pe;           // 1 = patch embed on split weights (W = hi + lo, 8-wave workgroups only); 0 = high-order term only
-    int ablate;             // timing experiments (builds with -DUITK_ABLATION_BUILDS only): ABL template value
-    int stagger;            // 0 = off, else shader cycles to delay every other workgroup generation
-    int stagger_group;      // workgroups per generation (= CU count)
-    int stagger_mode;       // 1 = by workgroup generation, 2 = by hardware wave slot
 };
 
 hipError_t launch_frontend(const FrontendArgs& a, int in_i16, int patch_layout, int n_cu, int wg_per_cu, hipStream_t stream);
 hipError_t launch_mel_export(const float* mel, const float* amax, float top_db, int64_t B, int nF, float* out,
                              hipStream_t stream);
-hipError_t launch_encoder(const EncoderArgs& a, int precision, int waves, int sched, hipStream_t stream);
+hipError_t launch_encoder(const EncoderArgs& a, int precision, int waves, hipStream_t stream);
 hipError_t launch_crop_reduce(const float* rowprobs, float* probs, int64_t B, int ncrops, int C, int eval_avg,
                               hipStream_t stream);
 // epilogue.hip: device-side post-processing of the probability rows (C <= 1024, k <= C)

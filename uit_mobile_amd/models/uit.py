@@ -166,10 +166,12 @@ class UITBase(nn.Module):
             raise NotImplementedError("uit_mobile_amd implements the uit_xs/xxs/xxxs family only: " + "; ".join(unsupported))
         if precision not in ('f16', 'bf16', 'fp8', 'f16x2', 'f16l6'):
             raise ValueError(f"Unknown precision ({precision})")
-        if precision in ('fp8', 'f16x2', 'f16l6') and (self.attention_full or self.act_gelu or pooling != 'mean'):
+        if precision in ('fp8', 'f16x2') and (self.attention_full or self.act_gelu or pooling != 'mean'):
             raise NotImplementedError(f"precision='{precision}' is built for the uit_* family (BNeckAttention + ReLU, mean pooling) only")
-        if pooling != 'mean' and precision != 'f16':
-            raise NotImplementedError("pooling='dm' / 'token' are built for precision='f16'")
+        if precision == 'f16l6' and (self.attention_full or self.act_gelu):
+            raise NotImplementedError("precision='f16l6' is built for BNeckAttention + ReLU (any pooling)")
+        if pooling != 'mean' and precision not in ('f16', 'f16l6'):
+            raise NotImplementedError("pooling='dm' / 'token' are built for precision='f16' / 'f16l6'")
 
         self.front_end = nn.Sequential(
             _MelSpectrogramParams(n_fft, self.win_size, f_min, f_max, self.n_mels, 16000), nn.Identity())
@@ -185,6 +187,7 @@ class UITBase(nn.Module):
         self.apply(self.init_weights)
         nn.init.normal_(self.cls_token, std=1e-6)
         self._handles = {}          # device index -> (_Handle, version stamp)
+        self._options = {}          # uitk_set_option settings, re-applied to every handle this model creates
 
     def init_weights(self, module):
         if isinstance(module, nn.Linear):
@@ -228,6 +231,13 @@ class UITBase(nn.Module):
         """Drop the uploaded parameter images: the next call re-packs the current weights.  Call it after editing a parameter
         in place (`p.data.mul_()`, a numpy view): only load_state_dict / .to() / .cuda() invalidate the images by themselves."""
         self._handles.clear()
+
+    def set_option(self, name, value):
+        """Explicit tuning / test option of the C library (uitk_set_option: 'fe_asym_pm', 'fe_wg_per_cu', 'enc_waves', 'split_pe',
+        'enc_generic_clamp').  None changes a result bit.  Applied to the live handles and to every handle created later."""
+        self._options[str(name)] = int(value)
+        for h, _ in self._handles.values():
+            _lib.check(_lib.load().uitk_set_option(h.ptr, str(name).encode(), int(value)), "uitk_set_option")
 
     def _apply(self, fn, *args, **kwargs):
         out = super()._apply(fn, *args, **kwargs)
@@ -300,6 +310,8 @@ class UITBase(nn.Module):
         out = ctypes.c_void_p()
         with torch.cuda.device(idx):
             _lib.check(L.uitk_create(ctypes.byref(cfg), ctypes.byref(w), ctypes.byref(out)), "uitk_create")
+            for name, value in self._options.items():
+                _lib.check(L.uitk_set_option(out, name.encode(), value), "uitk_set_option")
         self._handles[idx] = (_Handle(out.value), stamp)
         return out.value
 
