@@ -256,6 +256,10 @@ def main():
                     help="untimed set-up steps that bring the idle GPU's clocks up before the --warmup steps (0 = none)")
     ap.add_argument("--gather", default="rccl", choices=["rccl", "peer"],
                     help="N>1: RCCL all_gather_into_tensor (default) or the copy-engine fan-out into IPC-mapped peer buffers")
+    ap.add_argument("--gather-dtype", default="f32", choices=["f32", "f16"],
+                    help="N>1: payload of the gather: fp32 probabilities (2 148 B per clip, default) or float16 (1 074 B per clip)")
+    ap.add_argument("--gather-topk", type=int, default=0,
+                    help="N>1: gather only the device-side top-k (uitk_topk before the collective: 8 k bytes per clip) instead of [B,537]")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="torch.distributed backend (nccl = RCCL; gloo only for exercising the N>1 code path on a 1-GPU box)")
     ap.add_argument("--all-ranks-on-device0", action="store_true",
@@ -303,8 +307,22 @@ def main():
     cur = [0]
     import collections
     pending = collections.deque()
+    # what crosses xGMI per clip: fp32 / float16 probabilities, or the packed device-side top-k (values bit-cast next to indices)
+    if args.gather_topk > 0:
+        from uit_mobile_amd.postprocess import topk as dev_topk
+        pay_cols, pay_dtype = 2 * args.gather_topk, torch.int32
+
+        def payload(probs):
+            v, i = dev_topk(probs, args.gather_topk)
+            return torch.cat([v.contiguous().view(torch.int32), i.to(torch.int32)], 1)
+    elif args.gather_dtype == "f16":
+        pay_cols, pay_dtype = 537, torch.float16
+        payload = lambda probs: probs.to(torch.float16)
+    else:
+        pay_cols, pay_dtype = 537, torch.float32
+        payload = lambda probs: probs
     # 4 rotating buffers: at most 2 gathers are in flight and one result is being read
-    peer = PeerGather(Bl, 537, dev, nbuf=4) if (world > 1 and args.gather == "peer") else None
+    peer = PeerGather(Bl, pay_cols, dev, dtype=pay_dtype, nbuf=4) if (world > 1 and args.gather == "peer") else None
 
     def fe(n, rec=True):
         """front-end of step n (+ at N>1 the start of its amax all-reduce)"""
@@ -327,7 +345,8 @@ def main():
         probs = r.encode(st)
         if rec:
             evs[n][3].record()
-        pending.append(peer.gather_async(probs) if peer is not None else gather_outputs_async(probs))
+        send = payload(probs)
+        pending.append(peer.gather_async(send) if peer is not None else gather_outputs_async(send))
         return pending.popleft().wait() if len(pending) > 2 else None
 
     def run(first, count, rec=True):
@@ -375,7 +394,7 @@ def main():
     # per-kernel durations of the K timed steps, read after the closing synchronize
     fe_ms = [e[0].elapsed_time(e[1]) for e in evs[args.warmup:]]
     enc_ms = [e[2].elapsed_time(e[3]) for e in evs[args.warmup:]]
-    assert out.shape == (world * Bl, 537) and bool(torch.isfinite(out).all())
+    assert out.shape == (world * Bl, pay_cols) and (pay_dtype == torch.int32 or bool(torch.isfinite(out.float()).all()))
     t = torch.tensor([el], device=dev, dtype=torch.float64)
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -420,7 +439,9 @@ def main():
                        "setup": f"handles + workspace + RCCL communicator, then {args.spinup_steps} untimed steps of device "
                                 "spin-up (clock ramp) before the --warmup steps",
                        "parallelism": f"dp{world} (batch shards, in-place RCCL MAX all-reduce of the 64 amax slots + "
-                                      f"{'copy-engine peer fan-out' if peer is not None else 'RCCL all-gather'} of [B,537])"},
+                                      f"{'copy-engine peer fan-out' if peer is not None else 'RCCL all-gather'} of "
+                                      f"{'the device-side top-%d' % args.gather_topk if args.gather_topk else '[B,537] ' + args.gather_dtype}; "
+                                      f"{pay_cols * (2 if pay_dtype == torch.float16 else 4)} B per clip cross xGMI)"},
             "roofline": {"bound": "mfma", "kernel": "uit_encoder_kernel", "achieved": round(achieved, 2),
                          "peak": peak, "unit": "TFLOP/s", "frac": round(achieved / peak, 5),
                          "traffic": traffic, "traffic_source": traffic_source, "launch_ms": round(enc, 4),

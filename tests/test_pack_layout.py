@@ -240,3 +240,61 @@ def test_emulated_f16l6_low_order_term_cuts_the_weight_rounding_error(seed):
         assert np.abs(stages.mean(-1)).max() < 1e-3
     print(seed, err)
     assert err["f16l6"] < 0.6 * err["f16"] and err["f16l6"] < 4e-4
+
+
+@pytest.mark.parametrize("factory,kw", [("uit_xxxs", dict(precision="f16")), ("uit_xxxs", dict(precision="bf16")), ("uit_xxxs", dict(precision="fp8")),
+                                        ("uit_xxxs", dict(precision="f16x2")), ("uit_xxxs", dict(precision="f16l6")),
+                                        ("uit_xxxs", dict(precision="f16", pooling="dm")), ("uit_xxxs", dict(precision="f16l6", pooling="token")),
+                                        ("audio_transformer_h128_d4_m3", dict(precision="f16")),
+                                        ("audio_transformer_h128_d4_m3_relu", dict(precision="f16", pooling="token")), ("audio_transformer_h128_d4_m3_relu", dict(precision="bf16"))])
+def test_everything_added_to_the_residual_stream_is_centred_at_pack_time(factory, kw):
+    """The kernel's LayerNorm is mean-free (x * rsqrt(E[x^2] + eps), encoder.hip ln_stats): correct only while pack.cpp removes the
+    channel mean of EVERYTHING that is ever added to the residual stream.  Pack-time invariant, checked on the packed image for every
+    precision / attention / pooling family: the rows of the conv-bias + positional table (incl. the cls row), the proj and
+    fc2 bias vectors of every block -- exactly (fp32 tables) -- and, for the 16-bit single-weight layouts, the column sums of the
+    ROUNDED proj / fc2 / patch-embed operands over their 128 output channels (zero up to the operand rounding: |sum| <= 128 half-ulps)."""
+    import struct
+    from mfma_emu import HDR_FMT, HDR_FIELDS, to_f32
+    from synth_weights import make_trained_like_state_dict
+    full = factory.startswith("audio_transformer")
+    sd = make_trained_like_state_dict(factory, 3, attention="full" if full else "bneck")
+    m = getattr(models, factory)(outputdim=537, target_length=102, **kw)
+    m.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()}, strict=True)
+    img = m.eval().packed_image()
+    h = dict(zip(HDR_FIELDS, struct.unpack_from(HDR_FMT, img, 0)))
+    peb = np.frombuffer(img, np.float32, 25 * 128, h["off_pe_bias"]).reshape(25, 128)
+    assert np.abs(peb.astype(np.float64).mean(1)).max() < 1e-6 and np.abs(peb).max() > 1.0
+    b_proj, b_fc2 = (384, 896) if full else (96, 608)
+    for blk in range(h["depth"]):
+        bias = np.frombuffer(img, np.float32, 1024, h["off_bias"] + blk * 4096)
+        for off in (b_proj, b_fc2):
+            v = bias[off:off + 128].astype(np.float64)
+            assert abs(v.mean()) < 1e-6 and np.abs(v).max() > 0.05, (blk, off)
+    prec = kw["precision"]
+    if full or prec not in ("f16", "bf16"):
+        return
+    op = 0 if prec == "f16" else 1
+    frag = lambda stage, f: to_f32(np.frombuffer(img, np.uint16, 512, h["off_wstream"] + stage * 16384 + f * 1024).reshape(64, 8), op).astype(np.float64)
+    half_ulp = 2.0 ** (-11 if op == 0 else -8)
+    # patch embed: fragment (stage i, f) = rows 16 (2i + f/8) .., k-step f % 8; a column = one (lane group, element) slot summed over 16 rows x 8 tiles
+    col = np.zeros((8, 4, 8))
+    mx = 0.0
+    for i in range(4):
+        for f in range(16):
+            a = frag(i, f).reshape(4, 16, 8)                      # [g][row c][j]
+            col[f % 8] += a.sum(1)
+            mx = max(mx, np.abs(a).max())
+    assert np.abs(col).max() < 128 * half_ulp * mx, (np.abs(col).max(), mx)
+    for blk in range(h["depth"]):
+        st = 8 + blk * 14
+        colp, mxp = np.zeros((4, 8)), 0.0
+        for ft in range(8):                                       # proj: K = 32 = one k-step; fragment 8 + ft of stage VP
+            a = frag(st + 1, 8 + ft).reshape(4, 16, 8)
+            colp += a.sum(1); mxp = max(mxp, np.abs(a).max())
+        assert np.abs(colp).max() < 128 * half_ulp * mxp
+        for ch in range(12):                                      # fc2 k-step ch: fragments 8 + ft of MLP stage ch
+            colf, mxf = np.zeros((4, 8)), 0.0
+            for ft in range(8):
+                a = frag(st + 2 + ch, 8 + ft).reshape(4, 16, 8)
+                colf += a.sum(1); mxf = max(mxf, np.abs(a).max())
+            assert np.abs(colf).max() < 128 * half_ulp * mxf

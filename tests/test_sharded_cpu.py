@@ -62,6 +62,36 @@ def _worker(rank, world, port, q):
             amax_allreduce_finish(pnd)
         ok = ok and float(sl[0].max()) == 2.0 and float(sl[1].max()) == -3.0
         ok = ok and float(sl[0][5]) == 1.0 and float(sl[0][6]) == 2.0 and float(sl[0][7]) == float("-inf")   # slot-wise MAX
+        # reduced payloads (round 3: what crosses xGMI per clip can be cut before the collective)
+        h16 = ShardedUiT(fake_model, gather_dtype=torch.float16)(full[lo:hi])
+        ok = ok and h16.dtype == torch.float16 and torch.equal(h16, expect.to(torch.float16))
+        sl3 = ShardedUiT(fake_model, slice_classes=3)(full[lo:hi])
+        ok = ok and sl3.shape == (B, 3) and torch.equal(sl3, expect[:, :3])
+        host_topk = lambda p, k: tuple(t.contiguous() for t in p.topk(k))            # stands in for uitk_topk (device only)
+        tv, ti = ShardedUiT(fake_model, topk=2, topk_fn=host_topk)(full[lo:hi])
+        ev, ei = expect.topk(2)
+        ok = ok and torch.equal(tv, ev) and torch.equal(ti, ei) and ti.dtype == torch.int64
+        hh = ShardedUiT(fake_model, topk=2, topk_fn=host_topk)(full[lo:hi], async_gather=True)
+        tv, ti = hh.wait()
+        ok = ok and torch.equal(tv, ev) and torch.equal(ti, ei)
+        ok = ok and ShardedUiT(fake_model, topk=5).payload_bytes_per_clip(537) == 40
+        ok = ok and ShardedUiT(fake_model, gather_dtype=torch.float16, slice_classes=527).payload_bytes_per_clip(537) == 1054
+        # gather='peer' whose IPC precondition fails: EVERY rank falls back to the RCCL / gloo gather, loudly
+        import warnings
+        import uit_mobile_amd.sharded as S
+
+        class Refuses:
+            def __init__(self, *a, **k):
+                raise S.PeerGatherUnavailable("HSA_ENABLE_IPC_MODE_LEGACY=0 is not set (test)")
+        keep, S.PeerGather = S.PeerGather, Refuses
+        try:
+            sp = ShardedUiT(fake_model, gather="peer")
+            with warnings.catch_warnings(record=True) as w:
+                warnings.simplefilter("always")
+                outp = sp(full[lo:hi])
+            ok = ok and torch.equal(outp, expect) and sp.gather == "rccl" and any("falling back" in str(x.message) for x in w)
+        finally:
+            S.PeerGather = keep
         q.put((rank, bool(ok)))
     finally:
         dist.destroy_process_group()

@@ -1,4 +1,5 @@
-"""GPU diagnostic: where do an encoder block's cycles go?  (instrumented kernel build, s_memtime stamps)"""
+"""GPU diagnostic (needs a -DUITK_LAB library: tools/mklib.sh lab -DUITK_LAB; UITK_LIB_PATH=tools/ab/libuitk_lab.so): where do an
+encoder block's cycles go?  (instrumented kernel build, s_memtime stamps)"""
 import ctypes, os, sys
 from pathlib import Path
 import numpy as np, torch
@@ -14,8 +15,8 @@ names = ["LN1", "wait QK", "QK", "wait VP", "attn+proj", "LN2", "wait MLP(12)", 
 names2 = ["load wait", "prologue barrier", "patch embed", "epilogue total", "stream kick", "load issue", "clamp",
           "final LN+pool", "head LN+LDS", "epi barrier", "z reads", "head tiles+stores"]
 for waves, B in (("8", 8192),):
-    os.environ["UITK_ENC_WAVES"] = waves
-    m = models.uit_xs(outputdim=537, target_length=102).to(dev); m.load_state_dict(sd); m.eval()
+    m = models.uit_xs(outputdim=537, target_length=102, precision="f16").to(dev); m.load_state_dict(sd); m.eval()
+    m.set_option("enc_waves", int(waves))
     xb = x[:B]
     m(xb); torch.cuda.synchronize()
     nw = B // 2
