@@ -20,7 +20,7 @@ sys.path.insert(0, str(HERE))
 # imported BEFORE the stand-in torchaudio module is installed (transformers probes for the real package)
 from transformers.audio_utils import mel_filter_bank, spectrogram  # noqa: E402
 import _ref_shims  # noqa: E402
-from synth_weights import make_state_dict, make_trained_like_state_dict, synth_pcm_i16  # noqa: E402
+from synth_weights import make_kwargs_variant_state_dict, make_state_dict, make_trained_like_state_dict, synth_pcm_i16  # noqa: E402
 
 REF = Path("/root/reference")
 uit = _ref_shims.import_reference_uit(str(REF))
@@ -206,7 +206,34 @@ def main_token():
     np.savez_compressed(HERE / "pooling_token.npz", pcm=pcm, **out)
 
 
+def main_kwargs():
+    """Round-3 fixtures: the UITBase kwargs the wrapper used to refuse (models/uit.py:253-293): qkv_bias=False + LayerScale
+    (init_values) + init_bn=False (the reference's GlobalNormer) on one model; center=False (no reflect padding, 1 + (T - n_fft) / hop
+    frames) on 1 s clips (97 frames, one crop) and on 17 000-sample clips (104 frames, two crops)."""
+    pcm = synth_pcm_i16(6, 16000, seed=21)
+    pcm[4] = 0
+    m = uit.uit_xxxs(outputdim=537, target_length=102, qkv_bias=False, init_values=0.1, init_bn=False)
+    sd = {k: torch.from_numpy(np.asarray(v)) for k, v in make_kwargs_variant_state_dict("uit_xxxs", 33).items()}
+    assert not (set(m.state_dict().keys()) ^ set(sd.keys())), set(m.state_dict().keys()) ^ set(sd.keys())
+    m.load_state_dict(sd, strict=True)
+    r = run_ref(m.eval(), pcm, stages_for=2)
+    np.savez_compressed(HERE / "kwargs_uit_xxxs.npz", pcm=pcm, seed=33, probs=r["probs"], logits=r["logits"], stages=r["stages"])
+    print("kwargs variant logit range", r["logits"].min(), r["logits"].max())
+    out = {}
+    for tag, T in (("1s", 16000), ("2crop", 17000)):
+        p = synth_pcm_i16(4, T, seed=22)
+        p[3] = 0
+        m = uit.uit_xxxs(outputdim=537, target_length=102, center=False)
+        m.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in make_state_dict("uit_xxxs", 34, 2.0).items()}, strict=True)
+        r = run_ref(m.eval(), p)
+        out[f"{tag}_pcm"], out[f"{tag}_probs"], out[f"{tag}_logits"], out[f"{tag}_mel_db"] = p, r["probs"], r["logits"], r["mel_db"]
+        print("center=False", tag, "frames", r["mel_db"].shape[-1], "crops", r["logits"].shape[1])
+    np.savez_compressed(HERE / "nocenter_uit_xxxs.npz", seed=34, **out)
+
+
 def main():
+    if "--kwargs" in sys.argv:
+        return main_kwargs()
     if "--token" in sys.argv:
         return main_token()
     if "--dm" in sys.argv:
@@ -282,6 +309,7 @@ def main():
     main_variants()
     main_dm()
     main_token()
+    main_kwargs()
     print("done")
 
 

@@ -172,3 +172,17 @@ def make_trained_like_state_dict(name="uit_xs", seed=0, outputdim=537, target_le
     sd["outputlayer.1.weight"] = nrm(outputdim, dim, std=0.1)
     sd["outputlayer.1.bias"] = nrm(outputdim, std=2.0, mean=-4.5)
     return sd
+
+
+def make_kwargs_variant_state_dict(name="uit_xxxs", seed=0, scale=2.0, outputdim=537):
+    """Checkpoint of a model built with the OTHER kwargs of UITBase (models/uit.py:253-293, Block :206-243): qkv_bias=False (no
+    attn.qkv.bias keys), init_values=<x> (LayerScale: blocks.N.ls1.gamma / ls2.gamma, gains 0.2..1.2) and init_bn=False (no init_bn
+    keys: the reference's GlobalNormer(-10, 20) takes their place).  Otherwise make_state_dict's distributions."""
+    sd = dict(make_state_dict(name, seed, scale, outputdim))
+    rng = np.random.default_rng(9000 + seed)
+    for k in [k for k in sd if k.startswith("init_bn.") or k.endswith("attn.qkv.bias")]:
+        del sd[k]
+    for b in range(DEPTH[name]):
+        sd[f"blocks.{b}.ls1.gamma"] = (0.2 + rng.random(128)).astype(np.float32)
+        sd[f"blocks.{b}.ls2.gamma"] = (0.2 + rng.random(128)).astype(np.float32)
+    return sd

@@ -115,12 +115,7 @@ def test_strict_load_and_pos_embed_resize():
 
 def test_unsupported_variants_raise():
     with pytest.raises(NotImplementedError):
-        models.UITBase(embed_dim=128, depth=4, num_heads=2, mlp_ratio=3.0, pooling="mean", init_bn=False,
-                       attention_type="BNeckAttention", act_layer=torch.nn.ReLU)
-    with pytest.raises(NotImplementedError):
         models.uit_xs(patch_size=8, patch_stride=8)
-    with pytest.raises(NotImplementedError):
-        models.uit_xs(init_values=1e-4)                          # LayerScale
     assert models.uit_xs(pooling="dm").pooling == "dm"          # POOL = 1 instantiation
     assert models.UITBase(embed_dim=128, depth=4, num_heads=2, mlp_ratio=3.0).pooling == "token"   # the reference's defaults: POOL = 2
     with pytest.raises(NotImplementedError):
@@ -234,3 +229,20 @@ def test_parity_precision_is_part_of_the_interface():
         models.audio_transformer_h128_d4_m3(outputdim=537, target_length=102, precision="f16l6")
     with pytest.raises(ValueError):
         models.uit_xxxs(precision="f16l7")
+
+
+def test_other_kwargs_keep_the_reference_state_dict_layout():
+    """Round 3: qkv_bias=False, init_values (LayerScale) and init_bn=False are accepted; the state_dict then has exactly the keys the
+    REFERENCE's model has for these kwargs (make_golden.py --kwargs loads the same checkpoint into it with strict=True): no
+    attn.qkv.bias, no init_bn.*, blocks.N.ls{1,2}.gamma.  center=False changes the frame count rule.  All pack without a GPU."""
+    from synth_weights import make_kwargs_variant_state_dict
+    m = models.uit_xxxs(outputdim=537, target_length=102, qkv_bias=False, init_values=0.1, init_bn=False)
+    sd = make_kwargs_variant_state_dict("uit_xxxs", 33)
+    assert set(m.state_dict()) == set(sd)
+    assert float(m.blocks[0].ls1.gamma.detach()[0]) == pytest.approx(0.1)
+    m.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()}, strict=True)
+    assert len(m.eval().packed_image()) > 0
+    c = models.uit_xxxs(outputdim=537, target_length=102, center=False)
+    assert c.num_frames(16000) == 97 and c.num_crops(16000) == 1 and c.num_crops(17000) == 2
+    assert models.uit_xxxs().num_frames(16000) == 101
+    assert len(c.eval().packed_image()) > 0

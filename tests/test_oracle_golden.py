@@ -204,3 +204,19 @@ def test_pooling_token(golden):
         assert np.abs(r["logits"] - g[f"{tag}_logits"]).max() < 2e-4 and np.abs(r["probs"] - g[f"{tag}_probs"]).max() < 5e-5
         if tag == "xxxs":
             assert np.abs(o.forward(g["xxxs_short_pcm"])["logits"] - g["xxxs_short_logits"]).max() < 1e-4
+
+
+def test_other_kwargs_and_center_false(golden):
+    """Round 3: the oracle's restatement of qkv_bias=False / LayerScale / init_bn=False (GlobalNormer) and of center=False against
+    the fixtures the imported reference produced for those kwargs (tests/golden/make_golden.py --kwargs)."""
+    from synth_weights import make_kwargs_variant_state_dict, make_state_dict
+    g = golden("kwargs_uit_xxxs")
+    r = Oracle(make_kwargs_variant_state_dict("uit_xxxs", int(g["seed"]))).forward(g["pcm"])
+    assert np.abs(r["logits"] - g["logits"]).max() < 2e-4 and np.abs(r["probs"] - g["probs"]).max() < 5e-5
+    g = golden("nocenter_uit_xxxs")
+    o = Oracle(make_state_dict("uit_xxxs", int(g["seed"]), 2.0), center=False)
+    for tag, crops in (("1s", 1), ("2crop", 2)):
+        r = o.forward(g[f"{tag}_pcm"])
+        assert r["logits"].shape[1] == crops == g[f"{tag}_logits"].shape[1]
+        assert np.abs(r["logits"] - g[f"{tag}_logits"]).max() < 3e-4 and np.abs(r["probs"] - g[f"{tag}_probs"]).max() < 1e-4
+        assert r["mel_db"].shape == g[f"{tag}_mel_db"].shape

@@ -1,20 +1,40 @@
-"""Summarise a tools/prof.sh output dir: python tools/pmc_summary.py gpurun_out/prof_<tag> [out.json]"""
-import collections, csv, glob, json, sys
+"""Summarise a tools/prof.sh output dir: python tools/pmc_summary.py gpurun_out/prof_<tag> [out.json] [--latest profiles/pmc_latest.json --precision P]
+
+Per kernel: averages per launch over the STEADY launches only -- dispatches of the kernel's benchmark grid (the most frequent one)
+that start after the first benchmark-grid encoder dispatch (this excludes the B = 64 set-up launches and the short front-end
+launches with which uitk_reserve calibrates the pass split).  HBM bytes: FETCH_SIZE x 2 (gfx950 tallies the 128-B requests of wide
+streaming reads at 64 B: MI355X_MICROARCH.md, HBM section) + WRITE_SIZE, both reported in KiB."""
+import collections, csv, glob, hashlib, json, sys
+from pathlib import Path
+
 base = sys.argv[1]
 out = {}
 ks = glob.glob(base + '/trace/*/*_kernel_stats.csv')
 if ks:
     rows = list(csv.DictReader(open(ks[0])))
     out['kernel_stats'] = [{k: r[k] for k in ('Name', 'Calls', 'AverageNs', 'MinNs', 'MaxNs', 'Percentage')} for r in rows if 'uitk' in r['Name']]
-pm = {}
+short = lambda n: n.split('(')[0].replace('void ', '')
+pm, nlaunch = {}, {}
 for d in sorted(glob.glob(base + '/pmc_*/*/*_counter_collection.csv')):
+    rows = [r for r in csv.DictReader(open(d)) if 'uitk' in r['Kernel_Name']]
+    by_grid = collections.Counter((short(r['Kernel_Name']), r['Grid_Size']) for r in rows)
+    main = {}
+    for (k, g), n in by_grid.items():
+        if k not in main or n > by_grid[(k, main[k])]:
+            main[k] = g
+    enc_start = [int(r['Start_Timestamp']) for r in rows if 'encoder' in r['Kernel_Name'] and r['Grid_Size'] == main.get(short(r['Kernel_Name']))]
+    t0 = min(enc_start) if enc_start else 0
     agg = collections.defaultdict(lambda: collections.defaultdict(list))
-    for r in csv.DictReader(open(d)):
-        if 'uitk' in r['Kernel_Name']:
-            agg[r['Kernel_Name'].split('(')[0].replace('void ', '')][r['Counter_Name']].append(float(r['Counter_Value']))
+    for r in rows:
+        k = short(r['Kernel_Name'])
+        if r['Grid_Size'] != main[k] or int(r['Start_Timestamp']) < t0 - 2_000_000:      # (the front-end of the first step starts ~1 ms before its encoder)
+            continue
+        agg[k][r['Counter_Name']].append(float(r['Counter_Value']))
     for k, v in agg.items():
         pm.setdefault(k, {}).update({c: sum(x) / len(x) for c, x in v.items()})
+        nlaunch[k] = min(nlaunch.get(k, 10 ** 9), min(len(x) for x in v.values()))
 for k, v in pm.items():
+    v['steady_launches_per_pass'] = nlaunch.get(k)
     if 'GRBM_GUI_ACTIVE' in v and 'SQ_VALU_MFMA_BUSY_CYCLES' in v:
         cyc = v['GRBM_GUI_ACTIVE'] / 8.0
         v['derived_mfma_busy_frac'] = v['SQ_VALU_MFMA_BUSY_CYCLES'] / (cyc * 1024)
@@ -22,18 +42,42 @@ for k, v in pm.items():
     if 'SQ_WAVE_CYCLES' in v and 'SQ_WAIT_ANY' in v:
         for c in ('SQ_WAIT_ANY', 'SQ_WAIT_INST_ANY', 'SQ_ACTIVE_INST_ANY'):
             v['derived_frac_' + c] = v[c] / v['SQ_WAVE_CYCLES']
-    # HBM bytes per launch: FETCH_SIZE / WRITE_SIZE are in KiB-units of 1024 B? (rocprofv3: kilobytes)
+    if 'SQ_LDS_IDX_ACTIVE' in v and 'GRBM_GUI_ACTIVE' in v:
+        # LDS pipe busy: SQ_LDS_IDX_ACTIVE is summed over the chip's 256 CUs (cycles in which a CU's LDS index unit is active)
+        v['derived_lds_active_frac_per_cu'] = v['SQ_LDS_IDX_ACTIVE'] / (v['GRBM_GUI_ACTIVE'] / 8.0 * 256)
     if 'FETCH_SIZE' in v:
-        v['derived_fetch_MB'] = v['FETCH_SIZE'] * 1024 / 1e6
+        v['derived_fetch_MB_x2'] = 2 * v['FETCH_SIZE'] * 1024 / 1e6
     if 'WRITE_SIZE' in v:
         v['derived_write_MB'] = v['WRITE_SIZE'] * 1024 / 1e6
+    if 'FETCH_SIZE' in v and 'WRITE_SIZE' in v:
+        v['derived_hbm_bytes_per_launch'] = int(2 * v['FETCH_SIZE'] * 1024 + v['WRITE_SIZE'] * 1024)
 out['pmc_avg_per_launch'] = pm
 s = json.dumps(out, indent=1)
-if len(sys.argv) > 2:
-    open(sys.argv[2], 'w').write(s)
+args = [a for a in sys.argv[2:] if not a.startswith('--')]
+if args:
+    open(args[0], 'w').write(s)
+if '--latest' in sys.argv:
+    root = Path(__file__).resolve().parents[1]
+    h = hashlib.sha256()
+    for f in ("encoder.hip", "frontend.hip", "epilogue.hip", "uitk_dev.h", "pack.cpp"):
+        h.update((root / "uit_mobile_amd" / "csrc" / f).read_bytes())
+    enc = next((v for k, v in pm.items() if 'encoder' in k), {})
+    fe = next((v for k, v in pm.items() if 'frontend' in k), {})
+    prec = sys.argv[sys.argv.index('--precision') + 1] if '--precision' in sys.argv else 'f16l6'
+    latest = {"source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, tools/prof.sh), steady launches of the default bench workload "
+                        "(UiT-XS, 8192 f32 clips, 3 rotating input batches)",
+              "correction": "MI355X_MICROARCH.md HBM section: FETCH_SIZE (KiB) tallies 128-B requests at 64 B for 16-B-per-lane streaming reads -> x2; WRITE_SIZE exact",
+              "precision": prec, "kernel_sources_sha16": h.hexdigest()[:16],
+              "encoder_hbm_bytes_per_launch": enc.get('derived_hbm_bytes_per_launch'), "encoder_fetch_size_kib_raw": enc.get('FETCH_SIZE'),
+              "encoder_write_size_kib_raw": enc.get('WRITE_SIZE'),
+              "frontend_hbm_bytes_per_launch": fe.get('derived_hbm_bytes_per_launch'), "frontend_fetch_size_kib_raw": fe.get('FETCH_SIZE'),
+              "frontend_write_size_kib_raw": fe.get('WRITE_SIZE'),
+              "algorithmic_bytes_per_launch": {"encoder": 8192 * (12288 + 2148), "frontend": 8192 * (64000 + 12288)},
+              "encoder_mfma_busy_frac": enc.get('derived_mfma_busy_frac'), "encoder_valu_per_mfma": enc.get('derived_valu_per_mfma')}
+    open(sys.argv[sys.argv.index('--latest') + 1], 'w').write(json.dumps(latest, indent=1))
 for k, v in pm.items():
     print(k)
     for c in sorted(v):
-        print(f"   {c:32s} {v[c]:.6g}")
+        print(f"   {c:36s} {v[c]:.6g}" if isinstance(v[c], (int, float)) and v[c] is not None else f"   {c:36s} {v[c]}")
 for r in out.get('kernel_stats', []):
     print(r['Name'][:60], r['AverageNs'], r['Calls'])

@@ -129,7 +129,12 @@ int uitk_destroy(uitk_model* m) {
     return UITK_OK;
 }
 
-int uitk_num_frames(const uitk_model* m, int64_t T) { return m ? (int)(1 + T / m->cfg.hop_size) : -1; }
+// torch.stft (torchaudio Spectrogram): center=True pads n_fft/2 each side -> 1 + T/hop frames; center=False -> 1 + (T - n_fft)/hop
+int uitk_num_frames(const uitk_model* m, int64_t T) {
+    if (!m) return -1;
+    if (m->cfg.center) return (int)(1 + T / m->cfg.hop_size);
+    return T < m->cfg.n_fft ? 0 : (int)(1 + (T - m->cfg.n_fft) / m->cfg.hop_size);
+}
 
 int uitk_num_crops(const uitk_model* m, int64_t T) {
     if (!m) return -1;
@@ -141,6 +146,7 @@ static int check_shape(const uitk_model* m, int64_t B, int64_t T) {
     if (!m) return fail(UITK_ERR_INVALID_ARG, "null model");
     if (B < 1 || T < 1) return fail(UITK_ERR_INVALID_ARG, "B and T must be positive");
     if (T <= m->cfg.n_fft / 2) return fail(UITK_ERR_TOO_SHORT, "clip must be longer than n_fft/2 samples (reflect padding)");
+    if (!m->cfg.center && T < m->cfg.n_fft) return fail(UITK_ERR_TOO_SHORT, "center=False: clip shorter than one n_fft window");
     if (uitk_num_frames(m, T) < m->cfg.patch_size) return fail(UITK_ERR_TOO_SHORT, "clip shorter than one 16-frame patch");
     if (T >= (int64_t)1 << 30) return fail(UITK_ERR_INVALID_ARG, "T too large");
     if (B * (int64_t)uitk_num_frames(m, T) >= (int64_t)1 << 31) return fail(UITK_ERR_INVALID_ARG, "B * frames must be below 2^31 per call");
@@ -268,6 +274,7 @@ static int run_frontend(uitk_model* m, const void* pcm, int in_dtype, int64_t B,
     const ImageHeader& h = m->hdr;
     FrontendArgs a{};
     a.pcm = pcm; a.B = B; a.T = T; a.nF = uitk_num_frames(m, T); a.hop = m->cfg.hop_size;
+    a.pad = m->cfg.center ? m->cfg.n_fft / 2 : 0;
     a.window = (const float*)(m->image + h.off_window);
     a.tw256 = (const float2*)(m->image + h.off_tw256);
     a.tw512 = (const float2*)(m->image + h.off_tw512);

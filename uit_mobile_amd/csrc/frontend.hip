@@ -233,14 +233,14 @@ __global__ __launch_bounds__(FE_WAVES * 64, FE_OCC) void mel_frontend_kernel(Fro
     // slower than its three siblings (the workgroup ends with its slowest wave).
     const int sl_full = q * a.hop + 2 * p;                                // lane part of a full pass's first-sample index
     auto load_full = [&](int b, int k, int wq, c32 (&raw)[16]) {
-        load_frame((const char*)a.pcm + (int64_t)b * a.T * ES, (16 * k + 4 * wq) * a.hop - 256, sl_full, raw);
+        load_frame((const char*)a.pcm + (int64_t)b * a.T * ES, (16 * k + 4 * wq) * a.hop - a.pad, sl_full, raw);
     };
     auto load_tail = [&](int t, c32 (&raw)[16]) {
         if (4 * wave >= per_tail * rem) return;                           // fully dead quad of a tail pass (uniform)
         const int cb0 = t * per_tail;
         int b = cb0 + t_cl, f = 16 * full + t_fr;
         if (t_cl >= per_tail || b >= B) { b = cb0; f = 16 * full; }       // dead slot: any valid frame
-        load_frame((const char*)a.pcm + (int64_t)b * a.T * ES, f * a.hop - 256, 2 * p, raw);
+        load_frame((const char*)a.pcm + (int64_t)b * a.T * ES, f * a.hop - a.pad, 2 * p, raw);
     };
     unsigned long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tlast = 0;
     if constexpr (TIMING) tlast = fe_stamp();

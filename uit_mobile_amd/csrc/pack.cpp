@@ -225,7 +225,7 @@ int validate_config(const uitk_config* c, const char** why) {
     if (c->hop_size < 1 || c->hop_size > 512) return bad("hop_size out of range");
     if (c->patch_size != 16) return bad("patch_size must be 16");
     if (c->target_length / 16 != GT) return bad("target_length must give 6 time patches (96..111)");
-    if (c->center != 1) return bad("center must be True");
+    if (c->center != 0 && c->center != 1) return bad("center must be 0 or 1");
     if (c->depth < 1 || c->depth > 64) return bad("depth out of range");
     if (c->outputdim < 1 || c->outputdim > 65536) return bad("outputdim out of range");
     if (c->eval_avg != UITK_AVG_MEAN && c->eval_avg != UITK_AVG_MAX) return bad("unknown eval_avg");

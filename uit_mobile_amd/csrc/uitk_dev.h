@@ -80,6 +80,7 @@ struct FrontendArgs {
     const void* pcm;        // [B][T] f32 or i16
     int64_t B, T;
     int nF, hop;
+    int pad;                // samples of reflect padding in front of frame 0: n_fft/2 (center=True) or 0 (center=False: no frame leaves the clip)
     const float* window;    // [512]
     const float2* tw256;    // [16][16]  W256^(p*k1) = (cos, -sin)(2 pi p k1 / 256)
     const float2* tw512;    // [128]     (cos, sin)(2 pi k / 512)

@@ -79,7 +79,7 @@ def output_transform_kws(y_pred, y, threshold=0.2, num_fillers=527):
 
 
 class Evaluator:
-    def __init__(self, experiment_path, device=DEVICE, precision="f16"):
+    def __init__(self, experiment_path, device=DEVICE, precision=None):
         self.model = build_model(experiment_path, device=device, precision=precision)
         self.device = device
 

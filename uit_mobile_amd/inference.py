@@ -26,7 +26,7 @@ def load_label_map(path=LABELS):
         return {int(r["index"]): r["display_name"] for r in csv.DictReader(f)}
 
 
-def build_model(model_arg, device="cuda", precision="f16"):
+def build_model(model_arg, device="cuda", precision=None):
     """Both checkpoint formats of the reference (inference.py:35-48): a public name -> bare state_dict from the
     hub cache, or a path to {'model': sd, 'config': {model, model_args, num_classes}}."""
     if model_arg in PRETRAINED_CHECKPOINTS:
@@ -74,7 +74,8 @@ def main(argv=None):
     ap.add_argument("-m", "--model", type=str, nargs="?", default="uit_xs",
                     metavar=f"Public Checkpoint [{','.join(PRETRAINED_CHECKPOINTS)}] or Experiment Path")
     ap.add_argument("-k", "--topk", type=int, default=3, help="Print top-k results")
-    ap.add_argument("--precision", default="f16", choices=["f16", "bf16", "fp8"])
+    ap.add_argument("--precision", default=None, choices=["f16l6", "f16", "f16x2", "bf16", "fp8"],
+                    help="default: f16l6, the parity mode (fp16 operands + low-order weight term) where the model family has it, else f16")
     args = ap.parse_args(argv)
     label_maps = load_label_map()
     model = build_model(args.model, precision=args.precision)

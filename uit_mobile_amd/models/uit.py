@@ -90,13 +90,24 @@ class _MlpParams(nn.Module):
         self.fc2 = nn.Linear(hidden, dim)
 
 
+class _LayerScaleParams(nn.Module):
+    """LayerScale (uit.py:78-85): x * gamma.  Holds the parameter only; the gain is folded into the preceding linear when the
+    weights are handed to the C library (exact algebra)."""
+
+    def __init__(self, dim, init_values):
+        super().__init__()
+        self.gamma = nn.Parameter(init_values * torch.ones(dim))
+
+
 class _BlockParams(nn.Module):
-    def __init__(self, dim, hidden, qkv_bias, full_attention=False):
+    def __init__(self, dim, hidden, qkv_bias, full_attention=False, init_values=None):
         super().__init__()
         self.norm1 = nn.LayerNorm(dim, eps=1e-6)
         self.attn = _AttnParams(dim, qkv_bias, full_attention)
+        self.ls1 = _LayerScaleParams(dim, init_values) if init_values else nn.Identity()      # uit.py:230-231
         self.norm2 = nn.LayerNorm(dim, eps=1e-6)
         self.mlp = _MlpParams(dim, hidden)
+        self.ls2 = _LayerScaleParams(dim, init_values) if init_values else nn.Identity()      # uit.py:240-241
 
 
 class _Handle:
@@ -125,7 +136,7 @@ class UITBase(nn.Module):
                  mlp_ratio=4., qkv_bias=True, drop_rate=0., attn_drop_rate=0., drop_path_rate=0., init_bn=True,
                  norm_layer=None, act_layer=None, init_values=None, target_length=1012, pooling='token',
                  wavtransforms=None, spectransforms=None, time_patch_out=None, freq_patch_out=None,
-                 block_type='Block', attention_type='Attention', eval_avg='mean', precision='f16', **kwargs):
+                 block_type='Block', attention_type='Attention', eval_avg='mean', precision=None, **kwargs):
         super().__init__()
         assert pooling in ('mean', 'token', 'dm')
         self.outputdim = outputdim
@@ -157,13 +168,18 @@ class UITBase(nn.Module):
         if act_layer is not None and act_layer not in (nn.ReLU, nn.GELU): unsupported.append("act_layer must be nn.ReLU or nn.GELU / None")
         self.attention_full = attention_type == 'Attention'
         self.act_gelu = act_layer is None or act_layer is nn.GELU
-        if not init_bn: unsupported.append("init_bn must be True")
-        if init_values: unsupported.append("LayerScale (init_values) is not supported")
+        # round 3: init_bn=False (the reference's GlobalNormer(-10, 20), uit.py:310-316), LayerScale (init_values, uit.py:230-243) and
+        # qkv_bias=False are exact pack-time folds (see _host_weights); center=False is a front-end option (uitk_config.center)
+        self.use_init_bn, self.init_values, self.qkv_bias = bool(init_bn), init_values, bool(qkv_bias)
+        if not init_bn and self.n_mels != 64: unsupported.append("init_bn=False is defined for n_mels=64 only (as in the reference)")
         if patch_size != 16 or patch_stride != 16: unsupported.append("patch 16x16 stride 16 only")
         if block_type != 'Block': unsupported.append("block_type must be 'Block'")
-        if not qkv_bias: unsupported.append("qkv_bias must be True")
         if unsupported:
             raise NotImplementedError("uit_mobile_amd implements the uit_xs/xxs/xxxs family only: " + "; ".join(unsupported))
+        if precision is None:
+            # default = the parity mode where it is built (BNeckAttention + ReLU: the uit_* family, any pooling), plain fp16 otherwise
+            precision = 'f16' if (self.attention_full or self.act_gelu) else 'f16l6'
+            self.precision = precision
         if precision not in ('f16', 'bf16', 'fp8', 'f16x2', 'f16l6'):
             raise ValueError(f"Unknown precision ({precision})")
         if precision in ('fp8', 'f16x2') and (self.attention_full or self.act_gelu or pooling != 'mean'):
@@ -175,13 +191,14 @@ class UITBase(nn.Module):
 
         self.front_end = nn.Sequential(
             _MelSpectrogramParams(n_fft, self.win_size, f_min, f_max, self.n_mels, 16000), nn.Identity())
-        self.init_bn = nn.Sequential(nn.Identity(), nn.BatchNorm2d(self.n_mels, momentum=0.01), nn.Identity())
+        # init_bn=False: GlobalNormer has no parameters (no init_bn.* keys in the state_dict, as in the reference)
+        self.init_bn = nn.Sequential(nn.Identity(), nn.BatchNorm2d(self.n_mels, momentum=0.01), nn.Identity()) if init_bn else nn.Identity()
         self.patch_embed = _PatchEmbedParams((self.n_mels, target_length), patch_size, patch_stride, embed_dim)
         self.cls_token = nn.Parameter(torch.zeros(1, 1, embed_dim))
         self.token_pos_embed = nn.Parameter(torch.randn(1, embed_dim) * .02)
         self.time_pos_embed = nn.Parameter(torch.randn(1, embed_dim, 1, self.patch_embed.grid_size[1]) * .02)
         self.freq_pos_embed = nn.Parameter(torch.randn(1, embed_dim, self.patch_embed.grid_size[0], 1) * .02)
-        self.blocks = nn.Sequential(*[_BlockParams(embed_dim, self.mlp_hidden, qkv_bias, self.attention_full) for _ in range(depth)])
+        self.blocks = nn.Sequential(*[_BlockParams(embed_dim, self.mlp_hidden, qkv_bias, self.attention_full, init_values) for _ in range(depth)])
         self.norm = nn.LayerNorm(embed_dim, eps=1e-6)
         self.outputlayer = nn.Sequential(nn.LayerNorm(embed_dim), nn.Linear(embed_dim, outputdim))
         self.apply(self.init_weights)
@@ -260,10 +277,27 @@ class UITBase(nn.Module):
         sd = self.state_dict()
         keep = []
 
-        def ptr(key):
-            a = np.ascontiguousarray(sd[key].detach().to('cpu', torch.float32).numpy())
+        def arr(a):
+            a = np.ascontiguousarray(a, dtype=np.float32)
             keep.append(a)
             return a.ctypes.data
+
+        def ptr(key):
+            return arr(sd[key].detach().to('cpu', torch.float32).numpy())
+
+        def f64(key):
+            return sd[key].detach().to('cpu', torch.float64).numpy()
+
+        def block_ptr(b, f, k):
+            """per-block tensor with the kwargs folds: qkv_bias=False -> zero bias; LayerScale gamma -> rows of proj / fc2 and their biases"""
+            key = f"blocks.{b}.{k}"
+            if f == "qkv_b" and not self.qkv_bias:
+                return arr(np.zeros(sd[f"blocks.{b}.attn.qkv.weight"].shape[0]))
+            ls = {"proj_w": "ls1", "proj_b": "ls1", "fc2_w": "ls2", "fc2_b": "ls2"}.get(f)
+            if ls is not None and self.init_values:
+                g = f64(f"blocks.{b}.{ls}.gamma")
+                return arr(f64(key) * (g[:, None] if f.endswith("_w") else g))
+            return ptr(key)
 
         blocks = (_lib.BlockWeights * self.depth)()
         names = {"norm1_w": "norm1.weight", "norm1_b": "norm1.bias", "qkv_w": "attn.qkv.weight", "qkv_b": "attn.qkv.bias",
@@ -272,11 +306,17 @@ class UITBase(nn.Module):
                  "fc2_w": "mlp.fc2.weight", "fc2_b": "mlp.fc2.bias"}
         for b in range(self.depth):
             for f, k in names.items():
-                setattr(blocks[b], f, ptr(f"blocks.{b}.{k}"))
+                setattr(blocks[b], f, block_ptr(b, f, k))
         keep.append(blocks)
+        if self.use_init_bn:
+            bn = dict(bn_weight=ptr("init_bn.1.weight"), bn_bias=ptr("init_bn.1.bias"),
+                      bn_mean=ptr("init_bn.1.running_mean"), bn_var=ptr("init_bn.1.running_var"))
+        else:       # GlobalNormer(-10, 20): (x + 10) / (2 * 20)  ==  eval BatchNorm with weight 1, bias 0, mean -10, var + eps = 1600
+            M = self.n_mels
+            bn = dict(bn_weight=arr(np.ones(M)), bn_bias=arr(np.zeros(M)), bn_mean=arr(np.full(M, -10.0)),
+                      bn_var=arr(np.full(M, 1600.0 - 1e-5)))
         w = _lib.Weights(window=ptr("front_end.0.spectrogram.window"), mel_fb=ptr("front_end.0.mel_scale.fb"),
-                         bn_weight=ptr("init_bn.1.weight"), bn_bias=ptr("init_bn.1.bias"),
-                         bn_mean=ptr("init_bn.1.running_mean"), bn_var=ptr("init_bn.1.running_var"),
+                         **bn,
                          pe_w=ptr("patch_embed.proj.weight"), pe_b=ptr("patch_embed.proj.bias"),
                          time_pos=ptr("time_pos_embed"), freq_pos=ptr("freq_pos_embed"),
                          norm_w=ptr("norm.weight"), norm_b=ptr("norm.bias"),
@@ -331,6 +371,8 @@ class UITBase(nn.Module):
         return x.to(torch.float32).contiguous(), _lib.IN_F32
 
     def num_frames(self, T):
+        if not self.center:                                  # torch.stft without centring: no padding
+            return 1 + (T - self.n_fft) // self.hop_size
         return 1 + T // self.hop_size
 
     def num_crops(self, T):
@@ -421,15 +463,16 @@ class UITBase(nn.Module):
         return out
 
     def precision_margin(self, x, gate=1e-3):
-        """Which parity precision does THIS checkpoint need?  Runs `x` through precision 'f16' and 'f16x2' (same kernels, the latter
-        with every weight as two fp16 terms) and returns the largest logit difference: that difference is the weight-rounding term
-        of the fp16 path -- 90 % of its error at trained-checkpoint magnitudes.  'f16x2' is recommended when it
-        exceeds 0.6 * gate.  No reference, no CPU: two forward passes on the device."""
-        if self.precision not in ('f16', 'f16x2'):
-            raise ValueError("precision_margin compares the two parity precisions 'f16' and 'f16x2'")
+        """How much of this checkpoint's fp16 error is weight rounding?  Runs `x` through precision 'f16' (single fp16 weights) and
+        'f16l6' (the parity mode: the same operands plus the low-order term of the fc1 / fc2 / proj weights) and returns the largest
+        logit difference: that difference IS the weight-rounding term plain fp16 would carry -- most of its error at trained-checkpoint
+        magnitudes.  'f16' is recommended (it is 1.25x faster) only while the term stays under 0.3 * gate.  No
+        reference, no CPU: two forward passes on the device."""
+        if self.precision not in ('f16', 'f16x2', 'f16l6'):
+            raise ValueError("precision_margin compares the fp16 precisions 'f16' and 'f16l6'")
         keep, out = self.precision, {}
         try:
-            for prec in ('f16', 'f16x2'):
+            for prec in ('f16', 'f16l6'):
                 self.precision = prec
                 self.refresh()
                 with torch.no_grad():
@@ -437,9 +480,9 @@ class UITBase(nn.Module):
         finally:
             self.precision = keep
             self.refresh()
-        d = float((out['f16'] - out['f16x2']).abs().max())
-        return {'max_abs_logit_diff': d, 'max_abs_logit': float(out['f16x2'].abs().max()),
-                'recommended': 'f16x2' if d > 0.6 * gate else 'f16'}
+        d = float((out['f16'] - out['f16l6']).abs().max())
+        return {'max_abs_logit_diff': d, 'max_abs_logit': float(out['f16l6'].abs().max()),
+                'recommended': 'f16l6' if d > 0.3 * gate else 'f16'}
 
     def debug_tokens(self, x):
         """(probs, tokens[B, ncrops, depth+1, 24, 128]): residual stream after patch-embed and after each block."""
