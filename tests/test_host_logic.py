@@ -246,3 +246,28 @@ def test_other_kwargs_keep_the_reference_state_dict_layout():
     assert c.num_frames(16000) == 97 and c.num_crops(16000) == 1 and c.num_crops(17000) == 2
     assert models.uit_xxxs().num_frames(16000) == 101
     assert len(c.eval().packed_image()) > 0
+
+
+def test_pinned_batch_feeder_orders_batches_and_pads_like_the_collate():
+    """PinnedBatchFeeder (round 3): several producer threads fill a ring of int16 batches; the consumer receives
+    them in batch order, every clip zero right-padded (dataset.py:183-204) even when its buffer held a longer clip before; a producer
+    exception surfaces in the consumer."""
+    from uit_mobile_amd.streaming import PinnedBatchFeeder
+
+    def fill(i, out):
+        for r in range(out.shape[0]):
+            PinnedBatchFeeder.collate(out[r], np.full(100 + r - 5 * (i % 3), i * 10 + r, np.int16))
+    f = PinnedBatchFeeder(fill, 11, 4, 128, producers=3, pin=False)
+    got = [b.clone().numpy() for b in f]
+    assert len(got) == 11
+    for i, g in enumerate(got):
+        for r in range(4):
+            n = 100 + r - 5 * (i % 3)
+            assert (g[r, :n] == i * 10 + r).all() and (g[r, n:] == 0).all()
+
+    def bad(i, out):
+        if i == 2:
+            raise OSError("unreadable clip")
+        out[:] = i
+    with pytest.raises(OSError):
+        list(PinnedBatchFeeder(bad, 5, 2, 16, producers=2, pin=False))

@@ -66,3 +66,96 @@ class HostClipStreamer:
             if nxt is None:
                 return
             slot, n = slot ^ 1, n_next
+
+
+class PinnedBatchFeeder:
+    """Multi-producer front of the streamer (the reference's DataLoader workers, dataset.py:16-56, 183-204: `num_workers` processes
+    read int16 clips, collate = zero right-pad to the batch maximum).  `producers` host threads fill a ring of `depth` PINNED int16
+    batches in parallel -- each calls `fill(i, out)` for its own batch indices, `out` being the numpy view [batch_size, clip_samples] of
+    a pinned buffer it may write clip by clip (a clip shorter than clip_samples is zero-padded: `collate`) -- and hands them over IN
+    ORDER; iterating the feeder yields pinned tensors that `HostClipStreamer.run` sends without a CPU copy.  numpy / file reads
+    release the GIL, so the threads overlap; a buffer returns to the producers once the NEXT-BUT-ONE batch has been handed out (the
+    streamer keeps at most two batches in flight: one in H2D, one in the kernels).
+
+        feeder = PinnedBatchFeeder(fill, n_batches, batch_size=8192, clip_samples=16000, producers=8)
+        for probs in HostClipStreamer(model, 8192, 16000).run(feeder): ...
+    """
+
+    def __init__(self, fill, n_batches, batch_size, clip_samples, producers=4, depth=None, pin=True):
+        import queue
+        import threading
+        self.fill, self.n, self.B, self.T = fill, int(n_batches), int(batch_size), int(clip_samples)
+        self.depth = depth or max(4, producers + 2)
+        self.bufs = [torch.zeros((self.B, self.T), dtype=torch.int16) for _ in range(self.depth)]
+        if pin:                                            # (pin=False: host-logic tests without a device)
+            self.bufs = [b.pin_memory() for b in self.bufs]
+        self._free = queue.Queue()
+        for i in range(self.depth):
+            self._free.put(i)
+        self._done = {}                                    # batch index -> buffer index (filled)
+        self._cv = threading.Condition()
+        self._next = 0                                     # next batch index to hand to a producer
+        self._lock = threading.Lock()
+        self._err = None
+        self._stop = False
+        self._threads = [threading.Thread(target=self._work, daemon=True) for _ in range(max(1, int(producers)))]
+        for t in self._threads:
+            t.start()
+
+    @staticmethod
+    def collate(out_row, clip):
+        """dataset.py:183-204 for one clip: copy, zero right-pad (the row may hold an older, longer clip)"""
+        n = min(len(clip), out_row.shape[0])
+        out_row[:n] = clip[:n]
+        out_row[n:] = 0
+
+    def _work(self):
+        while True:
+            # a buffer FIRST, then the batch index: indices are handed out in the order buffers are obtained, so the lowest batch
+            # still outstanding always owns a buffer (index first would let later batches starve it of one: deadlock)
+            b = None
+            while b is None:                               # (bounded waits: a producer must notice close() and end with the process)
+                if self._stop:
+                    return
+                try:
+                    b = self._free.get(timeout=0.05)
+                except Exception:
+                    b = None
+            with self._lock:
+                i = self._next
+                if i >= self.n:
+                    return
+                self._next += 1
+            try:
+                self.fill(i, self.bufs[b].numpy())
+            except Exception as e:                         # surfaces in the consumer
+                with self._cv:
+                    self._err = e
+                    self._cv.notify_all()
+                return
+            with self._cv:
+                self._done[i] = b
+                self._cv.notify_all()
+
+    def close(self):
+        """Stop the producers (called when the iteration ends, normally or not)."""
+        self._stop = True
+        for t in self._threads:
+            t.join(timeout=5.0)
+
+    def __iter__(self):
+        held = []                                          # buffers handed out and possibly still read by an H2D copy
+        try:
+            for i in range(self.n):
+                with self._cv:
+                    while i not in self._done and self._err is None:
+                        self._cv.wait(timeout=0.5)
+                    if self._err is not None:
+                        raise self._err
+                    b = self._done.pop(i)
+                yield self.bufs[b]
+                held.append(b)
+                if len(held) > 2:                          # the streamer has moved two batches on: that copy has completed
+                    self._free.put(held.pop(0))
+        finally:
+            self.close()
