@@ -234,7 +234,7 @@ int uitk_set_timing_buffers(uitk_model* m, unsigned long long* enc_buf, unsigned
 #ifndef UITK_LAB
     if (enc_buf || fe_buf) return fail(UITK_ERR_UNSUPPORTED, "the instrumented kernels exist in -DUITK_LAB builds of the library only (tools/mklib.sh)");
 #else
-    if ((enc_buf || fe_buf) && (m->cfg.precision != UITK_PREC_F16 || m->cfg.attention_full || m->cfg.act_gelu || m->cfg.pooling))
+    if ((enc_buf || fe_buf) && ((m->cfg.precision != UITK_PREC_F16 && m->cfg.precision != UITK_PREC_F16L6) || m->cfg.attention_full || m->cfg.act_gelu || m->cfg.pooling))
         return fail(UITK_ERR_UNSUPPORTED, "the instrumented kernel builds exist for precision f16, BNeckAttention + ReLU only");
 #endif
     m->timing = enc_buf; m->timing_fe = fe_buf;

@@ -153,6 +153,11 @@ __device__ __forceinline__ void ring_step(const char* wstream, char* ring, int t
     asm volatile("" ::: "memory");
 }
 
+__device__ __forceinline__ int lane_id_now() {            // lane id from the exec-mask count: two VALU instructions, never a live register
+    int l;
+    asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l));
+    return l;
+}
 // scalar-base form of a 16-byte-per-lane LDS-DMA, written out: uniform 64-bit global base (SGPR pair) + ONE 32-bit lane offset, uniform
 // LDS address in M0.  The builtin selects the 64-bit per-lane address form, i.e. a register pair per distinct piece that stays live
 // (or is spilled and reloaded -- a vmem op the counted vmcnt scheme cannot see) across the whole block loop.
@@ -194,9 +199,13 @@ __device__ __forceinline__ float hsum(f4 x) { return (x[0] + x[1]) + (x[2] + x[3
 // softmax alone.  The hardware maximum needs no canonical inputs and the scores are never NaN.
 __device__ __forceinline__ float vmax(float a, float b) { float r; asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
 __device__ __forceinline__ float vmax3(float a, float b, float c) { float r; asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; }
+// hmax takes MFMA results: its FIRST instruction must be one the compiler sees (v_med3_f32 against FLT_MAX = the maximum of the other two, no
+// canonicalisation), so that the hazard recogniser pads the matrix-pipe -> VALU read.  An asm-only hmax read the accumulators zero to
+// two instructions behind the MFMA that writes them -- stale values, run-to-run different maxima (round 3, tools/l6_determinism.py).
 __device__ __forceinline__ float hmax(f4 x) {
+    const float m01 = __builtin_amdgcn_fmed3f(x[0], x[1], 3.4028234664e38f);          // (+inf instead would be folded to maxnum + canonicalise)
     float r;
-    asm("v_max3_f32 %0, %1, %2, %3\n\tv_max_f32 %0, %0, %4" : "=&v"(r) : "v"(x[0]), "v"(x[1]), "v"(x[2]), "v"(x[3]));
+    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(m01), "v"(x[2]), "v"(x[3]));
     return r;
 }
 
@@ -312,7 +321,8 @@ __device__ __forceinline__ void attention_proj(f4 (&R)[8][3], const typename OP:
                 for (int r = 0; r < 4; ++r) sv[r] = ((r < 2 ? pmask[i][0] : pmask[i][1]) >> (16 * (r & 1))) & 1u ? S[h][i][r] : -INFINITY;
                 tm[h][i] = hmax(sv);
             } else {
-                tm[h][i] = tvalid[i] ? hmax(S[h][i]) : -INFINITY;
+                const float hm = hmax(S[h][i]);                        // unconditional + select: the conditional form became a divergent branch
+                tm[h][i] = tvalid[i] ? hm : -INFINITY;
             }
         }
 #pragma unroll
@@ -967,16 +977,36 @@ __global__ __launch_bounds__(WAVES * 64, 2) void uit_encoder_kernel(EncoderArgs 
         // ================= precision f16l6: the f16 block + the low-order weight term on the MX-fp6 MFMA (uitk_dev.h) =================
         // Stage k of block blk lives in ring slot (2 blk + k) & 3 (14 stages per block); at step k the stage k + 2 is issued.
         static_assert(ATT == 0 && ACT == 0, "precision f16l6: BNeckAttention + ReLU (any pooling)");
+        // lane-derived values are re-derived per block from v_mbcnt (volatile: not hoisted): held across the block loop they are the
+        // register allocator's favourite spill candidates, and a reload right behind a ring step drains the DMAs just issued
+        const int lane = lane_id_now(), c = lane & 15, g = lane >> 4;
         const char* wblk = a.wstream + (size_t)PE_STAGES * STAGE_BYTES + (size_t)blk * L6_BLOCK_BYTES;
         const int sb = 2 * (blk & 1);
         auto slot_of = [&](int k) -> char* { return ring + ((sb + k) & 3) * L6_SLOT_BYTES; };
         const float* bias = (const float*)(breg + (blk & 1) * BIAS_FLOATS * 4);
         const int* sct = (const int*)(bias + L6_SCALES) + c;              // row-scale dwords [quad][row = c]
+#ifdef UITK_LAB
+        // lab diagnostic (tools/l6_canary.py): after the ring step of stage k, lane p compares the LAST dword of piece p of that stage's
+        // slot with the value the host read from the packed image -- a DMA that has not landed (or landed elsewhere) shows up as a count
+        auto canary = [&](int k, int np) {
+            if (a.timing == nullptr) return;
+            const int lid = threadIdx.x & 63;
+            if (lid < np) {
+                const unsigned got = *(const volatile unsigned*)(slot_of(k) + lid * FRAG_BYTES + 1020);
+                const unsigned want = ((const unsigned*)a.timing)[32 + (blk * 14 + k) * 32 + lid];
+                if (got != want) { atomicAdd((unsigned*)a.timing + k, 1u); atomicAdd((unsigned*)a.timing + 16 + (lid >> 2), 1u); }
+            }
+        };
+#define L6_CANARY(k, np) canary(k, np)
+#else
+#define L6_CANARY(k, np) ((void)0)
+#endif
         v8 X[4][3];
         layernorm_to_operand<OPC>(R, 1e-6f, X);
         // ===== stage QK (issue MLP stage 0; younger stages VP + M).  qkv keeps single fp16 weights: its rounding is the smallest of the
         // four weight terms and the stage has no register room for a second operand set
         l6_step<2, l6_dma_count<1>() + l6_dma_count<2>()>(wblk + l6_mlp_offset(0), slot_of(2), wave, lane);
+        L6_CANARY(0, 16);
         if (blk + 1 < a.depth) bias_issue<WAVES, true>(a.bias, breg, blk + 1, wave, lane);
         v4 Qh[2][3], Kh[2][3];
         {
@@ -1002,6 +1032,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void uit_encoder_kernel(EncoderArgs 
         }
         // ===== stage VP (issue MLP stage 1; younger stages M + M); proj on split fp16 weights (K = 32: 24 more MFMAs)
         l6_step<2, 2 * l6_dma_count<2>()>(wblk + l6_mlp_offset(1), slot_of(3), wave, lane);
+        L6_CANARY(1, 24);
         {
             const char* slot = slot_of(1);
             v4 Vh[3][2];
@@ -1045,10 +1076,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void uit_encoder_kernel(EncoderArgs 
         u6 X6[3];
 #pragma unroll
         for (int ct = 0; ct < 3; ++ct) X6[ct] = operand_to_fp6(X[0][ct], X[1][ct], X[2][ct], X[3][ct]);
-        // v_cvt_scalef32_pk32_fp6_f16 is a multi-pass VALU instruction whose 6-register result the matrix pipe may read too early: the
-        // compiler's hazard table pads a VALU -> MFMA operand dependency for single-pass producers only.  Measured: without these
-        // wait states the low-order term -- and so the last bits of the output -- differed from run to run (tools/l6_determinism.py).
-        asm volatile("s_nop 7\n\ts_nop 7" : "+v"(X6[0]), "+v"(X6[1]), "+v"(X6[2]));
+        asm volatile("" : "+v"(X6[0]), "+v"(X6[1]), "+v"(X6[2]));        // converted HERE, once per block (not re-materialised per chunk)
 #pragma unroll 1
         for (int q = 0; q < 3; ++q) {
 #pragma unroll
@@ -1064,6 +1092,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void uit_encoder_kernel(EncoderArgs 
                     if (q < 2) l6_step<2, 2 * l6_dma_count<2>()>(wblk + l6_mlp_offset(ch + 2), slot_of(ch + 4), wave, lane);
                     else l6_step<1, l6_dma_count<0>() + l6_dma_count<1>()>(wblk + L6_BLOCK_BYTES + L6_QK_BYTES, slot_of(ch + 4), wave, lane);
                 }
+                L6_CANARY(ch + 2, j == 3 ? 31 : 19);
                 const char* slot = slot_of(ch + 2);
                 v8 HX[3];
                 {
@@ -1074,10 +1103,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void uit_encoder_kernel(EncoderArgs 
                     // packed halves, before the next tile starts).  Each chain starts with its low-order MFMA: that one needs no f16
                     // fragment, so it and the fp6 conversions run while the fragment reads are still in flight.  The f16 k-steps are
                     // written k-step-major so that the 3 NT chains interleave.
-#ifndef L6_NT
-#define L6_NT 1
-#endif
-                    constexpr int NT = L6_NT;
+                    constexpr int NT = 1;
                     v4 P[2][3];
 #pragma unroll
                     for (int t0 = 0; t0 < 2; t0 += NT) {
@@ -1126,9 +1152,6 @@ __global__ __launch_bounds__(WAVES * 64, 2) void uit_encoder_kernel(EncoderArgs 
                         for (int ct = 0; ct < 3; ++ct) R[ft][ct] = OP::mfma32(A2[ft], HX[ct], R[ft][ct]);
                 }
                 if (j == 3 && !(L6_ABL & 2)) {                        // fc2 low-order term of k-group q
-                    // (same producer -> matrix-pipe hazard as after the fp6 conversion: v_cvt_scalef32_pk_fp4_f16 writes one byte of its
-                    // destination; the operand is normally long finished here -- 24 MFMAs lie in between -- the wait states make it certain)
-                    asm volatile("s_nop 7" : "+v"(HX4[0]), "+v"(HX4[1]), "+v"(HX4[2]));
                     const int s2a = sct[(6 + 2 * q) * 16], s2b = sct[(7 + 2 * q) * 16];
 #pragma unroll
                     for (int ft = 0; ft < 8; ++ft) {
@@ -1202,7 +1225,8 @@ __global__ __launch_bounds__(WAVES * 64, 2) void uit_encoder_kernel(EncoderArgs 
                     for (int r = 0; r < 4; ++r) sv[r] = ((r < 2 ? pmask[i][0] : pmask[i][1]) >> (16 * (r & 1))) & 1u ? S[i][r] : -INFINITY;
                     tm[i] = hmax(sv);
                 } else {
-                    tm[i] = tvalid[i] ? hmax(S[i]) : -INFINITY;
+                    const float hm = hmax(S[i]);
+                    tm[i] = tvalid[i] ? hm : -INFINITY;
                 }
             }
             mx[0] = xmax(vmax(tm[0], tm[1]));
@@ -1766,6 +1790,8 @@ static hipError_t launch_enc(const EncoderArgs& a, hipStream_t stream) {
 
 hipError_t launch_encoder(const EncoderArgs& a, int precision, int waves, hipStream_t stream) {
 #ifdef UITK_LAB
+    if (a.timing != nullptr && precision == 4)            // -DUITK_LAB: the f16l6 kernel with its DMA canary check (tools/l6_canary.py)
+        return a.nt < GT ? hipErrorInvalidValue : launch_enc<4, 8, false>(a, stream);
     if (a.timing != nullptr) {                            // -DUITK_LAB: build with in-kernel stamps (f16, full clips only; tools/phase_timing.py)
         if (a.nt < GT) return hipErrorInvalidValue;       // the instrumented build has no short-clip (masked padding) instantiation
         return waves == 4 ? launch_enc<0, 4, false, true>(a, stream) : launch_enc<0, 8, false, true>(a, stream);
