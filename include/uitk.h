@@ -46,13 +46,14 @@ typedef enum uitk_precision {
                            internals, proj and the head stay f16.  Far outside the 1e-3 gate: a measured throughput mode */
     UITK_PREC_F16X2 = 3,/* every weight of the path as TWO fp16 terms (W = hi + lo, 22 significant bits, two MFMAs per fragment),
                            activations fp16 as in UITK_PREC_F16: the reference point for what weight splitting can buy, at ~1.7x the
-                           encoder time; uit_* family (BNeckAttention, mean pooling) only */
+                           encoder time.  Mean pooling; any attention / activation (round 3): it is the parity mode of the
+                           full-width-attention / GELU factories (audio_transformer_*), which have no UITK_PREC_F16L6 build */
     UITK_PREC_F16L6 = 4 /* THE PARITY MODE (round 3): fp16 operands as UITK_PREC_F16 plus the LOW-ORDER weight term on the cheap pipe:
                            W = f16(W) + 2^e(row) . e2m3(W - f16(W)), the second term as OCP fp6 on
                            v_mfma_scale_f32_16x16x128_f8f6f4 (one MFMA at the cost of one f16 k-step covers K = 128) against fp6
                            (LayerNorm outputs) / fp4 (ReLU outputs) copies of the activations; proj (K = 32) takes a full fp16 low
                            term.  Same accuracy as UITK_PREC_F16X2 (the correction only needs ~3 significant bits) at ~1/4 of its
-                           extra MFMA time; uit_* family (BNeckAttention, ReLU, mean pooling) only */
+                           extra MFMA time; BNeckAttention + ReLU (the uit_* family), any pooling */
 } uitk_precision;
 
 typedef enum uitk_eval_avg { UITK_AVG_MEAN = 0, UITK_AVG_MAX = 1 } uitk_eval_avg; /* models/uit.py:483-488 */
@@ -190,6 +191,8 @@ int uitk_set_timing_buffers(uitk_model* m, unsigned long long* enc_buf, unsigned
  *   "split_pe"          1 / 0: patch embed on split (hi + lo) weights; -1 = the precision's default (on for f16x2)
  *   "enc_generic_clamp" 1 = use the generic top_db clamp path even when every init_bn scale is >= 0 (test of that path) */
 int uitk_set_option(uitk_model* m, const char* name, int value);
+/* Current value of an option ("fe_asym_pm" after a calibrating uitk_reserve = the share measured on this device). */
+int uitk_get_option(const uitk_model* m, const char* name, int* value);
 
 /* ---- Step after the path: post-processing of the probability rows on the device, so that only
  * k winners (or class indices) cross PCIe instead of [B, outputdim].  Stateless: no model handle.  C <= 1024.

@@ -207,7 +207,8 @@ def test_precision_margin_recommends_by_checkpoint(golden):
     error 1.1e-3 at |logit| 12) -> 'f16l6'.  The factories default to the parity mode."""
     x = torch.from_numpy(synth_pcm_i16(24, 16000, seed=3)).cuda()
     assert models.uit_xs(outputdim=537, target_length=102).precision == "f16l6"
-    assert models.audio_transformer_h128_d4_m3(outputdim=537, target_length=102).precision == "f16"
+    assert models.audio_transformer_h128_d4_m3(outputdim=537, target_length=102).precision == "f16x2"
+    assert models.audio_transformer_h128_d4_m3(outputdim=537, target_length=102, pooling="dm").precision == "f16"
     m, _ = build("uit_xs", 13)
     r = m.precision_margin(x)
     assert r["recommended"] == "f16" and r["max_abs_logit_diff"] < 3e-4 and m.precision == "f16"
@@ -270,23 +271,27 @@ def test_golden_other_factories(golden, name, act):
     trained = bool(g["trained"])
     sd = (make_trained_like_state_dict if trained else make_state_dict)(name, int(g["seed"]), attention="full")
     m = getattr(models, name)(outputdim=537, target_length=102)
+    assert m.precision == "f16x2"                                     # the family's parity mode (round 3: split weights on ATT = 1 / GELU)
     m.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()}, strict=True)
     m = m.to("cuda").eval()
     p, l = run(m, g["pcm"])
     dl, dp = np.abs(l - g["logits"]).max(), np.abs(p - g["probs"]).max()
     print(f"variant {name}: |logit|max {np.abs(g['logits']).max():.1f} max|dlogit| {dl:.2e} max|dprob| {dp:.2e}")
-    # init scale: the 1e-3 gate on logits and probabilities.  Trained-like magnitudes (|logit|max 12.3-12.7): the fp16 logit error
-    # is ~8e-5 of the logit range -- measured 9.6e-4 on the fixture, 1.03e-3 on a further batch -- so the logits
-    # are held to the MEASURED 1.5e-3 there, the probabilities (what the reference's API returns) to the gate.
-    tol_l = 1.5e-3 if trained else TOL
-    assert dl < tol_l and dp < TOL
+    # the 1e-3 gate on logits and probabilities at init scale AND at trained-like magnitudes (|logit|max 12.3-12.7).  Round 2 ran these
+    # factories on single fp16 weights and held the trained-like logits to a measured 1.5e-3; printed below for the record.
+    assert dl < TOL and dp < TOL
     _, toks = m.debug_tokens(torch.from_numpy(g["pcm"][:2]).cuda())
     assert np.abs(centred(toks.cpu().numpy()[:, 0]) - centred(g["stages"][:, 0])).max() < (2e-2 if trained else 8e-3)
     o = Oracle(sd, act=act)
     for pcm in (synth_pcm_i16(5, 16000, seed=3), synth_pcm_i16(3, 8000, seed=4), synth_pcm_i16(2, 16384, seed=5)):
         ref = o.forward(pcm)
         p, l = run(m, pcm)
-        assert np.abs(l - ref["logits"]).max() < tol_l and np.abs(p - ref["probs"]).max() < TOL
+        assert np.abs(l - ref["logits"]).max() < TOL and np.abs(p - ref["probs"]).max() < TOL
+    m16 = getattr(models, name)(outputdim=537, target_length=102, precision="f16")
+    m16.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()}, strict=True)
+    p16, l16 = run(m16.to("cuda").eval(), g["pcm"])
+    print(f"   single fp16 weights on the same fixture: max|dlogit| {np.abs(l16 - g['logits']).max():.2e}")
+    assert np.abs(p16 - g["probs"]).max() < TOL and (trained or np.abs(l16 - g["logits"]).max() < TOL)
 
 
 def test_golden_pooling_dm(golden):
@@ -546,6 +551,22 @@ def test_full_size_properties(name, B, seed):
     ref = Oracle(sd).forward(sub)
     assert np.abs(p[idx] - ref["probs"]).max() < TOL
     assert np.abs(l[idx] - ref["logits"]).max() < TOL
+
+
+@pytest.mark.parametrize("precision", ["f16l6", "f16", "f16x2"])
+def test_run_to_run_bit_identical(precision):
+    """The same batch twelve times: every output bit identical.  Round 3 found a build that was not (an inline-asm maximum read MFMA
+    accumulators before they were written -- DESIGN.md 2.2; only roundings moved, so every parity test passed): this is its guard.
+    UiT-3XS x 4096 (config #2's size: two waves per SIMD contend for issue slots, which is what made the hazard timing-dependent)."""
+    sd = make_state_dict("uit_xxxs", 5)
+    m = models.uit_xxxs(outputdim=537, target_length=102, precision=precision)
+    m.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()})
+    m = m.cuda().eval()
+    x = torch.from_numpy(synth_pcm_i16(4096, 16000, seed=41)).cuda()
+    with torch.no_grad():
+        first = m(x).clone()
+        differing = sum(int(not torch.equal(first, m(x))) for _ in range(12))
+    assert differing == 0
 
 
 def test_pass_distribution_does_not_change_results():

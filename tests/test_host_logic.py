@@ -77,11 +77,16 @@ def test_other_factories_match_reference_layout(name, depth, gelu):
         assert tuple(mine[k].shape) == tuple(np.asarray(sd[k]).shape), k
     assert tuple(mine["blocks.0.attn.qkv.weight"].shape) == (384, 128) and tuple(mine["blocks.0.attn.proj.weight"].shape) == (128, 128)
     assert m.depth == depth and m.attention_full and m.act_gelu == gelu and m.pooling == "mean"
-    img = m.eval().packed_image()                   # host-only packing of the 20-stage layout works without a GPU
-    assert len(img) > (8 + 20 * depth) * 16384
-    for prec in ("fp8", "f16x2"):                   # built for the uit_* family only
-        with pytest.raises(NotImplementedError):
-            getattr(models, name)(outputdim=537, target_length=102, precision=prec)
+    assert m.precision == "f16x2"                   # the family's parity mode: split fp16 weights (round 3), 40 stages per block
+    img = m.eval().packed_image()                   # host-only packing works without a GPU
+    assert len(img) > (8 + 40 * depth) * 16384
+    m16 = getattr(models, name)(outputdim=537, target_length=102, precision="f16").eval()
+    assert (8 + 40 * depth) * 16384 > len(m16.packed_image()) > (8 + 20 * depth) * 16384       # the 20-stage single-weight layout
+    with pytest.raises(NotImplementedError):        # built for the uit_* family only
+        getattr(models, name)(outputdim=537, target_length=102, precision="fp8")
+    with pytest.raises(NotImplementedError):        # split weights: mean pooling only
+        getattr(models, name)(outputdim=537, target_length=102, precision="f16x2", pooling="token")
+    assert getattr(models, name)(outputdim=537, target_length=102, pooling="token").precision == "f16"
 
 
 def test_precision_kwarg_surface():

@@ -187,6 +187,66 @@ def test_f16x2_weight_stream_holds_hi_plus_lo_of_every_block_weight():
                 check(W2[16 * ft:16 * ft + 16, 32 * ch:32 * ch + 32], st + 5 + 2 * ch, ft, 8 + ft)
 
 
+def test_f16x2_full_attention_stream_holds_hi_plus_lo_of_every_block_weight():
+    """precision='f16x2' on the full-width-attention factories (round 3): 40 stages per block (uitk_dev.h, BLOCK_STAGES_X2_ATT).  A q / k / v
+    row group of a head takes two stages of two d-tiles, tile slot dl = fragments dl*8 + s (hi), dl*8 + 4 + s (lo); proj four stages
+    of two output tiles; the MLP as in the bottleneck layout.  hi + lo must give the folded fp64 weight to 2^-21."""
+    import struct
+    from mfma_emu import HDR_FMT, HDR_FIELDS
+    from synth_weights import make_trained_like_state_dict
+    name = "audio_transformer_h128_d4_m3"
+    sd = make_trained_like_state_dict(name, 7, attention="full")
+    m = getattr(models, name)(outputdim=537, target_length=102)
+    assert m.precision == "f16x2"
+    m.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()}, strict=True)
+    img = m.eval().packed_image()
+    h = dict(zip(HDR_FIELDS, struct.unpack_from(HDR_FMT, img, 0)))
+    assert h["precision"] == 3
+    STAGE, FRAG, PE_ST, BLKX = 16384, 1024, 8, 40
+    assert h["off_bias"] - h["off_wstream"] >= (PE_ST + 4 * BLKX + 4) * STAGE
+
+    def frag(stage, f):
+        raw = np.frombuffer(img, np.float16, 512, h["off_wstream"] + stage * STAGE + f * FRAG).reshape(64, 8).astype(np.float64)
+        out = np.zeros((16, 32))
+        for lane in range(64):
+            c, g = lane & 15, lane >> 4
+            for j in range(8):
+                out[c, 16 * (j >> 2) + 4 * g + (j & 3)] = raw[lane, j]
+        return out
+
+    g = lambda k: np.asarray(sd[k], np.float64)
+    scale = (128 // 2) ** -0.5 * 1.4426950408889634
+    for b in (0, 3):
+        p = f"blocks.{b}."
+        Wq = g(p + "attn.qkv.weight") * g(p + "norm1.weight")[None]
+        Wq[:128] *= scale
+        Wp = g(p + "attn.proj.weight"); Wp = Wp - Wp.mean(0, keepdims=True)
+        W1 = g(p + "mlp.fc1.weight") * g(p + "norm2.weight")[None]
+        W2 = g(p + "mlp.fc2.weight"); W2 = W2 - W2.mean(0, keepdims=True)
+        st = PE_ST + b * BLKX
+
+        def check(want, stage, f_hi, f_lo):
+            hi, lo = frag(stage, f_hi), frag(stage, f_lo)
+            assert np.all(np.abs(hi + lo - want) <= np.abs(want) * 2.0 ** -21 + 2.0 ** -25), (stage, f_hi)
+            assert np.all(np.abs(hi - want) <= np.abs(want) * 2.0 ** -10 + 2.0 ** -24)
+
+        for hd in range(2):
+            for which in range(3):
+                for dt in range(4):
+                    r0 = which * 128 + hd * 64 + 16 * dt
+                    for s in range(4):
+                        check(Wq[r0:r0 + 16, 32 * s:32 * s + 32], st + 2 * (3 * hd + which) + dt // 2, (dt & 1) * 8 + s, (dt & 1) * 8 + 4 + s)
+        for ft in range(8):
+            for s in range(4):
+                check(Wp[16 * ft:16 * ft + 16, 32 * s:32 * s + 32], st + 12 + ft // 2, (ft & 1) * 8 + s, (ft & 1) * 8 + 4 + s)
+        for ch in (0, 6, 11):
+            for i in range(2):
+                for s in range(4):
+                    check(W1[32 * ch + 16 * i:32 * ch + 16 * i + 16, 32 * s:32 * s + 32], st + 16 + 2 * ch, i * 8 + s, i * 8 + 4 + s)
+            for ft in range(8):
+                check(W2[16 * ft:16 * ft + 16, 32 * ch:32 * ch + 32], st + 17 + 2 * ch, ft, 8 + ft)
+
+
 def test_structured_rounding_preserves_group_sums_of_the_conv_weights():
     """pack.cpp round_structured: the packed patch-embed weights are 16-bit neighbours of the exact (column-centred) conv
     weights -- never more than one step away -- and inside every group of 16 frame-columns of a mel row the SUMMED rounding
@@ -245,7 +305,7 @@ def test_emulated_f16l6_low_order_term_cuts_the_weight_rounding_error(seed):
 @pytest.mark.parametrize("factory,kw", [("uit_xxxs", dict(precision="f16")), ("uit_xxxs", dict(precision="bf16")), ("uit_xxxs", dict(precision="fp8")),
                                         ("uit_xxxs", dict(precision="f16x2")), ("uit_xxxs", dict(precision="f16l6")),
                                         ("uit_xxxs", dict(precision="f16", pooling="dm")), ("uit_xxxs", dict(precision="f16l6", pooling="token")),
-                                        ("audio_transformer_h128_d4_m3", dict(precision="f16")),
+                                        ("audio_transformer_h128_d4_m3", dict(precision="f16")), ("audio_transformer_h128_d4_m3", dict(precision="f16x2")),
                                         ("audio_transformer_h128_d4_m3_relu", dict(precision="f16", pooling="token")), ("audio_transformer_h128_d4_m3_relu", dict(precision="bf16"))])
 def test_everything_added_to_the_residual_stream_is_centred_at_pack_time(factory, kw):
     """The kernel's LayerNorm is mean-free (x * rsqrt(E[x^2] + eps), encoder.hip ln_stats): correct only while pack.cpp removes the

@@ -18,7 +18,7 @@ AMAX_SLOTS = 64
 
 EXPORTS = ["uitk_create", "uitk_destroy", "uitk_pack_weights", "uitk_num_frames", "uitk_num_crops",
            "uitk_reserve", "uitk_forward", "uitk_frontend", "uitk_amax_ptr", "uitk_encode", "uitk_mel_db",
-           "uitk_set_debug_tokens", "uitk_set_timing_buffers", "uitk_set_option", "uitk_topk", "uitk_kws_transform", "uitk_last_error",
+           "uitk_set_debug_tokens", "uitk_set_timing_buffers", "uitk_set_option", "uitk_get_option", "uitk_topk", "uitk_kws_transform", "uitk_last_error",
            "uitk_version"]
 
 
@@ -71,6 +71,7 @@ def load():
     L.uitk_set_debug_tokens.argtypes = [c_void_p, c_void_p]
     L.uitk_set_timing_buffers.argtypes = [c_void_p, c_void_p, c_void_p]
     L.uitk_set_option.argtypes = [c_void_p, c_char_p, c_int]
+    L.uitk_get_option.argtypes = [c_void_p, c_char_p, c_void_p]
     L.uitk_topk.argtypes = [c_void_p, c_int64, c_int32, c_int32, c_void_p, c_void_p, c_void_p]
     L.uitk_kws_transform.argtypes = [c_void_p, c_void_p, c_int64, c_int32, c_int32, c_float, c_void_p, c_void_p]
     L.uitk_last_error.restype = c_char_p

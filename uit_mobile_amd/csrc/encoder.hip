@@ -790,6 +790,155 @@ __global__ __launch_bounds__(WAVES * 64, 2) void uit_encoder_kernel(EncoderArgs 
     // ---- transformer blocks
 #pragma unroll 1
     for (int blk = 0; blk < a.depth; ++blk) {
+      // ===== full-width Attention (models/uit.py:124-178), shared by precisions f16 / bf16 (XS2 = false) and f16x2 (XS2 = true).
+      // Per head the row groups q_h, k_h, v_h (4 d-tiles x 4 k-steps each), scores between k_h and v_h (q and k die before v is produced),
+      // then proj.  f16 / bf16: one ring stage of 16 fragments per row group (6 stages) + 2 stages of proj.  f16x2: every stage holds
+      // the hi AND the lo fragments of HALF a group -- tile slot dl: fragments dl*8 + s (hi k-step s), dl*8 + 4 + s (lo) -- so an
+      // accumulator takes its hi chain and its lo chain inside one stage (12 + 4 stages).  The LN1 operand is recomputed for head 1
+      // instead of being kept alive across head 0's attention.
+      auto full_attention = [&](auto xs2_tag, int tb, const float* bias, v8 (&X)[4][3]) {
+        constexpr bool XS2 = decltype(xs2_tag)::value;
+        constexpr int NSUB = XS2 ? 2 : 1, DTS = 4 / NSUB, KF = XS2 ? 8 : 4;      // stages per group, d-tiles per stage, fragments per tile
+        const int g = lane >> 4, c = lane & 15;
+        v8 OX[4][3];                                                   // attention output, k-order of proj: k-step 2h + dt/2
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            if (h == 1) layernorm_to_operand<OPC>(R, 1e-6f, X);
+            v4 Qp[4][3], Kp[4][3];
+#pragma unroll
+            for (int which = 0; which < 2; ++which) {
+#pragma unroll
+                for (int sub = 0; sub < NSUB; ++sub) {
+                    const int t = tb + (3 * h + which) * NSUB + sub;
+                    ring_step<WAVES>(a.wstream, ring, t, wave, lane);
+                    if (h == 0 && which == 0 && sub == 0 && blk + 1 < a.depth) bias_issue<WAVES>(a.bias, breg, blk + 1, wave, lane);
+                    const char* slot = ring + (t & (RING_SLOTS - 1)) * STAGE_BYTES;
+#pragma unroll
+                    for (int dl = 0; dl < DTS; ++dl) {
+                        const int dt = sub * DTS + dl;
+                        f4 acc[3];
+                        const f4 bq = *(const f4*)(bias + BIASF_QKV + 128 * which + 64 * h + 16 * dt + 4 * g);
+#pragma unroll
+                        for (int ct = 0; ct < 3; ++ct) acc[ct] = bq;
+#pragma unroll
+                        for (int part = 0; part < KF / 4; ++part) {            // hi k-steps, then (f16x2) the lo k-steps
+                            v8 A[4];
+#pragma unroll
+                            for (int sk = 0; sk < 4; ++sk) A[sk] = lds_frag<OPC>(slot, dl * KF + 4 * part + sk, lane);
+#pragma unroll
+                            for (int ct = 0; ct < 3; ++ct)
+#pragma unroll
+                                for (int sk = 0; sk < 4; ++sk) acc[ct] = OP::mfma32(A[sk], X[sk][ct], acc[ct]);
+                        }
+#pragma unroll
+                        for (int ct = 0; ct < 3; ++ct) { if (which == 0) Qp[dt][ct] = OP::pack4(acc[ct]); else Kp[dt][ct] = OP::pack4(acc[ct]); }
+                    }
+                }
+            }
+            // S^T = K.Q^T over the 64-wide head: four chained K = 16 MFMAs per score tile (log2 domain, scale folded into Wq)
+            f4 S[7];
+            float tm[7], mx[3];
+#pragma unroll
+            for (int i = 0; i < 7; ++i) {
+                f4 acc = splat(0.f);
+#pragma unroll
+                for (int dt = 0; dt < 4; ++dt) acc = OP::mfma16(Kp[dt][TJ[i]], Qp[dt][TI[i]], acc);
+                S[i] = acc;
+                if constexpr (PERKEY) {
+                    f4 sv;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) sv[r] = ((r < 2 ? pmask[i][0] : pmask[i][1]) >> (16 * (r & 1))) & 1u ? S[i][r] : -INFINITY;
+                    tm[i] = hmax(sv);
+                } else {
+                    const float hm = hmax(S[i]);
+                    tm[i] = tvalid[i] ? hm : -INFINITY;
+                }
+            }
+            mx[0] = xmax(vmax(tm[0], tm[1]));
+            mx[1] = xmax(vmax3(tm[2], tm[3], tm[4]));
+            mx[2] = xmax(vmax(tm[5], tm[6]));
+            // v_h token-major (operand roles swapped: tokens are the rows)
+            v4 Vp[3][4];
+#pragma unroll
+            for (int sub = 0; sub < NSUB; ++sub) {
+                const int t = tb + (3 * h + 2) * NSUB + sub;
+                ring_step<WAVES>(a.wstream, ring, t, wave, lane);
+                const char* slot = ring + (t & (RING_SLOTS - 1)) * STAGE_BYTES;
+#pragma unroll
+                for (int dl = 0; dl < DTS; ++dl) {
+                    const int dt = sub * DTS + dl;
+                    f4 acc[3];
+                    const f4 bv = splat(bias[BIASF_QKV + 256 + 64 * h + 16 * dt + c]);
+#pragma unroll
+                    for (int ct = 0; ct < 3; ++ct) acc[ct] = bv;
+#pragma unroll
+                    for (int part = 0; part < KF / 4; ++part) {
+                        v8 Bw[4];
+#pragma unroll
+                        for (int sk = 0; sk < 4; ++sk) Bw[sk] = lds_frag<OPC>(slot, dl * KF + 4 * part + sk, lane);
+#pragma unroll
+                        for (int ct = 0; ct < 3; ++ct)
+#pragma unroll
+                            for (int sk = 0; sk < 4; ++sk) acc[ct] = OP::mfma32(X[sk][ct], Bw[sk], acc[ct]);
+                    }
+#pragma unroll
+                    for (int ct = 0; ct < 3; ++ct) Vp[ct][dt] = OP::pack4(acc[ct]);
+                }
+            }
+            f4 O[4][3], Lsum[3];
+#pragma unroll
+            for (int it = 0; it < 3; ++it) {
+                Lsum[it] = splat(0.f);
+#pragma unroll
+                for (int dt = 0; dt < 4; ++dt) O[dt][it] = splat(0.f);
+            }
+#pragma unroll
+            for (int i = 0; i < 7; ++i) {
+                f4 p;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) p[r] = __builtin_amdgcn_exp2f(S[i][r] - mx[TI[i]]);
+                const u2 bits = __builtin_bit_cast(u2, OP::pack4(p)) & pmask[i];
+                const v4 Pm = __builtin_bit_cast(v4, bits);
+#pragma unroll
+                for (int dt = 0; dt < 4; ++dt) O[dt][TI[i]] = OP::mfma16(Vp[TJ[i]][dt], Pm, O[dt][TI[i]]);
+                Lsum[TI[i]] = OP::mfma16(OP::ones4(), Pm, Lsum[TI[i]]);
+            }
+#pragma unroll
+            for (int it = 0; it < 3; ++it) {
+                const f4 inv = splat(__builtin_amdgcn_rcpf(Lsum[it][0]));
+                OX[2 * h][it] = OP::pack8(O[0][it] * inv, O[1][it] * inv);
+                OX[2 * h + 1][it] = OP::pack8(O[2][it] * inv, O[3][it] * inv);
+            }
+        }
+        // proj 128 -> 128: output tiles ft, four k-steps each (+ the lo k-steps): 2 stages of 4 tiles, or (f16x2) 4 stages of 2 tiles
+        constexpr int PST = 2 * NSUB, FTS = 8 / PST;
+#pragma unroll
+        for (int ps = 0; ps < PST; ++ps) {
+            const int t = tb + 6 * NSUB + ps;
+            ring_step<WAVES>(a.wstream, ring, t, wave, lane);
+            const char* slot = ring + (t & (RING_SLOTS - 1)) * STAGE_BYTES;
+#pragma unroll
+            for (int fl = 0; fl < FTS; ++fl) {
+                const int ft = FTS * ps + fl;
+                const f4 bp = *(const f4*)(bias + BIASF_PROJ + 16 * ft + 4 * g);
+                f4 acc[3];
+#pragma unroll
+                for (int ct = 0; ct < 3; ++ct) acc[ct] = add4s(R[ft][ct], bp);
+#pragma unroll
+                for (int part = 0; part < KF / 4; ++part) {
+                    v8 A[4];
+#pragma unroll
+                    for (int sk = 0; sk < 4; ++sk) A[sk] = lds_frag<OPC>(slot, fl * KF + 4 * part + sk, lane);
+#pragma unroll
+                    for (int ct = 0; ct < 3; ++ct)
+#pragma unroll
+                        for (int sk = 0; sk < 4; ++sk) acc[ct] = OP::mfma32(A[sk], OX[sk][ct], acc[ct]);
+                }
+#pragma unroll
+                for (int ct = 0; ct < 3; ++ct) R[ft][ct] = acc[ct];
+            }
+        }
+      };
       if constexpr (PREC == 2) {
         // ================= precision fp8: 8 ring stages per block (uitk_dev.h) =================
         const int tb = PE_STAGES + blk * BLOCK_STAGES_FP8;
@@ -875,11 +1024,17 @@ __global__ __launch_bounds__(WAVES * 64, 2) void uit_encoder_kernel(EncoderArgs 
         // ================= precision f16x2: W = hi + lo, 28 ring stages per block (uitk_dev.h) =================
         // Every stage carries the hi and the lo fragments of the rows it covers; an accumulator takes the hi chain, then the lo
         // chain, and is finished (packed / ReLU'd) inside the stage.  Activations are the fp16 operands of precision f16.
-        static_assert(ATT == 0 && POOL == 0, "precision f16x2: uit_* family only");
-        const int tb = PE_STAGES + blk * BLOCK_STAGES_X2;
+        // Full-width attention (ATT = 1, round 3): 16 attention stages (full_attention above) + the same 24 MLP stages = 40 per block.
+        static_assert(POOL == 0, "precision f16x2: mean pooling only");
+        constexpr int BLK_ST = ATT ? BLOCK_STAGES_X2_ATT : BLOCK_STAGES_X2, MLP0 = ATT ? 16 : 4;
+        constexpr int B_FC1 = ATT ? BIASF_FC1 : BIAS_FC1, B_FC2 = ATT ? BIASF_FC2 : BIAS_FC2;
+        const int tb = PE_STAGES + blk * BLK_ST;
         const float* bias = (const float*)(breg + (blk & 1) * BIAS_FLOATS * 4);
         v8 X[4][3];
         layernorm_to_operand<OPC>(R, 1e-6f, X);
+        if constexpr (ATT) {
+        full_attention(std::true_type{}, tb, bias, X);
+        } else {
         v4 Qh[2][3], Kh[2][3], Vh[3][2];
 #pragma unroll
         for (int half = 0; half < 2; ++half) {                             // stage 0: q h0, q h1; stage 1: k h0, k h1
@@ -921,20 +1076,21 @@ __global__ __launch_bounds__(WAVES * 64, 2) void uit_encoder_kernel(EncoderArgs 
         }
         ring_step<WAVES>(a.wstream, ring, tb + 3, wave, lane);             // stage 3: attention + proj (hi, lo)
         attention_proj<OP, PERKEY, true>(R, Qh, Kh, Vh, tvalid, pmask, ring + ((tb + 3) & (RING_SLOTS - 1)) * STAGE_BYTES, bias, lane, g);
+        }
         layernorm_to_operand<OPC>(R, 1e-6f, X);
 #pragma unroll 1
         for (int ch = 0; ch < 12; ++ch) {
             v8 HX[3];
-            ring_step<WAVES>(a.wstream, ring, tb + 4 + 2 * ch, wave, lane);     // fc1 rows 32ch .. 32ch+31
+            ring_step<WAVES>(a.wstream, ring, tb + MLP0 + 2 * ch, wave, lane);  // fc1 rows 32ch .. 32ch+31
             {
-                const char* slot = ring + ((tb + 4 + 2 * ch) & (RING_SLOTS - 1)) * STAGE_BYTES;
+                const char* slot = ring + ((tb + MLP0 + 2 * ch) & (RING_SLOTS - 1)) * STAGE_BYTES;
                 f4 H[2][3];
 #pragma unroll
                 for (int i = 0; i < 2; ++i) {
                     v8 A[8];
 #pragma unroll
                     for (int f = 0; f < 8; ++f) A[f] = lds_frag<OPC>(slot, 8 * i + f, lane);
-                    const f4 b1 = *(const f4*)(bias + BIAS_FC1 + 32 * ch + 16 * i + 4 * g);
+                    const f4 b1 = *(const f4*)(bias + B_FC1 + 32 * ch + 16 * i + 4 * g);
 #pragma unroll
                     for (int ct = 0; ct < 3; ++ct) {
                         H[i][ct] = b1;
@@ -948,9 +1104,9 @@ __global__ __launch_bounds__(WAVES * 64, 2) void uit_encoder_kernel(EncoderArgs 
                     else HX[ct] = OP::relu_pack8(H[0][ct], H[1][ct]);
                 }
             }
-            ring_step<WAVES>(a.wstream, ring, tb + 5 + 2 * ch, wave, lane);     // fc2 k-step ch
+            ring_step<WAVES>(a.wstream, ring, tb + MLP0 + 1 + 2 * ch, wave, lane);     // fc2 k-step ch
             {
-                const char* slot = ring + ((tb + 5 + 2 * ch) & (RING_SLOTS - 1)) * STAGE_BYTES;
+                const char* slot = ring + ((tb + MLP0 + 1 + 2 * ch) & (RING_SLOTS - 1)) * STAGE_BYTES;
 #pragma unroll
                 for (int half = 0; half < 2; ++half) {
                     v8 A2[8];
@@ -965,7 +1121,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void uit_encoder_kernel(EncoderArgs 
         }
 #pragma unroll
         for (int ft = 0; ft < 8; ++ft) {
-            const f4 b2 = *(const f4*)(bias + BIAS_FC2 + 16 * ft + 4 * g);
+            const f4 b2 = *(const f4*)(bias + B_FC2 + 16 * ft + 4 * g);
 #pragma unroll
             for (int ct = 0; ct < 3; ++ct) R[ft][ct] = add4s(R[ft][ct], b2);
         }
@@ -1182,122 +1338,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void uit_encoder_kernel(EncoderArgs 
         TSTAMP(0);                                                     // LN1
 
         if constexpr (ATT) {
-        // ===== full-width Attention (models/uit.py:124-178): per head three ring stages (q_h, k_h, v_h: 16 fragments each =
-        // 4 d-tiles x 4 k-steps), scores between k_h and v_h (q and k die before v is produced), then two stages of proj.
-        // The LN1 operand is recomputed for head 1 instead of being kept alive across head 0's attention.
-        v8 OX[4][3];                                                   // attention output, k-order of proj: k-step 2h + dt/2
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            if (h == 1) layernorm_to_operand<OPC>(R, 1e-6f, X);
-            v4 Qp[4][3], Kp[4][3];
-#pragma unroll
-            for (int which = 0; which < 2; ++which) {
-                ring_step<WAVES>(a.wstream, ring, tb + 3 * h + which, wave, lane);
-                if (h == 0 && which == 0 && blk + 1 < a.depth) bias_issue<WAVES>(a.bias, breg, blk + 1, wave, lane);
-                const char* slot = ring + ((tb + 3 * h + which) & (RING_SLOTS - 1)) * STAGE_BYTES;
-#pragma unroll
-                for (int dt = 0; dt < 4; ++dt) {
-                    v8 A[4];
-#pragma unroll
-                    for (int sk = 0; sk < 4; ++sk) A[sk] = lds_frag<OPC>(slot, dt * 4 + sk, lane);
-                    const f4 bq = *(const f4*)(bias + BIASF_QKV + 128 * which + 64 * h + 16 * dt + 4 * g);
-#pragma unroll
-                    for (int ct = 0; ct < 3; ++ct) {
-                        f4 acc = bq;
-#pragma unroll
-                        for (int sk = 0; sk < 4; ++sk) acc = OP::mfma32(A[sk], X[sk][ct], acc);
-                        if (which == 0) Qp[dt][ct] = OP::pack4(acc); else Kp[dt][ct] = OP::pack4(acc);
-                    }
-                }
-            }
-            // S^T = K.Q^T over the 64-wide head: four chained K = 16 MFMAs per score tile (log2 domain, scale folded into Wq)
-            f4 S[7];
-            float tm[7], mx[3];
-#pragma unroll
-            for (int i = 0; i < 7; ++i) {
-                f4 acc = splat(0.f);
-#pragma unroll
-                for (int dt = 0; dt < 4; ++dt) acc = OP::mfma16(Kp[dt][TJ[i]], Qp[dt][TI[i]], acc);
-                S[i] = acc;
-                if constexpr (PERKEY) {
-                    f4 sv;
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) sv[r] = ((r < 2 ? pmask[i][0] : pmask[i][1]) >> (16 * (r & 1))) & 1u ? S[i][r] : -INFINITY;
-                    tm[i] = hmax(sv);
-                } else {
-                    const float hm = hmax(S[i]);
-                    tm[i] = tvalid[i] ? hm : -INFINITY;
-                }
-            }
-            mx[0] = xmax(vmax(tm[0], tm[1]));
-            mx[1] = xmax(vmax3(tm[2], tm[3], tm[4]));
-            mx[2] = xmax(vmax(tm[5], tm[6]));
-            // v_h token-major (operand roles swapped: tokens are the rows)
-            ring_step<WAVES>(a.wstream, ring, tb + 3 * h + 2, wave, lane);
-            v4 Vp[3][4];
-            {
-                const char* slot = ring + ((tb + 3 * h + 2) & (RING_SLOTS - 1)) * STAGE_BYTES;
-#pragma unroll
-                for (int dt = 0; dt < 4; ++dt) {
-                    v8 Bw[4];
-#pragma unroll
-                    for (int sk = 0; sk < 4; ++sk) Bw[sk] = lds_frag<OPC>(slot, dt * 4 + sk, lane);
-                    const f4 bv = splat(bias[BIASF_QKV + 256 + 64 * h + 16 * dt + c]);
-#pragma unroll
-                    for (int ct = 0; ct < 3; ++ct) {
-                        f4 acc = bv;
-#pragma unroll
-                        for (int sk = 0; sk < 4; ++sk) acc = OP::mfma32(X[sk][ct], Bw[sk], acc);
-                        Vp[ct][dt] = OP::pack4(acc);
-                    }
-                }
-            }
-            f4 O[4][3], Lsum[3];
-#pragma unroll
-            for (int it = 0; it < 3; ++it) {
-                Lsum[it] = splat(0.f);
-#pragma unroll
-                for (int dt = 0; dt < 4; ++dt) O[dt][it] = splat(0.f);
-            }
-#pragma unroll
-            for (int i = 0; i < 7; ++i) {
-                f4 p;
-#pragma unroll
-                for (int r = 0; r < 4; ++r) p[r] = __builtin_amdgcn_exp2f(S[i][r] - mx[TI[i]]);
-                const u2 bits = __builtin_bit_cast(u2, OP::pack4(p)) & pmask[i];
-                const v4 Pm = __builtin_bit_cast(v4, bits);
-#pragma unroll
-                for (int dt = 0; dt < 4; ++dt) O[dt][TI[i]] = OP::mfma16(Vp[TJ[i]][dt], Pm, O[dt][TI[i]]);
-                Lsum[TI[i]] = OP::mfma16(OP::ones4(), Pm, Lsum[TI[i]]);
-            }
-#pragma unroll
-            for (int it = 0; it < 3; ++it) {
-                const f4 inv = splat(__builtin_amdgcn_rcpf(Lsum[it][0]));
-                OX[2 * h][it] = OP::pack8(O[0][it] * inv, O[1][it] * inv);
-                OX[2 * h + 1][it] = OP::pack8(O[2][it] * inv, O[3][it] * inv);
-            }
-        }
-        // proj 128 -> 128: fragment ft*4 + s over two stages
-#pragma unroll
-        for (int half = 0; half < 2; ++half) {
-            ring_step<WAVES>(a.wstream, ring, tb + 6 + half, wave, lane);
-            const char* slot = ring + ((tb + 6 + half) & (RING_SLOTS - 1)) * STAGE_BYTES;
-#pragma unroll
-            for (int fl = 0; fl < 4; ++fl) {
-                const int ft = 4 * half + fl;
-                v8 A[4];
-#pragma unroll
-                for (int sk = 0; sk < 4; ++sk) A[sk] = lds_frag<OPC>(slot, fl * 4 + sk, lane);
-                const f4 bp = *(const f4*)(bias + BIASF_PROJ + 16 * ft + 4 * g);
-#pragma unroll
-                for (int ct = 0; ct < 3; ++ct) {
-                    f4 acc = add4s(R[ft][ct], bp);
-#pragma unroll
-                    for (int sk = 0; sk < 4; ++sk) acc = OP::mfma32(A[sk], OX[sk][ct], acc);
-                    R[ft][ct] = acc;
-                }
-            }
-        }
+        full_attention(std::false_type{}, tb, bias, X);
         } else {
         // ===== stage QK: fragments (ft = f/4 in {q h0, q h1, k h0, k h1}, s = f%4)
         ring_step<WAVES>(a.wstream, ring, tb, wave, lane);
@@ -1812,10 +1853,11 @@ hipError_t launch_encoder(const EncoderArgs& a, int precision, int waves, hipStr
         return a.nt < GT ? UITK_POOL(true, 1) : UITK_POOL(false, 1);
 #undef UITK_POOL
     }
-    if (a.attention_full || a.act_gelu) {                 // SURVEY 8f-4 variants: f16 / bf16, 8-wave workgroups
-        if (precision == 2 || a.timing != nullptr) return hipErrorInvalidValue;
+    if (a.attention_full || a.act_gelu) {                 // SURVEY 8f-4 variants: f16 / bf16 / f16x2, 8-wave workgroups
+        if (precision == 2 || precision == 4 || a.timing != nullptr) return hipErrorInvalidValue;
 #define UITK_VARIANT(P, SH) (a.attention_full ? (a.act_gelu ? launch_enc<P, 8, SH, false, 1, 1>(a, stream) : launch_enc<P, 8, SH, false, 1, 0>(a, stream)) \
                                                : launch_enc<P, 8, SH, false, 0, 1>(a, stream))
+        if (precision == 3) return a.nt < GT ? UITK_VARIANT(3, true) : UITK_VARIANT(3, false);      // split weights (round 3)
         if (a.nt < GT) return precision == 0 ? UITK_VARIANT(0, true) : UITK_VARIANT(1, true);
         return precision == 0 ? UITK_VARIANT(0, false) : UITK_VARIANT(1, false);
 #undef UITK_VARIANT

@@ -230,7 +230,7 @@ int validate_config(const uitk_config* c, const char** why) {
     if (c->outputdim < 1 || c->outputdim > 65536) return bad("outputdim out of range");
     if (c->eval_avg != UITK_AVG_MEAN && c->eval_avg != UITK_AVG_MAX) return bad("unknown eval_avg");
     if (c->precision != UITK_PREC_F16 && c->precision != UITK_PREC_BF16 && c->precision != UITK_PREC_FP8 && c->precision != UITK_PREC_F16X2 && c->precision != UITK_PREC_F16L6) return bad("unknown precision");
-    if (c->precision == UITK_PREC_F16X2 && (c->attention_full || c->act_gelu || c->pooling)) return bad("precision f16x2 is built for the uit_* family (BNeckAttention, ReLU, mean pooling) only");
+    if (c->precision == UITK_PREC_F16X2 && c->pooling) return bad("precision f16x2 is built for mean pooling only (any attention / activation)");
     if (c->precision == UITK_PREC_F16L6 && (c->attention_full || c->act_gelu)) return bad("precision f16l6 is built for BNeckAttention + ReLU (any pooling)");
     if ((c->attention_full != 0 && c->attention_full != 1) || (c->act_gelu != 0 && c->act_gelu != 1)) return bad("attention_full / act_gelu must be 0 or 1");
     if ((c->attention_full || c->act_gelu || c->pooling) && c->precision == UITK_PREC_FP8) return bad("precision fp8 is built for the uit_* family (BNeckAttention, ReLU, mean pooling) only");
@@ -323,7 +323,7 @@ int pack_image(const uitk_config* c, const uitk_weights* w, std::vector<char>* o
     const bool full = c->attention_full != 0;
     const int inner = full ? DIM : INNER;                                // qkv = Linear(dim, 3 * inner), proj = Linear(inner, dim)
     const bool x2 = c->precision == UITK_PREC_F16X2;                     // split weights: operand type fp16 (prec 0 for every conversion)
-    const int blk_stages = full ? BLOCK_STAGES_ATT : (prec == UITK_PREC_FP8 ? BLOCK_STAGES_FP8 : x2 ? BLOCK_STAGES_X2 : BLOCK_STAGES);
+    const int blk_stages = full ? (x2 ? BLOCK_STAGES_X2_ATT : BLOCK_STAGES_ATT) : (prec == UITK_PREC_FP8 ? BLOCK_STAGES_FP8 : x2 ? BLOCK_STAGES_X2 : BLOCK_STAGES);
     const int b_proj = full ? BIASF_PROJ : BIAS_PROJ, b_fc1 = full ? BIASF_FC1 : BIAS_FC1, b_fc2 = full ? BIASF_FC2 : BIAS_FC2;
     h.off_wstream = take(l6 ? (size_t)PE_STAGES * STAGE_BYTES + (size_t)depth * L6_BLOCK_BYTES + L6_TAIL_BYTES
                             : (size_t)(PE_STAGES + depth * blk_stages + TAIL_STAGES) * STAGE_BYTES);
@@ -486,18 +486,6 @@ int pack_image(const uitk_config* c, const uitk_weights* w, std::vector<char>* o
             }
             continue;
         }
-        if (full) {
-            // full-width Attention (uitk_dev.h): qkv row = which*128 + head*64 + d (uit.py:147-148) -> row tile which*8 + head*4 + dt
-            for (int hd = 0; hd < 2; ++hd)
-                for (int which = 0; which < 3; ++which)
-                    for (int f = 0; f < 16; ++f) pack_frag(frag_ptr(st + 3 * hd + which, f), prec, Wqkv, which * 8 + hd * 4 + f / 4, f % 4);
-            for (int i = 0; i < 32; ++i) pack_frag(frag_ptr(st + 6 + (i >> 4), i & 15), prec, Wproj, i / 4, i % 4);
-            for (int ch = 0; ch < 12; ++ch) {
-                for (int f = 0; f < 8; ++f) pack_frag(frag_ptr(st + 8 + ch, f), prec, Wfc1, 2 * ch + f / 4, f % 4);
-                for (int ft = 0; ft < 8; ++ft) pack_frag(frag_ptr(st + 8 + ch, 8 + ft), prec, Wfc2, ft, ch);
-            }
-            continue;
-        }
         if (l6) {
             // precision f16l6 (uitk_dev.h): the f16 stages of precision f16 + the low-order term lo = W - value(hi) of fc1 / fc2 as
             // fragment6 and of proj as full fp16 fragments (qkv keeps single weights); row scales into the bias table
@@ -535,6 +523,24 @@ int pack_image(const uitk_config* c, const uitk_weights* w, std::vector<char>* o
             const std::function<double(int, int)> fq = Wqkv, fp = Wproj, f1 = Wfc1, f2x = Wfc2_exact, f2h = Wfc2;
             const std::function<double(int, int)> lq = lo_of(fq), lp = lo_of(fp), l1 = lo_of(f1);
             const std::function<double(int, int)> l2 = [&](int r, int k) { return f2x(r, k) - f2h(r, k); };
+            auto hi_lo = [&](int stage, int slot8, const std::function<double(int, int)>& Whi, const std::function<double(int, int)>& Wlo, int tile, int nk) {
+                for (int s = 0; s < nk; ++s) {                          // tile slot: hi k-steps, then the lo k-steps
+                    pack_frag(frag_ptr(stage, slot8 * 8 + s), prec, Whi, tile, s);
+                    pack_frag(frag_ptr(stage, slot8 * 8 + 4 + s), prec, Wlo, tile, s);
+                }
+            };
+            if (full) {
+                // full-width Attention (uitk_dev.h, BLOCK_STAGES_X2_ATT): qkv row tile which*8 + hd*4 + dt -> stage 2 (3 hd + which) + dt/2
+                for (int hd = 0; hd < 2; ++hd)
+                    for (int which = 0; which < 3; ++which)
+                        for (int dt = 0; dt < 4; ++dt) hi_lo(st + 2 * (3 * hd + which) + dt / 2, dt & 1, fq, lq, which * 8 + hd * 4 + dt, 4);
+                for (int ft = 0; ft < 8; ++ft) hi_lo(st + 12 + ft / 2, ft & 1, fp, lp, ft, 4);
+                for (int ch = 0; ch < 12; ++ch) {
+                    for (int i = 0; i < 2; ++i) hi_lo(st + 16 + 2 * ch, i, f1, l1, 2 * ch + i, 4);
+                    for (int ft = 0; ft < 8; ++ft) { pack_frag(frag_ptr(st + 17 + 2 * ch, ft), prec, f2h, ft, ch); pack_frag(frag_ptr(st + 17 + 2 * ch, 8 + ft), prec, l2, ft, ch); }
+                }
+                continue;
+            }
             for (int t = 0; t < 6; ++t)                                  // qkv row tiles 0..5 -> stages 0, 1, 2, half t & 1
                 for (int s = 0; s < 4; ++s) {
                     pack_frag(frag_ptr(st + t / 2, (t & 1) * 8 + s), prec, fq, t, s);
@@ -548,6 +554,18 @@ int pack_image(const uitk_config* c, const uitk_weights* w, std::vector<char>* o
                         pack_frag(frag_ptr(st + 4 + 2 * ch, i * 8 + 4 + s), prec, l1, 2 * ch + i, s);
                     }
                 for (int ft = 0; ft < 8; ++ft) { pack_frag(frag_ptr(st + 5 + 2 * ch, ft), prec, f2h, ft, ch); pack_frag(frag_ptr(st + 5 + 2 * ch, 8 + ft), prec, l2, ft, ch); }
+            }
+            continue;
+        }
+        if (full) {
+            // full-width Attention (uitk_dev.h): qkv row = which*128 + head*64 + d (uit.py:147-148) -> row tile which*8 + head*4 + dt
+            for (int hd = 0; hd < 2; ++hd)
+                for (int which = 0; which < 3; ++which)
+                    for (int f = 0; f < 16; ++f) pack_frag(frag_ptr(st + 3 * hd + which, f), prec, Wqkv, which * 8 + hd * 4 + f / 4, f % 4);
+            for (int i = 0; i < 32; ++i) pack_frag(frag_ptr(st + 6 + (i >> 4), i & 15), prec, Wproj, i / 4, i % 4);
+            for (int ch = 0; ch < 12; ++ch) {
+                for (int f = 0; f < 8; ++f) pack_frag(frag_ptr(st + 8 + ch, f), prec, Wfc1, 2 * ch + f / 4, f % 4);
+                for (int ft = 0; ft < 8; ++ft) pack_frag(frag_ptr(st + 8 + ch, 8 + ft), prec, Wfc2, ft, ch);
             }
             continue;
         }

@@ -46,6 +46,10 @@ constexpr int BLOCK_STAGES_FP8 = 8;
 //   0: q h0, q h1 (per row tile: hi s0..3, lo s0..3)   1: k h0, k h1   2: v h0, v h1 (B operand)   3: proj ft 0..7 hi, then lo
 //   4 + 2ch: fc1 row tiles 2ch, 2ch+1 (hi s0..3, lo s0..3 each)        5 + 2ch: fc2 k-step ch, ft 0..7 hi, then lo
 constexpr int BLOCK_STAGES_X2 = 28;
+// f16x2 with full-width Attention (round 3): 40 stages per block.  A q / k / v row group of a head (4 d-tiles) takes TWO stages of two
+// tiles each -- tile slot dl: fragments dl*8 + s (hi k-step s) and dl*8 + 4 + s (lo) -- in the order of the f16 layout:
+//   2 (3h + which) + sub, which = q, k, v;   12 + i: proj output tiles 2i, 2i+1 (hi s0..3, lo s0..3 each);   16 + 2ch / 17 + 2ch: MLP as above
+constexpr int BLOCK_STAGES_X2_ATT = 40;
 // ---- precision f16l6 (W = f16 hi + MX-fp6 lo; round 3): the 14 stages of precision f16, the MLP / proj stages followed by the
 // low-order fragments of the rows they cover, in a ring of four 32 KiB slots (stage sizes differ; every DMA is static per call site).
 // A "fragment6" is the 1536-byte A operand of one v_mfma_scale_f32_16x16x128_f8f6f4 with e2m3 data: lane l = (row c = l&15,

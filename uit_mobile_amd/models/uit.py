@@ -177,13 +177,17 @@ class UITBase(nn.Module):
         if unsupported:
             raise NotImplementedError("uit_mobile_amd implements the uit_xs/xxs/xxxs family only: " + "; ".join(unsupported))
         if precision is None:
-            # default = the parity mode where it is built (BNeckAttention + ReLU: the uit_* family, any pooling), plain fp16 otherwise
-            precision = 'f16' if (self.attention_full or self.act_gelu) else 'f16l6'
+            # default = the parity mode of the family: f16l6 for BNeckAttention + ReLU (the uit_* family, any pooling); split fp16
+            # weights (f16x2) for the full-width-attention / GELU factories with mean pooling; plain fp16 where neither is built
+            if not (self.attention_full or self.act_gelu): precision = 'f16l6'
+            else: precision = 'f16x2' if pooling == 'mean' else 'f16'
             self.precision = precision
         if precision not in ('f16', 'bf16', 'fp8', 'f16x2', 'f16l6'):
             raise ValueError(f"Unknown precision ({precision})")
-        if precision in ('fp8', 'f16x2') and (self.attention_full or self.act_gelu or pooling != 'mean'):
-            raise NotImplementedError(f"precision='{precision}' is built for the uit_* family (BNeckAttention + ReLU, mean pooling) only")
+        if precision == 'fp8' and (self.attention_full or self.act_gelu or pooling != 'mean'):
+            raise NotImplementedError("precision='fp8' is built for the uit_* family (BNeckAttention + ReLU, mean pooling) only")
+        if precision == 'f16x2' and pooling != 'mean':
+            raise NotImplementedError("precision='f16x2' is built for mean pooling only (any attention / activation)")
         if precision == 'f16l6' and (self.attention_full or self.act_gelu):
             raise NotImplementedError("precision='f16l6' is built for BNeckAttention + ReLU (any pooling)")
         if pooling != 'mean' and precision not in ('f16', 'f16l6'):
@@ -255,6 +259,17 @@ class UITBase(nn.Module):
         self._options[str(name)] = int(value)
         for h, _ in self._handles.values():
             _lib.check(_lib.load().uitk_set_option(h.ptr, str(name).encode(), int(value)), "uitk_set_option")
+
+    def get_option(self, name):
+        """Current value of a library option on the live handle(s) (uitk_get_option) -- e.g. 'fe_asym_pm' after the first full-size call:
+        the front-end pass split measured on this device.  {device: value}."""
+        import ctypes
+        out = {}
+        for dev, (h, _) in self._handles.items():
+            v = ctypes.c_int(0)
+            _lib.check(_lib.load().uitk_get_option(h.ptr, str(name).encode(), ctypes.byref(v)), "uitk_get_option")
+            out[dev] = v.value
+        return out
 
     def _apply(self, fn, *args, **kwargs):
         out = super()._apply(fn, *args, **kwargs)
@@ -469,10 +484,14 @@ class UITBase(nn.Module):
         magnitudes.  'f16' is recommended (it is 1.25x faster) only while the term stays under 0.3 * gate.  No
         reference, no CPU: two forward passes on the device."""
         if self.precision not in ('f16', 'f16x2', 'f16l6'):
-            raise ValueError("precision_margin compares the fp16 precisions 'f16' and 'f16l6'")
+            raise ValueError("precision_margin compares the fp16 precisions 'f16' and the family's parity mode")
+        # the parity mode of this family: f16l6 (BNeckAttention + ReLU), f16x2 (full-width attention / GELU, mean pooling)
+        par = 'f16l6' if not (self.attention_full or self.act_gelu) else 'f16x2'
+        if par == 'f16x2' and self.pooling != 'mean':
+            raise ValueError("no split-weight mode is built for this attention / pooling combination")
         keep, out = self.precision, {}
         try:
-            for prec in ('f16', 'f16l6'):
+            for prec in ('f16', par):
                 self.precision = prec
                 self.refresh()
                 with torch.no_grad():
@@ -480,9 +499,9 @@ class UITBase(nn.Module):
         finally:
             self.precision = keep
             self.refresh()
-        d = float((out['f16'] - out['f16l6']).abs().max())
-        return {'max_abs_logit_diff': d, 'max_abs_logit': float(out['f16l6'].abs().max()),
-                'recommended': 'f16l6' if d > 0.3 * gate else 'f16'}
+        d = float((out['f16'] - out[par]).abs().max())
+        return {'max_abs_logit_diff': d, 'max_abs_logit': float(out[par].abs().max()),
+                'recommended': par if d > 0.3 * gate else 'f16'}
 
     def debug_tokens(self, x):
         """(probs, tokens[B, ncrops, depth+1, 24, 128]): residual stream after patch-embed and after each block."""
