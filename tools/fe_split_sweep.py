@@ -30,7 +30,7 @@ for rnd in range(2):
     for pm in (450, 500, 530, 560, 590, 620, 650, 680):
         m.set_option("fe_asym_pm", pm)
         print(f"round {rnd} fe_asym_pm {pm}: median {fe_ms(m)[0]:.4f} min {fe_ms(m)[1]:.4f}")
-for k in range(4):
+for k in range(6):
     m2 = models.uit_xs(outputdim=537, target_length=102).to(dev); m2.load_state_dict(sd); m2.eval()
     m2(x)
     print(f"fresh handle {k}: calibration picked", m2.get_option("fe_asym_pm"), "-> median / min", fe_ms(m2))
