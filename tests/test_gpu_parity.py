@@ -149,6 +149,31 @@ def test_parity_mode_all_sweep_seeds(name):
     assert worst_l < 8e-4 and worst_p < 2e-4
 
 
+@pytest.mark.parametrize("name,act", [("audio_transformer_h128_d6_m3_relu", "relu"), ("audio_transformer_h128_d6_m3", "gelu"),
+                                      ("audio_transformer_h128_d4_m3", "gelu")])
+def test_full_attention_factories_parity_mode_all_sweep_seeds(name, act):
+    """The same statement for the full-width-attention / GELU factories in THEIR parity mode (f16x2, the factories' default since round 3):
+    all twelve trained-like checkpoints inside 1e-3 on logits and probabilities (|logit| up to 14.9).  Measured worst 5.4e-4 / 4.9e-4 /
+    6.5e-4; single fp16 weights on the same checkpoints: 1.2e-3 / 1.2e-3 / 1.6e-3 (profiles/round3/seed_sweep_*.log)."""
+    from bench import synth_batch
+    x = synth_batch(24, 16000, 0, "cpu", False).numpy()
+    xd = torch.from_numpy(x).cuda()
+    worst_l, worst_p = 0.0, 0.0
+    for seed in SWEEP_SEEDS:
+        sd = make_trained_like_state_dict(name, seed, attention="full")
+        m = getattr(models, name)(outputdim=537, target_length=102)
+        assert m.precision == "f16x2"
+        m.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()}, strict=True)
+        with torch.no_grad():
+            p, l = m.cuda().eval()(xd, return_logits=True)
+        r = Oracle(sd, act=act).forward(x)
+        worst_l = max(worst_l, float(np.abs(l.cpu().numpy().reshape(r["logits"].shape) - r["logits"]).max()))
+        worst_p = max(worst_p, float(np.abs(p.cpu().numpy() - r["probs"]).max()))
+        del m
+    print(f"f16x2 {name}: worst max|dlogit| {worst_l:.2e}, worst max|dprob| {worst_p:.2e} over {len(SWEEP_SEEDS)} checkpoints")
+    assert worst_l < 8e-4 and worst_p < 2e-4
+
+
 @pytest.mark.parametrize("name", ["uit_xs", "uit_xxxs"])
 def test_parity_mode_fixtures_and_shapes(golden, name):
     """precision='f16l6' against the fixtures of the imported reference: trained-like checkpoint (tighter than f16's own bound),

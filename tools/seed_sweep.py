@@ -15,7 +15,7 @@ x = synth_batch(24, 16000, 0, "cpu", False).numpy()
 worst = {}
 for name in ("uit_xs", "uit_xxs", "uit_xxxs"):
     for scale in (1.0, 2.0, 3.0):
-        for prec in ("f16",):
+        for prec in ("f16", "f16l6"):
             errs = []
             for seed in range(100, 100 + nseeds):
                 sd = make_state_dict(name, seed, scale)
@@ -29,18 +29,23 @@ for name in ("uit_xs", "uit_xxs", "uit_xxxs"):
             e = np.array(errs)
             print(f"{name:9s} scale {scale:.0f} {prec}: max|dlogit| {e[:,0].max():.2e} (median {np.median(e[:,0]):.2e})  "
                   f"max|dprob| {e[:,1].max():.2e}  |logit|max {e[:,2].max():.1f}", flush=True)
-# trained-checkpoint magnitudes (synth_weights.make_trained_like_state_dict): logits beyond -10; f16 and the split-weight mode
-import itertools
-for name, tprec in itertools.product(("uit_xs", "uit_xxs", "uit_xxxs"), ("f16", "f16x2")):
-    errs = []
+# trained-checkpoint magnitudes (synth_weights.make_trained_like_state_dict): logits beyond -10.  Per family every fp16 precision
+# it has: the uit_* family f16 / f16l6 (parity mode) / f16x2, the full-width-attention factories f16 / f16x2 (their parity mode).
+families = [(n, "bneck", "relu", ("f16", "f16l6", "f16x2")) for n in ("uit_xs", "uit_xxs", "uit_xxxs")] + \
+           [("audio_transformer_h128_d6_m3_relu", "full", "relu", ("f16", "f16x2")), ("audio_transformer_h128_d6_m3", "full", "gelu", ("f16", "f16x2")),
+            ("audio_transformer_h128_d4_m3", "full", "gelu", ("f16", "f16x2"))]
+for name, att, act, precs in families:
+    errs = {p: [] for p in precs}
     for seed in range(200, 200 + nseeds):
-        sd = make_trained_like_state_dict(name, seed)
-        m = getattr(models, name)(outputdim=537, target_length=102, precision=tprec)
-        m.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()}); m = m.cuda().eval()
-        p, l = m(torch.from_numpy(x).cuda(), return_logits=True)
-        r = Oracle(sd).forward(x); wp, wl = r["probs"], r["logits"]
-        errs.append((float(np.abs(l.cpu().numpy().reshape(wl.shape) - wl).max()), float(np.abs(p.cpu().numpy() - wp).max()),
-                     float(np.abs(wl).max())))
-    e = np.array(errs)
-    print(f"{name:9s} trained-like {tprec}: max|dlogit| {e[:,0].max():.2e} (median {np.median(e[:,0]):.2e}, per seed "
-          f"{' '.join('%.1e' % v for v in e[:,0])})  max|dprob| {e[:,1].max():.2e}  |logit|max {e[:,2].max():.1f}", flush=True)
+        sd = make_trained_like_state_dict(name, seed, attention=att)
+        r = Oracle(sd, act=act).forward(x); wp, wl = r["probs"], r["logits"]
+        for tprec in precs:
+            m = getattr(models, name)(outputdim=537, target_length=102, precision=tprec)
+            m.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()}); m = m.cuda().eval()
+            p, l = m(torch.from_numpy(x).cuda(), return_logits=True)
+            errs[tprec].append((float(np.abs(l.cpu().numpy().reshape(wl.shape) - wl).max()), float(np.abs(p.cpu().numpy() - wp).max()),
+                                float(np.abs(wl).max())))
+    for tprec in precs:
+        e = np.array(errs[tprec])
+        print(f"{name:34s} trained-like {tprec:5s}: max|dlogit| {e[:,0].max():.2e} (median {np.median(e[:,0]):.2e}, per seed "
+              f"{' '.join('%.1e' % v for v in e[:,0])})  max|dprob| {e[:,1].max():.2e}  |logit|max {e[:,2].max():.1f}", flush=True)
