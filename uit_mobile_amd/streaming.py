@@ -81,7 +81,7 @@ class PinnedBatchFeeder:
         for probs in HostClipStreamer(model, 8192, 16000).run(feeder): ...
     """
 
-    def __init__(self, fill, n_batches, batch_size, clip_samples, producers=4, depth=None, pin=True):
+    def __init__(self, fill, n_batches, batch_size, clip_samples, producers=4, depth=None, pin=True, autostart=True):
         import queue
         import threading
         self.fill, self.n, self.B, self.T = fill, int(n_batches), int(batch_size), int(clip_samples)
@@ -99,8 +99,15 @@ class PinnedBatchFeeder:
         self._err = None
         self._stop = False
         self._threads = [threading.Thread(target=self._work, daemon=True) for _ in range(max(1, int(producers)))]
-        for t in self._threads:
-            t.start()
+        self._started = False
+        if autostart:                                      # (autostart=False: buffers are allocated + pinned now -- ~0.1 s per GB --
+            self.start()                                   #  the producers begin with the first iteration: what a timed run wants)
+
+    def start(self):
+        if not self._started:
+            self._started = True
+            for t in self._threads:
+                t.start()
 
     @staticmethod
     def collate(out_row, clip):
@@ -141,10 +148,12 @@ class PinnedBatchFeeder:
         """Stop the producers (called when the iteration ends, normally or not)."""
         self._stop = True
         for t in self._threads:
-            t.join(timeout=5.0)
+            if t.is_alive():
+                t.join(timeout=5.0)
 
     def __iter__(self):
         held = []                                          # buffers handed out and possibly still read by an H2D copy
+        self.start()
         try:
             for i in range(self.n):
                 with self._cv:
