@@ -6,6 +6,7 @@
 // a separate phase (product order) or interleaved by the compiler into the other stream's MLP chunks (the two-stream proposal).
 //   mode 0: 8 waves x 1 stream, MLP only          mode 1: 4 waves x 2 streams, MLP only (a fragment read feeds 6 MFMAs instead of 3)
 //   mode 2: 8 waves x 1 stream, MLP + VALU phase  mode 3: 4 waves x 2 streams, stream A's VALU phase inside stream B's MLP and v.v.
+//   mode 4: two 4-wave workgroups per CU (own barriers), VALU phase then MLP, in phase      mode 6: the second one half a block off
 // Output: cycles per block and stream-pair on one SIMD (lower is better), and cycles per MFMA of the SIMD.
 //   hipcc --offload-arch=gfx950 -O3 -o two_stream_probe two_stream_probe.hip && ./two_stream_probe
 #include <hip/hip_runtime.h>
@@ -79,7 +80,7 @@ __device__ __forceinline__ void mlp_chunk(const char* slot, int lane, f4 (&R)[NT
 }
 
 template <int MODE>
-__global__ __launch_bounds__(MODE & 1 ? 256 : 512) void k(int nblk, unsigned long long* out, float* sink, const h8* src, float fk) {
+__global__ __launch_bounds__((MODE & 1) || MODE >= 4 ? 256 : 512, MODE >= 4 ? 2 : 1) void k(int nblk, unsigned long long* out, float* sink, const h8* src, float fk) {
     extern __shared__ char smem[];                         // 4 slots x 16 KiB of fragments
     constexpr int NS = (MODE & 1) ? 2 : 1;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -110,6 +111,22 @@ __global__ __launch_bounds__(MODE & 1 ? 256 : 512) void k(int nblk, unsigned lon
                 for (int i = 0; i < 48; ++i) F[i] = __builtin_fmaf(F[i], fk, F[(i + 7) % 48]);
 #pragma unroll 1
             for (int ch = 0; ch < CHUNKS; ++ch) mlp_chunk<1, 0, 1, 0>(smem + (ch & 3) * 16384, lane, R, X, F, fk);
+        } else if constexpr (MODE == 4 || MODE == 6) {     // two 4-wave workgroups per CU (own barriers): VALU phase + MLP, in phase (4) or the
+            const bool mlp_first = MODE == 6 && blockIdx.x >= gridDim.x / 2;       // second-dispatched workgroup of a CU half a block off (6)
+            if (!mlp_first) {
+#pragma unroll 1
+                for (int o = 0; o < VALU_PER_BLOCK / 48; ++o)
+#pragma unroll
+                    for (int i = 0; i < 48; ++i) F[i] = __builtin_fmaf(F[i], fk, F[(i + 7) % 48]);
+            }
+#pragma unroll 1
+            for (int ch = 0; ch < CHUNKS; ++ch) mlp_chunk<1, 0, 1, 0>(smem + (ch & 3) * 16384, lane, R, X, F, fk);
+            if (mlp_first) {
+#pragma unroll 1
+                for (int o = 0; o < VALU_PER_BLOCK / 48; ++o)
+#pragma unroll
+                    for (int i = 0; i < 48; ++i) F[i] = __builtin_fmaf(F[i], fk, F[(i + 7) % 48]);
+            }
         } else {                                           // two streams half a block apart: each stream's MLP chunk carries 1/12 of the other's VALU phase
 #pragma unroll 1
             for (int ch = 0; ch < CHUNKS; ++ch) mlp_chunk<2, 0, 1, VALU_PER_BLOCK / CHUNKS>(smem + (ch & 3) * 16384, lane, R, X, F, fk);
@@ -129,14 +146,14 @@ __global__ __launch_bounds__(MODE & 1 ? 256 : 512) void k(int nblk, unsigned lon
     if (lane == 0) out[blockIdx.x * 8 + w] = t1 - t0;
 }
 
-static unsigned long long* d_out; static float* d_sink; static h8* d_src; static std::vector<unsigned long long> h(256 * 8);
+static unsigned long long* d_out; static float* d_sink; static h8* d_src; static std::vector<unsigned long long> h(512 * 8);
 template <int MODE> double run(const char* name) {
-    const int nblk = 48, waves = (MODE & 1) ? 4 : 8;
+    const int nblk = 48, waves = (MODE & 1) || MODE >= 4 ? 4 : 8, grid = MODE >= 4 ? 512 : 256;
     hipFuncSetAttribute((const void*)k<MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
-    for (int rep = 0; rep < 3; ++rep) { k<MODE><<<256, waves * 64, 65536>>>(nblk, d_out, d_sink, d_src, 0.999f); hipDeviceSynchronize(); }
+    for (int rep = 0; rep < 3; ++rep) { k<MODE><<<grid, waves * 64, 65536>>>(nblk, d_out, d_sink, d_src, 0.999f); hipDeviceSynchronize(); }
     hipMemcpy(h.data(), d_out, h.size() * 8, hipMemcpyDeviceToHost);
     std::vector<double> v;
-    for (int b = 0; b < 256; ++b) for (int w = 0; w < waves; ++w) v.push_back((double)h[b * 8 + w]);
+    for (int b = 0; b < grid; ++b) for (int w = 0; w < waves; ++w) v.push_back((double)h[b * 8 + w]);
     std::sort(v.begin(), v.end());
     // s_memtime ticks at 100 MHz on gfx950; report in shader cycles via a measured ratio is not needed for an A/B: ticks per block + pair
     // streams per SIMD: both layouts carry 2 streams per SIMD; MFMAs per SIMD per block = 2 x 12 x 48
@@ -147,7 +164,7 @@ template <int MODE> double run(const char* name) {
     return per_block_pair;
 }
 int main() {
-    hipMalloc(&d_out, 256 * 8 * 8); hipMalloc(&d_sink, 4096); hipMalloc(&d_src, 1024 * 16);
+    hipMalloc(&d_out, 512 * 8 * 8); hipMalloc(&d_sink, 4096); hipMalloc(&d_src, 1024 * 16);
     std::vector<_Float16> init(1024 * 8);
     for (size_t i = 0; i < init.size(); ++i) init[i] = (_Float16)(((int)(i * 37 % 17) - 8) * 0.01f);
     hipMemcpy(d_src, init.data(), init.size() * 2, hipMemcpyHostToDevice);
@@ -156,5 +173,8 @@ int main() {
     const double c = run<2>("2: 2 waves/SIMD x 1 stream, VALU phase then MLP (product order)");
     const double d = run<3>("3: 1 wave/SIMD x 2 streams, each stream's VALU inside the other's MLP");
     printf("two-stream / product: MLP only %.3f, whole block %.3f\n", b / a, d / c);
+    const double e = run<4>("4: two 4-wave workgroups per CU, VALU phase then MLP, in phase");
+    const double f = run<6>("6: the same, the second workgroup of a CU half a block off (anti-phase)");
+    printf("anti-phase / in-phase (two workgroups per CU): %.3f;  in-phase two workgroups / one 8-wave workgroup: %.3f\n", f / e, e / c);
     return 0;
 }
