@@ -46,7 +46,7 @@ typedef enum uitk_precision {
                            internals, proj and the head stay f16.  Far outside the 1e-3 gate: a measured throughput mode */
     UITK_PREC_F16X2 = 3,/* every weight of the path as TWO fp16 terms (W = hi + lo, 22 significant bits, two MFMAs per fragment),
                            activations fp16 as in UITK_PREC_F16: the reference point for what weight splitting can buy, at ~1.7x the
-                           encoder time.  Mean pooling; any attention / activation (round 3): it is the parity mode of the
+                           encoder time.  Any attention / activation / pooling (round 3): it is the parity mode of the
                            full-width-attention / GELU factories (audio_transformer_*), which have no UITK_PREC_F16L6 build */
     UITK_PREC_F16L6 = 4 /* THE PARITY MODE (round 3): fp16 operands as UITK_PREC_F16 plus the LOW-ORDER weight term on the cheap pipe:
                            W = f16(W) + 2^e(row) . e2m3(W - f16(W)), the second term as OCP fp6 on

@@ -233,7 +233,7 @@ def test_precision_margin_recommends_by_checkpoint(golden):
     x = torch.from_numpy(synth_pcm_i16(24, 16000, seed=3)).cuda()
     assert models.uit_xs(outputdim=537, target_length=102).precision == "f16l6"
     assert models.audio_transformer_h128_d4_m3(outputdim=537, target_length=102).precision == "f16x2"
-    assert models.audio_transformer_h128_d4_m3(outputdim=537, target_length=102, pooling="dm").precision == "f16"
+    assert models.audio_transformer_h128_d4_m3(outputdim=537, target_length=102, pooling="dm").precision == "f16x2"
     m, _ = build("uit_xs", 13)
     r = m.precision_margin(x)
     assert r["recommended"] == "f16" and r["max_abs_logit_diff"] < 3e-4 and m.precision == "f16"
@@ -369,10 +369,10 @@ def test_golden_pooling_token(golden):
                                          ("h128", "audio_transformer_h128_d4_m3", False, "full", "gelu")):
         sd = dict((make_trained_like_state_dict if trained else make_state_dict)(name, int(g[f"{tag}_seed"]), attention=att))
         sd["cls_token"] = g[f"{tag}_cls_token"]
-        # trained-checkpoint magnitudes run in the parity mode (precision f16l6; round 2 held plain f16 to its measured 1.5e-3 here);
-        # the full-width-attention factory has no f16l6 build and stays on f16 (init scale)
-        prec = "f16l6" if (trained and att == "bneck") else "f16"
-        m = getattr(models, name)(outputdim=537, target_length=102, pooling="token", precision=prec)
+        # every family in its parity mode (round 2 held plain f16 to its measured 1.5e-3 on the trained-like fixture)
+        prec = "f16l6" if att == "bneck" else "f16x2"             # the family's parity mode = the factories' default
+        m = getattr(models, name)(outputdim=537, target_length=102, pooling="token")
+        assert m.precision == prec
         m.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()}, strict=True)
         m = m.to("cuda").eval()
         p, l = run(m, g["pcm"])
@@ -387,6 +387,31 @@ def test_golden_pooling_token(golden):
                 ref = o.forward(pcm)
                 p, l = run(m, pcm)
                 assert np.abs(l - ref["logits"]).max() < TOL and np.abs(p - ref["probs"]).max() < TOL
+
+
+@pytest.mark.parametrize("pooling", ["token", "dm"])
+def test_full_attention_factory_pooling_at_trained_magnitudes(pooling):
+    """Round 3: split fp16 weights (f16x2) with pooling 'token' / 'dm' on the full-width-attention GELU factory at trained-checkpoint
+    magnitudes, against the C oracle (ragged batch, a short clip): the 1e-3 gate -- single fp16 weights printed beside it."""
+    name = "audio_transformer_h128_d6_m3"
+    sd = dict(make_trained_like_state_dict(name, 205, attention="full"))
+    o = Oracle(sd, act="gelu", pooling=pooling)
+    res = {}
+    for prec in ("f16x2", "f16"):
+        m = getattr(models, name)(outputdim=537, target_length=102, pooling=pooling, precision=prec)
+        m.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()}, strict=True)
+        m = m.to("cuda").eval()
+        worst = 0.0
+        for pcm in (synth_pcm_i16(9, 16000, seed=71), synth_pcm_i16(3, 8000, seed=72)):
+            ref = o.forward(pcm)
+            with torch.no_grad():
+                out = m(torch.from_numpy(pcm).cuda(), return_logits=True) if pooling == "token" else (m(torch.from_numpy(pcm).cuda()), None)
+            worst = max(worst, float(np.abs(out[0].cpu().numpy() - ref["probs"]).max()))
+            if pooling == "token":
+                worst = max(worst, float(np.abs(out[1].cpu().numpy().reshape(ref["logits"].shape) - ref["logits"]).max()))
+        res[prec] = worst
+    print(f"full attention + GELU, pooling {pooling}, trained-like: f16x2 {res['f16x2']:.2e}, f16 {res['f16']:.2e}")
+    assert res["f16x2"] < TOL
 
 
 @pytest.mark.parametrize("avg", ["mean", "max"])

@@ -84,9 +84,8 @@ def test_other_factories_match_reference_layout(name, depth, gelu):
     assert (8 + 40 * depth) * 16384 > len(m16.packed_image()) > (8 + 20 * depth) * 16384       # the 20-stage single-weight layout
     with pytest.raises(NotImplementedError):        # built for the uit_* family only
         getattr(models, name)(outputdim=537, target_length=102, precision="fp8")
-    with pytest.raises(NotImplementedError):        # split weights: mean pooling only
-        getattr(models, name)(outputdim=537, target_length=102, precision="f16x2", pooling="token")
-    assert getattr(models, name)(outputdim=537, target_length=102, pooling="token").precision == "f16"
+    assert getattr(models, name)(outputdim=537, target_length=102, pooling="token").precision == "f16x2"      # any pooling
+    assert len(getattr(models, name)(outputdim=537, target_length=102, pooling="dm").eval().packed_image()) == len(img)
 
 
 def test_precision_kwarg_surface():
@@ -98,8 +97,9 @@ def test_precision_kwarg_surface():
         assert len(m.packed_image()) > (8 + stages * 4 + 4) * 16384
     with pytest.raises(ValueError):
         models.uit_xxxs(outputdim=537, target_length=102, precision="int8")
+    assert models.uit_xxxs(outputdim=537, target_length=102, precision="f16x2", pooling="token").eval().packed_image()      # (round 3: built)
     with pytest.raises(NotImplementedError):
-        models.uit_xxxs(outputdim=537, target_length=102, precision="f16x2", pooling="token")
+        models.uit_xxxs(outputdim=537, target_length=102, precision="fp8", pooling="token")
 
 
 def test_strict_load_and_pos_embed_resize():

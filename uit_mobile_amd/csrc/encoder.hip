@@ -1025,7 +1025,6 @@ __global__ __launch_bounds__(WAVES * 64, 2) void uit_encoder_kernel(EncoderArgs 
         // Every stage carries the hi and the lo fragments of the rows it covers; an accumulator takes the hi chain, then the lo
         // chain, and is finished (packed / ReLU'd) inside the stage.  Activations are the fp16 operands of precision f16.
         // Full-width attention (ATT = 1, round 3): 16 attention stages (full_attention above) + the same 24 MLP stages = 40 per block.
-        static_assert(POOL == 0, "precision f16x2: mean pooling only");
         constexpr int BLK_ST = ATT ? BLOCK_STAGES_X2_ATT : BLOCK_STAGES_X2, MLP0 = ATT ? 16 : 4;
         constexpr int B_FC1 = ATT ? BIASF_FC1 : BIAS_FC1, B_FC2 = ATT ? BIASF_FC2 : BIAS_FC2;
         const int tb = PE_STAGES + blk * BLK_ST;
@@ -1845,12 +1844,16 @@ hipError_t launch_encoder(const EncoderArgs& a, int precision, int waves, hipStr
         if (a.pooling == 2) return launch_enc<4, 8, true, false, 0, 0, 2>(a, stream);
         return a.nt < GT ? launch_enc<4, 8, true, false, 0, 0, 1>(a, stream) : launch_enc<4, 8, false, false, 0, 0, 1>(a, stream);
     }
-    if (a.pooling) {                                      // pooling 'dm' / 'token' (f16, 8-wave workgroups), any attention / activation
-        if (precision != 0 || a.timing != nullptr) return hipErrorInvalidValue;
-#define UITK_POOL(SH, PL) (a.attention_full ? (a.act_gelu ? launch_enc<0, 8, SH, false, 1, 1, PL>(a, stream) : launch_enc<0, 8, SH, false, 1, 0, PL>(a, stream)) \
-                                            : (a.act_gelu ? launch_enc<0, 8, SH, false, 0, 1, PL>(a, stream) : launch_enc<0, 8, SH, false, 0, 0, PL>(a, stream)))
-        if (a.pooling == 2) return UITK_POOL(true, 2);     // per-key softmax masks always (dead columns)
-        return a.nt < GT ? UITK_POOL(true, 1) : UITK_POOL(false, 1);
+    if (a.pooling) {                                      // pooling 'dm' / 'token' (f16 / f16x2, 8-wave workgroups), any attention / activation
+        if ((precision != 0 && precision != 3) || a.timing != nullptr) return hipErrorInvalidValue;
+#define UITK_POOL(P, SH, PL) (a.attention_full ? (a.act_gelu ? launch_enc<P, 8, SH, false, 1, 1, PL>(a, stream) : launch_enc<P, 8, SH, false, 1, 0, PL>(a, stream)) \
+                                               : (a.act_gelu ? launch_enc<P, 8, SH, false, 0, 1, PL>(a, stream) : launch_enc<P, 8, SH, false, 0, 0, PL>(a, stream)))
+        if (precision == 3) {                             // split weights (round 3): the parity mode of the full-width-attention factories
+            if (a.pooling == 2) return UITK_POOL(3, true, 2);
+            return a.nt < GT ? UITK_POOL(3, true, 1) : UITK_POOL(3, false, 1);
+        }
+        if (a.pooling == 2) return UITK_POOL(0, true, 2);  // per-key softmax masks always (dead columns)
+        return a.nt < GT ? UITK_POOL(0, true, 1) : UITK_POOL(0, false, 1);
 #undef UITK_POOL
     }
     if (a.attention_full || a.act_gelu) {                 // SURVEY 8f-4 variants: f16 / bf16 / f16x2, 8-wave workgroups

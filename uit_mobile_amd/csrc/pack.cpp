@@ -230,12 +230,12 @@ int validate_config(const uitk_config* c, const char** why) {
     if (c->outputdim < 1 || c->outputdim > 65536) return bad("outputdim out of range");
     if (c->eval_avg != UITK_AVG_MEAN && c->eval_avg != UITK_AVG_MAX) return bad("unknown eval_avg");
     if (c->precision != UITK_PREC_F16 && c->precision != UITK_PREC_BF16 && c->precision != UITK_PREC_FP8 && c->precision != UITK_PREC_F16X2 && c->precision != UITK_PREC_F16L6) return bad("unknown precision");
-    if (c->precision == UITK_PREC_F16X2 && c->pooling) return bad("precision f16x2 is built for mean pooling only (any attention / activation)");
+
     if (c->precision == UITK_PREC_F16L6 && (c->attention_full || c->act_gelu)) return bad("precision f16l6 is built for BNeckAttention + ReLU (any pooling)");
     if ((c->attention_full != 0 && c->attention_full != 1) || (c->act_gelu != 0 && c->act_gelu != 1)) return bad("attention_full / act_gelu must be 0 or 1");
     if ((c->attention_full || c->act_gelu || c->pooling) && c->precision == UITK_PREC_FP8) return bad("precision fp8 is built for the uit_* family (BNeckAttention, ReLU, mean pooling) only");
     if (c->pooling < 0 || c->pooling > 2) return bad("pooling must be 0 (mean), 1 (dm) or 2 (token)");
-    if (c->pooling && c->precision != UITK_PREC_F16 && c->precision != UITK_PREC_F16L6) return bad("pooling 'dm' / 'token' are built for precision f16 / f16l6");
+    if (c->pooling && c->precision != UITK_PREC_F16 && c->precision != UITK_PREC_F16L6 && c->precision != UITK_PREC_F16X2) return bad("pooling 'dm' / 'token' are built for precision f16 / f16l6 / f16x2");
     if (c->pooling == 1 && c->outputdim > 640) return bad("pooling 'dm' is built for outputdim <= 640");
     return UITK_OK;
 }

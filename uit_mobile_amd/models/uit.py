@@ -177,21 +177,18 @@ class UITBase(nn.Module):
         if unsupported:
             raise NotImplementedError("uit_mobile_amd implements the uit_xs/xxs/xxxs family only: " + "; ".join(unsupported))
         if precision is None:
-            # default = the parity mode of the family: f16l6 for BNeckAttention + ReLU (the uit_* family, any pooling); split fp16
-            # weights (f16x2) for the full-width-attention / GELU factories with mean pooling; plain fp16 where neither is built
-            if not (self.attention_full or self.act_gelu): precision = 'f16l6'
-            else: precision = 'f16x2' if pooling == 'mean' else 'f16'
+            # default = the parity mode of the family: f16l6 for BNeckAttention + ReLU (the uit_* family); split fp16 weights (f16x2) for
+            # the full-width-attention / GELU factories; any pooling
+            precision = 'f16l6' if not (self.attention_full or self.act_gelu) else 'f16x2'
             self.precision = precision
         if precision not in ('f16', 'bf16', 'fp8', 'f16x2', 'f16l6'):
             raise ValueError(f"Unknown precision ({precision})")
         if precision == 'fp8' and (self.attention_full or self.act_gelu or pooling != 'mean'):
             raise NotImplementedError("precision='fp8' is built for the uit_* family (BNeckAttention + ReLU, mean pooling) only")
-        if precision == 'f16x2' and pooling != 'mean':
-            raise NotImplementedError("precision='f16x2' is built for mean pooling only (any attention / activation)")
         if precision == 'f16l6' and (self.attention_full or self.act_gelu):
             raise NotImplementedError("precision='f16l6' is built for BNeckAttention + ReLU (any pooling)")
-        if pooling != 'mean' and precision not in ('f16', 'f16l6'):
-            raise NotImplementedError("pooling='dm' / 'token' are built for precision='f16' / 'f16l6'")
+        if pooling != 'mean' and precision not in ('f16', 'f16l6', 'f16x2'):
+            raise NotImplementedError("pooling='dm' / 'token' are built for precision='f16' / 'f16l6' / 'f16x2'")
 
         self.front_end = nn.Sequential(
             _MelSpectrogramParams(n_fft, self.win_size, f_min, f_max, self.n_mels, 16000), nn.Identity())
@@ -487,8 +484,6 @@ class UITBase(nn.Module):
             raise ValueError("precision_margin compares the fp16 precisions 'f16' and the family's parity mode")
         # the parity mode of this family: f16l6 (BNeckAttention + ReLU), f16x2 (full-width attention / GELU, mean pooling)
         par = 'f16l6' if not (self.attention_full or self.act_gelu) else 'f16x2'
-        if par == 'f16x2' and self.pooling != 'mean':
-            raise ValueError("no split-weight mode is built for this attention / pooling combination")
         keep, out = self.precision, {}
         try:
             for prec in ('f16', par):
