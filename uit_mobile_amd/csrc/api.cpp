@@ -196,6 +196,9 @@ static int calibrate_frontend_split(uitk_model* m, int64_t B, int64_t T) {
     if (wg != 2 || npass < 4 * (int64_t)m->n_cu * wg) return UITK_OK;      // no asymmetric split at this size: nothing to measure
     void* zero = nullptr;
     hipEvent_t e0 = nullptr, e1 = nullptr;
+    // the calibration launches write the workspace and the amax slots on the null stream: nothing enqueued earlier (possibly on a
+    // non-blocking stream) may still be using them
+    if (hipDeviceSynchronize() != hipSuccess) { (void)hipGetLastError(); return UITK_OK; }
     if (hipMalloc(&zero, (size_t)Bc * T * 4) != hipSuccess) { (void)hipGetLastError(); return UITK_OK; }   // calibration is optional
     int best = 590;
     if (hipMemset(zero, 0, (size_t)Bc * T * 4) == hipSuccess && hipEventCreate(&e0) == hipSuccess && hipEventCreate(&e1) == hipSuccess) {
@@ -226,6 +229,7 @@ static int calibrate_frontend_split(uitk_model* m, int64_t B, int64_t T) {
         }
         (void)hipGetLastError();
     }
+    (void)hipDeviceSynchronize();                                        // (also on the error paths: the zero batch is freed below)
     m->fe_asym_pm = best;
     m->fe_B = 0; m->fe_T = 0;
     if (e0) (void)hipEventDestroy(e0);
