@@ -933,6 +933,31 @@ def test_multi_producer_feeder_through_the_streamer_vs_oracle():
             assert np.abs(outs[i] - o.forward(padded)["probs"]).max() < TOL
 
 
+def test_clip_store_through_feeder_and_streamer_vs_oracle(tmp_path):
+    """a directory of clips of different lengths and dtypes (int16 as stored, float32 as the reference's loader returns
+    them) -> ClipStore -> pinned batches -> streamer: every clip's probabilities within 1e-3 of the oracle run on the padded batch,
+    the short last batch included."""
+    from uit_mobile_amd.dataset import ClipStore, to_int16
+    from uit_mobile_amd.streaming import HostClipStreamer
+    m, sd = build("uit_xxxs", 22, prec="f16l6")
+    B, T, n = 4, 16000, 10
+    src = synth_pcm_i16(n, T, seed=90)
+    lens = np.random.default_rng(4).integers(9000, T + 1, n)
+    lens[0] = T
+    for i in range(n):
+        c = src[i, :lens[i]]
+        np.save(tmp_path / f"c{i:02d}.npy", c if i % 2 else (c / 32768.0).astype(np.float32))
+    store = ClipStore.from_npy_dir(tmp_path)
+    outs = [o.cpu().numpy() for o in HostClipStreamer(m, B, T).run(store.feeder(B, T, producers=2))]
+    o = Oracle(sd)
+    for (first, count, names), probs in zip(store.batch_index(B), outs):
+        padded = np.zeros((B, T), np.int16)
+        for j in range(count):
+            padded[j, :lens[first + j]] = src[first + j, :lens[first + j]]
+        assert list(store.lengths(first)) == list(lens[first:first + count]) and names[0] == f"c{first:02d}"
+        assert np.abs(probs[:count] - o.forward(padded)["probs"][:count]).max() < TOL
+
+
 @pytest.mark.parametrize("T", [16001, 15999, 4099])
 def test_odd_clip_lengths_vs_oracle(T):
     """Odd sample counts: rows are no longer pair-aligned (the paired-sample fast path must switch off), frame counts

@@ -276,3 +276,34 @@ def test_pinned_batch_feeder_orders_batches_and_pads_like_the_collate():
         out[:] = i
     with pytest.raises(OSError):
         list(PinnedBatchFeeder(bad, 5, 2, 16, producers=2, pin=False))
+
+
+def test_clip_store_feeds_collated_int16_batches(tmp_path):
+    """SURVEY 8f-1 input side (dataset.py:16-56, 183-204): clips of different lengths and dtypes from a store -> int16 batches, truncated /
+    zero right-padded rows, a short last batch, the clips' own lengths and names beside them -- through the multi-producer feeder
+    (unpinned here: no device)."""
+    from uit_mobile_amd.dataset import ClipStore, to_int16
+    rng = np.random.default_rng(5)
+    clips = []
+    for i in range(11):
+        n = int(rng.integers(50, 400))
+        c = rng.integers(-32768, 32767, n).astype(np.int16)
+        clips.append(c if i % 3 else (c / 32768.0).astype(np.float32))        # the reference's float form of an int16 clip: exact round trip
+        np.save(tmp_path / f"clip_{i:02d}.npy", clips[-1])
+    assert np.array_equal(to_int16((np.array([-32768, -1, 0, 1, 32767]) / 32768.0).astype(np.float32)), [-32768, -1, 0, 1, 32767])
+    for store in (ClipStore.from_npy_dir(tmp_path), ClipStore.from_arrays(clips, [f"clip_{i:02d}" for i in range(11)])):
+        B, T = 4, 256
+        feeder = store.feeder(B, T, producers=3, pin=False)
+        index = store.batch_index(B)
+        assert [(f, c) for f, c, _ in index] == [(0, 4), (4, 4), (8, 3)] and index[2][2] == ["clip_08", "clip_09", "clip_10"]
+        got = [b.numpy().copy() for b in feeder]
+        assert len(got) == 3
+        for (first, count, names), batch in zip(index, got):
+            assert batch.shape == (B, T) and batch.dtype == np.int16
+            for j in range(count):
+                want = to_int16(clips[first + j])[:T]
+                assert np.array_equal(batch[j, :len(want)], want) and not batch[j, len(want):].any()
+            assert not batch[count:].any()
+            assert list(store.lengths(first)) == [len(clips[first + j]) for j in range(count)]
+    with pytest.raises(ImportError):
+        ClipStore.from_hdf5_table([("a", "b.h5")])          # h5py is not part of this image: a clear error, not a silent fallback
