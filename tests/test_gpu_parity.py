@@ -657,6 +657,25 @@ def test_errors_map_to_exceptions():
         m(torch.zeros(1, 16000, device="cuda"))
 
 
+def test_options_round_trip_and_calibration_reports_a_split():
+    """uitk_set_option / uitk_get_option: what is set is what is read; an unknown name is an error; after a full-size call the
+    front-end's pass split is one of the calibration's candidates (measured on this device) -- and, like every
+    option, changes no result bit."""
+    m, _ = build("uit_xxxs", 3, prec="f16l6")
+    x = torch.from_numpy(synth_pcm_i16(4096, 16000, seed=9)).cuda()
+    with torch.no_grad():
+        base = m(x).clone()
+    assert m.get_option("fe_asym_pm")[0] in (500, 550, 590, 630, 670)
+    m.set_option("fe_asym_pm", 520)
+    assert m.get_option("fe_asym_pm")[0] == 520 and m.get_option("enc_waves")[0] in (0, 8)
+    with torch.no_grad():
+        assert torch.equal(base, m(x))
+    with pytest.raises(ValueError):                       # UITK_ERR_UNSUPPORTED / UITK_ERR_INVALID_ARG -> ValueError (_lib.check)
+        m.get_option("no_such_option")
+    with pytest.raises(ValueError):
+        m.set_option("fe_asym_pm", 999)
+
+
 def test_inference_cli_counterpart_config1(golden, tmp_path, capsys):
     """BASELINE config #1 plumbing: `inference.py -m <ckpt> water_000.wav` through the counterpart CLI (own WAV reader,
     {'model','config'} checkpoint format of inference.py:42-48, label lookup, 'Keyword:' prefix)."""
