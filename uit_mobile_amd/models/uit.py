@@ -253,9 +253,9 @@ class UITBase(nn.Module):
     def set_option(self, name, value):
         """Explicit tuning / test option of the C library (uitk_set_option: 'fe_asym_pm', 'fe_wg_per_cu', 'enc_waves', 'split_pe',
         'enc_generic_clamp').  None changes a result bit.  Applied to the live handles and to every handle created later."""
-        self._options[str(name)] = int(value)
         for h, _ in self._handles.values():
             _lib.check(_lib.load().uitk_set_option(h.ptr, str(name).encode(), int(value)), "uitk_set_option")
+        self._options[str(name)] = int(value)            # (remembered only once the live handles have accepted it)
 
     def get_option(self, name):
         """Current value of a library option on the live handle(s) (uitk_get_option) -- e.g. 'fe_asym_pm' after the first full-size call:
