@@ -94,7 +94,10 @@ def forward(sd, mel_bn, depth, sch=None, record=None):
     B = mel_bn.shape[0]
     x = mel_bn[:, :, :96].reshape(B, 4, 16, 6, 16).permute(0, 1, 3, 2, 4).reshape(B, 24, 256)
     W = g("patch_embed.proj.weight").reshape(128, 256)
-    tok = r16(x) @ (W if PE_SPLIT else r16(W)).T + g("patch_embed.proj.bias")
+    if sch is not None and getattr(sch, "does_pe", False):                  # tools/calib_study.py: the patch embed through the scheme too
+        tok = sch.lin(x, W, "pe", -1) + g("patch_embed.proj.bias")
+    else:
+        tok = r16(x) @ (W if PE_SPLIT else r16(W)).T + g("patch_embed.proj.bias")
     tp, fp = g("time_pos_embed")[0, :, 0, :6], g("freq_pos_embed")[0, :, :, 0]
     tok = tok + (fp.T[:, None, :] + tp.T[None, :, :]).reshape(24, 128)
     scale = (128 // 2) ** -0.5 * 1.4426950408889634

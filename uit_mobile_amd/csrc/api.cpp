@@ -63,7 +63,30 @@ int uitk_pack_weights(const uitk_config* cfg, const uitk_weights* w, void* out, 
     if (int rc = validate_config(cfg, &why)) return fail(rc, why);
     std::vector<char> img;
     ImageHeader h;
-    if (int rc = pack_image(cfg, w, &img, &h)) return fail(rc, "pack failed");
+    if (int rc = pack_image(cfg, w, nullptr, &img, &h)) return fail(rc, "pack failed");
+    *needed = img.size();
+    if (out) {
+        if (cap < img.size()) return fail(UITK_ERR_INVALID_ARG, "output buffer too small");
+        std::memcpy(out, img.data(), img.size());
+    }
+    return UITK_OK;
+}
+
+size_t uitk_calib_stats_doubles(const uitk_config* cfg) {
+    const char* why = "";
+    if (!cfg || validate_config(cfg, &why) != UITK_OK) return 0;
+    return calib_stats_doubles(cfg);
+}
+
+int uitk_pack_weights_calibrated(const uitk_config* cfg, const uitk_weights* w, const double* stats, void* out, size_t cap, size_t* needed) {
+    if (!cfg || !w || !needed || !stats) return fail(UITK_ERR_INVALID_ARG, "null argument");
+    const char* why = "";
+    if (int rc = validate_config(cfg, &why)) return fail(rc, why);
+    if (cfg->precision != UITK_PREC_F16 && cfg->precision != UITK_PREC_BF16)
+        return fail(UITK_ERR_UNSUPPORTED, "calibrated rounding applies to the single-weight 16-bit precisions (f16, bf16)");
+    std::vector<char> img;
+    ImageHeader h;
+    if (int rc = pack_image(cfg, w, stats, &img, &h)) return fail(rc, "pack failed");
     *needed = img.size();
     if (out) {
         if (cap < img.size()) return fail(UITK_ERR_INVALID_ARG, "output buffer too small");
@@ -82,7 +105,7 @@ int uitk_create(const uitk_config* cfg, const uitk_weights* w, uitk_model** out)
     uitk_model* m = new uitk_model();
     m->cfg = *cfg;
     std::vector<char> img;
-    if (int rc = pack_image(cfg, w, &img, &m->hdr)) { delete m; return fail(rc, "pack failed"); }
+    if (int rc = pack_image(cfg, w, nullptr, &img, &m->hdr)) { delete m; return fail(rc, "pack failed"); }
     hipDeviceProp_t prop;
     if (hipGetDevice(&m->device) != hipSuccess || hipGetDeviceProperties(&prop, m->device) != hipSuccess) {
         delete m; return fail(UITK_ERR_NO_DEVICE, "cannot query HIP device");

@@ -19,7 +19,11 @@
 #include <cstdint>
 #include <cstdlib>
 #include <cstring>
+#include <algorithm>
+#include <atomic>
 #include <functional>
+#include <numeric>
+#include <thread>
 #include <vector>
 
 #include "../../include/uitk.h"
@@ -109,6 +113,90 @@ static std::vector<uint16_t> round_structured(int rows, int K, const std::functi
                 sum += dalt[best] - dq[best];
                 q[(size_t)r * K + best] = alt[best]; dq[best] = dalt[best]; used[best] = 1;
             }
+        }
+    }
+    return q;
+}
+
+// CALIBRATED ROUNDING (round 4): every row of a weight matrix is rounded to the 16-bit operand type one column at a
+// time, and the rounding error of column j is pushed onto the columns not yet rounded so that (W - Q) x stays small for the inputs x
+// the linear actually sees -- H = E[x x^T] (uncentred: the mean direction counts) from a calibration batch.  This is GPTQ (Frantar
+// et al. 2022: greedy optimal-brain-quantisation through the Cholesky factor of H^-1, columns in order of decreasing H_jj) on the
+// fp16 grid instead of an integer grid.  Costs nothing at run time: the kernel multiplies the same single fp16 weights.  The damping
+// (1 % of the mean diagonal) bounds what the rounding may do along directions the calibration batch never excited.
+// tools/calib_study.py: worst max|dlogit| over 12 trained-like XS checkpoints 1.4e-3 (nearest) -> 4.1e-4 = the floor set by the fp16
+// ACTIVATIONS (split weights, f16x2: 3.6e-4), calibrated on synthetic signals and scored on held-out recordings.
+static bool chol_lower(std::vector<double>& A, int n) {          // in place, lower triangle; false if not positive definite
+    for (int j = 0; j < n; ++j) {
+        double d = A[(size_t)j * n + j];
+        for (int k = 0; k < j; ++k) d -= A[(size_t)j * n + k] * A[(size_t)j * n + k];
+        if (!(d > 0.0)) return false;
+        d = std::sqrt(d);
+        A[(size_t)j * n + j] = d;
+        for (int i = j + 1; i < n; ++i) {
+            double v = A[(size_t)i * n + j];
+            const double* ai = &A[(size_t)i * n];
+            const double* aj = &A[(size_t)j * n];
+            for (int k = 0; k < j; ++k) v -= ai[k] * aj[k];
+            A[(size_t)i * n + j] = v / d;
+        }
+    }
+    return true;
+}
+
+static std::vector<uint16_t> round_gptq(int rows, int K, const std::function<double(int, int)>& W, int prec, const double* H, double damp = 0.01) {
+    std::vector<uint16_t> q((size_t)rows * K);
+    std::vector<int> perm(K);
+    std::iota(perm.begin(), perm.end(), 0);
+    std::stable_sort(perm.begin(), perm.end(), [&](int a, int b) { return H[(size_t)a * K + a] > H[(size_t)b * K + b]; });
+    std::vector<double> A((size_t)K * K);
+    double tr = 0.0;
+    for (int i = 0; i < K; ++i) {
+        for (int j = 0; j < K; ++j) A[(size_t)i * K + j] = H[(size_t)perm[i] * K + perm[j]];
+        if (!(A[(size_t)i * K + i] > 0.0)) A[(size_t)i * K + i] = 1.0;                      // an input that never fired
+        tr += A[(size_t)i * K + i];
+    }
+    bool ok = std::isfinite(tr);
+    for (int i = 0; i < K; ++i) A[(size_t)i * K + i] += damp * tr / K;
+    std::vector<double> U((size_t)K * K, 0.0);                   // upper triangular, (H + damping)^-1 = U^T U
+    if (ok) ok = chol_lower(A, K);
+    if (ok) {
+        // Linv (lower) by forward substitution, column by column; Hinv = Linv^T Linv
+        std::vector<double> Li((size_t)K * K, 0.0);
+        for (int c = 0; c < K; ++c) {
+            Li[(size_t)c * K + c] = 1.0 / A[(size_t)c * K + c];
+            for (int i = c + 1; i < K; ++i) {
+                double v = 0.0;
+                for (int k = c; k < i; ++k) v -= A[(size_t)i * K + k] * Li[(size_t)k * K + c];
+                Li[(size_t)i * K + c] = v / A[(size_t)i * K + i];
+            }
+        }
+        std::vector<double> Hi((size_t)K * K, 0.0);
+        for (int k = 0; k < K; ++k) {                            // Hi += Li[k][:]^T Li[k][:]  (row k of Li has entries 0..k)
+            const double* r = &Li[(size_t)k * K];
+            for (int i = 0; i <= k; ++i) {
+                const double ri = r[i];
+                if (ri == 0.0) continue;
+                double* hi = &Hi[(size_t)i * K];
+                for (int j = 0; j <= i; ++j) hi[j] += ri * r[j];
+            }
+        }
+        for (int i = 0; i < K; ++i) for (int j = i + 1; j < K; ++j) Hi[(size_t)i * K + j] = Hi[(size_t)j * K + i];
+        ok = chol_lower(Hi, K);
+        if (ok) for (int i = 0; i < K; ++i) for (int j = 0; j <= i; ++j) U[(size_t)j * K + i] = Hi[(size_t)i * K + j];
+    }
+    std::vector<double> wr(K);
+    for (int r = 0; r < rows; ++r) {
+        for (int k = 0; k < K; ++k) wr[k] = W(r, perm[k]);
+        for (int j = 0; j < K; ++j) {
+            const uint16_t u = cvt(wr[j], prec);
+            q[(size_t)r * K + perm[j]] = u;
+            if (!ok) continue;                                   // (statistics unusable: plain round-to-nearest)
+            const double v = op16_value(u, prec);
+            if (!std::isfinite(v)) continue;
+            const double e = (wr[j] - v) / U[(size_t)j * K + j];
+            const double* uj = &U[(size_t)j * K];
+            for (int k = j + 1; k < K; ++k) wr[k] -= e * uj[k];
         }
     }
     return q;
@@ -250,7 +338,95 @@ static void pack_frag(uint16_t* dst, int prec, const std::function<double(int, i
         }
 }
 
-int pack_image(const uitk_config* c, const uitk_weights* w, std::vector<char>* out, ImageHeader* hdr_out) {
+CalibOffsets calib_offsets(const uitk_config* c) {
+    const size_t inner = c->attention_full ? DIM : INNER;
+    CalibOffsets o;
+    o.pe = 0; o.ln1 = 256 * 256; o.att = o.ln1 + DIM * DIM; o.ln2 = o.att + inner * inner; o.hid = o.ln2 + DIM * DIM;
+    o.per_block = 2 * DIM * DIM + inner * inner + (size_t)HID * HID;
+    return o;
+}
+size_t calib_stats_doubles(const uitk_config* c) { return 256 * 256 + (size_t)c->depth * calib_offsets(c).per_block; }
+
+void fold_model(const uitk_config* c, const uitk_weights* w, Folded* F) {
+    const int depth = c->depth, inner = c->attention_full ? DIM : INNER;
+    F->depth = depth; F->inner = inner;
+    // patch embed: Conv2d weight [oc][0][fi][ti] as [oc][k = fi*16 + ti]; residual centring: mean over the 128 output channels removed
+    F->pe_w.assign((size_t)DIM * 256, 0.0);
+    for (int k = 0; k < 256; ++k) {
+        double cm = 0.0;
+        for (int oc = 0; oc < DIM; ++oc) cm += (double)w->pe_w[oc * 256 + k];
+        cm /= DIM;
+        for (int oc = 0; oc < DIM; ++oc) F->pe_w[(size_t)oc * 256 + k] = (double)w->pe_w[oc * 256 + k] - cm;
+    }
+    // conv bias + pos-embeds per token (uit.py:380-383), centred; row 24: the cls token of pooling 'token' (uit.py:389-391)
+    F->pe_bias.assign((size_t)(NTOK + 1) * DIM, 0.0);
+    const int gt_model = c->target_length / 16;
+    for (int pf = 0; pf < GF; ++pf)
+        for (int pt = 0; pt < GT; ++pt) {
+            double row[DIM], mean = 0.0;
+            for (int oc = 0; oc < DIM; ++oc) {
+                row[oc] = (double)w->pe_b[oc] + (double)w->time_pos[oc * gt_model + pt] + (double)w->freq_pos[oc * GF + pf];
+                mean += row[oc];
+            }
+            mean /= DIM;                                                // residual centring (see the file header)
+            for (int oc = 0; oc < DIM; ++oc) F->pe_bias[(size_t)(pf * GT + pt) * DIM + oc] = row[oc] - mean;
+        }
+    {
+        double row[DIM], mean = 0.0;
+        for (int oc = 0; oc < DIM; ++oc) {
+            row[oc] = (w->cls_token ? (double)w->cls_token[oc] : 0.0) + (w->token_pos ? (double)w->token_pos[oc] : 0.0);
+            mean += row[oc];
+        }
+        mean /= DIM;
+        for (int oc = 0; oc < DIM; ++oc) F->pe_bias[(size_t)NTOK * DIM + oc] = row[oc] - mean;
+    }
+    F->blocks.assign(depth, FoldedBlock());
+    // head_dim = dim // num_heads (uit.py:99-100); log2(e) rides along so the kernel's softmax is exp2
+    const double scale = 1.0 / std::sqrt((double)(DIM / 2)) * 1.4426950408889634074;
+    for (int b = 0; b < depth; ++b) {
+        const uitk_block_weights& bw = w->blocks[b];
+        FoldedBlock& fb = F->blocks[b];
+        fb.qkv_w.resize((size_t)3 * inner * DIM); fb.qkv_b.resize(3 * inner);
+        for (int r = 0; r < 3 * inner; ++r) {
+            const double sc = r < inner ? scale : 1.0;
+            double acc = bw.qkv_b[r];
+            for (int k = 0; k < DIM; ++k) {
+                fb.qkv_w[(size_t)r * DIM + k] = (double)bw.qkv_w[r * DIM + k] * (double)bw.norm1_w[k] * sc;
+                acc += (double)bw.qkv_w[r * DIM + k] * (double)bw.norm1_b[k];
+            }
+            fb.qkv_b[r] = acc * sc;
+        }
+        fb.proj_w.resize((size_t)DIM * inner); fb.proj_b.resize(DIM);
+        for (int k = 0; k < inner; ++k) {
+            double cm = 0.0;
+            for (int r = 0; r < DIM; ++r) cm += (double)bw.proj_w[r * inner + k];
+            cm /= DIM;
+            for (int r = 0; r < DIM; ++r) fb.proj_w[(size_t)r * inner + k] = (double)bw.proj_w[r * inner + k] - cm;
+        }
+        fb.fc2_w.resize((size_t)DIM * HID); fb.fc2_b.resize(DIM);
+        for (int k = 0; k < HID; ++k) {
+            double cm = 0.0;
+            for (int r = 0; r < DIM; ++r) cm += (double)bw.fc2_w[r * HID + k];
+            cm /= DIM;
+            for (int r = 0; r < DIM; ++r) fb.fc2_w[(size_t)r * HID + k] = (double)bw.fc2_w[r * HID + k] - cm;
+        }
+        double proj_bm = 0.0, fc2_bm = 0.0;
+        for (int r = 0; r < DIM; ++r) { proj_bm += (double)bw.proj_b[r]; fc2_bm += (double)bw.fc2_b[r]; }
+        proj_bm /= DIM; fc2_bm /= DIM;
+        for (int r = 0; r < DIM; ++r) { fb.proj_b[r] = (double)bw.proj_b[r] - proj_bm; fb.fc2_b[r] = (double)bw.fc2_b[r] - fc2_bm; }
+        fb.fc1_w.resize((size_t)HID * DIM); fb.fc1_b.resize(HID);
+        for (int r = 0; r < HID; ++r) {
+            double acc = bw.fc1_b[r];
+            for (int k = 0; k < DIM; ++k) {
+                fb.fc1_w[(size_t)r * DIM + k] = (double)bw.fc1_w[r * DIM + k] * (double)bw.norm2_w[k];
+                acc += (double)bw.fc1_w[r * DIM + k] * (double)bw.norm2_b[k];
+            }
+            fb.fc1_b[r] = acc;
+        }
+    }
+}
+
+int pack_image(const uitk_config* c, const uitk_weights* w, const double* calib, std::vector<char>* out, ImageHeader* hdr_out) {
     const bool l6 = c->precision == UITK_PREC_F16L6;                     // f16 operands + fp6 low-order weight term
     const int prec = (c->precision == UITK_PREC_F16X2 || l6) ? UITK_PREC_F16 : c->precision, depth = c->depth, C = c->outputdim;
     const int ntiles = (C + 15) / 16;
@@ -372,28 +548,12 @@ int pack_image(const uitk_config* c, const uitk_weights* w, std::vector<char>* o
         const double s = (double)w->bn_weight[m] / std::sqrt((double)w->bn_var[m] + 1e-5);
         sc[m] = (float)s; sh[m] = (float)((double)w->bn_bias[m] - (double)w->bn_mean[m] * s);
     }
-    // ---- conv bias + pos-embeds
+    // ---- everything that is folded at pack time, in double (shared with the calibration forward of uitk_calibrate)
+    Folded F;
+    fold_model(c, w, &F);
+    // ---- conv bias + pos-embeds (rows 0..23) and the cls token (row 24), centred
     float* peb = (float*)(img + h.off_pe_bias);
-    const int gt_model = c->target_length / 16;
-    for (int pf = 0; pf < GF; ++pf)
-        for (int pt = 0; pt < GT; ++pt) {
-            double row[DIM], mean = 0.0;
-            for (int oc = 0; oc < DIM; ++oc) {
-                row[oc] = (double)w->pe_b[oc] + (double)w->time_pos[oc * gt_model + pt] + (double)w->freq_pos[oc * GF + pf];
-                mean += row[oc];
-            }
-            mean /= DIM;                                                // residual centring (see the file header)
-            for (int oc = 0; oc < DIM; ++oc) peb[(pf * GT + pt) * DIM + oc] = (float)(row[oc] - mean);
-        }
-    {   // row 24: the cls token of pooling 'token' (cls_token + token_pos_embed, uit.py:389-391), centred like the others
-        double row[DIM], mean = 0.0;
-        for (int oc = 0; oc < DIM; ++oc) {
-            row[oc] = (w->cls_token ? (double)w->cls_token[oc] : 0.0) + (w->token_pos ? (double)w->token_pos[oc] : 0.0);
-            mean += row[oc];
-        }
-        mean /= DIM;
-        for (int oc = 0; oc < DIM; ++oc) peb[NTOK * DIM + oc] = (float)(row[oc] - mean);
-    }
+    for (int i = 0; i < (NTOK + 1) * DIM; ++i) peb[i] = (float)F.pe_bias[i];
     // ---- final norms
     float* fin = (float*)(img + h.off_fin);
     std::memcpy(fin + 0 * DIM, w->norm_w, DIM * 4); std::memcpy(fin + 1 * DIM, w->norm_b, DIM * 4);
@@ -404,19 +564,44 @@ int pack_image(const uitk_config* c, const uitk_weights* w, std::vector<char>* o
     auto frag_ptr = [&](int stage, int f) { return ws + ((size_t)stage * STAGE_FRAGS + f) * (FRAG_BYTES / 2); };
     // patch embed: k-slot (s,g,j) <-> (mel-in-patch fi = 2s + (g>>1), frame-in-patch ti = 8(g&1) + j), i.e. operand
     // offset fi*16 + ti = 32s + 8g + j in the front-end's [mel][frame] patch; Conv2d weight [oc][0][fi][ti]
-    std::vector<double> pe_colmean(256, 0.0);                          // residual centring: mean over the 128 output channels
-    for (int k = 0; k < 256; ++k) {
-        for (int oc = 0; oc < DIM; ++oc) pe_colmean[k] += (double)w->pe_w[oc * 256 + k];
-        pe_colmean[k] /= DIM;
-    }
     // conv weights: structured rounding, column groups = the 16 frames of one mel row of the patch (k = fi*16 + ti); the
     // low-order fragments hold the rounding residuals of the high-order ones (split patch embed, optional at run time)
     bool structured = true;
 #ifdef UITK_LAB
     structured = std::getenv("UITK_PACK_RTN") == nullptr;       // lab A/B: UITK_PACK_RTN=1 -> plain round-to-nearest
 #endif
-    auto Wpe = [&](int r, int k) { return (double)w->pe_w[r * 256 + k] - pe_colmean[k]; };
-    const std::vector<uint16_t> pe_q = round_structured(DIM, 256, Wpe, prec, structured ? 16 : 1);
+    auto Wpe = [&](int r, int k) { return F.pe_w[(size_t)r * 256 + k]; };
+    // CALIBRATED ROUNDING (round_gptq) of every single-weight linear when calibration statistics are given: the single-term 16-bit
+    // modes only (the split modes f16x2 / f16l6 carry the rounding residual as a second term; fp8 quantises the exact values).
+    // One task per matrix (1 + 4 per block, independent), spread over host threads: ~0.1 s for UiT-XS.
+    const bool calibrated = calib != nullptr && !x2 && !l6 && prec != UITK_PREC_FP8;
+    std::vector<uint16_t> pe_q;
+    std::vector<std::vector<uint16_t>> cq_qkv(depth), cq_proj(depth), cq_fc1(depth), cq_fc2(depth);
+    if (calibrated) {
+        const CalibOffsets co = calib_offsets(c);
+        const int ntask = 1 + 4 * depth;
+        std::atomic<int> next{0};
+        auto worker = [&]() {
+            for (int t = next.fetch_add(1); t < ntask; t = next.fetch_add(1)) {
+                if (t == 0) { pe_q = round_gptq(DIM, 256, Wpe, prec, calib + co.pe); continue; }
+                const int b = (t - 1) / 4, which = (t - 1) % 4;
+                const FoldedBlock& fb = F.blocks[b];
+                const double* base = calib + (size_t)b * co.per_block;
+                if (which == 0) cq_qkv[b] = round_gptq(3 * inner, DIM, [&](int r, int k) { return fb.qkv_w[(size_t)r * DIM + k]; }, prec, base + co.ln1);
+                else if (which == 1) cq_proj[b] = round_gptq(DIM, inner, [&](int r, int k) { return fb.proj_w[(size_t)r * inner + k]; }, prec, base + co.att);
+                else if (which == 2) cq_fc1[b] = round_gptq(HID, DIM, [&](int r, int k) { return fb.fc1_w[(size_t)r * DIM + k]; }, prec, base + co.ln2);
+                else cq_fc2[b] = round_gptq(DIM, HID, [&](int r, int k) { return fb.fc2_w[(size_t)r * HID + k]; }, prec, base + co.hid);
+            }
+        };
+        unsigned nth = std::thread::hardware_concurrency();
+        nth = nth == 0 ? 4 : nth > 16 ? 16 : nth;
+        std::vector<std::thread> pool;
+        for (unsigned i = 1; i < nth; ++i) pool.emplace_back(worker);
+        worker();
+        for (auto& th : pool) th.join();
+    } else {
+        pe_q = round_structured(DIM, 256, Wpe, prec, structured ? 16 : 1);
+    }
     for (int i = 0; i < PE_HI_STAGES; ++i)
         for (int f = 0; f < STAGE_FRAGS; ++f) {
             const int ft = 2 * i + f / 8, s = f % 8;
@@ -431,37 +616,25 @@ int pack_image(const uitk_config* c, const uitk_weights* w, std::vector<char>* o
         }
     float* bias = (float*)(img + h.off_bias);
     for (int b = 0; b < depth; ++b) {
-        const uitk_block_weights& bw = w->blocks[b];
+        const FoldedBlock& fb = F.blocks[b];
         const int st = PE_STAGES + b * blk_stages;
         float* bb = bias + (size_t)b * BIAS_FLOATS;
-        // head_dim = dim // num_heads (uit.py:99-100); log2(e) rides along so the kernel's softmax is exp2
-        const double scale = 1.0 / std::sqrt((double)(DIM / 2)) * 1.4426950408889634074;
-        auto Wqkv = [&](int r, int k) { return (double)bw.qkv_w[r * DIM + k] * (double)bw.norm1_w[k] * (r < inner ? scale : 1.0); };
-        double proj_cm[DIM], fc2_cm[HID], proj_bm = 0.0, fc2_bm = 0.0;        // residual centring: output-channel means
-        for (int k = 0; k < inner; ++k) { proj_cm[k] = 0.0; for (int r = 0; r < DIM; ++r) proj_cm[k] += (double)bw.proj_w[r * inner + k]; proj_cm[k] /= DIM; }
-        for (int k = 0; k < HID; ++k) { fc2_cm[k] = 0.0; for (int r = 0; r < DIM; ++r) fc2_cm[k] += (double)bw.fc2_w[r * HID + k]; fc2_cm[k] /= DIM; }
-        for (int r = 0; r < DIM; ++r) { proj_bm += (double)bw.proj_b[r]; fc2_bm += (double)bw.fc2_b[r]; }
-        proj_bm /= DIM; fc2_bm /= DIM;
-        auto Wproj = [&](int r, int k) { return (double)bw.proj_w[r * inner + k] - proj_cm[k]; };
-        auto Wfc1 = [&](int r, int k) { return (double)bw.fc1_w[r * DIM + k] * (double)bw.norm2_w[k]; };
-        auto Wfc2_exact = [&](int r, int k) { return (double)bw.fc2_w[r * HID + k] - fc2_cm[k]; };
+        // the folded weights; with calibration statistics: their calibrated 16-bit values (exactly representable, so the
+        // conversions below reproduce them)
+        auto Wqkv = [&](int r, int k) { return calibrated ? op16_value(cq_qkv[b][(size_t)r * DIM + k], prec) : fb.qkv_w[(size_t)r * DIM + k]; };
+        auto Wproj = [&](int r, int k) { return calibrated ? op16_value(cq_proj[b][(size_t)r * inner + k], prec) : fb.proj_w[(size_t)r * inner + k]; };
+        auto Wfc1 = [&](int r, int k) { return calibrated ? op16_value(cq_fc1[b][(size_t)r * DIM + k], prec) : fb.fc1_w[(size_t)r * DIM + k]; };
+        auto Wfc2_exact = [&](int r, int k) { return fb.fc2_w[(size_t)r * HID + k]; };
         // fc2 consumes ReLU / GELU outputs (a common non-negative level): structured rounding over each 32-wide k-step; the fp8
         // stream quantises the exact values itself
         std::vector<uint16_t> fc2_q;
-        if (prec != UITK_PREC_FP8) fc2_q = round_structured(DIM, HID, Wfc2_exact, prec, structured ? 32 : 1);
+        if (calibrated) fc2_q = cq_fc2[b];
+        else if (prec != UITK_PREC_FP8) fc2_q = round_structured(DIM, HID, Wfc2_exact, prec, structured ? 32 : 1);
         auto Wfc2 = [&](int r, int k) { return prec == UITK_PREC_FP8 ? Wfc2_exact(r, k) : op16_value(fc2_q[(size_t)r * HID + k], prec); };
-        for (int r = 0; r < 3 * inner; ++r) {
-            double acc = bw.qkv_b[r];
-            for (int k = 0; k < DIM; ++k) acc += (double)bw.qkv_w[r * DIM + k] * (double)bw.norm1_b[k];
-            bb[BIAS_QKV + r] = (float)(acc * (r < inner ? scale : 1.0));
-        }
-        for (int r = 0; r < DIM; ++r) bb[b_proj + r] = (float)((double)bw.proj_b[r] - proj_bm);
-        for (int r = 0; r < HID; ++r) {
-            double acc = bw.fc1_b[r];
-            for (int k = 0; k < DIM; ++k) acc += (double)bw.fc1_w[r * DIM + k] * (double)bw.norm2_b[k];
-            bb[b_fc1 + r] = (float)acc;
-        }
-        for (int r = 0; r < DIM; ++r) bb[b_fc2 + r] = (float)((double)bw.fc2_b[r] - fc2_bm);
+        for (int r = 0; r < 3 * inner; ++r) bb[BIAS_QKV + r] = (float)fb.qkv_b[r];
+        for (int r = 0; r < DIM; ++r) bb[b_proj + r] = (float)fb.proj_b[r];
+        for (int r = 0; r < HID; ++r) bb[b_fc1 + r] = (float)fb.fc1_b[r];
+        for (int r = 0; r < DIM; ++r) bb[b_fc2 + r] = (float)fb.fc2_b[r];
         if (prec == UITK_PREC_FP8) {
             // fp8 stream (uitk_dev.h): stage 0 qkv, stage 1 proj (f16) + MLP scales, then fc1 / fc2 per k-group q
             uint8_t* s0 = (uint8_t*)frag_ptr(st, 0);
