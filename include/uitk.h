@@ -85,6 +85,9 @@ typedef struct uitk_config {
                                   uitk_encode reject a non-NULL `logits`;
                               2 = 'token' (uit.py:389-392, 399-401; the UITBase default): cls_token + token_pos_embed is
                                   prepended as a 25th token and its output row alone feeds outputlayer                     */
+    int32_t fe_autotune;   /* 1: the first uitk_frontend / uitk_forward of a batch shape nobody in this process has measured yet measures the
+                              front-end's pass split on the caller's buffer and stream (~45 ms, event waits only; never under stream
+                              capture); 0: never inside a call -- use uitk_tune_frontend, or run on the built-in split */
 } uitk_config;
 
 /* Per-block parameters, fp32 host pointers in the reference's state_dict layout (blocks.N.*). */
@@ -132,15 +135,41 @@ int uitk_destroy(uitk_model* m);
  * layout tests).  *needed receives the byte size; out may be NULL to query. */
 int uitk_pack_weights(const uitk_config* cfg, const uitk_weights* w, void* out, size_t cap, size_t* needed);
 
+/* ---- Calibrated rounding (round 4).  The single-weight precisions (UITK_PREC_F16, UITK_PREC_BF16) round every weight matrix
+ * against the second moments E[x x^T] of the operand it multiplies, measured on a calibration batch (GPTQ on the fp16 grid,
+ * csrc/pack.cpp: round_gptq): same kernel, same speed, and the weight-rounding term of the logit error -- which dominates plain
+ * round-to-nearest at trained-checkpoint magnitudes -- drops to the floor set by the fp16 activations (the accuracy of
+ * UITK_PREC_F16X2 at the speed of UITK_PREC_F16).  The reference has no counterpart (it computes in fp32): this is how the
+ * replacement holds 1e-3 on logits at the fp16 MFMA rate.
+ *
+ * uitk_calibrate_weights: run pcm[B,T] (device pointer; NULL = the library's own 32 synthetic calibration signals) through the
+ * front-end and a plain fp32 forward of the folded network (csrc/calibrate.hip), measure the statistics, re-pack `w` (the SAME
+ * weights the handle was created from) with calibrated rounding and replace the handle's parameter image.  A pack-time operation:
+ * synchronises the device.  Clips must cover target_length frames; at most the first 1024 clips are used. */
+int uitk_calibrate_weights(uitk_model* m, const uitk_weights* w, const void* pcm, int in_dtype, int64_t B, int64_t T, void* stream);
+/* Number of doubles of a statistics block for this config: patch embed [256][256], then per block LayerNorm-1 output [128][128],
+ * attention output [inner][inner] (inner = 32, or 128 with attention_full), LayerNorm-2 output [128][128], activation output [384][384]. */
+size_t uitk_calib_stats_doubles(const uitk_config* cfg);
+/* The statistics the latest uitk_calibrate_weights of this handle measured (host buffer of uitk_calib_stats_doubles doubles). */
+int uitk_get_calib_stats(const uitk_model* m, double* out, size_t cap_doubles);
+/* Host-only (no GPU): uitk_pack_weights with calibrated rounding against caller-supplied statistics (layout tests, offline packing). */
+int uitk_pack_weights_calibrated(const uitk_config* cfg, const uitk_weights* w, const double* stats, void* out, size_t cap, size_t* needed);
+
 /* Frames and crops the reference makes for a T-sample clip: 1 + T/hop frames (center=True); more than
  * target_length frames are split into ceil(frames/target_length) crops, a short tail being replaced by the
  * last target_length frames (uit.py:468-481). */
 int uitk_num_frames(const uitk_model* m, int64_t T);
 int uitk_num_crops(const uitk_model* m, int64_t T);
 
-/* Pre-allocate the workspace for batches up to B clips of T samples (may synchronise; call outside timed /
- * captured regions).  forward/frontend grow it on demand otherwise. */
+/* Pre-allocate the workspace for batches up to B clips of T samples (synchronises only when a buffer has to grow; call outside
+ * timed / captured regions).  forward/frontend grow it on demand otherwise.  Measures nothing (round 4). */
 int uitk_reserve(uitk_model* m, int64_t B, int64_t T);
+
+/* Measure the front-end's pass split (option "fe_asym_pm") for batches of this shape on THIS device, on the caller's buffer
+ * pcm[B,T] (contents irrelevant) and stream: ~140 short launches (~45 ms at 8192 x 1 s), event waits only.  The result is shared by
+ * every handle of the process on this device; with uitk_config.fe_autotune = 1 the first uitk_frontend of an unmeasured shape
+ * does the same implicitly.  Never changes a result bit. */
+int uitk_tune_frontend(uitk_model* m, const void* pcm, int in_dtype, int64_t B, int64_t T, void* stream);
 
 /* The whole path: probs[B,outputdim] = model(pcm[B,T])   (UITBase.forward, uit.py:452-493, eval branch).
  *   pcm     device pointer, [B,T] row-major, float32 or int16 (in_dtype)
@@ -185,13 +214,14 @@ int uitk_set_timing_buffers(uitk_model* m, unsigned long long* enc_buf, unsigned
 /* Explicit tuning / test options of a model handle (the library reads no environment variables).  None of them changes a result
  * bit (tests/test_gpu_parity.py::test_pass_distribution_does_not_change_results).  Unknown name -> UITK_ERR_UNSUPPORTED.
  *   "fe_asym_pm"        300..700: per-mille share of the front-end passes walked by the first-dispatched workgroups of every CU;
- *                       -1 (default) = measured on this device by the next uitk_reserve (a few short launches)
+ *                       -1 (default) = the share measured for the batch shape on this device (uitk_tune_frontend / fe_autotune)
  *   "fe_wg_per_cu"      persistent front-end workgroups per CU (0 = default 2)
  *   "enc_waves"         8 (default: one 8-wave encoder workgroup per CU) or 4 (two 4-wave workgroups per CU; f16 / bf16 / fp8)
  *   "split_pe"          1 / 0: patch embed on split (hi + lo) weights; -1 = the precision's default (on for f16x2)
  *   "enc_generic_clamp" 1 = use the generic top_db clamp path even when every init_bn scale is >= 0 (test of that path) */
 int uitk_set_option(uitk_model* m, const char* name, int value);
-/* Current value of an option ("fe_asym_pm" after a calibrating uitk_reserve = the share measured on this device). */
+/* Current value of an option ("fe_asym_pm": the explicit setting, else the share the latest front-end launch used, -1 = the
+ * built-in 590 because nothing was measured for its shape); also "weights_calibrated" (read-only: 1 after uitk_calibrate_weights). */
 int uitk_get_option(const uitk_model* m, const char* name, int* value);
 
 /* ---- Step after the path: post-processing of the probability rows on the device, so that only

@@ -22,7 +22,7 @@ pytestmark = pytest.mark.gpu
 TOL = 1e-3
 
 
-def build(name, seed, scale=1.0, prec="f16", outputdim=537, **kw):
+def build(name, seed, scale=1.0, prec=None, outputdim=537, **kw):      # prec=None: the factory's own default = the product / bench mode
     sd = make_state_dict(name, int(seed), float(scale), outputdim=outputdim,
                          **({"target_length": kw.pop("ckpt_target_length")} if "ckpt_target_length" in kw else {}))
     m = getattr(models, name)(outputdim=outputdim, target_length=102, precision=prec, **kw)
@@ -30,7 +30,7 @@ def build(name, seed, scale=1.0, prec="f16", outputdim=537, **kw):
     return m.to("cuda").eval(), sd
 
 
-def build_trained(name, seed, prec="f16", **kw):
+def build_trained(name, seed, prec=None, **kw):
     """Trained-checkpoint magnitudes (synth_weights.make_trained_like_state_dict): reference logits beyond -10."""
     sd = make_trained_like_state_dict(name, int(seed))
     m = getattr(models, name)(outputdim=537, target_length=102, precision=prec, **kw)

@@ -358,3 +358,58 @@ def test_everything_added_to_the_residual_stream_is_centred_at_pack_time(factory
                 a = frag(st + 2 + ch, 8 + ft).reshape(4, 16, 8)
                 colf += a.sum(1); mxf = max(mxf, np.abs(a).max())
             assert np.abs(colf).max() < 128 * half_ulp * mxf
+
+
+@pytest.mark.parametrize("seed", [205, 207])
+def test_emulated_calibrated_rounding_cuts_the_weight_rounding_error(seed):
+    """Calibrated rounding (round 4; csrc/pack.cpp: round_gptq, uitk_pack_weights_calibrated): single fp16 weights rounded against the
+    operand statistics of a calibration batch.  The statistics come from the numpy restatement (tests/calib_ref.py) on ONE set of clips;
+    the packed image, executed by the emulator on OTHER clips of a trained-like checkpoint, must be much closer to the oracle than the
+    round-to-nearest image -- with the same kernel dataflow (nothing but the rounding direction of the weights differs) -- and every
+    calibrated weight must still be one of the two fp16 neighbours of the exact folded value."""
+    from calib_ref import calib_stats
+    from synth_weights import make_trained_like_state_dict
+    sd = make_trained_like_state_dict("uit_xxxs", seed)
+    stats = calib_stats(sd, synth_pcm_i16(16, 16000, seed=4242), depth=4)
+    pcm = synth_pcm_i16(2, 16000, seed=7)                                  # held out
+    o = Oracle(sd)
+    ref = o.forward(pcm, want_stages=True)
+    mel_raw, amax = o.melspec_db(pcm)
+    mel2 = np.ascontiguousarray(mel_raw.transpose(0, 2, 1))
+    m = models.uit_xxxs(outputdim=537, target_length=102, precision="f16c")
+    m.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()}, strict=True)
+    imgs = {"nearest": m.eval().packed_image(), "calibrated": m.packed_image(calib_stats=stats)}
+    assert len(imgs["nearest"]) == len(imgs["calibrated"])
+    err = {}
+    for kind, img in imgs.items():
+        logits, stages = EncoderEmu(img).run_wave(mel2, amax - 120.0, nt=6)
+        err[kind] = float(np.abs(logits - ref["logits"][:, 0]).max())
+        assert np.abs(stages.mean(-1)).max() < 2e-3
+    print(seed, err)
+    assert err["calibrated"] < 0.6 * err["nearest"] and err["calibrated"] < 4e-4
+    # the two weight streams hold the same matrices up to rounding-sized moves: the error feedback shifts a weight by a fraction of the
+    # rounding steps of its row's LARGE weights (many units in the last place of a small weight, never a visible change of the matrix)
+    h = EncoderEmu(imgs["nearest"]).h
+    n16 = (h["off_bias"] - h["off_wstream"]) // 2
+    a = np.frombuffer(imgs["nearest"], np.float16, n16, h["off_wstream"]).astype(np.float64)
+    b = np.frombuffer(imgs["calibrated"], np.float16, n16, h["off_wstream"]).astype(np.float64)
+    assert 0.02 < np.mean(a != b) < 0.9
+    assert np.linalg.norm(a - b) < 1.5e-3 * np.linalg.norm(a) and np.abs(a - b).max() < 2e-3 * np.abs(a).max()
+
+
+def test_calibrated_packing_rejects_bad_statistics_and_other_precisions():
+    import ctypes
+    from uit_mobile_amd import _lib
+    m, sd = _model("uit_xxxs", 3, "f16c")
+    with pytest.raises(ValueError):
+        m.packed_image(calib_stats=np.zeros(10))
+    L = _lib.load()
+    cfg = m._config()
+    n = L.uitk_calib_stats_doubles(ctypes.byref(cfg))
+    assert n == 256 * 256 + 4 * (2 * 128 * 128 + 32 * 32 + 384 * 384)
+    # all-zero statistics (no information): the image is plain round-to-nearest of every matrix, and still a valid image
+    img0 = m.packed_image(calib_stats=np.zeros(n))
+    assert EncoderEmu(img0).h["precision"] == 0
+    m2, _ = _model("uit_xxxs", 3, "f16l6")
+    with pytest.raises(ValueError):
+        m2.packed_image(calib_stats=np.zeros(L.uitk_calib_stats_doubles(ctypes.byref(m2._config()))))

@@ -19,14 +19,15 @@ AMAX_SLOTS = 64
 EXPORTS = ["uitk_create", "uitk_destroy", "uitk_pack_weights", "uitk_num_frames", "uitk_num_crops",
            "uitk_reserve", "uitk_forward", "uitk_frontend", "uitk_amax_ptr", "uitk_encode", "uitk_mel_db",
            "uitk_set_debug_tokens", "uitk_set_timing_buffers", "uitk_set_option", "uitk_get_option", "uitk_topk", "uitk_kws_transform", "uitk_last_error",
-           "uitk_version"]
+           "uitk_version", "uitk_calibrate_weights", "uitk_calib_stats_doubles", "uitk_get_calib_stats", "uitk_pack_weights_calibrated",
+           "uitk_tune_frontend"]
 
 
 class Config(Structure):
     _fields_ = [(n, c_int32) for n in ("depth", "embed_dim", "num_heads", "mlp_hidden", "outputdim",
                                        "target_length", "n_mels", "n_fft", "hop_size", "win_size", "patch_size",
                                        "center", "eval_avg", "precision")] + [("top_db", c_float), ("attention_full", c_int32),
-                                                                                 ("act_gelu", c_int32), ("pooling", c_int32)]
+                                                                                 ("act_gelu", c_int32), ("pooling", c_int32), ("fe_autotune", c_int32)]
 
 
 _BLOCK_FIELDS = ["norm1_w", "norm1_b", "qkv_w", "qkv_b", "proj_w", "proj_b", "norm2_w", "norm2_b",
@@ -76,6 +77,12 @@ def load():
     L.uitk_kws_transform.argtypes = [c_void_p, c_void_p, c_int64, c_int32, c_int32, c_float, c_void_p, c_void_p]
     L.uitk_last_error.restype = c_char_p
     L.uitk_version.restype = c_char_p
+    L.uitk_calibrate_weights.argtypes = [c_void_p, POINTER(Weights), c_void_p, c_int, c_int64, c_int64, c_void_p]
+    L.uitk_calib_stats_doubles.argtypes = [POINTER(Config)]
+    L.uitk_calib_stats_doubles.restype = c_size_t
+    L.uitk_get_calib_stats.argtypes = [c_void_p, c_void_p, c_size_t]
+    L.uitk_pack_weights_calibrated.argtypes = [POINTER(Config), POINTER(Weights), c_void_p, c_void_p, c_size_t, POINTER(c_size_t)]
+    L.uitk_tune_frontend.argtypes = [c_void_p, c_void_p, c_int, c_int64, c_int64, c_void_p]
     for name in EXPORTS:                      # every entry point include/uitk.h declares must be exported
         getattr(L, name)
     _lib = L

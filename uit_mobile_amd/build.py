@@ -14,7 +14,7 @@ from pathlib import Path
 HERE = Path(__file__).resolve().parent
 CSRC = HERE / "csrc"
 LIB = HERE / "libuitk.so"
-SOURCES = ["api.cpp", "pack.cpp", "frontend.hip", "encoder.hip", "epilogue.hip"]
+SOURCES = ["api.cpp", "pack.cpp", "frontend.hip", "encoder.hip", "epilogue.hip", "calibrate.hip"]
 HEADERS = ["uitk_dev.h", "pack.h", "../../include/uitk.h"]
 # -fno-slp-vectorize: the kernels write their packed math explicitly (float2 / ext_vector types); the SLP vectoriser's
 # own packing costs more v_mov than it saves (same-box A/B: front-end -4 %)

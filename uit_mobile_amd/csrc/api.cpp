@@ -8,7 +8,10 @@
 #include <cstdlib>
 #include <cstring>
 #include <algorithm>
+#include <map>
+#include <mutex>
 #include <string>
+#include <tuple>
 #include <vector>
 
 #include "../../include/uitk.h"
@@ -44,9 +47,11 @@ struct uitk_model {
     int split_pe_env = -1;        // option split_pe: patch embed on split weights (W = hi + lo); -1 = the precision's default (on for f16x2;
                                   // off for f16: measured no better than the structured rounding of pack.cpp at +1.6 % encoder time)
     int force_generic_clamp = 0;  // option enc_generic_clamp
-    int fe_calibrated = 0;        // the asymmetric front-end split has been measured on this device (uitk_reserve) or set explicitly
     int bn_nonneg = 0;            // every init_bn scale >= 0 (decided once from the packed table): the encoder's clamp fast path
-    int fe_asym_pm = -1;          // option fe_asym_pm: share of the first-dispatched front-end workgroups (-1 = not calibrated yet: 590)
+    int fe_asym_pm = -1;          // option fe_asym_pm: explicit share of the first-dispatched front-end workgroups; -1 = the measured one
+    int fe_asym_cur = -1;         // the share the latest front-end launch used (-1 = none measured for its shape: the kernel's 590)
+    int weights_calibrated = 0;   // the uploaded image carries calibrated rounding (uitk_calibrate_weights)
+    std::vector<double> calib_stats;   // statistics of the latest uitk_calibrate_weights (uitk_get_calib_stats)
     int fe_wg_per_cu = 0;         // option fe_wg_per_cu: persistent front-end workgroups per CU (0 = the kernel's occupancy target)
     int device = 0;
     int64_t fe_B = 0, fe_T = 0;   // shape of the latest uitk_frontend call (uitk_encode must match it)
@@ -177,13 +182,12 @@ static int check_shape(const uitk_model* m, int64_t B, int64_t T) {
     return UITK_OK;
 }
 
-static int calibrate_frontend_split(uitk_model* m, int64_t B, int64_t T);
-
 int uitk_reserve(uitk_model* m, int64_t B, int64_t T) {
     if (int rc = check_shape(m, B, T)) return rc;
     const int nc = uitk_num_crops(m, T);
     const size_t mel_bytes = (size_t)B * nc * NTOK * 256 * 2;
     const size_t rp_bytes = nc > 1 ? (size_t)B * nc * m->cfg.outputdim * 4 : 0;
+    // (growing a buffer frees the old one, which the device may still be reading: the only synchronisation in here)
     if (mel_bytes > m->mel_cap) {
         HIP_TRY(hipDeviceSynchronize());
         if (m->mel) (void)hipFree(m->mel);
@@ -198,49 +202,53 @@ int uitk_reserve(uitk_model* m, int64_t B, int64_t T) {
         HIP_TRY(hipMalloc((void**)&m->rowprobs, rp_bytes));
         m->rowprobs_cap = rp_bytes;
     }
-    if (!m->fe_calibrated && m->fe_asym_pm < 0 && nc == 1) return calibrate_frontend_split(m, B, T);
     return UITK_OK;
 }
 
 static int run_frontend(uitk_model* m, const void* pcm, int in_dtype, int64_t B, int64_t T, float* mel_out, int patch, hipStream_t s);
 
-// The asymmetric pass split of the front-end (frontend.hip: the first-dispatched workgroup of a CU is served first by the
-// instruction arbiter and gets a larger pool of passes) depends on dispatch order and arbitration, i.e. on the device: rounds 1-2
-// baked in 590 per mille from one box and saw +-8 % box-to-box spread.  Round 3: measured here, once per handle, on the first
-// uitk_reserve whose batch fills the persistent grid -- five candidate shares on a zero batch (the kernel has no data-dependent
-// control flow), measured round-robin after a clock warm-up, smallest median wins (~45 ms at 8192 clips, once per handle).  Results never depend on
-// the split (bit-identical: tests/test_gpu_parity.py::test_pass_distribution_does_not_change_results).
-static int calibrate_frontend_split(uitk_model* m, int64_t B, int64_t T) {
-    m->fe_calibrated = 1;
+// ---- the asymmetric pass split of the front-end (frontend.hip: the first-dispatched workgroup of a CU is served first by the
+// instruction arbiter and gets a larger pool of passes) depends on dispatch order and arbitration, i.e. on the device and on the
+// number of passes a workgroup walks.  It is MEASURED: five candidate shares, round-robin after a clock warm-up, smallest median
+// wins.  Round 4: one result per (device, workgroups per CU, passes-per-workgroup bucket) for the whole PROCESS -- every handle
+// shares it; measured on the caller's own input buffer (the kernel has no data-dependent control flow) and stream, with event waits
+// only: no allocation, no hipDeviceSynchronize.  Who measures: uitk_tune_frontend (explicit), or -- uitk_config.fe_autotune = 1 --
+// the first uitk_frontend / uitk_forward of a shape nobody has measured yet (~45 ms once per process and shape; never under stream
+// capture).  Results never depend on the split (tests/test_gpu_parity.py::test_pass_distribution_does_not_change_results).
+static std::mutex g_fe_mu;
+static std::map<std::tuple<int, int, int>, int> g_fe_split;      // (device, workgroups per CU, bucket) -> per-mille share
+
+static bool fe_split_key(const uitk_model* m, int64_t B, int64_t T, std::tuple<int, int, int>* key) {
     const int nF = uitk_num_frames(m, T), rem = nF & 15;
-    const int64_t Bc = B < 8192 ? B : 8192;                              // at the caller's batch: the best share moves with the passes per workgroup
-    const int64_t npass = Bc * (int64_t)(nF >> 4) + (rem ? (Bc + 16 / rem - 1) / (16 / rem) : 0);
+    const int64_t npass = B * (int64_t)(nF >> 4) + (rem ? (B + 16 / rem - 1) / (16 / rem) : 0);
     const int wg = m->fe_wg_per_cu > 0 ? m->fe_wg_per_cu : 2;
-    if (wg != 2 || npass < 4 * (int64_t)m->n_cu * wg) return UITK_OK;      // no asymmetric split at this size: nothing to measure
-    void* zero = nullptr;
+    if (wg != 2 || uitk_num_crops(m, T) != 1 || npass < 4 * (int64_t)m->n_cu * wg) return false;   // no asymmetric split at this size
+    const double per_wg = (double)npass / ((double)m->n_cu * wg);
+    *key = std::make_tuple(m->device, wg, (int)std::lround(2.0 * std::log2(per_wg)));
+    return true;
+}
+
+static int tune_frontend_split(uitk_model* m, const void* pcm, int in_dtype, int64_t B, int64_t T, hipStream_t s, int* best_out) {
     hipEvent_t e0 = nullptr, e1 = nullptr;
-    // the calibration launches write the workspace and the amax slots on the null stream: nothing enqueued earlier (possibly on a
-    // non-blocking stream) may still be using them
-    if (hipDeviceSynchronize() != hipSuccess) { (void)hipGetLastError(); return UITK_OK; }
-    if (hipMalloc(&zero, (size_t)Bc * T * 4) != hipSuccess) { (void)hipGetLastError(); return UITK_OK; }   // calibration is optional
     int best = 590;
-    if (hipMemset(zero, 0, (size_t)Bc * T * 4) == hipSuccess && hipEventCreate(&e0) == hipSuccess && hipEventCreate(&e1) == hipSuccess) {
-        // The first reserve of a process finds the device cold: its clocks ramp over the first few milliseconds of work, and a candidate
-        // measured during the ramp loses (round 3: fresh processes picked 590, 630 or 670 on the same kind of box, the wrong pick costing
-        // 5 % of the kernel).  So: 48 untimed launches first, then the candidates ROUND-ROBIN (9 rounds), median per candidate.
+    const int keep = m->fe_asym_cur;
+    if (hipEventCreate(&e0) == hipSuccess && hipEventCreate(&e1) == hipSuccess) {
+        // A cold device ramps its clocks over the first milliseconds of work, and a candidate measured during the ramp loses (round 3:
+        // fresh processes picked 590, 630 or 670 on the same kind of box, the wrong pick costing 5 % of the kernel).  So: 48 untimed
+        // launches first, then the candidates ROUND-ROBIN (9 rounds), median per candidate.
         constexpr int NC = 5, ROUNDS = 9;
         const int cands[NC] = {500, 550, 590, 630, 670};
         float t[NC][ROUNDS];
         bool ok = true;
-        m->fe_asym_pm = 590;
-        for (int i = 0; i < 48 && ok; ++i) ok = run_frontend(m, zero, UITK_IN_F32, Bc, T, m->mel, 1, nullptr) == UITK_OK;
+        m->fe_asym_cur = 590;
+        for (int i = 0; i < 48 && ok; ++i) ok = run_frontend(m, pcm, in_dtype, B, T, m->mel, 1, s) == UITK_OK;
         for (int r = 0; r < ROUNDS && ok; ++r)
             for (int ci = 0; ci < NC && ok; ++ci) {
-                m->fe_asym_pm = cands[ci];
-                ok = run_frontend(m, zero, UITK_IN_F32, Bc, T, m->mel, 1, nullptr) == UITK_OK;      // (the first launch of a split: untimed)
-                (void)hipEventRecord(e0, nullptr);
-                ok = ok && run_frontend(m, zero, UITK_IN_F32, Bc, T, m->mel, 1, nullptr) == UITK_OK;
-                (void)hipEventRecord(e1, nullptr);
+                m->fe_asym_cur = cands[ci];
+                ok = run_frontend(m, pcm, in_dtype, B, T, m->mel, 1, s) == UITK_OK;       // (the first launch of a split: untimed)
+                (void)hipEventRecord(e0, s);
+                ok = ok && run_frontend(m, pcm, in_dtype, B, T, m->mel, 1, s) == UITK_OK;
+                (void)hipEventRecord(e1, s);
                 ok = ok && hipEventSynchronize(e1) == hipSuccess && hipEventElapsedTime(&t[ci][r], e0, e1) == hipSuccess;
             }
         if (ok) {
@@ -252,12 +260,47 @@ static int calibrate_frontend_split(uitk_model* m, int64_t B, int64_t T) {
         }
         (void)hipGetLastError();
     }
-    (void)hipDeviceSynchronize();                                        // (also on the error paths: the zero batch is freed below)
-    m->fe_asym_pm = best;
-    m->fe_B = 0; m->fe_T = 0;
     if (e0) (void)hipEventDestroy(e0);
     if (e1) (void)hipEventDestroy(e1);
-    (void)hipFree(zero);
+    m->fe_asym_cur = keep;
+    m->fe_B = 0; m->fe_T = 0;
+    *best_out = best;
+    return UITK_OK;
+}
+
+// the share this launch uses: the explicit option, else the process-wide measurement for this shape (measuring it now if allowed)
+static void pick_frontend_split(uitk_model* m, const void* pcm, int in_dtype, int64_t B, int64_t T, hipStream_t s, bool may_tune) {
+    if (m->fe_asym_pm >= 0) { m->fe_asym_cur = m->fe_asym_pm; return; }
+    std::tuple<int, int, int> key;
+    if (!fe_split_key(m, B, T, &key)) { m->fe_asym_cur = -1; return; }
+    {
+        std::lock_guard<std::mutex> lk(g_fe_mu);
+        auto it = g_fe_split.find(key);
+        if (it != g_fe_split.end()) { m->fe_asym_cur = it->second; return; }
+    }
+    m->fe_asym_cur = -1;
+    if (!may_tune) return;
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(s, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone) { (void)hipGetLastError(); return; }
+    int best = 590;
+    (void)tune_frontend_split(m, pcm, in_dtype, B < 8192 ? B : 8192, T, s, &best);
+    std::lock_guard<std::mutex> lk(g_fe_mu);
+    g_fe_split.emplace(key, best);                                  // (a concurrent handle may have been first: its result stands)
+    m->fe_asym_cur = g_fe_split[key];
+}
+
+int uitk_tune_frontend(uitk_model* m, const void* pcm, int in_dtype, int64_t B, int64_t T, void* stream) {
+    if (int rc = check_shape(m, B, T)) return rc;
+    if (!pcm) return fail(UITK_ERR_INVALID_ARG, "null pcm");
+    if (in_dtype != UITK_IN_F32 && in_dtype != UITK_IN_I16) return fail(UITK_ERR_INVALID_ARG, "unknown in_dtype");
+    if (int rc = uitk_reserve(m, B, T)) return rc;
+    std::tuple<int, int, int> key;
+    if (!fe_split_key(m, B, T, &key)) return UITK_OK;               // nothing to measure at this size
+    int best = 590;
+    if (int rc = tune_frontend_split(m, pcm, in_dtype, B < 8192 ? B : 8192, T, (hipStream_t)stream, &best)) return rc;
+    std::lock_guard<std::mutex> lk(g_fe_mu);
+    g_fe_split[key] = best;                                         // an explicit measurement replaces an earlier one
+    if (m->fe_asym_pm < 0) m->fe_asym_cur = best;
     return UITK_OK;
 }
 
@@ -287,7 +330,7 @@ int uitk_set_option(uitk_model* m, const char* name, int value) {
     const std::string n = name;
     if (n == "fe_asym_pm") {                  // per-mille share of the front-end passes for the first-dispatched workgroups; -1 = calibrate
         if (value != -1 && (value < 300 || value > 700)) return fail(UITK_ERR_INVALID_ARG, "fe_asym_pm: -1 or 300..700");
-        m->fe_asym_pm = value; m->fe_calibrated = value != -1;
+        m->fe_asym_pm = value; m->fe_asym_cur = value;
     } else if (n == "fe_wg_per_cu") {         // persistent front-end workgroups per CU (0 = the kernel's occupancy target)
         if (value < 0 || value > 4) return fail(UITK_ERR_INVALID_ARG, "fe_wg_per_cu: 0..4");
         m->fe_wg_per_cu = value;
@@ -307,7 +350,8 @@ int uitk_set_option(uitk_model* m, const char* name, int value) {
 int uitk_get_option(const uitk_model* m, const char* name, int* value) {
     if (!m || !name || !value) return fail(UITK_ERR_INVALID_ARG, "null argument");
     const std::string n = name;
-    if (n == "fe_asym_pm") *value = m->fe_asym_pm;                         // after a calibrating uitk_reserve: the measured share
+    if (n == "fe_asym_pm") *value = m->fe_asym_pm >= 0 ? m->fe_asym_pm : m->fe_asym_cur;      // explicit, else what the latest launch used
+    else if (n == "weights_calibrated") *value = m->weights_calibrated;
     else if (n == "fe_wg_per_cu") *value = m->fe_wg_per_cu;
     else if (n == "enc_waves") *value = m->enc_waves;
     else if (n == "split_pe") *value = m->split_pe_env;
@@ -336,7 +380,7 @@ static int run_frontend(uitk_model* m, const void* pcm, int in_dtype, int64_t B,
     // no memset per call: this launch fills one set of slots and re-arms (0xFFFFFFFF) the other for the next launch
     m->amax_cur ^= 1;
     a.mel = mel_out; a.amax = m->amax + m->amax_cur * AMAX_SLOTS; a.amax_rearm = m->amax + (m->amax_cur ^ 1) * AMAX_SLOTS;
-    a.asym_pm = m->fe_asym_pm;
+    a.asym_pm = m->fe_asym_cur;
     a.bn_sc = (const float*)(m->image + h.off_bn_sc); a.bn_sh = (const float*)(m->image + h.off_bn_sh);
     a.op_bf16 = m->cfg.precision == UITK_PREC_BF16;
     a.timing = m->timing_fe;
@@ -351,6 +395,7 @@ int uitk_frontend(uitk_model* m, const void* pcm, int in_dtype, int64_t B, int64
     if (in_dtype != UITK_IN_F32 && in_dtype != UITK_IN_I16) return fail(UITK_ERR_INVALID_ARG, "unknown in_dtype");
     if (int rc = uitk_reserve(m, B, T)) return rc;
     m->fe_B = 0; m->fe_T = 0;
+    pick_frontend_split(m, pcm, in_dtype, B, T, (hipStream_t)stream, m->cfg.fe_autotune != 0);
     if (int rc = run_frontend(m, pcm, in_dtype, B, T, m->mel, 1, (hipStream_t)stream)) return rc;
     m->fe_B = B; m->fe_T = T;
     return UITK_OK;
@@ -414,6 +459,137 @@ int uitk_mel_db(uitk_model* m, const void* pcm, int in_dtype, int64_t B, int64_t
     m->fe_B = 0; m->fe_T = 0;                                  // the amax slots now belong to this call, not to the operands
     if (int rc = run_frontend(m, pcm, in_dtype, B, T, m->mel_frames, 0, (hipStream_t)stream)) return rc;
     HIP_TRY(launch_mel_export(m->mel_frames, m->amax + m->amax_cur * AMAX_SLOTS, m->cfg.top_db, B, nF, out, (hipStream_t)stream));
+    return UITK_OK;
+}
+
+// ---- calibrated rounding of the weights (pack.cpp: round_gptq; calibrate.hip) ---------------------------------
+// The library's own calibration signals (used when the caller passes none): 32 clips of eight kinds -- white noise at four levels,
+// pure tones, noise with a silent tail, near-silence, chirps, low-passed noise, amplitude-modulated noise bursts, vibrato harmonic
+// stacks with a syllable-rate envelope -- deterministic (an LCG), int16.  They only have to EXCITE the directions real audio excites:
+// the rounding stays within half a step of nearest in any case, and the damping of round_gptq bounds what it may do elsewhere.
+static void builtin_calibration_set(int n, int64_t T, std::vector<int16_t>* out) {
+    out->assign((size_t)n * T, 0);
+    uint32_t lcg = 0x2545F491u;
+    auto noise = [&]() { lcg = lcg * 1664525u + 1013904223u; return (double)(lcg >> 8) / 16777216.0 - 0.5; };
+    std::vector<double> x(T);
+    for (int i = 0; i < n; ++i) {
+        const int kind = i & 7, v = (i >> 3) & 3;
+        const double sr = 16000.0;
+        switch (kind) {
+        case 0: { const double g[4] = {1.0, 0.3, 0.1, 0.03}; for (int64_t t = 0; t < T; ++t) x[t] = g[v] * noise(); break; }
+        case 1: { const double f = 220.0 * std::pow(1.9, v) + 37.0 * v;
+                  for (int64_t t = 0; t < T; ++t) x[t] = 0.9 * std::sin(2.0 * M_PI * f * t / sr) + 1e-3 * noise(); break; }
+        case 2: { for (int64_t t = 0; t < T; ++t) x[t] = t < T - T / 4 ? (0.25 + 0.25 * v) * noise() : 0.0; break; }
+        case 3: { for (int64_t t = 0; t < T; ++t) x[t] = 1e-3 * (v + 1) * noise(); break; }
+        case 4: { const double f0 = v & 1 ? 7500.0 : 100.0, f1 = v & 1 ? 100.0 : 7500.0, dur = (double)T / sr;
+                  for (int64_t t = 0; t < T; ++t) { const double tt = t / sr; x[t] = (v < 2 ? 0.5 : 0.05) * std::sin(2.0 * M_PI * (f0 + 0.5 * (f1 - f0) * tt / dur) * tt); }
+                  break; }
+        case 5: { const double a[4] = {0.9, 0.97, 0.99, 0.7}; double y = 0.0, pk = 1e-9;
+                  for (int64_t t = 0; t < T; ++t) { y = a[v] * y + noise(); x[t] = y; pk = std::fmax(pk, std::fabs(y)); }
+                  for (int64_t t = 0; t < T; ++t) x[t] *= 0.6 / pk;
+                  break; }
+        case 6: { for (int64_t t = 0; t < T; ++t) { const double e = 0.5 + 0.5 * std::sin(2.0 * M_PI * (2.0 + 3.0 * v) * t / sr); x[t] = 0.8 * e * e * e * e * noise(); } break; }
+        default: { const double f0 = 100.0 + 40.0 * v;
+                   for (int64_t t = 0; t < T; ++t) {
+                       const double tt = t / sr, ph = 2.0 * M_PI * (f0 * tt + 0.8 * std::sin(2.0 * M_PI * 5.0 * tt));
+                       double acc = 0.0;
+                       for (int hh = 1; hh <= 24; ++hh) {
+                           const double fh = hh * f0, form = std::exp(-0.5 * std::pow((fh - 700.0 - 300.0 * v) / 400.0, 2)) + 0.5 * std::exp(-0.5 * std::pow((fh - 2200.0) / 600.0, 2));
+                           acc += (0.15 + form) / hh * std::sin(hh * ph);
+                       }
+                       const double env = std::pow(0.5 + 0.5 * std::sin(2.0 * M_PI * 3.0 * tt), 2);
+                       x[t] = 0.25 * env * acc + 2e-4 * noise();
+                   }
+                   break; }
+        }
+        for (int64_t t = 0; t < T; ++t) {
+            double s = std::nearbyint(x[t] * 32768.0);
+            s = s > 32767.0 ? 32767.0 : s < -32768.0 ? -32768.0 : s;
+            (*out)[(size_t)i * T + t] = (int16_t)s;
+        }
+    }
+}
+
+int uitk_calibrate_weights(uitk_model* m, const uitk_weights* w, const void* pcm, int in_dtype, int64_t B, int64_t T, void* stream) {
+    if (!m || !w) return fail(UITK_ERR_INVALID_ARG, "null argument");
+    if (m->cfg.precision != UITK_PREC_F16 && m->cfg.precision != UITK_PREC_BF16)
+        return fail(UITK_ERR_UNSUPPORTED, "calibrated rounding applies to the single-weight 16-bit precisions (f16, bf16)");
+    hipStream_t s = (hipStream_t)stream;
+    void* own_pcm = nullptr;
+    if (!pcm) {                                                  // the library's own signals: full-length clips for this front-end
+        B = 32; in_dtype = UITK_IN_I16;
+        T = std::max<int64_t>(100 * (int64_t)m->cfg.hop_size, (int64_t)(m->cfg.target_length / 16 * 16) * m->cfg.hop_size + m->cfg.n_fft);
+        std::vector<int16_t> host;
+        builtin_calibration_set((int)B, T, &host);
+        HIP_TRY(hipMalloc(&own_pcm, host.size() * 2));
+        if (hipMemcpy(own_pcm, host.data(), host.size() * 2, hipMemcpyHostToDevice) != hipSuccess) { (void)hipFree(own_pcm); return fail(UITK_ERR_HIP, "calibration set upload failed"); }
+        pcm = own_pcm;
+    }
+    struct Cleanup { void* a = nullptr; void* b = nullptr; void* c = nullptr; ~Cleanup() { if (a) (void)hipFree(a); if (b) (void)hipFree(b); if (c) (void)hipFree(c); } } tmp;
+    tmp.a = own_pcm;
+    if (B > 1024) B = 1024;                                      // more clips do not change a second moment that 768+ tokens already pin
+    if (int rc = check_shape(m, B, T)) return rc;
+    if (crop_nt(m, T) != GT) return fail(UITK_ERR_TOO_SHORT, "calibration clips must cover the full target_length (every time patch valid)");
+    if (int rc = uitk_frontend(m, pcm, in_dtype, B, T, stream)) return rc;
+    const int rows = (int)(B * uitk_num_crops(m, T)), ntok = m->cfg.pooling == 2 ? NTOK + 1 : NTOK, M = rows * ntok;
+    // the folded network as floats
+    Folded F;
+    fold_model(&m->cfg, w, &F);
+    const int inner = F.inner;
+    CalibArgs a{};
+    a.o_qkv_w = 0; a.o_qkv_b = a.o_qkv_w + (size_t)3 * inner * DIM; a.o_proj_w = a.o_qkv_b + 3 * inner; a.o_proj_b = a.o_proj_w + (size_t)DIM * inner;
+    a.o_fc1_w = a.o_proj_b + DIM; a.o_fc1_b = a.o_fc1_w + (size_t)HID * DIM; a.o_fc2_w = a.o_fc1_b + HID; a.o_fc2_b = a.o_fc2_w + (size_t)DIM * HID;
+    a.block_floats = a.o_fc2_b + DIM;
+    const size_t n_model = (size_t)DIM * 256 + (size_t)(NTOK + 1) * DIM + (size_t)m->cfg.depth * a.block_floats;
+    std::vector<float> hostw(n_model);
+    {
+        float* p = hostw.data();
+        for (double v : F.pe_w) *p++ = (float)v;
+        for (double v : F.pe_bias) *p++ = (float)v;
+        for (const FoldedBlock& fb : F.blocks)
+            for (const std::vector<double>* arr : {&fb.qkv_w, &fb.qkv_b, &fb.proj_w, &fb.proj_b, &fb.fc1_w, &fb.fc1_b, &fb.fc2_w, &fb.fc2_b})
+                for (double v : *arr) *p++ = (float)v;
+    }
+    const CalibOffsets co = calib_offsets(&m->cfg);
+    const size_t n_stats = calib_stats_doubles(&m->cfg);
+    const size_t n_work = (size_t)M * (256 + DIM + DIM + 3 * inner + inner + HID);
+    HIP_TRY(hipMalloc(&tmp.b, n_model * 4));
+    HIP_TRY(hipMalloc(&tmp.c, (n_work + n_stats) * 4));
+    HIP_TRY(hipMemcpyAsync(tmp.b, hostw.data(), n_model * 4, hipMemcpyHostToDevice, s));
+    const float* dw = (const float*)tmp.b;
+    float* wk = (float*)tmp.c;
+    a.mel = (const unsigned short*)m->mel; a.amax = m->amax + m->amax_cur * AMAX_SLOTS; a.top_db = m->cfg.top_db;
+    a.bn_sc = (const float*)(m->image + m->hdr.off_bn_sc); a.bn_sh = (const float*)(m->image + m->hdr.off_bn_sh);
+    a.op_bf16 = m->cfg.precision == UITK_PREC_BF16;
+    a.rows = rows; a.ntok = ntok; a.depth = m->cfg.depth; a.inner = inner; a.act_gelu = m->cfg.act_gelu;
+    a.pe_w = dw; a.pe_bias = dw + (size_t)DIM * 256; a.blocks = a.pe_bias + (size_t)(NTOK + 1) * DIM;
+    a.X0 = wk; a.R = a.X0 + (size_t)M * 256; a.Xn = a.R + (size_t)M * DIM; a.QKV = a.Xn + (size_t)M * DIM; a.O = a.QKV + (size_t)M * 3 * inner;
+    a.Hd = a.O + (size_t)M * inner; a.stats = a.Hd + (size_t)M * HID;
+    a.off_pe = co.pe; a.off_ln1 = co.ln1; a.off_att = co.att; a.off_ln2 = co.ln2; a.off_hid = co.hid; a.per_block = co.per_block;
+    HIP_TRY(launch_calibration(a, s));
+    std::vector<float> stats_f(n_stats);
+    HIP_TRY(hipMemcpyAsync(stats_f.data(), a.stats, n_stats * 4, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    m->calib_stats.assign(stats_f.begin(), stats_f.end());
+    for (double v : m->calib_stats) if (!std::isfinite(v)) { m->calib_stats.clear(); return fail(UITK_ERR_HIP, "calibration statistics are not finite"); }
+    // re-pack with the calibrated rounding and replace the image (same layout, same size); pack-time operation: device-synchronous
+    std::vector<char> img;
+    ImageHeader h;
+    if (int rc = pack_image(&m->cfg, w, m->calib_stats.data(), &img, &h)) return fail(rc, "pack failed");
+    if (img.size() != m->hdr.total_bytes) return fail(UITK_ERR_INVALID_ARG, "calibrated image has a different layout (other weights than at uitk_create?)");
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(m->image, img.data(), img.size(), hipMemcpyHostToDevice));
+    m->hdr = h;
+    m->fe_B = 0; m->fe_T = 0;
+    m->weights_calibrated = 1;
+    return UITK_OK;
+}
+
+int uitk_get_calib_stats(const uitk_model* m, double* out, size_t cap_doubles) {
+    if (!m || !out) return fail(UITK_ERR_INVALID_ARG, "null argument");
+    if (m->calib_stats.empty()) return fail(UITK_ERR_INVALID_ARG, "no uitk_calibrate_weights call on this handle");
+    if (cap_doubles < m->calib_stats.size()) return fail(UITK_ERR_INVALID_ARG, "output buffer too small");
+    std::memcpy(out, m->calib_stats.data(), m->calib_stats.size() * sizeof(double));
     return UITK_OK;
 }
 

@@ -1,0 +1,194 @@
+// calibrate.hip -- PACK-TIME ONLY: operand statistics for the calibrated rounding of pack.cpp (round_gptq).
+//
+// uitk_calibrate (api.cpp) runs a calibration batch through the product front-end kernel and then through the plain fp32 forward
+// below -- the folded network of pack.h (`Folded`: exactly the numbers pack.cpp rounds), one simple kernel per operation -- and
+// accumulates, for every single-weight linear of the path, the uncentred second moment E[x x^T] of its input operand:
+//     patch embed  <- the clamped log-mel patch operands                     (models/uit.py:63-66)
+//     qkv          <- LayerNorm-1 output (its affine is folded into qkv)     (:223, 103 / 139)
+//     proj         <- attention output                                       (:119-120 / :175-176)
+//     fc1          <- LayerNorm-2 output                                     (:235, 192)
+//     fc2          <- ReLU / GELU output                                     (:193-194)
+// Nothing here is on the inference path and nothing here produces an output of the model: the statistics only decide, at pack
+// time, in which direction each fp16 weight is rounded.  The kernels are written for clarity, not speed (a calibration pass over
+// 32 clips of UiT-XS is ~2 GFLOP).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "uitk_dev.h"
+
+namespace uitk {
+
+constexpr int TS = 16;
+
+__device__ __forceinline__ float op16_to_f32(unsigned short u, int bf16) {
+    if (bf16) return __uint_as_float((unsigned)u << 16);
+    return (float)__builtin_bit_cast(_Float16, u);
+}
+__device__ __forceinline__ float round_op16(float v, int bf16) {          // the value the MFMA operand holds
+    if (bf16) return (float)(__bf16)v;
+    return (float)(_Float16)v;
+}
+
+// X0[(row * ntok + tok)][k] = the patch operand the encoder's patch embed multiplies: init_bn(dB) as stored by the front-end
+// ([rows][24][fi 16][ti 16], 16-bit), clamped at the batch's top_db floor (encoder.hip prologue); the cls row of pooling 'token'
+// (tok 0 when ntok == 25) carries no patch: zero.
+__global__ void cal_patch_kernel(const unsigned short* __restrict__ mel, const float* __restrict__ amax, float top_db,
+                                 const float* __restrict__ bn_sc, const float* __restrict__ bn_sh, int bf16, int rows, int ntok,
+                                 float* __restrict__ X0) {
+    float amx = amax[0];
+    for (int i = 1; i < AMAX_SLOTS; ++i) amx = fmaxf(amx, amax[i]);
+    const float floor_db = amx - top_db;
+    const int64_t n = (int64_t)rows * ntok * 256;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const int k = (int)(i & 255);
+        const int64_t rt = i >> 8;
+        const int tok = (int)(rt % ntok), row = (int)(rt / ntok);
+        const int ptok = ntok == NTOK ? tok : tok - 1;                     // patch index; -1 = the cls token
+        float v = 0.f;
+        if (ptok >= 0) {
+            const int melbin = 16 * (ptok / GT) + (k >> 4);
+            const float sc = bn_sc[melbin], th = round_op16(floor_db * sc + bn_sh[melbin], bf16);
+            const float y = op16_to_f32(mel[((int64_t)row * NTOK + ptok) * 256 + k], bf16);
+            v = sc >= 0.f ? fmaxf(y, th) : fminf(y, th);
+        }
+        X0[i] = v;
+    }
+}
+
+// R[m][c] = table[token row of m][c]: conv bias + positional embeddings (rows 0..23), cls token (row 24)
+__global__ void cal_init_stream_kernel(const float* __restrict__ table, int M, int ntok, float* __restrict__ R) {
+    const int64_t n = (int64_t)M * DIM;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i & (DIM - 1));
+        const int tok = (int)((i >> 7) % ntok);
+        const int trow = ntok == NTOK ? tok : (tok == 0 ? NTOK : tok - 1);
+        R[i] = table[trow * DIM + c];
+    }
+}
+
+// Y[m][o] = (accumulate ? Y[m][o] : 0) + act(bias[o] + sum_k X[m][k] W[o][k]);  K multiple of 16.  act: 0 none, 1 ReLU, 2 exact GELU
+__global__ void cal_linear_kernel(const float* __restrict__ X, const float* __restrict__ W, const float* __restrict__ bias,
+                                  float* __restrict__ Y, int M, int K, int O, int act, int accumulate) {
+    __shared__ float xs[TS][TS + 1], ws[TS][TS + 1];
+    const int tx = threadIdx.x, ty = threadIdx.y;
+    const int m = blockIdx.y * TS + ty, o = blockIdx.x * TS + tx, ow = blockIdx.x * TS + ty;
+    float acc = 0.f;
+    for (int k0 = 0; k0 < K; k0 += TS) {
+        xs[ty][tx] = m < M ? X[(int64_t)m * K + k0 + tx] : 0.f;
+        ws[ty][tx] = ow < O ? W[(int64_t)ow * K + k0 + tx] : 0.f;
+        __syncthreads();
+#pragma unroll
+        for (int kk = 0; kk < TS; ++kk) acc += xs[ty][kk] * ws[tx][kk];
+        __syncthreads();
+    }
+    if (m < M && o < O) {
+        float v = acc + (bias ? bias[o] : 0.f);
+        if (act == 1) v = fmaxf(v, 0.f);
+        else if (act == 2) v = 0.5f * v * (1.0f + erff(v * 0.70710678118654752f));
+        float* y = Y + (int64_t)m * O + o;
+        *y = accumulate ? *y + v : v;
+    }
+}
+
+// Xn[m][:] = (R[m][:] - mean) / sqrt(var + eps): one wave per token, two elements per lane (the affine lives in the next linear)
+__global__ void cal_layernorm_kernel(const float* __restrict__ R, float* __restrict__ Xn, int M, float eps) {
+    const int m = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (m >= M) return;
+    const float a = R[(int64_t)m * DIM + lane], b = R[(int64_t)m * DIM + 64 + lane];
+    float s = a + b;
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    const float mean = s * (1.0f / DIM);
+    const float da = a - mean, db = b - mean;
+    float q = da * da + db * db;
+    for (int o = 32; o > 0; o >>= 1) q += __shfl_xor(q, o);
+    const float rstd = 1.0f / sqrtf(q * (1.0f / DIM) + eps);
+    Xn[(int64_t)m * DIM + lane] = da * rstd;
+    Xn[(int64_t)m * DIM + 64 + lane] = db * rstd;
+}
+
+// softmax attention of one (clip-crop, head): QKV[m][which * inner + h * hd + d] (models/uit.py:110-111 / 147-148), the q rows
+// already carry 0.125 log2(e) (pack-time fold), so probabilities are exp2(s - max).  O[m][h * hd + d] (:119 / :175).
+__global__ void cal_attention_kernel(const float* __restrict__ QKV, float* __restrict__ O, int ntok, int inner) {
+    const int row = blockIdx.x, h = blockIdx.y, t = threadIdx.x, hd = inner / 2;
+    if (t >= ntok) return;
+    const float* base = QKV + (int64_t)row * ntok * 3 * inner;
+    const float* q = base + (int64_t)t * 3 * inner + h * hd;
+    float s[NTOK + 1], mx = -INFINITY;
+    for (int j = 0; j < ntok; ++j) {
+        const float* k = base + (int64_t)j * 3 * inner + inner + h * hd;
+        float acc = 0.f;
+        for (int d = 0; d < hd; ++d) acc += q[d] * k[d];
+        s[j] = acc; mx = fmaxf(mx, acc);
+    }
+    float sum = 0.f;
+    for (int j = 0; j < ntok; ++j) { s[j] = exp2f(s[j] - mx); sum += s[j]; }
+    const float inv = 1.0f / sum;
+    float* o = O + ((int64_t)row * ntok + t) * inner + h * hd;
+    for (int d = 0; d < hd; ++d) {
+        float acc = 0.f;
+        for (int j = 0; j < ntok; ++j) acc += s[j] * base[(int64_t)j * 3 * inner + 2 * inner + h * hd + d];
+        o[d] = acc * inv;
+    }
+}
+
+// G[i][j] = scale * sum_m x[m][i] x[m][j], x = the 16-bit operand value of X;  K multiple of 16
+__global__ void cal_gram_kernel(const float* __restrict__ X, float* __restrict__ G, int M, int K, float scale, int bf16) {
+    __shared__ float xi[TS][TS + 1], xj[TS][TS + 1];
+    const int tx = threadIdx.x, ty = threadIdx.y;
+    const int i0 = blockIdx.y * TS, j0 = blockIdx.x * TS;
+    float acc = 0.f;
+    for (int m0 = 0; m0 < M; m0 += TS) {
+        const int m = m0 + ty;
+        xi[ty][tx] = m < M ? round_op16(X[(int64_t)m * K + i0 + tx], bf16) : 0.f;
+        xj[ty][tx] = m < M ? round_op16(X[(int64_t)m * K + j0 + tx], bf16) : 0.f;
+        __syncthreads();
+#pragma unroll
+        for (int mm = 0; mm < TS; ++mm) acc += xi[mm][ty] * xj[mm][tx];
+        __syncthreads();
+    }
+    G[(int64_t)(i0 + ty) * K + j0 + tx] = acc * scale;
+}
+
+static hipError_t linear(const float* X, const float* W, const float* b, float* Y, int M, int K, int O, int act, int accumulate, hipStream_t s) {
+    hipLaunchKernelGGL(cal_linear_kernel, dim3((O + TS - 1) / TS, (M + TS - 1) / TS), dim3(TS, TS), 0, s, X, W, b, Y, M, K, O, act, accumulate);
+    return hipGetLastError();
+}
+static hipError_t gram(const float* X, float* G, int M, int K, float scale, int bf16, hipStream_t s) {
+    hipLaunchKernelGGL(cal_gram_kernel, dim3(K / TS, K / TS), dim3(TS, TS), 0, s, X, G, M, K, scale, bf16);
+    return hipGetLastError();
+}
+
+hipError_t launch_calibration(const CalibArgs& a, hipStream_t s) {
+#define CAL_TRY(e) do { hipError_t _e = (e); if (_e != hipSuccess) return _e; } while (0)
+    const int M = a.rows * a.ntok, inner = a.inner;
+    const int npatch = a.rows * NTOK;                                      // tokens that carry a patch
+    hipLaunchKernelGGL(cal_patch_kernel, dim3(1024), dim3(256), 0, s, a.mel, a.amax, a.top_db, a.bn_sc, a.bn_sh, a.op_bf16, a.rows, a.ntok, a.X0);
+    CAL_TRY(hipGetLastError());
+    CAL_TRY(gram(a.X0, a.stats + a.off_pe, M, 256, 1.0f / (float)npatch, a.op_bf16, s));
+    hipLaunchKernelGGL(cal_init_stream_kernel, dim3(512), dim3(256), 0, s, a.pe_bias, M, a.ntok, a.R);
+    CAL_TRY(hipGetLastError());
+    CAL_TRY(linear(a.X0, a.pe_w, nullptr, a.R, M, 256, DIM, 0, 1, s));
+    const float inv_m = 1.0f / (float)M;
+    for (int b = 0; b < a.depth; ++b) {
+        const float* wb = a.blocks + (size_t)b * a.block_floats;
+        float* st = a.stats + (size_t)b * a.per_block;
+        hipLaunchKernelGGL(cal_layernorm_kernel, dim3((M + 3) / 4), dim3(256), 0, s, a.R, a.Xn, M, 1e-6f);
+        CAL_TRY(hipGetLastError());
+        CAL_TRY(gram(a.Xn, st + a.off_ln1, M, DIM, inv_m, a.op_bf16, s));
+        CAL_TRY(linear(a.Xn, wb + a.o_qkv_w, wb + a.o_qkv_b, a.QKV, M, DIM, 3 * inner, 0, 0, s));
+        hipLaunchKernelGGL(cal_attention_kernel, dim3(a.rows, 2), dim3(32), 0, s, a.QKV, a.O, a.ntok, inner);
+        CAL_TRY(hipGetLastError());
+        CAL_TRY(gram(a.O, st + a.off_att, M, inner, inv_m, a.op_bf16, s));
+        CAL_TRY(linear(a.O, wb + a.o_proj_w, wb + a.o_proj_b, a.R, M, inner, DIM, 0, 1, s));
+        hipLaunchKernelGGL(cal_layernorm_kernel, dim3((M + 3) / 4), dim3(256), 0, s, a.R, a.Xn, M, 1e-6f);
+        CAL_TRY(hipGetLastError());
+        CAL_TRY(gram(a.Xn, st + a.off_ln2, M, DIM, inv_m, a.op_bf16, s));
+        CAL_TRY(linear(a.Xn, wb + a.o_fc1_w, wb + a.o_fc1_b, a.Hd, M, DIM, HID, a.act_gelu ? 2 : 1, 0, s));
+        CAL_TRY(gram(a.Hd, st + a.off_hid, M, HID, inv_m, a.op_bf16, s));
+        CAL_TRY(linear(a.Hd, wb + a.o_fc2_w, wb + a.o_fc2_b, a.R, M, HID, DIM, 0, 1, s));
+    }
+#undef CAL_TRY
+    return hipSuccess;
+}
+
+}  // namespace uitk

@@ -132,6 +132,26 @@ struct EncoderArgs {
     int split_pe;           // 1 = patch embed on split weights (W = hi + lo, 8-wave workgroups only); 0 = high-order term only
 };
 
+// calibrate.hip (pack time only): the plain fp32 forward of the folded network (pack.h: Folded) that measures the operand statistics
+// of the calibrated rounding.  Every pointer is device memory; `blocks` holds per block the eight folded arrays as floats at the
+// o_* offsets; `stats` receives the second moments as floats in the layout of pack.h: calib_offsets (off_* / per_block in floats).
+struct CalibArgs {
+    const unsigned short* mel;  // [rows][24][256] the front-end's patch operands (full clips: every time patch valid)
+    const float* amax;          // [AMAX_SLOTS] of the same front-end launch
+    float top_db;
+    const float* bn_sc; const float* bn_sh;
+    int op_bf16;
+    int rows, ntok, depth, inner, act_gelu;       // ntok: 24, or 25 with the cls token of pooling 'token' in front
+    const float* pe_w;          // [128][256]
+    const float* pe_bias;       // [25][128]
+    const float* blocks;        // [depth][block_floats]
+    size_t block_floats, o_qkv_w, o_qkv_b, o_proj_w, o_proj_b, o_fc1_w, o_fc1_b, o_fc2_w, o_fc2_b;
+    float* X0; float* R; float* Xn; float* QKV; float* O; float* Hd;      // work buffers [rows*ntok][256 | 128 | 128 | 3 inner | inner | 384]
+    float* stats;
+    size_t off_pe, off_ln1, off_att, off_ln2, off_hid, per_block;
+};
+hipError_t launch_calibration(const CalibArgs& a, hipStream_t stream);
+
 hipError_t launch_frontend(const FrontendArgs& a, int in_i16, int patch_layout, int n_cu, int wg_per_cu, hipStream_t stream);
 hipError_t launch_mel_export(const float* mel, const float* amax, float top_db, int64_t B, int nF, float* out,
                              hipStream_t stream);

@@ -25,7 +25,10 @@ import os
 
 from .. import _lib
 
-_CHECK_WEIGHTS = os.environ.get('UITK_CHECK_WEIGHTS', '0') == '1'   # debug: re-scan every tensor's (pointer, version) on every call
+_CHECK_WEIGHTS = os.environ.get('UITK_CHECK_WEIGHTS', '1') == '1'   # every call compares a cheap version stamp of the weights (~15 us);
+                                                                     # UITK_CHECK_WEIGHTS=0: benchmark loops that never touch the weights
+_OPTIONS = ('fe_asym_pm', 'fe_wg_per_cu', 'enc_waves', 'split_pe', 'enc_generic_clamp')      # uitk_set_option names
+_PRECISIONS = {'f16': _lib.PREC_F16, 'f16c': _lib.PREC_F16, 'bf16': _lib.PREC_BF16, 'fp8': _lib.PREC_FP8, 'f16x2': _lib.PREC_F16X2, 'f16l6': _lib.PREC_F16L6}
 
 __all__ = ["UITBase", "uit_xs", "uit_xxs", "uit_xxxs", "PRETRAINED_CHECKPOINTS",
            "audio_transformer_h128_d4_m3", "audio_transformer_h128_d4_m3_relu",
@@ -136,7 +139,7 @@ class UITBase(nn.Module):
                  mlp_ratio=4., qkv_bias=True, drop_rate=0., attn_drop_rate=0., drop_path_rate=0., init_bn=True,
                  norm_layer=None, act_layer=None, init_values=None, target_length=1012, pooling='token',
                  wavtransforms=None, spectransforms=None, time_patch_out=None, freq_patch_out=None,
-                 block_type='Block', attention_type='Attention', eval_avg='mean', precision=None, **kwargs):
+                 block_type='Block', attention_type='Attention', eval_avg='mean', precision=None, fe_autotune=True, **kwargs):
         super().__init__()
         assert pooling in ('mean', 'token', 'dm')
         self.outputdim = outputdim
@@ -156,6 +159,7 @@ class UITBase(nn.Module):
         self.freq_patch_out = freq_patch_out
         self.target_length = target_length
         self.precision = precision
+        self.fe_autotune = bool(fe_autotune)
         self.depth = depth
         self.num_heads = num_heads
         self.mlp_hidden = int(embed_dim * mlp_ratio)
@@ -177,18 +181,19 @@ class UITBase(nn.Module):
         if unsupported:
             raise NotImplementedError("uit_mobile_amd implements the uit_xs/xxs/xxxs family only: " + "; ".join(unsupported))
         if precision is None:
-            # default = the parity mode of the family: f16l6 for BNeckAttention + ReLU (the uit_* family); split fp16 weights (f16x2) for
-            # the full-width-attention / GELU factories; any pooling
-            precision = 'f16l6' if not (self.attention_full or self.act_gelu) else 'f16x2'
+            # default = THE PARITY MODE (round 4), for every family and pooling: single fp16 weights with CALIBRATED rounding ('f16c':
+            # the kernels of 'f16', the weights rounded against operand statistics -- uitk_calibrate_weights -- of the library's own
+            # calibration signals or of `model.calibrate(x)`): the accuracy of split weights at the plain fp16 rate
+            precision = 'f16c'
             self.precision = precision
-        if precision not in ('f16', 'bf16', 'fp8', 'f16x2', 'f16l6'):
+        if precision not in _PRECISIONS:
             raise ValueError(f"Unknown precision ({precision})")
         if precision == 'fp8' and (self.attention_full or self.act_gelu or pooling != 'mean'):
             raise NotImplementedError("precision='fp8' is built for the uit_* family (BNeckAttention + ReLU, mean pooling) only")
         if precision == 'f16l6' and (self.attention_full or self.act_gelu):
             raise NotImplementedError("precision='f16l6' is built for BNeckAttention + ReLU (any pooling)")
-        if pooling != 'mean' and precision not in ('f16', 'f16l6', 'f16x2'):
-            raise NotImplementedError("pooling='dm' / 'token' are built for precision='f16' / 'f16l6' / 'f16x2'")
+        if pooling != 'mean' and precision not in ('f16', 'f16c', 'f16l6', 'f16x2'):
+            raise NotImplementedError("pooling='dm' / 'token' are built for precision='f16' / 'f16c' / 'f16l6' / 'f16x2'")
 
         self.front_end = nn.Sequential(
             _MelSpectrogramParams(n_fft, self.win_size, f_min, f_max, self.n_mels, 16000), nn.Identity())
@@ -206,6 +211,8 @@ class UITBase(nn.Module):
         nn.init.normal_(self.cls_token, std=1e-6)
         self._handles = {}          # device index -> (_Handle, version stamp)
         self._options = {}          # uitk_set_option settings, re-applied to every handle this model creates
+        self._calib_input = None    # calibrate(x): the caller's calibration clips (None = the library's own signals)
+        self._tensors = None        # cached list of parameter / buffer tensors for the per-call stamp
 
     def init_weights(self, module):
         if isinstance(module, nn.Linear):
@@ -239,20 +246,44 @@ class UITBase(nn.Module):
 
     # ------------------------------------------------------------------ C-ABI plumbing
     def _stamp(self):
-        """Identity of the weights the uploaded image was packed from: (storage pointer, version counter) per tensor.  A walk over
-        all 163 tensors (0.3 ms of Python), so it is NOT on the hot path: handles are invalidated by the hooks below
-        (`load_state_dict`, `_apply` = .to / .cuda / .half / .float, `refresh()`); the scan runs on every call only with
-        UITK_CHECK_WEIGHTS=1 (debug: also catches in-place edits such as `p.data.mul_()` that no hook sees)."""
-        return tuple((t.data_ptr(), int(t._version)) for t in list(self.parameters()) + list(self.buffers()))
+        """Identity of the weights the uploaded image was packed from, cheap enough for every call (~15 us: one pass over a cached
+        tensor list): the sum of the tensors' version counters + the storage pointers of the first and last tensor.  In-place edits
+        under no_grad (`p.mul_()`, `p.copy_()`, nn.init.*, vector_to_parameters, a sub-module's load_state_dict) bump a counter and are
+        seen; `load_state_dict`, `_apply` (.to / .cuda / .half) and `refresh()` drop the images outright.  NOT seen: writes through
+        `p.data` or a numpy view (they bypass the counter) -- call `refresh()` after those."""
+        ts = self._tensors
+        if ts is None:
+            ts = self._tensors = list(self.parameters()) + list(self.buffers())
+        v = 0
+        for t in ts:
+            v += t._version
+        return (v, ts[0].data_ptr(), ts[-1].data_ptr(), len(ts))
 
     def refresh(self):
-        """Drop the uploaded parameter images: the next call re-packs the current weights.  Call it after editing a parameter
-        in place (`p.data.mul_()`, a numpy view): only load_state_dict / .to() / .cuda() invalidate the images by themselves."""
+        """Drop the uploaded parameter images: the next call re-packs (and re-calibrates) the current weights.  Needed only after
+        editing a parameter through `p.data` / a numpy view; everything else is noticed by itself (see _stamp)."""
         self._handles.clear()
+        self._tensors = None
+
+    def calibrate(self, x=None):
+        """Choose the calibration clips of precision 'f16c' (calibrated rounding, uitk_calibrate_weights): `x` = [B, T] device tensor
+        (float32 / int16) of representative audio covering target_length frames, at most the first 1024 clips are used; None = the
+        library's own synthetic signals (the default).  Takes effect when the parameter image is (re)built -- now, for live handles.
+        Results stay within the parity tolerance either way (tests/test_gpu_parity.py::test_calibrated_rounding_*): calibration only
+        decides in which direction each fp16 weight is rounded."""
+        if self.precision != 'f16c':
+            raise ValueError("calibrate() applies to precision='f16c' (single fp16 weights, calibrated rounding)")
+        if x is not None:
+            x, _ = self._prep_input(x)
+        self._calib_input = x
+        self._handles.clear()
+        return self
 
     def set_option(self, name, value):
         """Explicit tuning / test option of the C library (uitk_set_option: 'fe_asym_pm', 'fe_wg_per_cu', 'enc_waves', 'split_pe',
         'enc_generic_clamp').  None changes a result bit.  Applied to the live handles and to every handle created later."""
+        if str(name) not in _OPTIONS:                    # (validated here too: without a live handle nothing else would reject it)
+            raise ValueError(f"uitk_set_option: unknown option: {name}")
         for h, _ in self._handles.values():
             _lib.check(_lib.load().uitk_set_option(h.ptr, str(name).encode(), int(value)), "uitk_set_option")
         self._options[str(name)] = int(value)            # (remembered only once the live handles have accepted it)
@@ -272,6 +303,7 @@ class UITBase(nn.Module):
         out = super()._apply(fn, *args, **kwargs)
         if hasattr(self, '_handles'):
             self._handles.clear()
+            self._tensors = None                          # .to() / .cuda() replace the tensors
         return out
 
     def _config(self):
@@ -280,9 +312,9 @@ class UITBase(nn.Module):
                            n_mels=self.n_mels, n_fft=self.n_fft, hop_size=self.hop_size, win_size=self.win_size,
                            patch_size=self.patch_size, center=int(bool(self.center)),
                            eval_avg={'mean': _lib.AVG_MEAN, 'max': _lib.AVG_MAX}.get(self.eval_avg, -1),
-                           precision={'f16': _lib.PREC_F16, 'bf16': _lib.PREC_BF16, 'fp8': _lib.PREC_FP8, 'f16x2': _lib.PREC_F16X2, 'f16l6': _lib.PREC_F16L6}[self.precision], top_db=120.0,
+                           precision=_PRECISIONS[self.precision], top_db=120.0,
                            attention_full=int(self.attention_full), act_gelu=int(self.act_gelu),
-                           pooling={'mean': 0, 'dm': 1, 'token': 2}[self.pooling])
+                           pooling={'mean': 0, 'dm': 1, 'token': 2}[self.pooling], fe_autotune=int(self.fe_autotune))
 
     def _host_weights(self):
         """-> (Weights struct, keep-alive list) with fp32 host pointers in reference layout."""
@@ -337,16 +369,34 @@ class UITBase(nn.Module):
                          cls_token=ptr("cls_token"), token_pos=ptr("token_pos_embed"))
         return w, keep
 
-    def packed_image(self):
-        """Host-only: the packed parameter image uitk_create would upload (bytes).  No GPU needed."""
+    def packed_image(self, calib_stats=None):
+        """Host-only: the packed parameter image uitk_create would upload (bytes).  No GPU needed.  calib_stats: float64 array of
+        uitk_calib_stats_doubles values -> the image uitk_calibrate_weights would build from those statistics (uitk_pack_weights_calibrated)."""
         L = _lib.load()
         cfg = self._config()
         w, keep = self._host_weights()
         need = ctypes.c_size_t()
-        _lib.check(L.uitk_pack_weights(ctypes.byref(cfg), ctypes.byref(w), None, 0, ctypes.byref(need)), "uitk_pack_weights")
+        if calib_stats is None:
+            pack = lambda out, cap: L.uitk_pack_weights(ctypes.byref(cfg), ctypes.byref(w), out, cap, ctypes.byref(need))
+        else:
+            st = np.ascontiguousarray(calib_stats, dtype=np.float64)
+            if st.size != L.uitk_calib_stats_doubles(ctypes.byref(cfg)):
+                raise ValueError(f"calib_stats must hold {L.uitk_calib_stats_doubles(ctypes.byref(cfg))} doubles (include/uitk.h), got {st.size}")
+            pack = lambda out, cap: L.uitk_pack_weights_calibrated(ctypes.byref(cfg), ctypes.byref(w), ctypes.c_void_p(st.ctypes.data), out, cap, ctypes.byref(need))
+        _lib.check(pack(None, 0), "uitk_pack_weights")
         buf = (ctypes.c_char * need.value)()
-        _lib.check(L.uitk_pack_weights(ctypes.byref(cfg), ctypes.byref(w), buf, need.value, ctypes.byref(need)), "uitk_pack_weights")
+        _lib.check(pack(buf, need.value), "uitk_pack_weights")
         return bytes(buf)
+
+    def calib_stats(self, device=None):
+        """The operand statistics the live handle's calibration measured (float64, layout of include/uitk.h: uitk_calib_stats_doubles)."""
+        L = _lib.load()
+        device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+        h = self._handle(device)
+        cfg = self._config()
+        out = np.empty(L.uitk_calib_stats_doubles(ctypes.byref(cfg)), np.float64)
+        _lib.check(L.uitk_get_calib_stats(h, ctypes.c_void_p(out.ctypes.data), out.size), "uitk_get_calib_stats")
+        return out
 
     def _handle(self, device):
         if self.eval_avg not in ('mean', 'max'):
@@ -362,9 +412,20 @@ class UITBase(nn.Module):
         out = ctypes.c_void_p()
         with torch.cuda.device(idx):
             _lib.check(L.uitk_create(ctypes.byref(cfg), ctypes.byref(w), ctypes.byref(out)), "uitk_create")
+            handle = _Handle(out.value)                   # owned from here on: a failure below destroys it instead of leaking it
             for name, value in self._options.items():
                 _lib.check(L.uitk_set_option(out, name.encode(), value), "uitk_set_option")
-        self._handles[idx] = (_Handle(out.value), stamp)
+            if self.precision == 'f16c':                  # calibrated rounding: the caller's clips, else the library's own signals
+                x = self._calib_input
+                stream = ctypes.c_void_p(torch.cuda.current_stream(idx).cuda_stream)
+                if x is None:
+                    _lib.check(L.uitk_calibrate_weights(out, ctypes.byref(w), None, _lib.IN_I16, 0, 0, stream), "uitk_calibrate_weights")
+                else:
+                    x = x.to(torch.device("cuda", idx))
+                    _lib.check(L.uitk_calibrate_weights(out, ctypes.byref(w), ctypes.c_void_p(x.data_ptr()),
+                                                        _lib.IN_I16 if x.dtype == torch.int16 else _lib.IN_F32, x.shape[0], x.shape[1], stream),
+                               "uitk_calibrate_weights")
+        self._handles[idx] = (handle, stamp)
         return out.value
 
     @staticmethod
@@ -480,7 +541,7 @@ class UITBase(nn.Module):
         logit difference: that difference IS the weight-rounding term plain fp16 would carry -- most of its error at trained-checkpoint
         magnitudes.  'f16' is recommended (it is 1.25x faster) only while the term stays under 0.3 * gate.  No
         reference, no CPU: two forward passes on the device."""
-        if self.precision not in ('f16', 'f16x2', 'f16l6'):
+        if self.precision not in ('f16', 'f16c', 'f16x2', 'f16l6'):
             raise ValueError("precision_margin compares the fp16 precisions 'f16' and the family's parity mode")
         # the parity mode of this family: f16l6 (BNeckAttention + ReLU), f16x2 (full-width attention / GELU, mean pooling)
         par = 'f16l6' if not (self.attention_full or self.act_gelu) else 'f16x2'
