@@ -20,7 +20,7 @@ sys.path.insert(0, str(HERE))
 # imported BEFORE the stand-in torchaudio module is installed (transformers probes for the real package)
 from transformers.audio_utils import mel_filter_bank, spectrogram  # noqa: E402
 import _ref_shims  # noqa: E402
-from synth_weights import make_kwargs_variant_state_dict, make_state_dict, make_trained_like_state_dict, synth_pcm_i16  # noqa: E402
+from uit_mobile_amd.synth import make_kwargs_variant_state_dict, make_state_dict, make_trained_like_state_dict, synth_pcm_i16  # noqa: E402
 
 REF = Path("/root/reference")
 uit = _ref_shims.import_reference_uit(str(REF))

@@ -33,7 +33,20 @@ int main() {
                 const char* why = "";
                 if (uitk::validate_config(&c, &why)) { std::printf("validate failed: %s\n", why); ++fails; continue; }
                 std::vector<char> img; uitk::ImageHeader h{};
-                if (uitk::pack_image(&c, &w, &img, &h) || img.size() != h.total_bytes || h.magic != uitk::IMAGE_MAGIC) ++fails;
+                if (uitk::pack_image(&c, &w, nullptr, &img, &h) || img.size() != h.total_bytes || h.magic != uitk::IMAGE_MAGIC) ++fails;
+                if (prec < 2 && depth == 1) {                  // calibrated rounding (round_gptq, its worker threads): random PSD statistics
+                    std::vector<double> st(uitk::calib_stats_doubles(&c));
+                    const uitk::CalibOffsets co = uitk::calib_offsets(&c);
+                    auto psd = [&](double* H, int K) {          // H = X^T X / n of n = 48 random rows (rank-deficient for K > 48: the damping's job)
+                        std::vector<double> X((size_t)48 * K);
+                        for (double& v : X) v = (double)rand() / RAND_MAX - 0.3;
+                        for (int i = 0; i < K; ++i) for (int j = 0; j < K; ++j) { double a = 0; for (int n = 0; n < 48; ++n) a += X[(size_t)n * K + i] * X[(size_t)n * K + j]; H[(size_t)i * K + j] = a / 48; }
+                    };
+                    const int inner = full ? 128 : 32;
+                    psd(st.data() + co.pe, 256); psd(st.data() + co.ln1, 128); psd(st.data() + co.att, inner); psd(st.data() + co.ln2, 128); psd(st.data() + co.hid, 384);
+                    std::vector<char> img2; uitk::ImageHeader h2{};
+                    if (uitk::pack_image(&c, &w, st.data(), &img2, &h2) || img2.size() != img.size() || img2 == img) ++fails;
+                }
             }
         }
     std::printf("pack sanitizer run: %d failures\n", fails);

@@ -1,0 +1,51 @@
+"""CPU: checks on the BUILT library's gfx950 ISA (tools/kernel_isa.py: .hip_fatbin -> code objects -> llvm-objdump), no GPU.
+
+The encoder's weight ring counts vmcnt: a compiler-generated scratch reload inside the block loop is a vector-memory load the compiler
+waits for with s_waitcnt vmcnt(0), which drains every weight DMA in flight (1.56 ms instead of 0.47 when it happened).
+So the instantiations the product launches by default must keep every loop scratch-free, whatever the compiler version does."""
+import sys
+from pathlib import Path
+
+import pytest
+
+ROOT = Path(__file__).resolve().parents[1]
+sys.path.insert(0, str(ROOT / "tools"))
+import kernel_isa  # noqa: E402
+
+pytestmark = pytest.mark.skipif(not (kernel_isa.LLVM / "llvm-objdump").exists() or not (ROOT / "uit_mobile_amd" / "libuitk.so").exists(),
+                                reason="llvm-objdump / built library not available")
+
+
+@pytest.fixture(scope="module")
+def kernels():
+    return kernel_isa.kernels()
+
+
+def _find(kernels, prefix):
+    hits = [k for k in kernels if k.startswith(prefix)]
+    assert len(hits) == 1, (prefix, hits)
+    return kernels[hits[0]]
+
+
+@pytest.mark.parametrize("inst,max_spill", [("<0, 8, false, false, 0, 0, 0>", 0),      # f16 / f16c, full clips, mean pooling: THE bench kernel
+                                            ("<4, 8, false, false, 0, 0, 0>", 16),     # f16l6 (round 3's parity mode): spills in prologue / epilogue only
+                                            ("<3, 8, false, false, 0, 0, 0>", 8)])     # f16x2
+def test_default_encoder_loops_are_scratch_free(kernels, inst, max_spill):
+    k = _find(kernels, f"void uitk::uit_encoder_kernel{inst}")
+    s = kernel_isa.summary(k)
+    assert s["mfma"] > 600 and s["vgpr"] <= 256
+    assert s["vgpr_spill"] <= max_spill, s
+    # the block loop = the loop that holds most of the kernel's MFMAs (the epilogue's head-tile loop and the prologue may spill)
+    mf = lambda lo, hi: sum(1 for a, t in k["insts"] if lo <= a <= hi and t.startswith("v_mfma"))
+    lo, hi = max(kernel_isa.loops(k["insts"]), key=lambda sp: (mf(*sp), sp[1] - sp[0]))
+    assert mf(lo, hi) >= 200, mf(lo, hi)
+    in_loop = [(hex(a), t) for a, t in k["insts"] if t.startswith("scratch_") and lo <= a <= hi]
+    assert not in_loop, in_loop
+    if max_spill == 0:
+        assert s["scratch_insts"] == 0 and s["scratch_bytes"] == 0, s
+
+
+def test_frontend_kernel_has_no_vector_spills(kernels):
+    for inst in ("<false, true, false>", "<true, true, false>"):           # f32 / int16 input, patch layout: what uitk_frontend launches
+        s = kernel_isa.summary(_find(kernels, f"void uitk::mel_frontend_kernel{inst}"))
+        assert s["vgpr_spill"] == 0 and s["scratch_insts"] == 0 and s["mfma"] >= 52, s

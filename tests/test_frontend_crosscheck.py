@@ -11,7 +11,7 @@ import pytest
 
 from conftest import assert_mel_close
 from oracle.oracle import Oracle
-from synth_weights import make_state_dict, synth_pcm_i16
+from uit_mobile_amd.synth import make_state_dict, synth_pcm_i16
 
 audio_utils = pytest.importorskip("transformers.audio_utils")
 

@@ -195,7 +195,7 @@ def test_front_end_tables_and_split_algebra_reproduce_the_oracle_mel():
     import torch
     from mfma_emu import HDR_FMT, HDR_FIELDS
     from oracle.oracle import Oracle
-    from synth_weights import make_state_dict, synth_pcm_i16
+    from uit_mobile_amd.synth import make_state_dict, synth_pcm_i16
     from uit_mobile_amd import models
     sd = make_state_dict("uit_xxxs", 21)
     m = models.uit_xxxs(outputdim=537, target_length=102)

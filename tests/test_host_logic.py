@@ -7,7 +7,7 @@ import numpy as np
 import pytest
 import torch
 
-from synth_weights import make_state_dict
+from uit_mobile_amd.synth import make_state_dict
 from uit_mobile_amd import _lib, models
 from uit_mobile_amd.evaluate import pad_to_target, sequential_pad
 from uit_mobile_amd.inference import load_label_map, topk_lines
@@ -77,15 +77,16 @@ def test_other_factories_match_reference_layout(name, depth, gelu):
         assert tuple(mine[k].shape) == tuple(np.asarray(sd[k]).shape), k
     assert tuple(mine["blocks.0.attn.qkv.weight"].shape) == (384, 128) and tuple(mine["blocks.0.attn.proj.weight"].shape) == (128, 128)
     assert m.depth == depth and m.attention_full and m.act_gelu == gelu and m.pooling == "mean"
-    assert m.precision == "f16x2"                   # the family's parity mode: split fp16 weights (round 3), 40 stages per block
-    img = m.eval().packed_image()                   # host-only packing works without a GPU
-    assert len(img) > (8 + 40 * depth) * 16384
+    assert m.precision == "f16c"                    # the default of every factory (round 4): single fp16 weights, calibrated rounding
     m16 = getattr(models, name)(outputdim=537, target_length=102, precision="f16").eval()
     assert (8 + 40 * depth) * 16384 > len(m16.packed_image()) > (8 + 20 * depth) * 16384       # the 20-stage single-weight layout
+    assert len(m.eval().packed_image()) == len(m16.packed_image())                             # f16c: the same layout, other roundings
+    img = getattr(models, name)(outputdim=537, target_length=102, precision="f16x2").eval().packed_image()      # split weights (round 3)
+    assert len(img) > (8 + 40 * depth) * 16384      # host-only packing works without a GPU
     with pytest.raises(NotImplementedError):        # built for the uit_* family only
         getattr(models, name)(outputdim=537, target_length=102, precision="fp8")
-    assert getattr(models, name)(outputdim=537, target_length=102, pooling="token").precision == "f16x2"      # any pooling
-    assert len(getattr(models, name)(outputdim=537, target_length=102, pooling="dm").eval().packed_image()) == len(img)
+    assert getattr(models, name)(outputdim=537, target_length=102, pooling="token").precision == "f16c"       # any pooling
+    assert len(getattr(models, name)(outputdim=537, target_length=102, pooling="dm", precision="f16x2").eval().packed_image()) == len(img)
 
 
 def test_precision_kwarg_surface():
@@ -197,21 +198,29 @@ def test_load_pretrained_filters_by_shape_and_resizes_pos_embed():
         load_pretrained(m, {"unrelated": torch.zeros(1)})
 
 
-def test_uploaded_image_is_invalidated_by_hooks_not_by_a_per_call_scan(monkeypatch):
-    """The (pointer, version) walk over all 163 tensors is off the hot path (round 3): a cached handle is returned without
-    touching the parameters; load_state_dict, .to()/.float() (= _apply) and refresh() drop the handles.  UITK_CHECK_WEIGHTS=1
-    keeps the old per-call scan as a debug mode."""
+def test_uploaded_image_follows_the_weights(monkeypatch):
+    """Round 4: every call compares a CHEAP stamp of the weights (sum of the tensors' version counters + two storage
+    pointers, one pass over a cached tensor list) with the one the uploaded image was packed from -- in-place edits under no_grad,
+    nn.init.*, a sub-module's load_state_dict are seen; load_state_dict, .to()/.float() (= _apply) and refresh() drop the handles
+    outright.  UITK_CHECK_WEIGHTS=0 (benchmark loops) returns the cached handle without looking."""
     from uit_mobile_amd.models import uit as U
     m = models.uit_xxxs(outputdim=537, target_length=102).eval()
 
     class H:                                            # stand-in for _Handle
         ptr = 1234
 
-    m._handles[0] = (H(), m._stamp())
-    calls = []
-    monkeypatch.setattr(m, "_stamp", lambda: calls.append(1) or ())
     dev = torch.device("cuda", 0)
-    assert m._handle(dev) == 1234 and calls == []                       # hot path: dict lookup only
+    assert U._CHECK_WEIGHTS                             # the default
+    m._handles[0] = (H(), m._stamp())
+    assert m._handle(dev) == 1234                       # unchanged weights: the cached handle
+    for edit in (lambda: m.norm.weight.mul_(2.0), lambda: torch.nn.init.zeros_(m.blocks[1].mlp.fc2.bias),
+                 lambda: m.outputlayer.load_state_dict(m.outputlayer.state_dict()),
+                 lambda: torch.nn.utils.vector_to_parameters(torch.nn.utils.parameters_to_vector(m.parameters()), m.parameters())):
+        m._handles[0] = (H(), m._stamp())
+        with torch.no_grad():
+            edit()
+        assert m._handles[0][1] != m._stamp()           # the stamp moved: _handle would re-pack (and re-calibrate)
+    m._handles[0] = (H(), m._stamp())
     m.float()                                                           # _apply hook
     assert m._handles == {}
     m._handles[0] = (H(), ())
@@ -220,9 +229,14 @@ def test_uploaded_image_is_invalidated_by_hooks_not_by_a_per_call_scan(monkeypat
     m._handles[0] = (H(), ())
     m.refresh()
     assert m._handles == {}
-    m._handles[0] = (H(), ())
-    monkeypatch.setattr(U, "_CHECK_WEIGHTS", True)
-    assert m._handle(dev) == 1234 and calls == [1]                      # debug mode: the scan runs (and matches)
+    m._handles[0] = (H(), ())                           # a stale stamp ...
+    monkeypatch.setattr(U, "_CHECK_WEIGHTS", False)
+    calls = []
+    monkeypatch.setattr(m, "_stamp", lambda: calls.append(1) or ())
+    assert m._handle(dev) == 1234 and calls == []       # ... is not even looked at with UITK_CHECK_WEIGHTS=0
+    with pytest.raises(ValueError):                     # option names are validated without a live handle (no leak, no poisoned state)
+        m.set_option("no_such_option", 1)
+    assert "no_such_option" not in m._options
 
 
 def test_parity_precision_is_part_of_the_interface():
@@ -240,7 +254,7 @@ def test_other_kwargs_keep_the_reference_state_dict_layout():
     """Round 3: qkv_bias=False, init_values (LayerScale) and init_bn=False are accepted; the state_dict then has exactly the keys the
     REFERENCE's model has for these kwargs (make_golden.py --kwargs loads the same checkpoint into it with strict=True): no
     attn.qkv.bias, no init_bn.*, blocks.N.ls{1,2}.gamma.  center=False changes the frame count rule.  All pack without a GPU."""
-    from synth_weights import make_kwargs_variant_state_dict
+    from uit_mobile_amd.synth import make_kwargs_variant_state_dict
     m = models.uit_xxxs(outputdim=537, target_length=102, qkv_bias=False, init_values=0.1, init_bn=False)
     sd = make_kwargs_variant_state_dict("uit_xxxs", 33)
     assert set(m.state_dict()) == set(sd)

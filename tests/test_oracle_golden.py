@@ -11,7 +11,7 @@ import numpy as np
 import pytest
 
 from oracle.oracle import Oracle
-from synth_weights import make_state_dict
+from uit_mobile_amd.synth import make_state_dict
 from conftest import assert_mel_close
 
 MODELS = ["uit_xxxs", "uit_xxs", "uit_xs"]
@@ -124,7 +124,7 @@ def test_trained_like_checkpoint(golden, name):
     """The oracle at trained-checkpoint magnitudes: reference logits beyond -10 (tests/golden/make_golden.py main_round2,
     weights from synth_weights.make_trained_like_state_dict loaded into the reference's own UITBase)."""
     from conftest import centred
-    from synth_weights import make_trained_like_state_dict
+    from uit_mobile_amd.synth import make_trained_like_state_dict
     g = golden(f"trained_{name}")
     assert np.abs(g["logits"]).max() >= 10.0
     r = Oracle(make_trained_like_state_dict(name, int(g["seed"]))).forward(g["pcm"], want_stages=True)
@@ -134,7 +134,7 @@ def test_trained_like_checkpoint(golden, name):
 
 
 def test_trained_like_checkpoint_on_sample_clips(golden):
-    from synth_weights import make_trained_like_state_dict
+    from uit_mobile_amd.synth import make_trained_like_state_dict
     g, pcm = golden("trained_samples_uit_xs"), golden("samples_uit_xs")
     o = Oracle(make_trained_like_state_dict("uit_xs", int(g["seed"])))
     for key in ("water_000", "water_003", "85b877b5_nohash_0"):
@@ -144,7 +144,7 @@ def test_trained_like_checkpoint_on_sample_clips(golden):
 
 
 def test_trained_like_short_clip(golden):
-    from synth_weights import make_trained_like_state_dict
+    from uit_mobile_amd.synth import make_trained_like_state_dict
     g = golden("trained_short_uit_xxxs")
     r = Oracle(make_trained_like_state_dict("uit_xxxs", int(g["seed"]))).forward(g["pcm"])
     assert np.abs(r["logits"] - g["logits"]).max() < 2e-4
@@ -171,7 +171,7 @@ def test_other_factories_full_attention_and_gelu(golden, name, act):
     """full-width Attention (models/uit.py:124-178) and the exact-erf GELU MLP of the non-bottleneck factories
     (:514-579), d4 at init scale, d6 at trained-like magnitudes, against the imported reference (make_golden.py --variants)."""
     from conftest import centred
-    from synth_weights import make_trained_like_state_dict
+    from uit_mobile_amd.synth import make_trained_like_state_dict
     g = golden(f"variant_{name}")
     mk = make_trained_like_state_dict if bool(g["trained"]) else make_state_dict
     r = Oracle(mk(name, int(g["seed"]), attention="full"), act=act).forward(g["pcm"], want_stages=True)
@@ -182,7 +182,7 @@ def test_other_factories_full_attention_and_gelu(golden, name, act):
 
 def test_pooling_dm(golden):
     """pooling='dm' (models/uit.py:405-412) against the imported reference: 3XS (full, short, two-crop clips), trained-like XS."""
-    from synth_weights import make_trained_like_state_dict
+    from uit_mobile_amd.synth import make_trained_like_state_dict
     g = golden("pooling_dm")
     o = Oracle(make_state_dict("uit_xxxs", int(g["xxxs_seed"])), pooling="dm")
     for pcm, want in ((g["pcm"], g["xxxs_probs"]), (g["xxxs_short_pcm"], g["xxxs_short_probs"]), (g["xxxs_crops_pcm"], g["xxxs_crops_probs"])):
@@ -193,7 +193,7 @@ def test_pooling_dm(golden):
 
 def test_pooling_token(golden):
     """pooling='token' (models/uit.py:389-392, 399-401; the UITBase default) against the imported reference."""
-    from synth_weights import make_trained_like_state_dict
+    from uit_mobile_amd.synth import make_trained_like_state_dict
     g = golden("pooling_token")
     for tag, name, trained, att, act in (("xxxs", "uit_xxxs", False, "bneck", "relu"), ("xs_trained", "uit_xs", True, "bneck", "relu"),
                                          ("h128", "audio_transformer_h128_d4_m3", False, "full", "gelu")):
@@ -209,7 +209,7 @@ def test_pooling_token(golden):
 def test_other_kwargs_and_center_false(golden):
     """Round 3: the oracle's restatement of qkv_bias=False / LayerScale / init_bn=False (GlobalNormer) and of center=False against
     the fixtures the imported reference produced for those kwargs (tests/golden/make_golden.py --kwargs)."""
-    from synth_weights import make_kwargs_variant_state_dict, make_state_dict
+    from uit_mobile_amd.synth import make_kwargs_variant_state_dict, make_state_dict
     g = golden("kwargs_uit_xxxs")
     r = Oracle(make_kwargs_variant_state_dict("uit_xxxs", int(g["seed"]))).forward(g["pcm"])
     assert np.abs(r["logits"] - g["logits"]).max() < 2e-4 and np.abs(r["probs"] - g["probs"]).max() < 5e-5

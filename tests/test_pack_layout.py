@@ -8,7 +8,7 @@ import torch
 from conftest import centred
 from mfma_emu import EncoderEmu
 from oracle.oracle import Oracle
-from synth_weights import make_state_dict, synth_pcm_i16
+from uit_mobile_amd.synth import make_state_dict, synth_pcm_i16
 from uit_mobile_amd import models
 
 
@@ -193,11 +193,10 @@ def test_f16x2_full_attention_stream_holds_hi_plus_lo_of_every_block_weight():
     of two output tiles; the MLP as in the bottleneck layout.  hi + lo must give the folded fp64 weight to 2^-21."""
     import struct
     from mfma_emu import HDR_FMT, HDR_FIELDS
-    from synth_weights import make_trained_like_state_dict
+    from uit_mobile_amd.synth import make_trained_like_state_dict
     name = "audio_transformer_h128_d4_m3"
     sd = make_trained_like_state_dict(name, 7, attention="full")
-    m = getattr(models, name)(outputdim=537, target_length=102)
-    assert m.precision == "f16x2"
+    m = getattr(models, name)(outputdim=537, target_length=102, precision="f16x2")
     m.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()}, strict=True)
     img = m.eval().packed_image()
     h = dict(zip(HDR_FIELDS, struct.unpack_from(HDR_FMT, img, 0)))
@@ -284,7 +283,7 @@ def test_emulated_f16l6_low_order_term_cuts_the_weight_rounding_error(seed):
     fp6 / fp4 activation copies and the K = 128 MFMA lane map (tools/probe/mx6_layout.hip), executed by the emulator on a
     trained-like checkpoint, must be CLOSER to the oracle than the same emulation of precision f16 -- i.e. the low-order term is
     applied to the right rows / columns / scales (a misplaced correction adds error instead of removing it)."""
-    from synth_weights import make_trained_like_state_dict
+    from uit_mobile_amd.synth import make_trained_like_state_dict
     sd = make_trained_like_state_dict("uit_xxxs", seed)
     pcm = synth_pcm_i16(2, 16000, seed=7)
     o = Oracle(sd)
@@ -315,7 +314,7 @@ def test_everything_added_to_the_residual_stream_is_centred_at_pack_time(factory
     ROUNDED proj / fc2 / patch-embed operands over their 128 output channels (zero up to the operand rounding: |sum| <= 128 half-ulps)."""
     import struct
     from mfma_emu import HDR_FMT, HDR_FIELDS, to_f32
-    from synth_weights import make_trained_like_state_dict
+    from uit_mobile_amd.synth import make_trained_like_state_dict
     full = factory.startswith("audio_transformer")
     sd = make_trained_like_state_dict(factory, 3, attention="full" if full else "bneck")
     m = getattr(models, factory)(outputdim=537, target_length=102, **kw)
@@ -368,7 +367,7 @@ def test_emulated_calibrated_rounding_cuts_the_weight_rounding_error(seed):
     round-to-nearest image -- with the same kernel dataflow (nothing but the rounding direction of the weights differs) -- and every
     calibrated weight must still be one of the two fp16 neighbours of the exact folded value."""
     from calib_ref import calib_stats
-    from synth_weights import make_trained_like_state_dict
+    from uit_mobile_amd.synth import make_trained_like_state_dict
     sd = make_trained_like_state_dict("uit_xxxs", seed)
     stats = calib_stats(sd, synth_pcm_i16(16, 16000, seed=4242), depth=4)
     pcm = synth_pcm_i16(2, 16000, seed=7)                                  # held out

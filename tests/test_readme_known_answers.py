@@ -75,7 +75,7 @@ def test_oracle_reproduces_readme(golden, name, clip):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("precision", ["f16", "f16x2"])
+@pytest.mark.parametrize("precision", [None, "f16l6", "f16", "f16x2"])            # None = the factories' default (f16c)
 @pytest.mark.parametrize("name,clip", sorted(KNOWN))
 def test_hip_path_reproduces_readme(golden, name, clip, precision):
     import torch

@@ -30,7 +30,7 @@ import numpy as np
 from pathlib import Path
 import oracle.oracle as O
 O.build = lambda force=False: Path({str(ROOT / 'oracle' / 'liboracle_asan.so')!r})
-from synth_weights import make_state_dict, synth_pcm_i16
+from uit_mobile_amd.synth import make_state_dict, synth_pcm_i16
 for name, att, act in (("uit_xxxs", "bneck", "relu"), ("audio_transformer_h128_d4_m3", "full", "gelu")):
     o = O.Oracle(make_state_dict(name, 3, attention=att), act=act)
     for T in (16000, 8000, 16384, 4099):
@@ -48,7 +48,7 @@ print("sanitizer run ok")
 def test_host_packer_under_sanitizers(tmp_path):
     exe = tmp_path / "asan_pack"
     subprocess.check_call(["g++", "-O1", "-g", "-std=c++17", "-fsanitize=address,undefined", "-fno-sanitize-recover=undefined",
-                           "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include", "-o", str(exe),
+                           "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include", "-pthread", "-o", str(exe),
                            str(ROOT / "tests" / "native" / "asan_pack_main.cpp"), str(ROOT / "uit_mobile_amd" / "csrc" / "pack.cpp")])
     out = subprocess.run([str(exe)], env=dict(os.environ, ASAN_OPTIONS="detect_leaks=1"), capture_output=True, text=True, timeout=600)
     assert out.returncode == 0 and "0 failures" in out.stdout, (out.stdout + out.stderr)[-3000:]

@@ -17,7 +17,7 @@ sys.path[:0] = [str(ROOT), str(ROOT / "tests" / "golden"), str(ROOT / "tests")]
 from bench import synth_batch  # noqa: E402
 from calib_ref import calib_stats  # noqa: E402
 from oracle.oracle import Oracle  # noqa: E402
-from synth_weights import DEPTH, make_trained_like_state_dict, synth_pcm_i16  # noqa: E402
+from uit_mobile_amd.synth import DEPTH, make_trained_like_state_dict, synth_pcm_i16  # noqa: E402
 from uit_mobile_amd import models  # noqa: E402
 
 
@@ -34,18 +34,20 @@ def main():
     name = sys.argv[1] if len(sys.argv) > 1 else "uit_xs"
     nseeds = int(sys.argv[2]) if len(sys.argv) > 2 else 12
     depth = DEPTH[name]
+    full = name.startswith("audio_transformer")
+    att, act, inner = ("full" if full else "bneck"), ("gelu" if full and not name.endswith("_relu") else "relu"), (128 if full else 32)
     cal = synth_pcm_i16(32, 16000, seed=4242)
     cal_d = torch.from_numpy(cal).cuda()
     # (1) statistics
-    sd = make_trained_like_state_dict(name, 200)
+    sd = make_trained_like_state_dict(name, 200, attention=att)
     m = build(name, sd, "f16c", cal_d)
     t0 = time.perf_counter()
     got = m.calib_stats()
     torch.cuda.synchronize()
     t_build = time.perf_counter() - t0
-    want = calib_stats(sd, cal, depth)
+    want = calib_stats(sd, cal, depth, inner=inner, act=act)
     off, worst = 0, 0.0
-    sizes = [("pe", 256)] + [(f"b{b}.{k}", n) for b in range(depth) for k, n in (("ln1", 128), ("att", 32), ("ln2", 128), ("hid", 384))]
+    sizes = [("pe", 256)] + [(f"b{b}.{k}", n) for b in range(depth) for k, n in (("ln1", 128), ("att", inner), ("ln2", 128), ("hid", 384))]
     for nm, n in sizes:
         g, w = got[off:off + n * n], want[off:off + n * n]
         rel = np.linalg.norm(g - w) / np.linalg.norm(w)
@@ -72,11 +74,11 @@ def main():
     odd = np.stack([0.5 * np.sin(2 * np.pi * 3000 * t), 0.3 * np.sign(np.sin(2 * np.pi * 200 * t)), np.zeros(16000), 1e-3 * rng.standard_normal(16000),
                     np.cumsum(rng.standard_normal(16000)) / 200.0, 0.8 * np.sin(2 * np.pi * (100 + 3000 * t) * t)])
     evals["odd"] = np.clip(np.round(odd * 32768), -32768, 32767).astype(np.int16)
-    modes = [("f16", None), ("f16c", None), ("f16c+x", cal_d), ("f16l6", None), ("f16x2", None)]
+    modes = [("f16", None), ("f16c", None), ("f16c+x", cal_d)] + ([] if full else [("f16l6", None)]) + [("f16x2", None)]
     res = {}
     for seed in range(200, 200 + nseeds):
-        sd = make_trained_like_state_dict(name, seed)
-        o = Oracle(sd)
+        sd = make_trained_like_state_dict(name, seed, attention=att)
+        o = Oracle(sd, act=act)
         refs = {k: o.forward(v) for k, v in evals.items()}
         line = []
         for mode, c in modes:

@@ -17,7 +17,7 @@ import torch
 ROOT = Path(__file__).resolve().parents[1]
 sys.path[:0] = [str(ROOT), str(ROOT / "tests" / "golden")]
 from oracle.oracle import Oracle  # noqa: E402
-from synth_weights import make_state_dict, make_trained_like_state_dict, synth_pcm_i16  # noqa: E402
+from uit_mobile_amd.synth import make_state_dict, make_trained_like_state_dict, synth_pcm_i16  # noqa: E402
 
 
 def rnd(x, mode):

@@ -7,7 +7,7 @@ ROOT = Path(__file__).resolve().parents[1]
 sys.path[:0] = [str(ROOT), str(ROOT / "tests"), str(ROOT / "tests" / "golden")]
 import fp8_emu
 from oracle.oracle import Oracle
-from synth_weights import make_state_dict, make_trained_like_state_dict, synth_pcm_i16
+from uit_mobile_amd.synth import make_state_dict, make_trained_like_state_dict, synth_pcm_i16
 from uit_mobile_amd import models
 from bench import synth_batch
 

@@ -4,7 +4,7 @@ from pathlib import Path
 import numpy as np, torch
 ROOT = Path(__file__).resolve().parents[1]
 sys.path[:0] = [str(ROOT), str(ROOT / "tests" / "golden")]
-from synth_weights import make_state_dict
+from uit_mobile_amd.synth import make_state_dict
 from uit_mobile_amd import models
 from bench import synth_batch
 dev = torch.device("cuda", 0)

@@ -5,7 +5,7 @@ from pathlib import Path
 import numpy as np, torch
 ROOT = Path(__file__).resolve().parents[1]
 sys.path[:0] = [str(ROOT), str(ROOT / "tests"), str(ROOT / "tests" / "golden")]
-from synth_weights import make_state_dict, synth_pcm_i16
+from uit_mobile_amd.synth import make_state_dict, synth_pcm_i16
 from uit_mobile_amd import models, _lib
 from mfma_emu import HDR_FMT, HDR_FIELDS, L6_BLOCK, L6_QK, l6_mlp_offset, PE_STAGES, STAGE
 name, depth = "uit_xxxs", 4

@@ -4,7 +4,7 @@ from pathlib import Path
 import numpy as np, torch
 ROOT = Path(__file__).resolve().parents[1]
 sys.path[:0] = [str(ROOT), str(ROOT / "tests" / "golden")]
-from synth_weights import make_state_dict, synth_pcm_i16
+from uit_mobile_amd.synth import make_state_dict, synth_pcm_i16
 from uit_mobile_amd import models
 pcm = synth_pcm_i16(4096, 16000, seed=41)
 perm = np.random.default_rng(3).permutation(2048) * 2

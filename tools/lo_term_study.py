@@ -19,7 +19,7 @@ import torch
 ROOT = Path(__file__).resolve().parents[1]
 sys.path[:0] = [str(ROOT), str(ROOT / "tests" / "golden")]
 from oracle.oracle import Oracle  # noqa: E402
-from synth_weights import make_trained_like_state_dict, synth_pcm_i16  # noqa: E402
+from uit_mobile_amd.synth import make_trained_like_state_dict, synth_pcm_i16  # noqa: E402
 
 F64 = torch.float64
 PE_SPLIT = True     # patch-embed weights as hi + lo (the product rounds them structurally, which removes most of the same term)

@@ -8,7 +8,7 @@ sys.path[:0] = [str(ROOT), str(ROOT / "tests" / "golden")]
 
 
 def main():
-    from synth_weights import make_state_dict
+    from uit_mobile_amd.synth import make_state_dict
     from uit_mobile_amd import models
     from bench import synth_batch
     dev = torch.device("cuda", 0)

@@ -747,14 +747,15 @@ __global__ __launch_bounds__(WAVES * 64, 2) void uit_encoder_kernel(EncoderArgs 
         for (int i = 0; i < PREFETCH; ++i) ring_issue<WAVES>(a.wstream, ring, PE_STAGES + i, wave, lane);
     }
 
-    auto dbg_store = [&](int stage) {                      // (debug path: recomputes its token map instead of keeping it live)
+    auto dbg_store = [&](int stage) {                      // (debug path: recomputes its token map from v_mbcnt -- volatile, so that no
+        const int dl = lane_id_now();                      //  lane-dependent address is hoisted out of the block loop and spilled there)
 #pragma unroll
         for (int ct = 0; ct < 3; ++ct) {
-            const int col = 16 * ct + (threadIdx.x & 15);
+            const int col = 16 * ct + (dl & 15);
             const int dclip = (!TOK && col >= NTOK) ? 1 : 0, dtk = TOK ? (col >= 1 && col <= NTOK ? col - 1 : 0) : col - NTOK * dclip;
             const int row = r0 + dclip;
             if (row < a.rows) {
-                float* dst = a.dbg + (((int64_t)row * (a.depth + 1) + stage) * NTOK + dtk) * DIM + 4 * (int)((threadIdx.x & 63) >> 4);
+                float* dst = a.dbg + (((int64_t)row * (a.depth + 1) + stage) * NTOK + dtk) * DIM + 4 * (dl >> 4);
 #pragma unroll
                 for (int ft = 0; ft < 8; ++ft) *(f4*)(dst + 16 * ft) = R[ft][ct];
             }

@@ -74,8 +74,8 @@ def main(argv=None):
     ap.add_argument("-m", "--model", type=str, nargs="?", default="uit_xs",
                     metavar=f"Public Checkpoint [{','.join(PRETRAINED_CHECKPOINTS)}] or Experiment Path")
     ap.add_argument("-k", "--topk", type=int, default=3, help="Print top-k results")
-    ap.add_argument("--precision", default=None, choices=["f16l6", "f16", "f16x2", "bf16", "fp8"],
-                    help="default: f16l6, the parity mode (fp16 operands + low-order weight term) for the uit_* family, f16x2 (split fp16 weights) for the full-width-attention factories")
+    ap.add_argument("--precision", default=None, choices=["f16c", "f16l6", "f16", "f16x2", "bf16", "fp8"],
+                    help="default: f16c, the parity mode of every factory (the fp16 kernels on weights with calibrated rounding)")
     args = ap.parse_args(argv)
     label_maps = load_label_map()
     model = build_model(args.model, precision=args.precision)

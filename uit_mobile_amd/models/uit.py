@@ -489,6 +489,17 @@ class UITBase(nn.Module):
         with torch.cuda.device(device):
             _lib.check(_lib.load().uitk_reserve(self._handle(device), int(B), int(T)), "uitk_reserve")
 
+    def tune_frontend(self, x):
+        """Measure the front-end's pass split for batches shaped like `x` on x's device now (uitk_tune_frontend: ~140 short launches
+        on x's buffer and the current stream, event waits only).  The result is shared by every model of the process on that device;
+        with fe_autotune=True (default) the first forward of an unmeasured shape does this by itself."""
+        x, in_dtype = self._prep_input(x)
+        B, T = x.shape
+        h = self._handle(x.device)
+        with torch.cuda.device(x.device):
+            stream = ctypes.c_void_p(torch.cuda.current_stream(x.device).cuda_stream)
+            _lib.check(_lib.load().uitk_tune_frontend(h, ctypes.c_void_p(x.data_ptr()), in_dtype, B, T, stream), "uitk_tune_frontend")
+
     # the two stages of forward(), for callers that put work between them (the amax all-reduce of the data-parallel
     # wrapper; a pipelined caller that runs the next batch's front-end on a second replica before this batch's encoder)
     def frontend(self, x):

@@ -125,8 +125,8 @@ class PeerGather:
     following gather_async call.  nbuf = 3 (default) covers the pipelined pattern "wait handle N after enqueuing gather N+1";
     nbuf = 2 is enough when every result is waited and consumed before the next gather.
 
-    Buffers are allocated once and exchanged once through torch's IPC handles (hipIpcGetMemHandle / dmabuf; this driver needs
-    HSA_ENABLE_IPC_MODE_LEGACY=0).  The precondition is CHECKED: if any rank cannot export or map a buffer, every rank raises
+    Buffers are allocated once and exchanged once through torch's IPC handles (hipIpcGetMemHandle / dmabuf; this pool's driver needs
+    HSA_ENABLE_IPC_MODE_LEGACY=0).  The precondition is CHECKED by doing it: if any rank cannot export or map a buffer, every rank raises
     PeerGatherUnavailable (ShardedUiT then falls back to the RCCL gather with a warning).  All ranks must live on one node."""
 
     def __init__(self, rows, cols, device, group=None, dtype=torch.float32, nbuf=3):
@@ -145,15 +145,14 @@ class PeerGather:
         self.peers = [[None] * nbuf for _ in range(self.world)]
         if self.world > 1:
             import os
-            err = None
-            if os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "") != "0":
-                err = "HSA_ENABLE_IPC_MODE_LEGACY=0 is not set (the host driver only supports dmabuf IPC)"
-            mine = None
-            if err is None:
-                try:
-                    mine = [reduce_tensor(t) for t in self.out]
-                except Exception as e:              # hipIpcGetMemHandle refused
-                    err = f"cannot export the output buffers: {e}"
+            # the actual export / map decides; the environment only explains a failure (drivers with legacy IPC work without the variable)
+            hint = "" if os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "") == "0" else \
+                " (HSA_ENABLE_IPC_MODE_LEGACY=0 is not set: a host driver that only supports dmabuf IPC needs it)"
+            err, mine = None, None
+            try:
+                mine = [reduce_tensor(t) for t in self.out]
+            except Exception as e:                  # hipIpcGetMemHandle refused
+                err = f"cannot export the output buffers: {e}{hint}"
             everyone = [None] * self.world
             dist.all_gather_object(everyone, (mine, err), group=group)
             if all(e is None for _, e in everyone):
@@ -162,7 +161,7 @@ class PeerGather:
                         if r != self.rank:
                             self.peers[r] = [fn(*args) for fn, args in handles]     # peer buffers mapped into this process
                 except Exception as e:              # hipIpcOpenMemHandle refused
-                    err = f"cannot map a peer's buffers: {e}"
+                    err = f"cannot map a peer's buffers: {e}{hint}"
             verdict = [None] * self.world
             dist.all_gather_object(verdict, err, group=group)                       # every rank takes the same decision
             bad = [(r, e) for r, e in enumerate(verdict) if e is not None] + [(r, e) for r, (_, e) in enumerate(everyone) if e is not None]
@@ -232,9 +231,10 @@ class ShardedUiT:
     pooled in mirrored lane order), on nothing else."""
 
     def __init__(self, model, group=None, global_floor=True, gather="rccl", gather_dtype=None, slice_classes=None, topk=None,
-                 topk_fn=None):
+                 topk_fn=None, peer_nbuf=3):
         if gather not in ("rccl", "peer"):
             raise ValueError(f"Unknown gather ({gather})")
+        self.peer_nbuf = int(peer_nbuf)             # PeerGather's rotating buffers: 3 = "wait handle n after enqueuing gather n+1"
         if gather_dtype not in (None, torch.float32, torch.float16):
             raise ValueError("gather_dtype must be None / torch.float32 / torch.float16")
         if topk is not None and (gather_dtype is torch.float16 or slice_classes is not None):
@@ -285,7 +285,7 @@ class ShardedUiT:
         if self.gather == "peer" and multi:
             if self._peer is None or self._peer.rows != send.shape[0] or self._peer.cols != send.shape[1] or self._peer.out[0].dtype != send.dtype:
                 try:
-                    self._peer = PeerGather(send.shape[0], send.shape[1], send.device, self.group, send.dtype)
+                    self._peer = PeerGather(send.shape[0], send.shape[1], send.device, self.group, send.dtype, nbuf=self.peer_nbuf)
                 except PeerGatherUnavailable as e:
                     import warnings
                     warnings.warn(f"{e} -- falling back to gather='rccl'")

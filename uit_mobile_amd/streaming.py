@@ -27,12 +27,15 @@ class HostClipStreamer:
     def _stage(self, slot, batch):
         """CPU copy into pinned memory, then async H2D on the copy stream."""
         n = batch.shape[0]
+        # The HOST waits here for the H2D copy issued two batches ago into this slot (the `free` event below only orders the copy
+        # stream against the kernels).  Both paths need it: the staging buffer below is about to be overwritten -- and a PINNED batch
+        # handed in by a producer ring (PinnedBatchFeeder) is recycled by its owner once the streamer has taken two more batches,
+        # which is only safe if "taken" implies "that copy has completed": without this wait the host runs ahead of the copy stream
+        # (an H2D of 262 MB takes ~5 ms, a loop iteration ~0.1 ms) and the producers overwrite a buffer the DMA is still reading.
+        self.ready[slot].synchronize()
         if batch.is_pinned() and batch.dtype == self.dtype:
             src = batch                                         # producer wrote straight into pinned memory: no CPU copy
         else:
-            # the H2D copy issued two batches ago may still be reading this pinned buffer: the HOST must wait for it
-            # (the `free` event below only orders the copy stream against the kernels)
-            self.ready[slot].synchronize()
             self.host[slot][:n].copy_(batch)                    # CPU memcpy (+ dtype conversion) into the staging buffer
             src = self.host[slot][:n]
         with torch.cuda.stream(self.copy_stream):
@@ -74,8 +77,10 @@ class PinnedBatchFeeder:
     batches in parallel -- each calls `fill(i, out)` for its own batch indices, `out` being the numpy view [batch_size, clip_samples] of
     a pinned buffer it may write clip by clip (a clip shorter than clip_samples is zero-padded: `collate`) -- and hands them over IN
     ORDER; iterating the feeder yields pinned tensors that `HostClipStreamer.run` sends without a CPU copy.  numpy / file reads
-    release the GIL, so the threads overlap; a buffer returns to the producers once the NEXT-BUT-ONE batch has been handed out (the
-    streamer keeps at most two batches in flight: one in H2D, one in the kernels).
+    release the GIL, so the threads overlap; a buffer returns to the producers once THREE later batches have been requested -- by then
+    the streamer has staged the next-but-one batch, and staging batch k waits (on the host) for the H2D copy of batch k-2
+    (HostClipStreamer._stage), so the returned buffer's copy has completed.  A consumer other than HostClipStreamer must give the
+    same guarantee: a batch's buffer may be overwritten once three later batches have been requested.
 
         feeder = PinnedBatchFeeder(fill, n_batches, batch_size=8192, clip_samples=16000, producers=8)
         for probs in HostClipStreamer(model, 8192, 16000).run(feeder): ...

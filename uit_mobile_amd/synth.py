@@ -1,4 +1,5 @@
-"""Deterministic synthetic checkpoints in the reference's state_dict layout (numpy only).
+"""Deterministic synthetic checkpoints and PCM in the reference's state_dict layout (numpy only): what bench.py, the smoke test and
+the test-suite feed the product and the oracle with.
 
 No pretrained UiT checkpoint is reachable from the build container (zenodo, models/uit.py:643-653), so parity
 is pinned on seeded weights.  The SAME function is used by make_golden.py (to load the weights into the
