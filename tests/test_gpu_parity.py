@@ -1250,23 +1250,32 @@ def test_device_kws_transform_matches_reference_loop():
             assert torch.equal(a.cpu(), b) and torch.equal(ya.cpu(), yb)
 
 
-@pytest.mark.parametrize("gather", ["rccl", "peer"])
-def test_bench_two_rank_pipeline_runs_on_one_gpu(gather):
+@pytest.mark.parametrize("gather,launcher", [("rccl", "torchrun"), ("peer", "torchrun"), ("auto", "self")])
+def test_bench_two_rank_pipeline_runs_on_one_gpu(gather, launcher):
     """bench.py's N > 1 code path (shards, pipelined front-end / amax all-reduce / encoder / asynchronous gathers, barrier
     + max-over-ranks timing) exercised end to end with two ranks on one GPU over gloo -- RCCL itself needs one GPU per rank;
-    what is checked is that the pipeline runs, every gather completes and rank 0 prints one well-formed JSON line."""
+    what is checked is that the pipeline runs, every gather completes, rank 0 prints one well-formed JSON line and the sampled rows
+    of the last timed step match the oracle.  launcher 'self' = `python bench.py --gpus 2 ...` as the driver types it: the script
+    starts its own ranks as a child torch.distributed.run (round 4; it used to exit with "launch with torch.distributed.run")."""
     import json
     import subprocess
     import sys
     from pathlib import Path
     root = Path(__file__).resolve().parents[1]
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", str(29700 + os.getpid() % 200), str(root / "bench.py"), "--gpus", "2", "--steps", "6", "--warmup", "2",
-           "--spinup-steps", "2", "--batch-per-gpu", "512", "--backend", "gloo", "--all-ranks-on-device0", "--gather", gather]
-    out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=str(root))
+    args = [str(root / "bench.py"), "--gpus", "2", "--steps", "6", "--warmup", "2", "--batch-per-gpu", "512", "--backend", "gloo",
+            "--all-ranks-on-device0", "--gather", gather]
+    if launcher == "torchrun":
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+               "--master-port", str(29700 + os.getpid() % 200)] + args
+    else:
+        cmd = [sys.executable] + args
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=str(root), env=env)
     assert out.returncode == 0, out.stderr[-2000:]
     lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["steps"] == 6 and d["config"]["global_batch"] == 1024 and d["value"] > 0
-    assert d["scaling"] == "weak" and "cpu_baseline" not in d and ("peer" in d["config"]["parallelism"]) == (gather == "peer")
+    assert d["scaling"] == "weak" and "cpu_baseline" not in d and d["rccl_ranks"] == 2
+    assert d["gather"] == ("rccl" if gather == "rccl" else "peer") and ("peer" in d["config"]["parallelism"]) == (gather != "rccl")
+    assert d["precision"] == "f16c" and d["max_abs_dprob"] is not None and d["max_abs_dprob"] < TOL, d.get("parity_check")

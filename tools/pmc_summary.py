@@ -63,7 +63,7 @@ if '--latest' in sys.argv:
         h.update((root / "uit_mobile_amd" / "csrc" / f).read_bytes())
     enc = next((v for k, v in pm.items() if 'encoder' in k), {})
     fe = next((v for k, v in pm.items() if 'frontend' in k), {})
-    prec = sys.argv[sys.argv.index('--precision') + 1] if '--precision' in sys.argv else 'f16l6'
+    prec = sys.argv[sys.argv.index('--precision') + 1] if '--precision' in sys.argv else 'f16c'
     latest = {"source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, tools/prof.sh), steady launches of the default bench workload "
                         "(UiT-XS, 8192 f32 clips, 3 rotating input batches)",
               "correction": "MI355X_MICROARCH.md HBM section: FETCH_SIZE (KiB) tallies 128-B requests at 64 B for 16-B-per-lane streaming reads -> x2; WRITE_SIZE exact",

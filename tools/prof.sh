@@ -15,5 +15,5 @@ for C in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_B
   N=$(echo $C | tr ' ' '_' | cut -c1-40)
   rocprofv3 --pmc $C --output-format csv -d $OUT/pmc_$N -- $PCMD > $OUT/pmc_$N.log 2>&1
 done
-python3 tools/pmc_summary.py $OUT $OUT/${TAG}_pmc.json --latest $OUT/pmc_latest.json > $OUT/pmc_summary.log 2>&1
+python3 tools/pmc_summary.py $OUT $OUT/${TAG}_pmc.json --latest $OUT/pmc_latest.json --precision ${PREC:-f16c} > $OUT/pmc_summary.log 2>&1
 cat $OUT/steady.log; tail -1 $OUT/trace.log

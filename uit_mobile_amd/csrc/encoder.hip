@@ -131,6 +131,8 @@ constexpr int ENC_LDS_W8 = ENC_LDS_SPLIT_PE + LDS_PEB;        // 8-wave workgrou
 // WAR safety: the slot overwritten at step t held stage t+PREFETCH-RING_SLOTS <= t-2, and a wave can only be
 // at step t after all waves passed barrier(t-1), i.e. finished reading stage t-2.
 // The stream is padded with PREFETCH dummy stages (pack.cpp) so the issue and the vmcnt immediate never vary.
+// (The scalar-base asm form of the DMA -- dma_b128 below, one lane-offset VGPR instead of a v_lshl_add_u64 + VGPR pair per piece --
+// was measured here too in round 4: 36 VALU instructions less per block, but an s_mov m0 + s_nop per piece more, same time.)
 template <int WAVES>
 __device__ __forceinline__ void ring_issue(const char* wstream, char* ring, int stage, int wave, int lane) {
     constexpr int PER_WAVE = STAGE_FRAGS / WAVES;
@@ -333,20 +335,21 @@ __device__ __forceinline__ void attention_proj(f4 (&R)[8][3], const typename OP:
     }
     f4 Lsum[2][3];
 #pragma unroll
-    for (int h = 0; h < 2; ++h)
-#pragma unroll
-        for (int it = 0; it < 3; ++it) { O[h][it] = splat(0.f); Lsum[h][it] = splat(0.f); }
-#pragma unroll
     for (int i = 0; i < 7; ++i)
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
             f4 p;
 #pragma unroll
             for (int r = 0; r < 4; ++r) p[r] = __builtin_amdgcn_exp2f(S[h][i][r] - mx[h][TI[i]]);
-            const u2 bits = __builtin_bit_cast(u2, OP::pack4(p)) & pmask[i];
+            // full clips: the diagonal tiles (0,0) and (2,2) hold one clip's keys and queries only -- every probability counts
+            // (their masks are all-ones by construction: 4 packed ANDs per block less)
+            const bool all_valid = !SHORT && (i == 0 || i == 6);
+            const u2 bits = all_valid ? __builtin_bit_cast(u2, OP::pack4(p)) : (__builtin_bit_cast(u2, OP::pack4(p)) & pmask[i]);
             const v4 Pm = __builtin_bit_cast(v4, bits);
-            O[h][TI[i]] = OP::mfma16(Vh[TJ[i]][h], Pm, O[h][TI[i]]);
-            Lsum[h][TI[i]] = OP::mfma16(OP::ones4(), Pm, Lsum[h][TI[i]]);
+            // the first tile of a query tile starts its accumulators from the literal 0 (an inline constant of the MFMA: no v_mov per register)
+            const bool first = i == 0 || i == 2 || i == 5;
+            O[h][TI[i]] = OP::mfma16(Vh[TJ[i]][h], Pm, first ? splat(0.f) : O[h][TI[i]]);
+            Lsum[h][TI[i]] = OP::mfma16(OP::ones4(), Pm, first ? splat(0.f) : Lsum[h][TI[i]]);
         }
 #pragma unroll
     for (int h = 0; h < 2; ++h)

@@ -108,7 +108,11 @@ __device__ __forceinline__ void fft16(c32 (&v)[16]) {
 }
 
 constexpr int FE_WAVES = 4;
+#if defined(UITK_LAB) && defined(FE_OCC_LAB)
+constexpr int FE_OCC = FE_OCC_LAB;                       // lab builds only (tools/mklib.sh -DUITK_LAB -DFE_OCC_LAB=3 -DFE_NOCONST): the occupancy probe of DESIGN.md 4.1
+#else
 constexpr int FE_OCC = 2;                                // workgroups per CU the register allocation aims at (a third buys nothing: DESIGN.md 4.1)
+#endif
 constexpr int FE_ROW = 17;                               // padded row stride (complex) of the transpose tile
 constexpr int FE_ZROW = 272;                             // per-frame stride (complex) of the natural-order Z tile
 constexpr int FE_WAVE_LDS = 4 * FE_ZROW * 8;             // 8704 B per wave: E[4][16][17] (8704 B) / Z[4][272]
@@ -167,11 +171,25 @@ __global__ __launch_bounds__(FE_WAVES * 64, FE_OCC) void mel_frontend_kernel(Fro
         }
         __syncthreads();
     };
+#if defined(UITK_LAB) && defined(FE_NOCONST)
+    // Occupancy probe (timing only, WRONG results): ONE window pair and ONE twiddle serve every m1 / k1 -- the instruction stream is the
+    // product's, instruction for instruction, but 60 VGPRs of per-lane constants are gone, so that a third wave per SIMD fits without
+    // paying for it with LDS reads or extra arithmetic: what a third wave could buy at best (round 4).
+    c32 win1 = *(const c32*)(a.window + 2 * p), tw1;
+    { const float2 t = a.tw256[p * 16 + 1]; tw1 = c32{t.x, t.y}; }
+    asm volatile("" : "+v"(win1), "+v"(tw1));
+    c32 pw_[8];
+#define win_(m1) win1
+#define tw_(k1) tw1
+#else
     c32 win_[16], tw_[16], pw_[8];                                       // per-lane VGPR constants
 #pragma unroll
     for (int m1 = 0; m1 < 16; ++m1) win_[m1] = *(const c32*)(a.window + 32 * m1 + 2 * p);
 #pragma unroll
     for (int k1 = 0; k1 < 16; ++k1) { const float2 t = a.tw256[p * 16 + k1]; tw_[k1] = c32{t.x, t.y}; }
+#define win_(m1) win_[m1]
+#define tw_(k1) tw_[k1]
+#endif
 #pragma unroll
     for (int j = 0; j < 8; ++j) { const float2 t = a.tw512[p + 16 * j]; pw_[j] = c32{-t.y, -t.x}; }   // -i conj(w), w = (cos, sin)(2 pi k/512)
 
@@ -258,11 +276,11 @@ __global__ __launch_bounds__(FE_WAVES * 64, FE_OCC) void mel_frontend_kernel(Fro
     // -------------------------------------------------------------------------------- FFT phase of one pass (VALU + LDS)
     auto fft_phase = [&](c32 (&v)[16]) {
 #pragma unroll
-        for (int m1 = 0; m1 < 16; ++m1) v[m1] = v[m1] * win_[m1];
+        for (int m1 = 0; m1 < 16; ++m1) v[m1] = v[m1] * win_(m1);
         fft16(v);                                        // over m1 -> k1 (at FPOS), for m2 = p
 #pragma unroll
         for (int k1 = 0; k1 < 16; ++k1) {                // twiddle + transpose write E[q][k1][m2 = p]
-            const c32 y = k1 == 0 ? v[FPOS(0)] : cmul(v[FPOS(k1)], tw_[k1]);
+            const c32 y = k1 == 0 ? v[FPOS(0)] : cmul(v[FPOS(k1)], tw_(k1));
             E[(q * 16 + k1) * FE_ROW + p] = y;
         }
         FSTAMP(1);                                       // window + FFT-1 + twiddle + transpose write
