@@ -15,6 +15,7 @@ path: a non-HIP input raises RuntimeError.
 """
 import ctypes
 import math
+import operator
 from functools import partial
 
 import numpy as np
@@ -27,6 +28,7 @@ from .. import _lib
 
 _CHECK_WEIGHTS = os.environ.get('UITK_CHECK_WEIGHTS', '1') == '1'   # every call compares a cheap version stamp of the weights (~15 us);
                                                                      # UITK_CHECK_WEIGHTS=0: benchmark loops that never touch the weights
+_VERSION_OF = operator.attrgetter("_version")
 _OPTIONS = ('fe_asym_pm', 'fe_wg_per_cu', 'enc_waves', 'split_pe', 'enc_generic_clamp')      # uitk_set_option names
 _PRECISIONS = {'f16': _lib.PREC_F16, 'f16c': _lib.PREC_F16, 'bf16': _lib.PREC_BF16, 'fp8': _lib.PREC_FP8, 'f16x2': _lib.PREC_F16X2, 'f16l6': _lib.PREC_F16L6}
 
@@ -254,10 +256,7 @@ class UITBase(nn.Module):
         ts = self._tensors
         if ts is None:
             ts = self._tensors = list(self.parameters()) + list(self.buffers())
-        v = 0
-        for t in ts:
-            v += t._version
-        return (v, ts[0].data_ptr(), ts[-1].data_ptr(), len(ts))
+        return (sum(map(_VERSION_OF, ts)), ts[0].data_ptr(), ts[-1].data_ptr(), len(ts))
 
     def refresh(self):
         """Drop the uploaded parameter images: the next call re-packs (and re-calibrates) the current weights.  Needed only after
@@ -513,12 +512,12 @@ class UITBase(nn.Module):
         with torch.cuda.device(x.device):
             stream = ctypes.c_void_p(torch.cuda.current_stream(x.device).cuda_stream)
             _lib.check(_lib.load().uitk_frontend(h, ctypes.c_void_p(x.data_ptr()), in_dtype, B, T, stream), "uitk_frontend")
-        return (B, T, x.device)
+        return (B, T, x.device, h)                # (the handle rides along: `encode` need not look the weights over a second time)
 
     def encode(self, state, return_logits=False):
         """Stage 2 (uitk_encode) on the operands of the latest `frontend` call of this instance."""
-        B, T, device = state
-        h = self._handle(device)
+        B, T, device = state[:3]
+        h = state[3] if len(state) > 3 else self._handle(device)
         with torch.cuda.device(device):
             stream = ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
             probs = torch.empty((B, self.outputdim), device=device, dtype=torch.float32)
