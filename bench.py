@@ -344,8 +344,10 @@ def main():
         if args.gather in ("auto", "peer"):
             try:
                 peer = PeerGather(Bl, pay_cols, dev, dtype=pay_dtype, nbuf=4)
+                peer.self_test()                           # a known pattern through every buffer, verified on every rank
                 gather_kind = "peer"
             except PeerGatherUnavailable as e:
+                peer = None
                 if args.gather == "peer":
                     raise
                 if rank == 0:

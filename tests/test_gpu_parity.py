@@ -1250,22 +1250,25 @@ def test_device_kws_transform_matches_reference_loop():
             assert torch.equal(a.cpu(), b) and torch.equal(ya.cpu(), yb)
 
 
-@pytest.mark.parametrize("gather,launcher", [("rccl", "torchrun"), ("peer", "torchrun"), ("auto", "self")])
-def test_bench_two_rank_pipeline_runs_on_one_gpu(gather, launcher):
+@pytest.mark.parametrize("gather,launcher,ranks", [("rccl", "torchrun", 2), ("peer", "torchrun", 2), ("auto", "self", 2), ("auto", "self", 8)])
+def test_bench_two_rank_pipeline_runs_on_one_gpu(gather, launcher, ranks):
     """bench.py's N > 1 code path (shards, pipelined front-end / amax all-reduce / encoder / asynchronous gathers, barrier
     + max-over-ranks timing) exercised end to end with two ranks on one GPU over gloo -- RCCL itself needs one GPU per rank;
     what is checked is that the pipeline runs, every gather completes, rank 0 prints one well-formed JSON line and the sampled rows
-    of the last timed step match the oracle.  launcher 'self' = `python bench.py --gpus 2 ...` as the driver types it: the script
-    starts its own ranks as a child torch.distributed.run (round 4; it used to exit with "launch with torch.distributed.run")."""
+    of the last timed step match the oracle.  launcher 'self' = `python bench.py --gpus N ...` as the driver types it: the script
+    starts its own ranks as a child torch.distributed.run (round 4; it used to exit with "launch with torch.distributed.run").
+    The 8-rank case is the driver's N = 8 command line with every rank on the one GPU: eight handles, the 8-way peer fan-out with its
+    self-test, eight-way amax reduction -- everything but RCCL itself."""
     import json
     import subprocess
     import sys
     from pathlib import Path
     root = Path(__file__).resolve().parents[1]
-    args = [str(root / "bench.py"), "--gpus", "2", "--steps", "6", "--warmup", "2", "--batch-per-gpu", "512", "--backend", "gloo",
+    per = 512 if ranks == 2 else 256
+    args = [str(root / "bench.py"), "--gpus", str(ranks), "--steps", "6", "--warmup", "2", "--batch-per-gpu", str(per), "--backend", "gloo",
             "--all-ranks-on-device0", "--gather", gather]
     if launcher == "torchrun":
-        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(ranks), "--master-addr", "127.0.0.1",
                "--master-port", str(29700 + os.getpid() % 200)] + args
     else:
         cmd = [sys.executable] + args
@@ -1275,7 +1278,7 @@ def test_bench_two_rank_pipeline_runs_on_one_gpu(gather, launcher):
     lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1
     d = json.loads(lines[0])
-    assert d["n_gpus"] == 2 and d["steps"] == 6 and d["config"]["global_batch"] == 1024 and d["value"] > 0
-    assert d["scaling"] == "weak" and "cpu_baseline" not in d and d["rccl_ranks"] == 2
+    assert d["n_gpus"] == ranks and d["steps"] == 6 and d["config"]["global_batch"] == ranks * per and d["value"] > 0
+    assert d["scaling"] == "weak" and "cpu_baseline" not in d and d["rccl_ranks"] == ranks
     assert d["gather"] == ("rccl" if gather == "rccl" else "peer") and ("peer" in d["config"]["parallelism"]) == (gather != "rccl")
     assert d["precision"] == "f16c" and d["max_abs_dprob"] is not None and d["max_abs_dprob"] < TOL, d.get("parity_check")

@@ -200,6 +200,29 @@ class PeerGather:
     def gather(self, local):
         return self.gather_async(local).wait()
 
+    def self_test(self):
+        """One gather of a known pattern through every buffer, verified on EVERY rank: rank r sends rows filled with r + 1; each rank
+        checks that block r of its result holds r + 1, and the verdicts are MIN-all-reduced, so all ranks agree.  Catches what the
+        export / map check at construction cannot: peer copies that land nowhere (no P2P route) or in the wrong place.  Raises
+        PeerGatherUnavailable on all ranks together.  Costs `nbuf` small gathers; call it once at set-up."""
+        if self.world == 1:
+            return True
+        ok = True
+        try:
+            for _ in range(len(self.out)):
+                send = torch.full((self.rows, self.cols), float(self.rank + 1), device=self.device).to(self.out[0].dtype)
+                got = self.gather_async(send).wait()
+                torch.cuda.current_stream(self.device).synchronize()
+                want = torch.arange(1, self.world + 1, device=self.device).repeat_interleave(self.rows).to(got.dtype)
+                ok = ok and bool((got == want[:, None]).all())
+        except Exception:
+            ok = False
+        flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device=self.device if _backend_is_device(self.group) else "cpu")
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=self.group)
+        if int(flag.item()) != 1:
+            raise PeerGatherUnavailable("PeerGather self-test failed: a peer copy did not arrive where it should (no usable P2P route?)")
+        return True
+
 
 class _PeerHandle:
     def __init__(self, work, done, out, keep):
@@ -286,6 +309,7 @@ class ShardedUiT:
             if self._peer is None or self._peer.rows != send.shape[0] or self._peer.cols != send.shape[1] or self._peer.out[0].dtype != send.dtype:
                 try:
                     self._peer = PeerGather(send.shape[0], send.shape[1], send.device, self.group, send.dtype, nbuf=self.peer_nbuf)
+                    self._peer.self_test()
                 except PeerGatherUnavailable as e:
                     import warnings
                     warnings.warn(f"{e} -- falling back to gather='rccl'")
