@@ -289,8 +289,27 @@ __global__ __launch_bounds__(FE_WAVES * 64, FE_OCC) void mel_frontend_kernel(Fro
 #pragma unroll
         for (int m2 = 0; m2 < 16; ++m2) v[m2] = E[(q * 16 + p) * FE_ROW + m2];   // lane k1 = p gathers its row
         fft16(v);                                        // over m2 -> Z[k1 + 16 k2], k1 = p, k2 at FPOS
+        __builtin_amdgcn_wave_barrier();                 // every lane has read its E row: the tile may be reused
+        asm volatile("" ::: "memory");
+#ifndef FE_PAIR_VIA_Z
+        // Real-FFT split partners (round 4).  Lane k1 = p holds Z[p + 16 k2] at v[FPOS(k2)].  Bin k = p + 16 j (j < 8) pairs with
+        // 256 - k = (16 - p) + 16 (15 - j): the UPPER half (k2 >= 8) of lane 16 - p; for p = 0 with 16 (16 - j): lane 0's own k2 = 16 - j
+        // (j = 0: Z[0] itself).  So a lane keeps its lower half in registers and only its upper half (+ Z[k1], row 8, for the p = 0 case)
+        // goes through LDS: 9 writes + 8 reads per lane instead of the 16 + 17 of a natural-order Z tile.  Tile U[q][9][16] c32, frame
+        // stride 9 rows = 1152 B (= 128 mod 256: the two frames of a 32-lane half hit disjoint banks).
+        c32* U = E + q * (9 * 16);
+#pragma unroll
+        for (int k2 = 8; k2 < 16; ++k2) U[(k2 - 8) * 16 + p] = v[FPOS(k2)];
+        U[8 * 16 + p] = v[FPOS(0)];
         __builtin_amdgcn_wave_barrier();
         asm volatile("" ::: "memory");
+        FSTAMP(2);                                       // transpose read + FFT-2 + upper-half write
+        const c32* Ur = U + (p == 0 ? 16 : 0) + ((16 - p) & 15);
+        c32 za[8], zb[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { za[j] = v[FPOS(j)]; zb[j] = Ur[(7 - j) * 16]; }
+        const c32 z128 = v[FPOS(8)];                     // lane p = 0: Z[128]
+#else
         c32* Z = E;                                      // natural order Z[q][k], frame stride 272 (bank offset 32)
 #pragma unroll
         for (int k2 = 0; k2 < 16; ++k2) Z[q * FE_ZROW + 16 * k2 + p] = v[FPOS(k2)];
@@ -305,7 +324,8 @@ __global__ __launch_bounds__(FE_WAVES * 64, FE_OCC) void mel_frontend_kernel(Fro
             zb[j] = Z[q * FE_ZROW + ((256 - k) & 255)];
         }
         const c32 z128 = Z[q * FE_ZROW + 128];
-        __builtin_amdgcn_wave_barrier();                 // every Z value is in registers: the power row may overwrite the Z row
+#endif
+        __builtin_amdgcn_wave_barrier();                 // every partner value is in registers: the power row may overwrite the tile
         asm volatile("" ::: "memory");
         // power spectrum of bins k and 256-k into the wave's own tile P[frame q][bin]
 #pragma unroll
@@ -334,12 +354,19 @@ __global__ __launch_bounds__(FE_WAVES * 64, FE_OCC) void mel_frontend_kernel(Fro
             // every read to just before its use and expose the latency once per group)
             constexpr int NG = MEL_BMAX / 4, MEL_AHEAD = 6;
             f4a A4[NG], B4[NG];
+#if defined(UITK_LAB) && defined(FE_B_GLOBAL)
+            // lab variant: the filterbank operands from global memory (L1-resident 13 KiB table) instead of LDS: 21 % of the pass's LDS
+            // bytes move to the vector-memory path
+            const float* Bsrc = a.mel_b + 64 + lane * 4;
+#else
+            const float* Bsrc = Bl;
+#endif
 #pragma unroll
-            for (int c = 0; c < MEL_AHEAD; ++c) { A4[c] = *(const f4a*)(Ar + 4 * c); B4[c] = *(const f4a*)(Bl + 256 * c); }
+            for (int c = 0; c < MEL_AHEAD; ++c) { A4[c] = *(const f4a*)(Ar + 4 * c); B4[c] = *(const f4a*)(Bsrc + 256 * c); }
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int c = 0; c < NG; ++c) {
-                if (c + MEL_AHEAD < NG) { A4[c + MEL_AHEAD] = *(const f4a*)(Ar + 4 * (c + MEL_AHEAD)); B4[c + MEL_AHEAD] = *(const f4a*)(Bl + 256 * (c + MEL_AHEAD)); }
+                if (c + MEL_AHEAD < NG) { A4[c + MEL_AHEAD] = *(const f4a*)(Ar + 4 * (c + MEL_AHEAD)); B4[c + MEL_AHEAD] = *(const f4a*)(Bsrc + 256 * (c + MEL_AHEAD)); }
                 acc0 = __builtin_amdgcn_mfma_f32_4x4x1f32(A4[c][0], B4[c][0], acc0, 0, 0, 0);
                 acc1 = __builtin_amdgcn_mfma_f32_4x4x1f32(A4[c][1], B4[c][1], acc1, 0, 0, 0);
                 acc0 = __builtin_amdgcn_mfma_f32_4x4x1f32(A4[c][2], B4[c][2], acc0, 0, 0, 0);
