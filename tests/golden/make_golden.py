@@ -4,7 +4,7 @@ Run only in the build container (needs /root/reference):
     PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden.py
 
 The reference module is imported unmodified from where it lies (see _ref_shims.py for the three stand-in
-packages); the weights are the deterministic synthetic checkpoints of synth_weights.py loaded with
+packages); the weights are the deterministic synthetic checkpoints of uit_mobile_amd/synth.py loaded with
 `load_state_dict(strict=True)` (this pins the state_dict key set and shapes too).  Everything stored is data:
 inputs (int16 PCM; float input = pcm/32768, exact) and the reference's outputs at the stage boundaries of
 SURVEY.md section 8a.  Stage tensors are captured with forward hooks on the reference's own sub-modules.
@@ -16,7 +16,7 @@ import numpy as np
 import torch
 
 HERE = Path(__file__).resolve().parent
-sys.path.insert(0, str(HERE))
+sys.path[:0] = [str(HERE), str(HERE.parents[1])]           # _ref_shims (here) and the package (uit_mobile_amd.synth: the seeded checkpoints)
 # imported BEFORE the stand-in torchaudio module is installed (transformers probes for the real package)
 from transformers.audio_utils import mel_filter_bank, spectrogram  # noqa: E402
 import _ref_shims  # noqa: E402

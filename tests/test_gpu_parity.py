@@ -786,6 +786,21 @@ def test_calibrated_rounding_with_the_callers_clips_and_weight_edits(golden):
     assert np.abs(l2.cpu().numpy().reshape(ref2["logits"].shape) - ref2["logits"]).max() < 6e-4
     with pytest.raises(ValueError):
         m.calibrate(torch.from_numpy(synth_pcm_i16(4, 8000, seed=1)).cuda())(xd[:2])      # clips shorter than target_length frames
+    # calibration is deterministic: two handles built from the same weights hold the same statistics and give the same bits (what
+    # makes the ranks of a sharded run agree without exchanging anything); long calibration clips count as their crops
+    pair = []
+    for _ in range(2):
+        mm = models.uit_xxxs(outputdim=537, target_length=102)
+        mm.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in make_trained_like_state_dict("uit_xxxs", 203).items()}, strict=True)
+        mm = mm.cuda().eval()
+        with torch.no_grad():
+            pair.append((mm(xd).clone(), mm.calib_stats()))
+    assert torch.equal(pair[0][0], pair[1][0]) and np.array_equal(pair[0][1], pair[1][1])
+    mm.calibrate(torch.from_numpy(synth_pcm_i16(6, 64000, seed=31)).cuda())               # 4 s clips: 4 crops each = 24 calibration rows
+    with torch.no_grad():
+        p4 = mm(xd)
+    ref3 = Oracle(make_trained_like_state_dict("uit_xxxs", 203)).forward(x)
+    assert np.abs(p4.cpu().numpy() - ref3["probs"]).max() < 2.5e-4 and not np.array_equal(mm.calib_stats(), pair[1][1])
 
 
 def test_inference_cli_counterpart_config1(golden, tmp_path, capsys):
