@@ -1410,23 +1410,17 @@ __global__ __launch_bounds__(WAVES * 64, 2) void uit_encoder_kernel(EncoderArgs 
             const f4 b10 = *(const f4*)(bias + B_FC1 + 32 * ch + 4 * g), b11 = *(const f4*)(bias + B_FC1 + 32 * ch + 16 + 4 * g);
 #pragma unroll
             for (int f = 0; f < 8; ++f) A2[f] = lds_frag<OPC>(slot, 8 + f, lane);   // fc2 fragments of this chunk
-            f4 H0[3], H1[3];
+            // token-tile-major (round 4: -1.0 % encoder time against the row-tile-major order): a tile's two accumulators finish after its
+            // eight MFMAs, so its conversion + ReLU issue under the NEXT tile's MFMAs instead of piling up behind the last one; fc2 below
+            // consumes the tiles in the same order.  (Measured no better: one VALU instruction pinned behind each MFMA with
+            // sched_group_barrier; the last tile's conversion deferred behind the next ring step.)
 #pragma unroll
             for (int ct = 0; ct < 3; ++ct) {
-                H0[ct] = b10;
+                f4 H0 = b10, H1 = b11;
 #pragma unroll
-                for (int s = 0; s < 4; ++s) H0[ct] = OP::mfma32(A[s], X[s][ct], H0[ct]);
-            }
-#pragma unroll
-            for (int ct = 0; ct < 3; ++ct) {
-                H1[ct] = b11;
-#pragma unroll
-                for (int s = 0; s < 4; ++s) H1[ct] = OP::mfma32(A[4 + s], X[s][ct], H1[ct]);
-            }
-#pragma unroll
-            for (int ct = 0; ct < 3; ++ct) {
-                if constexpr (ACT == 1) HX[ct] = OP::pack8(gelu4(H0[ct]), gelu4(H1[ct]));
-                else HX[ct] = OP::relu_pack8(H0[ct], H1[ct]);
+                for (int s = 0; s < 4; ++s) { H0 = OP::mfma32(A[s], X[s][ct], H0); H1 = OP::mfma32(A[4 + s], X[s][ct], H1); }
+                if constexpr (ACT == 1) HX[ct] = OP::pack8(gelu4(H0), gelu4(H1));
+                else HX[ct] = OP::relu_pack8(H0, H1);
             }
         };
         {   // chunk 0 (peeled: defines A2 / HX before the steady-state loop)
@@ -1449,16 +1443,16 @@ __global__ __launch_bounds__(WAVES * 64, 2) void uit_encoder_kernel(EncoderArgs 
 #pragma unroll
             for (int f = 0; f < 8; ++f) A[f] = lds_frag<OPC>(slot, f, lane);   // fc1 fragments: in flight ...
 #pragma unroll
-            for (int ft = 0; ft < 8; ++ft)                                              // ... under chunk ch-1's fc2
+            for (int ct = 0; ct < 3; ++ct)                                              // ... under chunk ch-1's fc2, token tile by token tile
 #pragma unroll
-                for (int ct = 0; ct < 3; ++ct) R[ft][ct] = OP::mfma32(A2[ft], HX[ct], R[ft][ct]);
+                for (int ft = 0; ft < 8; ++ft) R[ft][ct] = OP::mfma32(A2[ft], HX[ct], R[ft][ct]);
             fc1_chunk(slot, ch, A);
             TSTAMP(7);                                                 // MLP chunk compute (sum of 12)
         }
 #pragma unroll
-        for (int ft = 0; ft < 8; ++ft)
+        for (int ct = 0; ct < 3; ++ct)
 #pragma unroll
-            for (int ct = 0; ct < 3; ++ct) R[ft][ct] = OP::mfma32(A2[ft], HX[ct], R[ft][ct]);
+            for (int ft = 0; ft < 8; ++ft) R[ft][ct] = OP::mfma32(A2[ft], HX[ct], R[ft][ct]);
 #pragma unroll
         for (int ft = 0; ft < 8; ++ft) {
             const f4 b2 = *(const f4*)(bias + B_FC2 + 16 * ft + 4 * g);
