@@ -69,7 +69,7 @@ typedef struct uitk_config {
     int32_t n_mels;        /* 64   uit.py:287 */
     int32_t n_fft;         /* 512  uit.py:288 */
     int32_t hop_size;      /* 160  uit.py:289 */
-    int32_t win_size;      /* 512  uit.py:290 */
+    int32_t win_size;      /* 512 (any 1..n_fft: the window is zero-padded to n_fft as torch.stft does)  uit.py:290 */
     int32_t patch_size;    /* 16 (== stride)  uit.py:583 */
     int32_t center;        /* 1 (default) or 0: torch.stft centring, uit.py:293.  0: no reflect padding, 1 + (T - n_fft)/hop frames */
     int32_t eval_avg;      /* uitk_eval_avg   uit.py:294 */

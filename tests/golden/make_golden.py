@@ -229,6 +229,20 @@ def main_kwargs():
         out[f"{tag}_pcm"], out[f"{tag}_probs"], out[f"{tag}_logits"], out[f"{tag}_mel_db"] = p, r["probs"], r["logits"], r["mel_db"]
         print("center=False", tag, "frames", r["mel_db"].shape[-1], "crops", r["logits"].shape[1])
     np.savez_compressed(HERE / "nocenter_uit_xxxs.npz", seed=34, **out)
+    # round 4: win_size < n_fft (models/uit.py:290, 301-303: MelSpectrogram(win_length=400, n_fft=512) -> torch.stft pads the window)
+    from uit_mobile_amd.synth import hann_periodic
+    out = {}
+    for tag, T, center in (("1s", 16000, True), ("2crop", 16384, True), ("nocenter", 16000, False)):
+        p = synth_pcm_i16(4, T, seed=23)
+        p[2] = 0
+        m = uit.uit_xxxs(outputdim=537, target_length=102, win_size=400, center=center)
+        sd = dict(make_state_dict("uit_xxxs", 35, 2.0))
+        sd["front_end.0.spectrogram.window"] = hann_periodic(400)
+        m.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()}, strict=True)
+        r = run_ref(m.eval(), p)
+        out[f"{tag}_pcm"], out[f"{tag}_probs"], out[f"{tag}_logits"], out[f"{tag}_mel_db"] = p, r["probs"], r["logits"], r["mel_db"]
+        print("win_size=400", tag, "frames", r["mel_db"].shape[-1], "crops", r["logits"].shape[1])
+    np.savez_compressed(HERE / "win400_uit_xxxs.npz", seed=35, **out)
 
 
 def main():

@@ -519,6 +519,28 @@ def test_golden_other_kwargs_and_center_false(golden):
         m(torch.zeros(1, 400).cuda())
 
 
+def test_golden_win_size_shorter_than_n_fft(golden):
+    """Round 4: win_size = 400 with n_fft = 512 (the window zero-padded to n_fft at pack time, as torch.stft does): mel, logits and
+    probabilities against the fixtures of the imported reference, centre and no-centre framing, one and two crops; a window longer
+    than n_fft is refused."""
+    from uit_mobile_amd.synth import hann_periodic
+    g = golden("win400_uit_xxxs")
+    sd = dict(make_state_dict("uit_xxxs", int(g["seed"]), 2.0))
+    sd["front_end.0.spectrogram.window"] = hann_periodic(400)
+    for tag, crops, center in (("1s", 1, True), ("2crop", 2, True), ("nocenter", 1, False)):
+        m = models.uit_xxxs(outputdim=537, target_length=102, win_size=400, center=center)
+        m.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()}, strict=True)
+        m = m.to("cuda").eval()
+        p, l = run(m, g[f"{tag}_pcm"])
+        assert l.shape[1] == crops
+        assert np.abs(l - g[f"{tag}_logits"]).max() < TOL and np.abs(p - g[f"{tag}_probs"]).max() < TOL
+        with torch.no_grad():
+            mel = m.melspec_db(torch.from_numpy(g[f"{tag}_pcm"]).cuda()).cpu().numpy()
+        assert_mel_close(mel, g[f"{tag}_mel_db"])
+    with pytest.raises(ValueError):
+        models.uit_xxxs(outputdim=537, target_length=102, win_size=640).to("cuda").eval()(torch.zeros(1, 16000).cuda())
+
+
 def test_golden_short_clip(golden):
     g = golden("short_uit_xxxs")
     m, _ = build("uit_xxxs", g["seed"])

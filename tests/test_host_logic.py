@@ -321,3 +321,22 @@ def test_clip_store_feeds_collated_int16_batches(tmp_path):
             assert list(store.lengths(first)) == [len(clips[first + j]) for j in range(count)]
     with pytest.raises(ImportError):
         ClipStore.from_hdf5_table([("a", "b.h5")])          # h5py is not part of this image: a clear error, not a silent fallback
+
+
+def test_shorter_window_is_zero_padded_to_n_fft_at_pack_time():
+    """win_size < n_fft (models/uit.py:290): the packed front-end window table holds the state_dict's window centred in 512 zeros
+    (what torch.stft does with win_length < n_fft); win_size > n_fft and other n_fft are refused by the packer."""
+    import struct
+    m = models.uit_xxxs(outputdim=537, target_length=102, win_size=400, precision="f16").eval()
+    assert tuple(m.state_dict()["front_end.0.spectrogram.window"].shape) == (400,)
+    img = m.packed_image()
+    from mfma_emu import parse_header
+    h = parse_header(img)
+    tab = np.frombuffer(img, np.float32, 512, h["off_window"])
+    want = np.zeros(512, np.float32)
+    want[56:456] = m.state_dict()["front_end.0.spectrogram.window"].numpy()
+    assert np.array_equal(tab, want)
+    with pytest.raises(ValueError):
+        models.uit_xxxs(outputdim=537, target_length=102, win_size=640, precision="f16").eval().packed_image()
+    with pytest.raises(ValueError):
+        models.uit_xxxs(outputdim=537, target_length=102, n_fft=1024, win_size=1024, precision="f16").eval().packed_image()

@@ -220,3 +220,17 @@ def test_other_kwargs_and_center_false(golden):
         assert r["logits"].shape[1] == crops == g[f"{tag}_logits"].shape[1]
         assert np.abs(r["logits"] - g[f"{tag}_logits"]).max() < 3e-4 and np.abs(r["probs"] - g[f"{tag}_probs"]).max() < 1e-4
         assert r["mel_db"].shape == g[f"{tag}_mel_db"].shape
+
+
+def test_win_size_shorter_than_n_fft(golden):
+    """Round 4: win_size = 400 < n_fft = 512 (models/uit.py:290, 301-303 -> torch.stft zero-pads the window to n_fft, centred): the
+    oracle's restatement against the fixtures of the imported reference (centre and no-centre framing, one and two crops), mel included."""
+    from uit_mobile_amd.synth import hann_periodic, make_state_dict
+    g = golden("win400_uit_xxxs")
+    sd = dict(make_state_dict("uit_xxxs", int(g["seed"]), 2.0))
+    sd["front_end.0.spectrogram.window"] = hann_periodic(400)
+    for tag, crops, center in (("1s", 1, True), ("2crop", 2, True), ("nocenter", 1, False)):
+        r = Oracle(sd, center=center).forward(g[f"{tag}_pcm"])
+        assert r["logits"].shape[1] == crops == g[f"{tag}_logits"].shape[1] and r["mel_db"].shape == g[f"{tag}_mel_db"].shape
+        assert_mel_close(r["mel_db"], g[f"{tag}_mel_db"])
+        assert np.abs(r["logits"] - g[f"{tag}_logits"]).max() < 3e-4 and np.abs(r["probs"] - g[f"{tag}_probs"]).max() < 1e-4

@@ -309,7 +309,8 @@ int validate_config(const uitk_config* c, const char** why) {
     if (c->num_heads != 2) return bad("num_heads must be 2");
     if (c->mlp_hidden != HID) return bad("mlp hidden must be 384 (mlp_ratio 3.0)");
     if (c->n_mels != NMEL) return bad("n_mels must be 64");
-    if (c->n_fft != 512 || c->win_size != 512) return bad("n_fft and win_size must be 512");
+    if (c->n_fft != 512) return bad("n_fft must be 512");
+    if (c->win_size < 1 || c->win_size > c->n_fft) return bad("win_size must be 1..n_fft (the window is zero-padded to n_fft as torch.stft does)");
     if (c->hop_size < 1 || c->hop_size > 512) return bad("hop_size out of range");
     if (c->patch_size != 16) return bad("patch_size must be 16");
     if (c->target_length / 16 != GT) return bad("target_length must give 6 time patches (96..111)");
@@ -519,7 +520,8 @@ int pack_image(const uitk_config* c, const uitk_weights* w, const double* calib,
     std::memcpy(img, &h, sizeof h);
 
     // ---- front-end tables
-    std::memcpy(img + h.off_window, w->window, 512 * 4);
+    // win_size < n_fft (uit.py:290, 301-303): torch.stft zero-pads the window on both sides to n_fft, left = (n_fft - win_size) / 2
+    std::memcpy(img + h.off_window + (size_t)((c->n_fft - c->win_size) / 2) * 4, w->window, (size_t)c->win_size * 4);
     float* tw256 = (float*)(img + h.off_tw256);
     for (int p = 0; p < 16; ++p)
         for (int k1 = 0; k1 < 16; ++k1) {
