@@ -328,15 +328,28 @@ __global__ __launch_bounds__(FE_WAVES * 64, FE_OCC) void mel_frontend_kernel(Fro
         __builtin_amdgcn_wave_barrier();                 // every partner value is in registers: the power row may overwrite the tile
         asm volatile("" ::: "memory");
         // power spectrum of bins k and 256-k into the wave's own tile P[frame q][bin]
+        // 4 |X[k]|^2 and 4 |X[256-k]|^2 (the 1/4 lives in the filterbank operand, pack.cpp); k = 0 writes bin 256 (Nyquist).  The sixteen
+        // values leave as eight ds_write2_b32 (two dwords 16 j apart from one base; round 4: -1.5 % against sixteen b32 writes -- the
+        // compiler does not pair them).  LDS operations of a wave complete in order, so the plain reads of the mel phase behind the wave
+        // barrier see them; the asm reads VALU results only (no inline-asm reader of an MFMA result: DESIGN_LOG.md 2.2).
+        float PX[8], PY[8];
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-            const int k = p + 16 * j;
             const c32 A = add_conj(za[j], zb[j]), Bm = sub_conj(za[j], zb[j]);   // Z[k] +- conj Z[256-k]
             const c32 Tw = cmul(Bm, pw_[j]);                                         // -i e^{-2 pi i k/512} (Z[k] - conj Z[256-k])
             const c32 X = A + Tw, Y = A - Tw;                                        // 2 X[k], 2 conj X[256-k]
-            Pq[k] = X.x * X.x + X.y * X.y;                       // 4 |X[k]|^2: the 1/4 lives in the filterbank operand (pack.cpp)
-            Pq[256 - k] = Y.x * Y.x + Y.y * Y.y;                 // k = 0 writes bin 256 (Nyquist)
+            PX[j] = X.x * X.x + X.y * X.y;
+            PY[j] = Y.x * Y.x + Y.y * Y.y;
         }
+        {
+            const unsigned bx = (unsigned)(size_t)(__attribute__((address_space(3))) float*)(Pq + p);                 // bins p + 16 j
+            const unsigned by = (unsigned)(size_t)(__attribute__((address_space(3))) float*)(Pq + 256 - p - 112);      // bins 256 - p - 16 j
+#define FE_W2(base, v0, v1, o0, o1) asm volatile("ds_write2_b32 %0, %1, %2 offset0:" #o0 " offset1:" #o1 :: "v"(base), "v"(v0), "v"(v1) : "memory")
+            FE_W2(bx, PX[0], PX[1], 0, 16); FE_W2(bx, PX[2], PX[3], 32, 48); FE_W2(bx, PX[4], PX[5], 64, 80); FE_W2(bx, PX[6], PX[7], 96, 112);
+            FE_W2(by, PY[0], PY[1], 112, 96); FE_W2(by, PY[2], PY[3], 80, 64); FE_W2(by, PY[4], PY[5], 48, 32); FE_W2(by, PY[6], PY[7], 16, 0);
+#undef FE_W2
+        }
+
         if (p == 0) Pq[128] = 4.0f * (z128.x * z128.x + z128.y * z128.y);
     };
 
