@@ -367,19 +367,14 @@ __global__ __launch_bounds__(FE_WAVES * 64, FE_OCC) void mel_frontend_kernel(Fro
             // every read to just before its use and expose the latency once per group)
             constexpr int NG = MEL_BMAX / 4, MEL_AHEAD = 6;
             f4a A4[NG], B4[NG];
-#if defined(UITK_LAB) && defined(FE_B_GLOBAL)
-            // lab variant: the filterbank operands from global memory (L1-resident 13 KiB table) instead of LDS: 21 % of the pass's LDS
-            // bytes move to the vector-memory path
-            const float* Bsrc = a.mel_b + 64 + lane * 4;
-#else
-            const float* Bsrc = Bl;
-#endif
+            // (round 4, measured: the filterbank operands from global memory instead of LDS +25 %; the first three groups' operands
+            // kept in registers: neutral -- DESIGN_LOG.md)
 #pragma unroll
-            for (int c = 0; c < MEL_AHEAD; ++c) { A4[c] = *(const f4a*)(Ar + 4 * c); B4[c] = *(const f4a*)(Bsrc + 256 * c); }
+            for (int c = 0; c < MEL_AHEAD; ++c) { A4[c] = *(const f4a*)(Ar + 4 * c); B4[c] = *(const f4a*)(Bl + 256 * c); }
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int c = 0; c < NG; ++c) {
-                if (c + MEL_AHEAD < NG) { A4[c + MEL_AHEAD] = *(const f4a*)(Ar + 4 * (c + MEL_AHEAD)); B4[c + MEL_AHEAD] = *(const f4a*)(Bsrc + 256 * (c + MEL_AHEAD)); }
+                if (c + MEL_AHEAD < NG) { A4[c + MEL_AHEAD] = *(const f4a*)(Ar + 4 * (c + MEL_AHEAD)); B4[c + MEL_AHEAD] = *(const f4a*)(Bl + 256 * (c + MEL_AHEAD)); }
                 acc0 = __builtin_amdgcn_mfma_f32_4x4x1f32(A4[c][0], B4[c][0], acc0, 0, 0, 0);
                 acc1 = __builtin_amdgcn_mfma_f32_4x4x1f32(A4[c][1], B4[c][1], acc1, 0, 0, 0);
                 acc0 = __builtin_amdgcn_mfma_f32_4x4x1f32(A4[c][2], B4[c][2], acc0, 0, 0, 0);
