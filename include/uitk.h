@@ -218,7 +218,9 @@ int uitk_set_timing_buffers(uitk_model* m, unsigned long long* enc_buf, unsigned
  *   "fe_wg_per_cu"      persistent front-end workgroups per CU (0 = default 2)
  *   "enc_waves"         8 (default: one 8-wave encoder workgroup per CU) or 4 (two 4-wave workgroups per CU; f16 / bf16 / fp8)
  *   "split_pe"          1 / 0: patch embed on split (hi + lo) weights; -1 = the precision's default (on for f16x2)
- *   "enc_generic_clamp" 1 = use the generic top_db clamp path even when every init_bn scale is >= 0 (test of that path) */
+ *   "enc_generic_clamp" 1 = use the generic top_db clamp path even when every init_bn scale is >= 0 (test of that path)
+ *   "fe_tail_skip"      1 (default) / 0: a clip's leftover frames (1 s clips: frames 96..100, which only count for the batch amax)
+ *                       skip their FFT when a Parseval bound shows they cannot raise it; 0 transforms every frame (test of the skip) */
 int uitk_set_option(uitk_model* m, const char* name, int value);
 /* Current value of an option ("fe_asym_pm": the explicit setting, else the share the latest front-end launch used, -1 = the
  * built-in 590 because nothing was measured for its shape); also "weights_calibrated" (read-only: 1 after uitk_calibrate_weights). */

@@ -671,7 +671,7 @@ def test_pass_distribution_does_not_change_results():
     pcm[3] = 0
     x = torch.from_numpy(pcm).cuda()
     outs = []
-    for opts in ({}, {"fe_asym_pm": 500}, {"fe_asym_pm": 700}, {"fe_asym_pm": 300}, {"enc_generic_clamp": 1}):
+    for opts in ({}, {"fe_asym_pm": 500}, {"fe_asym_pm": 700}, {"fe_asym_pm": 300}, {"enc_generic_clamp": 1}, {"fe_tail_skip": 0}):
         m, _ = build("uit_xxxs", 31)
         for k, v in opts.items():
             m.set_option(k, v)
@@ -683,6 +683,36 @@ def test_pass_distribution_does_not_change_results():
     with pytest.raises(ValueError):                     # unknown option: UITK_ERR_UNSUPPORTED when the handle is created
         m.set_option("no_such_option", 1)
         m(x[:2])
+
+
+def test_leftover_frames_still_decide_the_floor_when_they_are_the_loudest():
+    """Round 4: the front-end skips the FFT of a clip's leftover frames (1 s clips: frames 96..100, which never reach the encoder) when a
+    Parseval bound shows that they cannot raise the batch amax.  The bound must never skip a frame that DOES: here the batch's loudest
+    content sits in the last 40 ms of one otherwise quiet clip, so the top_db floor -- visible in every silent region of the batch -- is
+    set by a leftover frame; mel, probabilities and logits against the oracle, and bit-identical with the skip switched off."""
+    B, T = 600, 16000                                       # enough passes for the persistent grid; clip 7 carries the burst
+    pcm = (synth_pcm_i16(B, T, seed=77).astype(np.float32) * 0.02).astype(np.int16)      # a quiet batch (-34 dB re full scale)
+    t = np.arange(T - 15500)
+    pcm[7, 15500:] = np.round(30000.0 * np.sin(2 * np.pi * 1234.0 * t / 16000.0)).astype(np.int16)    # frames 97..100 only
+    pcm[8] = 0                                              # digital silence: shows the floor
+    m, sd = build("uit_xxxs", 12)
+    x = torch.from_numpy(pcm).cuda()
+    with torch.no_grad():
+        p1, l1 = m(x, return_logits=True)
+        mel1 = m.melspec_db(x[:16])
+    o = Oracle(sd)
+    ref_mel, amax = o.melspec_db(pcm)
+    assert ref_mel[7, :, 97:].max() == pytest.approx(amax, abs=1e-3) and ref_mel[:, :, :96].max() < amax - 10.0    # the burst IS the amax
+    sub = np.r_[0:16]
+    # (the oracle's floor is that of the batch it is given: hand it the whole batch for the mel, a subset with clip 7 for the head)
+    assert_mel_close(mel1.cpu().numpy(), Oracle(sd).melspec_db(pcm[:16])[0])
+    assert mel1.cpu().numpy()[8].max() == pytest.approx(amax - 120.0, abs=2e-3)           # silence sits on the floor the burst sets
+    ref = o.forward(pcm[sub])
+    assert np.abs(p1.cpu().numpy()[sub] - ref["probs"]).max() < TOL and np.abs(l1.cpu().numpy()[sub, 0] - ref["logits"][:, 0]).max() < TOL
+    m.set_option("fe_tail_skip", 0)
+    with torch.no_grad():
+        p0, l0 = m(x, return_logits=True)
+    assert torch.equal(p0, p1) and torch.equal(l0, l1)
 
 
 def test_errors_map_to_exceptions():

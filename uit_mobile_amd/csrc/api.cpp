@@ -47,6 +47,7 @@ struct uitk_model {
     int split_pe_env = -1;        // option split_pe: patch embed on split weights (W = hi + lo); -1 = the precision's default (on for f16x2;
                                   // off for f16: measured no better than the structured rounding of pack.cpp at +1.6 % encoder time)
     int force_generic_clamp = 0;  // option enc_generic_clamp
+    int fe_tail_skip = 1;         // option fe_tail_skip: leftover frames that provably cannot raise the batch amax skip their FFT (0: always transform)
     int bn_nonneg = 0;            // every init_bn scale >= 0 (decided once from the packed table): the encoder's clamp fast path
     int fe_asym_pm = -1;          // option fe_asym_pm: explicit share of the first-dispatched front-end workgroups; -1 = the measured one
     int fe_asym_cur = -1;         // the share the latest front-end launch used (-1 = none measured for its shape: the kernel's 590)
@@ -54,6 +55,7 @@ struct uitk_model {
     std::vector<double> calib_stats;   // statistics of the latest uitk_calibrate_weights (uitk_get_calib_stats)
     int fe_wg_per_cu = 0;         // option fe_wg_per_cu: persistent front-end workgroups per CU (0 = the kernel's occupancy target)
     int device = 0;
+    float fb_max = 0.f;           // largest mel filterbank entry (front-end: Parseval bound of the leftover-frame skip)
     int64_t fe_B = 0, fe_T = 0;   // shape of the latest uitk_frontend call (uitk_encode must match it)
 };
 
@@ -120,6 +122,8 @@ int uitk_create(const uitk_config* cfg, const uitk_weights* w, uitk_model** out)
         return fail(UITK_ERR_NO_DEVICE, "libuitk is built for gfx950 only, found " + arch);
     }
     m->n_cu = prop.multiProcessorCount;
+    for (int i = 0; i < (cfg->n_fft / 2 + 1) * NMEL; ++i) if (w->mel_fb[i] > m->fb_max) m->fb_max = w->mel_fb[i];
+    if (!std::isfinite(m->fb_max)) m->fb_max = 0.f;
     {
         const float* sc = (const float*)(img.data() + m->hdr.off_bn_sc);
         m->bn_nonneg = 1;
@@ -341,6 +345,8 @@ int uitk_set_option(uitk_model* m, const char* name, int value) {
         m->split_pe_env = value < 0 ? -1 : (value != 0);
     } else if (n == "enc_generic_clamp") {    // 1 = take the generic top_db clamp path even when every init_bn scale is >= 0 (tests)
         m->force_generic_clamp = value != 0;
+    } else if (n == "fe_tail_skip") {         // 0 = transform every leftover frame even when it provably cannot raise the batch amax (tests)
+        m->fe_tail_skip = value != 0;
     } else {
         return fail(UITK_ERR_UNSUPPORTED, "unknown option: " + n);
     }
@@ -356,6 +362,7 @@ int uitk_get_option(const uitk_model* m, const char* name, int* value) {
     else if (n == "enc_waves") *value = m->enc_waves;
     else if (n == "split_pe") *value = m->split_pe_env;
     else if (n == "enc_generic_clamp") *value = m->force_generic_clamp;
+    else if (n == "fe_tail_skip") *value = m->fe_tail_skip;
     else return fail(UITK_ERR_UNSUPPORTED, "unknown option: " + n);
     return UITK_OK;
 }
@@ -381,6 +388,7 @@ static int run_frontend(uitk_model* m, const void* pcm, int in_dtype, int64_t B,
     m->amax_cur ^= 1;
     a.mel = mel_out; a.amax = m->amax + m->amax_cur * AMAX_SLOTS; a.amax_rearm = m->amax + (m->amax_cur ^ 1) * AMAX_SLOTS;
     a.asym_pm = m->fe_asym_cur;
+    a.fb_max = m->fe_tail_skip ? m->fb_max : 0.f;
     a.bn_sc = (const float*)(m->image + h.off_bn_sc); a.bn_sh = (const float*)(m->image + h.off_bn_sh);
     a.op_bf16 = m->cfg.precision == UITK_PREC_BF16;
     a.timing = m->timing_fe;

@@ -501,14 +501,51 @@ __global__ __launch_bounds__(FE_WAVES * 64, FE_OCC) void mel_frontend_kernel(Fro
     };
     if (idx < iend) issue_loads(idx, ck, cb, 0, v);
     lds_setup();
+    // Tail frames that cannot matter (round 4).  For single-crop clips the leftover frames of a clip (1 s: frames 96..100) never reach
+    // the encoder; they are transformed only because they count for the batch amax (top_db floor).  A frame's loudest mel bin is
+    // bounded by Parseval: mel[m] = sum_k fb[k][m] P[k] <= max(fb) * sum_k |X[k]|^2 <= max(fb) * 512 * sum_n (w[n] x[n])^2 -- sixteen
+    // packed fmas on the windowed samples the lane holds anyway.  If that bound (+0.05 dB for the roundings on both sides) does not
+    // exceed what THIS wave has already seen (a lower bound of the batch amax), the quad's FFT, mel and log are skipped: the amax --
+    // and with it every output bit -- is the same.  Wave-uniform decision; the wave's own maximum is reduced once, when its first
+    // tail pass starts.
+    const bool tail_skippable = PATCH && a.ncrops == 1 && a.fb_max > 0.f;
+    float lmax_w = -INFINITY;
+    bool lmax_w_valid = false;
     while (idx < iend) {
         FSTAMP(0);
         const bool is_full = idx < nfull;                                             // uniform
         const int wq = (wave + rnd) & 3;
+        bool skipped = false;
         if (is_full) {
             fft_phase(v);
-        } else if (4 * wave < per_tail * rem) {
-            fft_phase(v);                                // uniform per wave: fully dead quads of a tail pass skip the FFT
+        } else if (4 * wave < per_tail * rem) {          // uniform per wave: fully dead quads of a tail pass skip the FFT
+            bool need = true;
+            if (tail_skippable) {
+                if (!lmax_w_valid) {
+                    lmax_w = lmax;
+#pragma unroll
+                    for (int o = 32; o > 0; o >>= 1) lmax_w = fmaxf(lmax_w, __shfl_xor(lmax_w, o));
+                    lmax_w_valid = true;
+                }
+                c32 e2 = {0.f, 0.f};
+#pragma unroll
+                for (int m1 = 0; m1 < 16; ++m1) { const c32 t = v[m1] * win_[m1]; e2 = __builtin_elementwise_fma(t, t, e2); }
+                float e = e2.x + e2.y;                   // this lane's share of sum (w x)^2; then the sum over the frame's 16 lanes
+                e += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(e), 0xB1, 0xF, 0xF, true));    // quad_perm [1,0,3,2]
+                e += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(e), 0x4E, 0xF, 0xF, true));    // quad_perm [2,3,0,1]
+                e += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(e), 0x141, 0xF, 0xF, true));   // row_half_mirror
+                e += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(e), 0x140, 0xF, 0xF, true));   // row_mirror
+                const float bound_db = to_db(512.0f * a.fb_max * e) + 0.05f;
+                need = __builtin_amdgcn_ballot_w64(bound_db > lmax_w) != 0ull;
+            }
+            if (need) fft_phase(v); else skipped = true;
+        }
+        if (skipped) {                                   // nothing of this quad is stored or counted: straight to the next pass
+            int nidx = idx + stride, nb = cb + gb, nk = ck + gk;
+            if (nb >= B) { nb -= B; ++nk; }
+            if (nidx < iend) issue_loads(nidx, nk, nb, rnd + 1, v);
+            idx = nidx; cb = nb; ck = nk; ++rnd;
+            continue;
         }
         FSTAMP(3);                                       // Z read + split + power write
         __builtin_amdgcn_wave_barrier();                 // the power rows are wave-private: LDS ops of one wave complete in

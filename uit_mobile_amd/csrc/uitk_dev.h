@@ -102,6 +102,8 @@ struct FrontendArgs {
     float* amax;            // [AMAX_SLOTS] filled by this launch (pre-armed with 0xFFFFFFFF)
     float* amax_rearm;      // [AMAX_SLOTS] the other set: re-armed by this launch for the next one
     int asym_pm;            // per-mille share of the passes for the first-dispatched half of the grid (500 = symmetric, -1 = not calibrated: 590)
+    float fb_max;           // largest filterbank entry (> 0): the Parseval bound that lets leftover frames which cannot raise the batch amax
+                            // skip their FFT (frontend.hip); 0 disables the skip
 };
 
 struct EncoderArgs {

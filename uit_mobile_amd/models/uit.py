@@ -29,7 +29,7 @@ from .. import _lib
 _CHECK_WEIGHTS = os.environ.get('UITK_CHECK_WEIGHTS', '1') == '1'   # every call compares a cheap version stamp of the weights (~15 us);
                                                                      # UITK_CHECK_WEIGHTS=0: benchmark loops that never touch the weights
 _VERSION_OF = operator.attrgetter("_version")
-_OPTIONS = ('fe_asym_pm', 'fe_wg_per_cu', 'enc_waves', 'split_pe', 'enc_generic_clamp')      # uitk_set_option names
+_OPTIONS = ('fe_asym_pm', 'fe_wg_per_cu', 'enc_waves', 'split_pe', 'enc_generic_clamp', 'fe_tail_skip')      # uitk_set_option names
 _PRECISIONS = {'f16': _lib.PREC_F16, 'f16c': _lib.PREC_F16, 'bf16': _lib.PREC_BF16, 'fp8': _lib.PREC_FP8, 'f16x2': _lib.PREC_F16X2, 'f16l6': _lib.PREC_F16L6}
 
 __all__ = ["UITBase", "uit_xs", "uit_xxs", "uit_xxxs", "PRETRAINED_CHECKPOINTS",
@@ -280,7 +280,7 @@ class UITBase(nn.Module):
 
     def set_option(self, name, value):
         """Explicit tuning / test option of the C library (uitk_set_option: 'fe_asym_pm', 'fe_wg_per_cu', 'enc_waves', 'split_pe',
-        'enc_generic_clamp').  None changes a result bit.  Applied to the live handles and to every handle created later."""
+        'enc_generic_clamp', 'fe_tail_skip').  None changes a result bit.  Applied to the live handles and to every handle created later."""
         if str(name) not in _OPTIONS:                    # (validated here too: without a live handle nothing else would reject it)
             raise ValueError(f"uitk_set_option: unknown option: {name}")
         for h, _ in self._handles.values():
