@@ -145,13 +145,26 @@ int uitk_pack_weights(const uitk_config* cfg, const uitk_weights* w, void* out, 
  * uitk_calibrate_weights: run pcm[B,T] (device pointer; NULL = the library's own 32 synthetic calibration signals) through the
  * front-end and a plain fp32 forward of the folded network (csrc/calibrate.hip), measure the statistics, re-pack `w` (the SAME
  * weights the handle was created from) with calibrated rounding and replace the handle's parameter image.  A pack-time operation:
- * synchronises the device.  Clips must cover target_length frames; at most the first 1024 clips are used. */
+ * synchronises the device.  Clips must cover target_length frames; at most the first 1024 clips are used.
+ *
+ * Acceptance check (option "calib_accept_pct", default 105): before the calibrated image is installed, it and the image uitk_create
+ * packed (every weight rounded to nearest) both run the PRODUCT kernels on sixteen HELD-OUT clips of the library (a second signal family,
+ * never the calibration clips), and are compared with what the unrounded network answers there (the fp32 forward of calibrate.hip
+ * finished in double on the host).  The calibrated image is kept only if its largest logit deviation is at most calib_accept_pct per
+ * cent of the nearest image's (default: 5 % slack for ties); otherwise the handle keeps the nearest image and
+ * get_option("weights_calibrated") stays 0 -- a calibration on unrepresentative clips falls back to precision f16 instead of
+ * installing a rounding that is worse than nearest where it was not fitted.  uitk_get_calib_check reports the four numbers. */
 int uitk_calibrate_weights(uitk_model* m, const uitk_weights* w, const void* pcm, int in_dtype, int64_t B, int64_t T, void* stream);
 /* Number of doubles of a statistics block for this config: patch embed [256][256], then per block LayerNorm-1 output [128][128],
  * attention output [inner][inner] (inner = 32, or 128 with attention_full), LayerNorm-2 output [128][128], activation output [384][384]. */
 size_t uitk_calib_stats_doubles(const uitk_config* cfg);
 /* The statistics the latest uitk_calibrate_weights of this handle measured (host buffer of uitk_calib_stats_doubles doubles). */
 int uitk_get_calib_stats(const uitk_model* m, double* out, size_t cap_doubles);
+/* What the acceptance check of the latest uitk_calibrate_weights measured on its held-out clips, five floats:
+ * [0] max |d| of the nearest-rounded image, [1] max |d| of the calibrated image, [2] / [3] the same as root mean squares,
+ * [4] 1 = calibrated image installed, 0 = rejected (the handle runs the nearest image); d = pre-sigmoid logits against the unrounded
+ * network (probabilities for pooling 'dm', which has no logits).  All -1: no check has run (option calib_accept_pct 0, or no calibration). */
+int uitk_get_calib_check(const uitk_model* m, float* out5);
 /* Host-only (no GPU): uitk_pack_weights with calibrated rounding against caller-supplied statistics (layout tests, offline packing). */
 int uitk_pack_weights_calibrated(const uitk_config* cfg, const uitk_weights* w, const double* stats, void* out, size_t cap, size_t* needed);
 
@@ -212,7 +225,8 @@ int uitk_set_debug_tokens(uitk_model* m, float* dev_buf);
 int uitk_set_timing_buffers(uitk_model* m, unsigned long long* enc_buf, unsigned long long* fe_buf);
 
 /* Explicit tuning / test options of a model handle (the library reads no environment variables).  None of them changes a result
- * bit (tests/test_gpu_parity.py::test_pass_distribution_does_not_change_results).  Unknown name -> UITK_ERR_UNSUPPORTED.
+ * bit (tests/test_gpu_parity.py::test_pass_distribution_does_not_change_results) -- "calib_accept_pct" decides whether a calibrated
+ * image may be refused, not what an image computes.  Unknown name -> UITK_ERR_UNSUPPORTED.
  *   "fe_asym_pm"        300..700: per-mille share of the front-end passes walked by the first-dispatched workgroups of every CU;
  *                       -1 (default) = the share measured for the batch shape on this device (uitk_tune_frontend / fe_autotune)
  *   "fe_wg_per_cu"      persistent front-end workgroups per CU (0 = default 2)
@@ -220,10 +234,14 @@ int uitk_set_timing_buffers(uitk_model* m, unsigned long long* enc_buf, unsigned
  *   "split_pe"          1 / 0: patch embed on split (hi + lo) weights; -1 = the precision's default (on for f16x2)
  *   "enc_generic_clamp" 1 = use the generic top_db clamp path even when every init_bn scale is >= 0 (test of that path)
  *   "fe_tail_skip"      1 (default) / 0: a clip's leftover frames (1 s clips: frames 96..100, which only count for the batch amax)
- *                       skip their FFT when a Parseval bound shows they cannot raise it; 0 transforms every frame (test of the skip) */
+ *                       skip their FFT when a Parseval bound shows they cannot raise it; 0 transforms every frame (test of the skip)
+ *   "calib_accept_pct"  0..1000 (default 105): uitk_calibrate_weights installs its image only if its largest deviation on the library's
+ *                       held-out clips is at most this many per cent of the nearest-rounded image's (see there); 0 = no check, install
+ *                       unconditionally; 1 = refuse in practice (test of the fallback) */
 int uitk_set_option(uitk_model* m, const char* name, int value);
 /* Current value of an option ("fe_asym_pm": the explicit setting, else the share the latest front-end launch used, -1 = the
- * built-in 590 because nothing was measured for its shape); also "weights_calibrated" (read-only: 1 after uitk_calibrate_weights). */
+ * built-in 590 because nothing was measured for its shape); also "weights_calibrated" (read-only: 1 when the
+ * handle runs an image uitk_calibrate_weights built AND its acceptance check kept). */
 int uitk_get_option(const uitk_model* m, const char* name, int* value);
 
 /* ---- Step after the path: post-processing of the probability rows on the device, so that only

@@ -855,6 +855,76 @@ def test_calibrated_rounding_with_the_callers_clips_and_weight_edits(golden):
     assert np.abs(p4.cpu().numpy() - ref3["probs"]).max() < 2.5e-4 and not np.array_equal(mm.calib_stats(), pair[1][1])
 
 
+def test_calibration_acceptance_check(golden):
+    """uitk_calibrate_weights installs its image only after a held-out comparison with the nearest-rounded image (round 4): both run
+    the product kernels on sixteen clips of the library's second signal family; the reference there is the fp32 forward of
+    calibrate.hip finished in double on the host.  (a) The report's numbers are those an oracle run would give: same order as the
+    C oracle's errors on the test's own held-out inputs.  (b) With calib_accept_pct = 1 the calibrated image is refused: the handle
+    answers bit for bit like precision 'f16' and says so.  (c) A calibration on digital silence -- statistics of rank ~24 -- either
+    passes the check or is refused, and stays inside the gate either way.  (d) Every pooling and the full-attention / GELU family
+    go through the same check (pooling 'dm' is compared on probabilities)."""
+    x = held_out_inputs(golden)
+    xd = torch.from_numpy(x).cuda()
+    sd = make_trained_like_state_dict("uit_xs", 207)
+    tsd = {k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()}
+    ref = Oracle(sd).forward(x)
+
+    def make(prec, **opts):
+        m = models.uit_xs(outputdim=537, target_length=102, precision=prec)
+        m.load_state_dict(tsd, strict=True)
+        m = m.cuda().eval()
+        for k, v in opts.items():
+            m.set_option(k, v)
+        return m
+
+    def err_of(m):
+        with torch.no_grad():
+            p, l = m(xd, return_logits=True)
+        return float(np.abs(l.cpu().numpy().reshape(ref["logits"].shape) - ref["logits"]).max()), p.clone()
+
+    # (a)
+    m = make("f16c")
+    e_cal, p_cal = err_of(m)
+    rep = m.calibration_report()
+    e_near, p_near = err_of(make("f16"))
+    print(f"acceptance check, XS seed 207: {rep}; C oracle on the test's held-out inputs: nearest {e_near:.2e}, calibrated {e_cal:.2e}")
+    assert rep is not None and rep["accepted"] and m.get_option("weights_calibrated")[0] == 1
+    assert rep["max_calibrated"] < 0.7 * rep["max_nearest"] and rep["rms_calibrated"] < rep["rms_nearest"]
+    assert 0.4 < rep["max_nearest"] / e_near < 2.5 and 0.4 < rep["max_calibrated"] / e_cal < 2.5
+    assert make("f16").calibration_report() is None
+    # (b)
+    m = make("f16c", calib_accept_pct=1)
+    e_ref, p_ref = err_of(m)
+    rep = m.calibration_report()
+    assert rep is not None and not rep["accepted"] and m.get_option("weights_calibrated")[0] == 0
+    assert torch.equal(p_ref, p_near) and e_ref == e_near
+    m = make("f16c", calib_accept_pct=0)                                # no check: installed unconditionally, nothing to report
+    e0, p0 = err_of(m)
+    assert m.calibration_report() is None and m.get_option("weights_calibrated")[0] == 1 and torch.equal(p0, p_cal)
+    # (c)
+    m = make("f16c").calibrate(torch.zeros((32, 16000), dtype=torch.int16, device="cuda"))
+    e_sil, p_sil = err_of(m)
+    rep = m.calibration_report()
+    print(f"calibrated on digital silence: {rep}; C oracle, held-out inputs: {e_sil:.2e}")
+    assert rep is not None and (m.get_option("weights_calibrated")[0] == 1) == rep["accepted"]
+    if rep["accepted"]:
+        assert rep["max_calibrated"] <= 1.05 * rep["max_nearest"]
+    else:
+        assert torch.equal(p_sil, p_near)
+    assert e_sil < 1.3 * e_near
+    # (d)
+    for name, att, pooling in (("uit_xxxs", "bneck", "dm"), ("uit_xxxs", "bneck", "token"), ("audio_transformer_h128_d4_m3", "full", "mean")):
+        mm = getattr(models, name)(outputdim=537, target_length=102, pooling=pooling)
+        mm.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in make_trained_like_state_dict(name, 203, attention=att).items()}, strict=True)
+        mm = mm.cuda().eval()
+        with torch.no_grad():
+            mm(xd[:4])
+        rep = mm.calibration_report()
+        print(f"{name} pooling {pooling}: {rep}")
+        assert rep is not None and 0 < rep["max_calibrated"] < 1e-3 and 0 < rep["max_nearest"] < 3e-3
+        assert (mm.get_option("weights_calibrated")[0] == 1) == rep["accepted"]
+
+
 def test_inference_cli_counterpart_config1(golden, tmp_path, capsys):
     """BASELINE config #1 plumbing: `inference.py -m <ckpt> water_000.wav` through the counterpart CLI (own WAV reader,
     {'model','config'} checkpoint format of inference.py:42-48, label lookup, 'Keyword:' prefix)."""

@@ -53,6 +53,11 @@ struct uitk_model {
     int fe_asym_cur = -1;         // the share the latest front-end launch used (-1 = none measured for its shape: the kernel's 590)
     int weights_calibrated = 0;   // the uploaded image carries calibrated rounding (uitk_calibrate_weights)
     std::vector<double> calib_stats;   // statistics of the latest uitk_calibrate_weights (uitk_get_calib_stats)
+    std::vector<char> img_nearest;     // host copy of the image uitk_create packed (data-free rounding): what the held-out check of
+                                       // uitk_calibrate_weights compares the calibrated image with, and what it falls back to
+    int calib_accept_pct = 105;        // option calib_accept_pct: uitk_calibrate_weights keeps its image only if, on the held-out clips, its
+                                       // largest deviation is at most this many per cent of the nearest-rounded image's; 0 = no check
+    float calib_report[5] = {-1.f, -1.f, -1.f, -1.f, -1.f};   // uitk_get_calib_check
     int fe_wg_per_cu = 0;         // option fe_wg_per_cu: persistent front-end workgroups per CU (0 = the kernel's occupancy target)
     int device = 0;
     float fb_max = 0.f;           // largest mel filterbank entry (front-end: Parseval bound of the leftover-frame skip)
@@ -113,6 +118,7 @@ int uitk_create(const uitk_config* cfg, const uitk_weights* w, uitk_model** out)
     m->cfg = *cfg;
     std::vector<char> img;
     if (int rc = pack_image(cfg, w, nullptr, &img, &m->hdr)) { delete m; return fail(rc, "pack failed"); }
+    if (cfg->precision == UITK_PREC_F16 || cfg->precision == UITK_PREC_BF16) m->img_nearest = img;
     hipDeviceProp_t prop;
     if (hipGetDevice(&m->device) != hipSuccess || hipGetDeviceProperties(&prop, m->device) != hipSuccess) {
         delete m; return fail(UITK_ERR_NO_DEVICE, "cannot query HIP device");
@@ -347,6 +353,9 @@ int uitk_set_option(uitk_model* m, const char* name, int value) {
         m->force_generic_clamp = value != 0;
     } else if (n == "fe_tail_skip") {         // 0 = transform every leftover frame even when it provably cannot raise the batch amax (tests)
         m->fe_tail_skip = value != 0;
+    } else if (n == "calib_accept_pct") {     // 0 = uitk_calibrate_weights installs its image without the held-out comparison
+        if (value < 0 || value > 1000) return fail(UITK_ERR_INVALID_ARG, "calib_accept_pct: 0..1000");
+        m->calib_accept_pct = value;
     } else {
         return fail(UITK_ERR_UNSUPPORTED, "unknown option: " + n);
     }
@@ -363,6 +372,7 @@ int uitk_get_option(const uitk_model* m, const char* name, int* value) {
     else if (n == "split_pe") *value = m->split_pe_env;
     else if (n == "enc_generic_clamp") *value = m->force_generic_clamp;
     else if (n == "fe_tail_skip") *value = m->fe_tail_skip;
+    else if (n == "calib_accept_pct") *value = m->calib_accept_pct;
     else return fail(UITK_ERR_UNSUPPORTED, "unknown option: " + n);
     return UITK_OK;
 }
@@ -475,37 +485,43 @@ int uitk_mel_db(uitk_model* m, const void* pcm, int in_dtype, int64_t B, int64_t
 // pure tones, noise with a silent tail, near-silence, chirps, low-passed noise, amplitude-modulated noise bursts, vibrato harmonic
 // stacks with a syllable-rate envelope -- deterministic (an LCG), int16.  They only have to EXCITE the directions real audio excites:
 // the rounding stays within half a step of nearest in any case, and the damping of round_gptq bounds what it may do elsewhere.
-static void builtin_calibration_set(int n, int64_t T, std::vector<int16_t>* out) {
+// `held_out` selects the second family (other noise seed, other tone / chirp / resonance / envelope / pitch parameters): the clips the
+// acceptance check of uitk_calibrate_weights scores both roundings on -- never the ones the statistics were measured on.
+static void builtin_calibration_set(int n, int64_t T, std::vector<int16_t>* out, bool held_out = false) {
     out->assign((size_t)n * T, 0);
-    uint32_t lcg = 0x2545F491u;
+    uint32_t lcg = held_out ? 0x9E3779B9u : 0x2545F491u;
     auto noise = [&]() { lcg = lcg * 1664525u + 1013904223u; return (double)(lcg >> 8) / 16777216.0 - 0.5; };
+    const double alt = held_out ? 1.0 : 0.0;
     std::vector<double> x(T);
     for (int i = 0; i < n; ++i) {
-        const int kind = i & 7, v = (i >> 3) & 3;
+        const int ii = held_out ? i + 3 : i;                     // (the held-out family also starts at another kind)
+        const int kind = ii & 7, v = (ii >> 3) & 3;
         const double sr = 16000.0;
         switch (kind) {
-        case 0: { const double g[4] = {1.0, 0.3, 0.1, 0.03}; for (int64_t t = 0; t < T; ++t) x[t] = g[v] * noise(); break; }
-        case 1: { const double f = 220.0 * std::pow(1.9, v) + 37.0 * v;
+        case 0: { const double g[4] = {1.0, 0.3, 0.1, 0.03}; for (int64_t t = 0; t < T; ++t) x[t] = (1.0 - 0.4 * alt) * g[v] * noise(); break; }
+        case 1: { const double f = (220.0 * std::pow(1.9, v) + 37.0 * v) * (1.0 + 0.31 * alt);
                   for (int64_t t = 0; t < T; ++t) x[t] = 0.9 * std::sin(2.0 * M_PI * f * t / sr) + 1e-3 * noise(); break; }
-        case 2: { for (int64_t t = 0; t < T; ++t) x[t] = t < T - T / 4 ? (0.25 + 0.25 * v) * noise() : 0.0; break; }
-        case 3: { for (int64_t t = 0; t < T; ++t) x[t] = 1e-3 * (v + 1) * noise(); break; }
-        case 4: { const double f0 = v & 1 ? 7500.0 : 100.0, f1 = v & 1 ? 100.0 : 7500.0, dur = (double)T / sr;
+        case 2: { const int64_t cut = held_out ? T - T / 3 : T - T / 4;
+                  for (int64_t t = 0; t < T; ++t) x[t] = t < cut ? (0.25 + 0.25 * v) * noise() : 0.0; break; }
+        case 3: { for (int64_t t = 0; t < T; ++t) x[t] = 1e-3 * (v + 1 + 0.5 * alt) * noise(); break; }
+        case 4: { const bool down = ((v & 1) != 0) != held_out;
+                  const double f0 = down ? 7500.0 - 900.0 * alt : 100.0 + 150.0 * alt, f1 = down ? 100.0 + 150.0 * alt : 7500.0 - 900.0 * alt, dur = (double)T / sr;
                   for (int64_t t = 0; t < T; ++t) { const double tt = t / sr; x[t] = (v < 2 ? 0.5 : 0.05) * std::sin(2.0 * M_PI * (f0 + 0.5 * (f1 - f0) * tt / dur) * tt); }
                   break; }
-        case 5: { const double a[4] = {0.9, 0.97, 0.99, 0.7}; double y = 0.0, pk = 1e-9;
-                  for (int64_t t = 0; t < T; ++t) { y = a[v] * y + noise(); x[t] = y; pk = std::fmax(pk, std::fabs(y)); }
+        case 5: { const double a0[4] = {0.9, 0.97, 0.99, 0.7}, a1[4] = {0.95, 0.8, 0.985, 0.5}; const double a = held_out ? a1[v] : a0[v]; double y = 0.0, pk = 1e-9;
+                  for (int64_t t = 0; t < T; ++t) { y = a * y + noise(); x[t] = y; pk = std::fmax(pk, std::fabs(y)); }
                   for (int64_t t = 0; t < T; ++t) x[t] *= 0.6 / pk;
                   break; }
-        case 6: { for (int64_t t = 0; t < T; ++t) { const double e = 0.5 + 0.5 * std::sin(2.0 * M_PI * (2.0 + 3.0 * v) * t / sr); x[t] = 0.8 * e * e * e * e * noise(); } break; }
-        default: { const double f0 = 100.0 + 40.0 * v;
+        case 6: { for (int64_t t = 0; t < T; ++t) { const double e = 0.5 + 0.5 * std::sin(2.0 * M_PI * (2.0 + 3.0 * v + 1.5 * alt) * t / sr); x[t] = 0.8 * e * e * e * e * noise(); } break; }
+        default: { const double f0 = 100.0 + 40.0 * v + 23.0 * alt;
                    for (int64_t t = 0; t < T; ++t) {
                        const double tt = t / sr, ph = 2.0 * M_PI * (f0 * tt + 0.8 * std::sin(2.0 * M_PI * 5.0 * tt));
                        double acc = 0.0;
                        for (int hh = 1; hh <= 24; ++hh) {
-                           const double fh = hh * f0, form = std::exp(-0.5 * std::pow((fh - 700.0 - 300.0 * v) / 400.0, 2)) + 0.5 * std::exp(-0.5 * std::pow((fh - 2200.0) / 600.0, 2));
+                           const double fh = hh * f0, form = std::exp(-0.5 * std::pow((fh - 700.0 - 300.0 * v - 150.0 * alt) / 400.0, 2)) + 0.5 * std::exp(-0.5 * std::pow((fh - 2200.0 - 250.0 * alt) / 600.0, 2));
                            acc += (0.15 + form) / hh * std::sin(hh * ph);
                        }
-                       const double env = std::pow(0.5 + 0.5 * std::sin(2.0 * M_PI * 3.0 * tt), 2);
+                       const double env = std::pow(0.5 + 0.5 * std::sin(2.0 * M_PI * (3.0 + alt) * tt), 2);
                        x[t] = 0.25 * env * acc + 2e-4 * noise();
                    }
                    break; }
@@ -518,33 +534,25 @@ static void builtin_calibration_set(int n, int64_t T, std::vector<int16_t>* out)
     }
 }
 
-int uitk_calibrate_weights(uitk_model* m, const uitk_weights* w, const void* pcm, int in_dtype, int64_t B, int64_t T, void* stream) {
-    if (!m || !w) return fail(UITK_ERR_INVALID_ARG, "null argument");
-    if (m->cfg.precision != UITK_PREC_F16 && m->cfg.precision != UITK_PREC_BF16)
-        return fail(UITK_ERR_UNSUPPORTED, "calibrated rounding applies to the single-weight 16-bit precisions (f16, bf16)");
-    hipStream_t s = (hipStream_t)stream;
-    void* own_pcm = nullptr;
-    if (!pcm) {                                                  // the library's own signals: full-length clips for this front-end
-        B = 32; in_dtype = UITK_IN_I16;
-        T = std::max<int64_t>(100 * (int64_t)m->cfg.hop_size, (int64_t)(m->cfg.target_length / 16 * 16) * m->cfg.hop_size + m->cfg.n_fft);
-        std::vector<int16_t> host;
-        builtin_calibration_set((int)B, T, &host);
-        HIP_TRY(hipMalloc(&own_pcm, host.size() * 2));
-        if (hipMemcpy(own_pcm, host.data(), host.size() * 2, hipMemcpyHostToDevice) != hipSuccess) { (void)hipFree(own_pcm); return fail(UITK_ERR_HIP, "calibration set upload failed"); }
-        pcm = own_pcm;
-    }
-    struct Cleanup { void* a = nullptr; void* b = nullptr; void* c = nullptr; ~Cleanup() { if (a) (void)hipFree(a); if (b) (void)hipFree(b); if (c) (void)hipFree(c); } } tmp;
-    tmp.a = own_pcm;
-    if (B > 1024) B = 1024;                                      // more clips do not change a second moment that 768+ tokens already pin
-    if (int rc = check_shape(m, B, T)) return rc;
-    if (crop_nt(m, T) != GT) return fail(UITK_ERR_TOO_SHORT, "calibration clips must cover the full target_length (every time patch valid)");
-    if (int rc = uitk_frontend(m, pcm, in_dtype, B, T, stream)) return rc;
-    const int rows = (int)(B * uitk_num_crops(m, T)), ntok = m->cfg.pooling == 2 ? NTOK + 1 : NTOK, M = rows * ntok;
-    // the folded network as floats
+namespace {
+struct DevBuf {                                                  // scoped device allocation of the pack-time helpers
+    void* p = nullptr;
+    ~DevBuf() { if (p) (void)hipFree(p); }
+};
+
+// The folded network (pack.h) as one float array on the device + where everything sits in it: what the plain fp32 forward of
+// calibrate.hip multiplies with.
+struct NaiveNet {
+    DevBuf weights, work;
+    CalibArgs a{};
+    size_t n_work_per_token = 0;
+};
+
+int naive_net_upload(const uitk_model* m, const uitk_weights* w, NaiveNet* nn, hipStream_t s) {
     Folded F;
     fold_model(&m->cfg, w, &F);
     const int inner = F.inner;
-    CalibArgs a{};
+    CalibArgs& a = nn->a;
     a.o_qkv_w = 0; a.o_qkv_b = a.o_qkv_w + (size_t)3 * inner * DIM; a.o_proj_w = a.o_qkv_b + 3 * inner; a.o_proj_b = a.o_proj_w + (size_t)DIM * inner;
     a.o_fc1_w = a.o_proj_b + DIM; a.o_fc1_b = a.o_fc1_w + (size_t)HID * DIM; a.o_fc2_w = a.o_fc1_b + HID; a.o_fc2_b = a.o_fc2_w + (size_t)DIM * HID;
     a.block_floats = a.o_fc2_b + DIM;
@@ -558,21 +566,162 @@ int uitk_calibrate_weights(uitk_model* m, const uitk_weights* w, const void* pcm
             for (const std::vector<double>* arr : {&fb.qkv_w, &fb.qkv_b, &fb.proj_w, &fb.proj_b, &fb.fc1_w, &fb.fc1_b, &fb.fc2_w, &fb.fc2_b})
                 for (double v : *arr) *p++ = (float)v;
     }
-    const CalibOffsets co = calib_offsets(&m->cfg);
-    const size_t n_stats = calib_stats_doubles(&m->cfg);
-    const size_t n_work = (size_t)M * (256 + DIM + DIM + 3 * inner + inner + HID);
-    HIP_TRY(hipMalloc(&tmp.b, n_model * 4));
-    HIP_TRY(hipMalloc(&tmp.c, (n_work + n_stats) * 4));
-    HIP_TRY(hipMemcpyAsync(tmp.b, hostw.data(), n_model * 4, hipMemcpyHostToDevice, s));
-    const float* dw = (const float*)tmp.b;
-    float* wk = (float*)tmp.c;
-    a.mel = (const unsigned short*)m->mel; a.amax = m->amax + m->amax_cur * AMAX_SLOTS; a.top_db = m->cfg.top_db;
+    HIP_TRY(hipMalloc(&nn->weights.p, n_model * 4));
+    HIP_TRY(hipMemcpyAsync(nn->weights.p, hostw.data(), n_model * 4, hipMemcpyHostToDevice, s));
+    HIP_TRY(hipStreamSynchronize(s));                            // (hostw goes out of scope)
+    const float* dw = (const float*)nn->weights.p;
+    a.top_db = m->cfg.top_db;
     a.bn_sc = (const float*)(m->image + m->hdr.off_bn_sc); a.bn_sh = (const float*)(m->image + m->hdr.off_bn_sh);
     a.op_bf16 = m->cfg.precision == UITK_PREC_BF16;
-    a.rows = rows; a.ntok = ntok; a.depth = m->cfg.depth; a.inner = inner; a.act_gelu = m->cfg.act_gelu;
+    a.ntok = m->cfg.pooling == 2 ? NTOK + 1 : NTOK; a.depth = m->cfg.depth; a.inner = inner; a.act_gelu = m->cfg.act_gelu;
     a.pe_w = dw; a.pe_bias = dw + (size_t)DIM * 256; a.blocks = a.pe_bias + (size_t)(NTOK + 1) * DIM;
-    a.X0 = wk; a.R = a.X0 + (size_t)M * 256; a.Xn = a.R + (size_t)M * DIM; a.QKV = a.Xn + (size_t)M * DIM; a.O = a.QKV + (size_t)M * 3 * inner;
-    a.Hd = a.O + (size_t)M * inner; a.stats = a.Hd + (size_t)M * HID;
+    nn->n_work_per_token = (size_t)(256 + DIM + DIM + 3 * inner + inner + HID);
+    return UITK_OK;
+}
+
+// work buffers for `rows` clip-crops (+ `n_stats` floats of statistics behind them, 0 = none: forward only)
+int naive_net_bind(const uitk_model* m, NaiveNet* nn, int rows, size_t n_stats) {
+    CalibArgs& a = nn->a;
+    const size_t M = (size_t)rows * a.ntok;
+    if (nn->work.p) { (void)hipFree(nn->work.p); nn->work.p = nullptr; }
+    HIP_TRY(hipMalloc(&nn->work.p, (M * nn->n_work_per_token + n_stats) * 4));
+    float* wk = (float*)nn->work.p;
+    a.rows = rows;
+    a.mel = (const unsigned short*)m->mel; a.amax = m->amax + m->amax_cur * AMAX_SLOTS;
+    a.X0 = wk; a.R = a.X0 + M * 256; a.Xn = a.R + M * DIM; a.QKV = a.Xn + M * DIM; a.O = a.QKV + M * 3 * a.inner;
+    a.Hd = a.O + M * a.inner; a.stats = n_stats ? a.Hd + M * HID : nullptr;
+    return UITK_OK;
+}
+
+// What the reference computes from the last block's residual stream (models/uit.py:395, 398-412), in double on the host:
+// final LayerNorm (eps 1e-6) -> pooling -> outputlayer = LayerNorm (eps 1e-5) + Linear.  R: [rows][ntok][128] (the folded stream is
+// centred per token, which LayerNorm does not see).  out: [rows][C] pre-sigmoid logits; pooling 'dm': probabilities (it has no logits).
+void head_reference(const uitk_config& c, const uitk_weights* w, const float* R, int rows, int ntok, std::vector<double>* out) {
+    const int C = c.outputdim;
+    out->assign((size_t)rows * C, 0.0);
+    auto layernorm = [](const double* x, const float* g, const float* b, double eps, double* y) {
+        double mean = 0.0, var = 0.0;
+        for (int i = 0; i < DIM; ++i) mean += x[i];
+        mean /= DIM;
+        for (int i = 0; i < DIM; ++i) var += (x[i] - mean) * (x[i] - mean);
+        const double rstd = 1.0 / std::sqrt(var / DIM + eps);
+        for (int i = 0; i < DIM; ++i) y[i] = (x[i] - mean) * rstd * g[i] + b[i];
+    };
+    std::vector<double> tokn((size_t)ntok * DIM), z(DIM), zn(DIM), x(DIM);
+    auto head = [&](const double* pooled, double* logits) {
+        layernorm(pooled, w->head_ln_w, w->head_ln_b, 1e-5, zn.data());
+        for (int o = 0; o < C; ++o) {
+            double acc = w->head_b[o];
+            for (int i = 0; i < DIM; ++i) acc += zn[i] * (double)w->head_w[(size_t)o * DIM + i];
+            logits[o] = acc;
+        }
+    };
+    std::vector<double> lg(C);
+    for (int r = 0; r < rows; ++r) {
+        for (int t = 0; t < ntok; ++t) {
+            for (int i = 0; i < DIM; ++i) x[i] = R[((size_t)r * ntok + t) * DIM + i];
+            layernorm(x.data(), w->norm_w, w->norm_b, 1e-6, tokn.data() + (size_t)t * DIM);
+        }
+        double* dst = out->data() + (size_t)r * C;
+        if (c.pooling == 2) {                                    // 'token': the cls row
+            head(tokn.data(), dst);
+        } else if (c.pooling == 0) {                             // 'mean' over the 24 tokens
+            for (int i = 0; i < DIM; ++i) { double acc = 0.0; for (int t = 0; t < NTOK; ++t) acc += tokn[(size_t)t * DIM + i]; z[i] = acc / NTOK; }
+            head(z.data(), dst);
+        } else {                                                 // 'dm': mean over frequency patches, head + sigmoid per time patch, mean over time
+            for (int tp = 0; tp < GT; ++tp) {
+                for (int i = 0; i < DIM; ++i) { double acc = 0.0; for (int f = 0; f < NTOK / GT; ++f) acc += tokn[(size_t)(f * GT + tp) * DIM + i]; z[i] = acc / (NTOK / GT); }
+                head(z.data(), lg.data());
+                for (int o = 0; o < C; ++o) dst[o] += 1.0 / (1.0 + std::exp(-lg[o])) / GT;
+            }
+        }
+    }
+}
+}  // namespace
+
+// The acceptance check of uitk_calibrate_weights: both candidate images -- rounded to nearest (uitk_create's) and calibrated -- run the
+// PRODUCT kernels on sixteen held-out clips of the library; the plain fp32 forward of calibrate.hip + head_reference give what the
+// unrounded network answers; the calibrated image is installed only if its largest deviation is at most calib_accept_pct per cent of
+// the nearest image's (default 105: 5 % slack for ties).  report: max |d| nearest, max |d| calibrated, rms nearest, rms calibrated, accepted.  Leaves the chosen image on
+// the device.  Returns UITK_OK with report[4] = -1 when the check does not apply (no single-crop clip length covers target_length).
+static int calibration_acceptance(uitk_model* m, const uitk_weights* w, NaiveNet* nn, const std::vector<char>& img_cal, hipStream_t s, float* report) {
+    const int Be = 16, C = m->cfg.outputdim;
+    int64_t Te = 0;
+    for (int64_t k = GT * 16 - 1; k < 4096 && !Te; ++k) {
+        const int64_t T = k * (int64_t)m->cfg.hop_size + (m->cfg.center ? 0 : m->cfg.n_fft);
+        if (uitk_num_crops(m, T) == 1 && uitk_num_frames(m, T) >= GT * 16 && uitk_num_frames(m, T) <= m->cfg.target_length) Te = T;
+    }
+    for (int i = 0; i < 5; ++i) report[i] = -1.f;
+    if (!Te) return UITK_OK;
+    std::vector<int16_t> host;
+    builtin_calibration_set(Be, Te, &host, true);
+    DevBuf pcm, outb;
+    HIP_TRY(hipMalloc(&pcm.p, host.size() * 2));
+    HIP_TRY(hipMemcpy(pcm.p, host.data(), host.size() * 2, hipMemcpyHostToDevice));
+    HIP_TRY(hipMalloc(&outb.p, (size_t)2 * Be * C * 4));
+    float* d_probs = (float*)outb.p;
+    float* d_logits = m->cfg.pooling == 1 ? nullptr : d_probs + (size_t)Be * C;
+    if (int rc = uitk_frontend(m, pcm.p, UITK_IN_I16, Be, Te, (void*)s)) return rc;
+    if (int rc = naive_net_bind(m, nn, Be, 0)) return rc;
+    HIP_TRY(launch_calibration(nn->a, s));
+    const int ntok = nn->a.ntok;
+    std::vector<float> R((size_t)Be * ntok * DIM);
+    HIP_TRY(hipMemcpyAsync(R.data(), nn->a.R, R.size() * 4, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    std::vector<double> ref;
+    head_reference(m->cfg, w, R.data(), Be, ntok, &ref);
+    std::vector<float> got((size_t)Be * C);
+    double mx[2] = {0.0, 0.0}, sq[2] = {0.0, 0.0};
+    for (int which = 0; which < 2; ++which) {                    // 0: nearest, 1: calibrated (stays on the device if accepted)
+        const std::vector<char>& img = which ? img_cal : m->img_nearest;
+        HIP_TRY(hipDeviceSynchronize());
+        HIP_TRY(hipMemcpy(m->image, img.data(), img.size(), hipMemcpyHostToDevice));
+        if (int rc = uitk_encode(m, Be, Te, d_probs, d_logits, (void*)s)) return rc;
+        HIP_TRY(hipMemcpyAsync(got.data(), d_logits ? d_logits : d_probs, got.size() * 4, hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipStreamSynchronize(s));
+        for (size_t i = 0; i < got.size(); ++i) {
+            const double d = std::fabs((double)got[i] - ref[i]);
+            if (!(d <= mx[which])) mx[which] = d;                // (NaN counts as the maximum)
+            sq[which] += d * d;
+        }
+    }
+    const bool accept = std::isfinite(mx[1]) && mx[1] * 100.0 <= (double)m->calib_accept_pct * mx[0];
+    if (!accept) {
+        HIP_TRY(hipDeviceSynchronize());
+        HIP_TRY(hipMemcpy(m->image, m->img_nearest.data(), m->img_nearest.size(), hipMemcpyHostToDevice));
+    }
+    report[0] = (float)mx[0]; report[1] = (float)mx[1];
+    report[2] = (float)std::sqrt(sq[0] / got.size()); report[3] = (float)std::sqrt(sq[1] / got.size());
+    report[4] = accept ? 1.f : 0.f;
+    return UITK_OK;
+}
+
+int uitk_calibrate_weights(uitk_model* m, const uitk_weights* w, const void* pcm, int in_dtype, int64_t B, int64_t T, void* stream) {
+    if (!m || !w) return fail(UITK_ERR_INVALID_ARG, "null argument");
+    if (m->cfg.precision != UITK_PREC_F16 && m->cfg.precision != UITK_PREC_BF16)
+        return fail(UITK_ERR_UNSUPPORTED, "calibrated rounding applies to the single-weight 16-bit precisions (f16, bf16)");
+    hipStream_t s = (hipStream_t)stream;
+    DevBuf own_pcm;
+    if (!pcm) {                                                  // the library's own signals: full-length clips for this front-end
+        B = 32; in_dtype = UITK_IN_I16;
+        T = std::max<int64_t>(100 * (int64_t)m->cfg.hop_size, (int64_t)(m->cfg.target_length / 16 * 16) * m->cfg.hop_size + m->cfg.n_fft);
+        std::vector<int16_t> host;
+        builtin_calibration_set((int)B, T, &host);
+        HIP_TRY(hipMalloc(&own_pcm.p, host.size() * 2));
+        HIP_TRY(hipMemcpy(own_pcm.p, host.data(), host.size() * 2, hipMemcpyHostToDevice));
+        pcm = own_pcm.p;
+    }
+    if (B > 1024) B = 1024;                                      // more clips do not change a second moment that 768+ tokens already pin
+    if (int rc = check_shape(m, B, T)) return rc;
+    if (crop_nt(m, T) != GT) return fail(UITK_ERR_TOO_SHORT, "calibration clips must cover the full target_length (every time patch valid)");
+    if (int rc = uitk_frontend(m, pcm, in_dtype, B, T, stream)) return rc;
+    const int rows = (int)(B * uitk_num_crops(m, T));
+    NaiveNet nn;
+    if (int rc = naive_net_upload(m, w, &nn, s)) return rc;
+    const CalibOffsets co = calib_offsets(&m->cfg);
+    const size_t n_stats = calib_stats_doubles(&m->cfg);
+    if (int rc = naive_net_bind(m, &nn, rows, n_stats)) return rc;
+    CalibArgs& a = nn.a;
     a.off_pe = co.pe; a.off_ln1 = co.ln1; a.off_att = co.att; a.off_ln2 = co.ln2; a.off_hid = co.hid; a.per_block = co.per_block;
     HIP_TRY(launch_calibration(a, s));
     std::vector<float> stats_f(n_stats);
@@ -584,12 +733,34 @@ int uitk_calibrate_weights(uitk_model* m, const uitk_weights* w, const void* pcm
     std::vector<char> img;
     ImageHeader h;
     if (int rc = pack_image(&m->cfg, w, m->calib_stats.data(), &img, &h)) return fail(rc, "pack failed");
-    if (img.size() != m->hdr.total_bytes) return fail(UITK_ERR_INVALID_ARG, "calibrated image has a different layout (other weights than at uitk_create?)");
+    if (img.size() != m->hdr.total_bytes || img.size() != m->img_nearest.size())
+        return fail(UITK_ERR_INVALID_ARG, "calibrated image has a different layout (other weights than at uitk_create?)");
+    m->fe_B = 0; m->fe_T = 0;
+    if (m->calib_accept_pct > 0) {
+        const int rc = calibration_acceptance(m, w, &nn, img, s, m->calib_report);
+        m->fe_B = 0; m->fe_T = 0;
+        if (rc != UITK_OK) {                                     // whatever happened, the handle must not keep a half-decided image
+            (void)hipDeviceSynchronize();
+            (void)hipMemcpy(m->image, m->img_nearest.data(), m->img_nearest.size(), hipMemcpyHostToDevice);
+            m->weights_calibrated = 0;
+            return rc;
+        }
+        if (m->calib_report[4] >= 0.f) {                         // the check applied and left its choice on the device
+            m->weights_calibrated = m->calib_report[4] > 0.f;
+            return UITK_OK;
+        }
+    } else {
+        for (float& v : m->calib_report) v = -1.f;
+    }
     HIP_TRY(hipDeviceSynchronize());
     HIP_TRY(hipMemcpy(m->image, img.data(), img.size(), hipMemcpyHostToDevice));
-    m->hdr = h;
-    m->fe_B = 0; m->fe_T = 0;
     m->weights_calibrated = 1;
+    return UITK_OK;
+}
+
+int uitk_get_calib_check(const uitk_model* m, float* out5) {
+    if (!m || !out5) return fail(UITK_ERR_INVALID_ARG, "null argument");
+    std::memcpy(out5, m->calib_report, sizeof m->calib_report);
     return UITK_OK;
 }
 

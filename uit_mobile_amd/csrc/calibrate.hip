@@ -164,27 +164,27 @@ hipError_t launch_calibration(const CalibArgs& a, hipStream_t s) {
     const int npatch = a.rows * NTOK;                                      // tokens that carry a patch
     hipLaunchKernelGGL(cal_patch_kernel, dim3(1024), dim3(256), 0, s, a.mel, a.amax, a.top_db, a.bn_sc, a.bn_sh, a.op_bf16, a.rows, a.ntok, a.X0);
     CAL_TRY(hipGetLastError());
-    CAL_TRY(gram(a.X0, a.stats + a.off_pe, M, 256, 1.0f / (float)npatch, a.op_bf16, s));
+    if (a.stats) CAL_TRY(gram(a.X0, a.stats + a.off_pe, M, 256, 1.0f / (float)npatch, a.op_bf16, s));
     hipLaunchKernelGGL(cal_init_stream_kernel, dim3(512), dim3(256), 0, s, a.pe_bias, M, a.ntok, a.R);
     CAL_TRY(hipGetLastError());
     CAL_TRY(linear(a.X0, a.pe_w, nullptr, a.R, M, 256, DIM, 0, 1, s));
     const float inv_m = 1.0f / (float)M;
     for (int b = 0; b < a.depth; ++b) {
         const float* wb = a.blocks + (size_t)b * a.block_floats;
-        float* st = a.stats + (size_t)b * a.per_block;
+        float* st = a.stats ? a.stats + (size_t)b * a.per_block : nullptr;      // nullptr: forward only (the acceptance check)
         hipLaunchKernelGGL(cal_layernorm_kernel, dim3((M + 3) / 4), dim3(256), 0, s, a.R, a.Xn, M, 1e-6f);
         CAL_TRY(hipGetLastError());
-        CAL_TRY(gram(a.Xn, st + a.off_ln1, M, DIM, inv_m, a.op_bf16, s));
+        if (st) CAL_TRY(gram(a.Xn, st + a.off_ln1, M, DIM, inv_m, a.op_bf16, s));
         CAL_TRY(linear(a.Xn, wb + a.o_qkv_w, wb + a.o_qkv_b, a.QKV, M, DIM, 3 * inner, 0, 0, s));
         hipLaunchKernelGGL(cal_attention_kernel, dim3(a.rows, 2), dim3(32), 0, s, a.QKV, a.O, a.ntok, inner);
         CAL_TRY(hipGetLastError());
-        CAL_TRY(gram(a.O, st + a.off_att, M, inner, inv_m, a.op_bf16, s));
+        if (st) CAL_TRY(gram(a.O, st + a.off_att, M, inner, inv_m, a.op_bf16, s));
         CAL_TRY(linear(a.O, wb + a.o_proj_w, wb + a.o_proj_b, a.R, M, inner, DIM, 0, 1, s));
         hipLaunchKernelGGL(cal_layernorm_kernel, dim3((M + 3) / 4), dim3(256), 0, s, a.R, a.Xn, M, 1e-6f);
         CAL_TRY(hipGetLastError());
-        CAL_TRY(gram(a.Xn, st + a.off_ln2, M, DIM, inv_m, a.op_bf16, s));
+        if (st) CAL_TRY(gram(a.Xn, st + a.off_ln2, M, DIM, inv_m, a.op_bf16, s));
         CAL_TRY(linear(a.Xn, wb + a.o_fc1_w, wb + a.o_fc1_b, a.Hd, M, DIM, HID, a.act_gelu ? 2 : 1, 0, s));
-        CAL_TRY(gram(a.Hd, st + a.off_hid, M, HID, inv_m, a.op_bf16, s));
+        if (st) CAL_TRY(gram(a.Hd, st + a.off_hid, M, HID, inv_m, a.op_bf16, s));
         CAL_TRY(linear(a.Hd, wb + a.o_fc2_w, wb + a.o_fc2_b, a.R, M, HID, DIM, 0, 1, s));
     }
 #undef CAL_TRY

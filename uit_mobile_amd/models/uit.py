@@ -29,7 +29,7 @@ from .. import _lib
 _CHECK_WEIGHTS = os.environ.get('UITK_CHECK_WEIGHTS', '1') == '1'   # every call compares a cheap version stamp of the weights (~15 us);
                                                                      # UITK_CHECK_WEIGHTS=0: benchmark loops that never touch the weights
 _VERSION_OF = operator.attrgetter("_version")
-_OPTIONS = ('fe_asym_pm', 'fe_wg_per_cu', 'enc_waves', 'split_pe', 'enc_generic_clamp', 'fe_tail_skip')      # uitk_set_option names
+_OPTIONS = ('fe_asym_pm', 'fe_wg_per_cu', 'enc_waves', 'split_pe', 'enc_generic_clamp', 'fe_tail_skip', 'calib_accept_pct')      # uitk_set_option names
 _PRECISIONS = {'f16': _lib.PREC_F16, 'f16c': _lib.PREC_F16, 'bf16': _lib.PREC_BF16, 'fp8': _lib.PREC_FP8, 'f16x2': _lib.PREC_F16X2, 'f16l6': _lib.PREC_F16L6}
 
 __all__ = ["UITBase", "uit_xs", "uit_xxs", "uit_xxxs", "PRETRAINED_CHECKPOINTS",
@@ -396,6 +396,19 @@ class UITBase(nn.Module):
         out = np.empty(L.uitk_calib_stats_doubles(ctypes.byref(cfg)), np.float64)
         _lib.check(L.uitk_get_calib_stats(h, ctypes.c_void_p(out.ctypes.data), out.size), "uitk_get_calib_stats")
         return out
+
+    def calibration_report(self, device=None):
+        """What the acceptance check of the live handle's calibration measured on the library's held-out clips (uitk_get_calib_check):
+        {'max_nearest', 'max_calibrated', 'rms_nearest', 'rms_calibrated', 'accepted'} -- deviations of the pre-sigmoid logits
+        (probabilities for pooling 'dm') from the unrounded network, for the nearest-rounded and the calibrated parameter image;
+        accepted False = the handle kept the nearest image.  None when no check has run."""
+        device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+        h = self._handle(device)
+        out = (ctypes.c_float * 5)()
+        _lib.check(_lib.load().uitk_get_calib_check(h, out), "uitk_get_calib_check")
+        if out[4] < 0:
+            return None
+        return {"max_nearest": out[0], "max_calibrated": out[1], "rms_nearest": out[2], "rms_calibrated": out[3], "accepted": out[4] > 0}
 
     def _handle(self, device):
         if self.eval_avg not in ('mean', 'max'):
