@@ -488,6 +488,10 @@ def main():
             # the arithmetic type: fp16 MFMA operands (fp32 accumulate / residual stream / LayerNorm / softmax); `precision` names the mode
             "dtype": {"f16c": "f16", "f16l6": "f16l6", "f16x2": "f16x2"}.get(args.precision, args.precision), "precision": args.precision,
             "max_abs_dprob": None if parity is None else parity.get("max_abs_dprob"), "parity_check": parity,
+            # what the library's own acceptance check measured when it calibrated this handle's weights (logits, held-out clips of the
+            # library, against the unrounded network; include/uitk.h: uitk_get_calib_check) -- None for the uncalibrated precisions
+            "calibration_check": (lambda r: None if r is None else {k: (v if isinstance(v, bool) else float(f"{v:.3e}")) for k, v in r.items()})(
+                reps[0].calibration_report() if args.precision == "f16c" else None),
             "step_ms_median": round(float(np.median(period_ms)), 4) if period_ms else None,
             "rccl_ranks": dist.get_world_size() if world > 1 else 1,
             "rccl_version": ".".join(str(v) for v in torch.cuda.nccl.version()) if world > 1 and args.backend == "nccl" else None,
