@@ -501,7 +501,9 @@ def main():
                                    f"16 kHz x 1 s clips per GPU ({'int16 PCM' if args.pcm16 else 'float32 wave'} "
                                    f"resident in HBM), global batch {world * Bl}",
                        "global_batch": world * Bl, "clip_samples": T, "input_buffers": nbuf_in,
-                       "weights": PARITY_NOTE[args.precision],
+                       "weights": PARITY_NOTE[args.precision] + (
+                           " -- NOT in this run: the library's acceptance check refused the calibrated image, the handle runs nearest-rounded fp16 weights"
+                           if args.precision == "f16c" and (reps[0].calibration_report() or {}).get("accepted") is False else ""),
                        "setup": "handles (weight calibration) + workspace + front-end pass-split tuning + RCCL communicator"
                                 + (f", then {args.spinup_steps} extra untimed steps" if args.spinup_steps else ""),
                        "parallelism": f"dp{world} (batch shards, in-place RCCL MAX all-reduce of the 64 amax slots + "
