@@ -163,7 +163,9 @@ int uitk_get_calib_stats(const uitk_model* m, double* out, size_t cap_doubles);
 /* What the acceptance check of the latest uitk_calibrate_weights measured on its held-out clips, five floats:
  * [0] max |d| of the nearest-rounded image, [1] max |d| of the calibrated image, [2] / [3] the same as root mean squares,
  * [4] 1 = calibrated image installed, 0 = rejected (the handle runs the nearest image); d = pre-sigmoid logits against the unrounded
- * network (probabilities for pooling 'dm', which has no logits).  All -1: no check has run (option calib_accept_pct 0, or no calibration). */
+ * network (probabilities for pooling 'dm', which has no logits).  Both sides start from the same 16-bit patch operands of the product
+ * front-end: the numbers measure the encoder's arithmetic (weight + activation rounding), not the front-end's.
+ * All -1: no check has run (option calib_accept_pct 0, or no calibration). */
 int uitk_get_calib_check(const uitk_model* m, float* out5);
 /* Host-only (no GPU): uitk_pack_weights with calibrated rounding against caller-supplied statistics (layout tests, offline packing). */
 int uitk_pack_weights_calibrated(const uitk_config* cfg, const uitk_weights* w, const double* stats, void* out, size_t cap, size_t* needed);
