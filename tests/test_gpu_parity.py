@@ -671,7 +671,8 @@ def test_pass_distribution_does_not_change_results():
     pcm[3] = 0
     x = torch.from_numpy(pcm).cuda()
     outs = []
-    for opts in ({}, {"fe_asym_pm": 500}, {"fe_asym_pm": 700}, {"fe_asym_pm": 300}, {"enc_generic_clamp": 1}, {"fe_tail_skip": 0}):
+    for opts in ({}, {"fe_asym_pm": 500}, {"fe_asym_pm": 700}, {"fe_asym_pm": 300}, {"enc_generic_clamp": 1}, {"fe_tail_skip": 0},
+                 {"enc_waves": 4}, {"enc_waves": 8}):
         m, _ = build("uit_xxxs", 31)
         for k, v in opts.items():
             m.set_option(k, v)
@@ -679,6 +680,16 @@ def test_pass_distribution_does_not_change_results():
             outs.append((m(x).cpu().numpy(), m.melspec_db(x[:64]).cpu().numpy()))
     for p, mel in outs[1:]:
         assert np.array_equal(p, outs[0][0]) and np.array_equal(mel, outs[0][1])
+    # the encoder's workgroup shape follows the batch size (4-wave workgroups up to 8 clip rows per CU): small batches give the bits
+    # of either explicit shape, short clips (masked time patches) included
+    for xs in (x[:100], x[:2048], x[:2049], x[:7, :9000]):
+        trio = []
+        for waves in (0, 4, 8):
+            m, _ = build("uit_xxxs", 31, fe_autotune=False)         # (no pass-split measurement for these shapes: a later test counts them)
+            m.set_option("enc_waves", waves)
+            with torch.no_grad():
+                trio.append(m(xs).cpu().numpy())
+        assert np.array_equal(trio[0], trio[1]) and np.array_equal(trio[0], trio[2])
     m, _ = build("uit_xxxs", 31)
     with pytest.raises(ValueError):                     # unknown option: UITK_ERR_UNSUPPORTED when the handle is created
         m.set_option("no_such_option", 1)

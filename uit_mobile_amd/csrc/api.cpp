@@ -43,7 +43,8 @@ struct uitk_model {
     unsigned long long* timing = nullptr;
     unsigned long long* timing_fe = nullptr;
     int n_cu = 256;
-    int enc_waves = 8;            // option enc_waves: waves per encoder workgroup (8 = one WG per CU; 4 = two independent WGs per CU)
+    int enc_waves = 0;            // option enc_waves: waves per encoder workgroup (8 = one WG per CU; 4 = two independent WGs per CU;
+                                  // 0 = by batch size: 4 while the batch fits one 4-wave workgroup per CU, see uitk_encode)
     int split_pe_env = -1;        // option split_pe: patch embed on split weights (W = hi + lo); -1 = the precision's default (on for f16x2;
                                   // off for f16: measured no better than the structured rounding of pack.cpp at +1.6 % encoder time)
     int force_generic_clamp = 0;  // option enc_generic_clamp
@@ -345,7 +346,7 @@ int uitk_set_option(uitk_model* m, const char* name, int value) {
         if (value < 0 || value > 4) return fail(UITK_ERR_INVALID_ARG, "fe_wg_per_cu: 0..4");
         m->fe_wg_per_cu = value;
     } else if (n == "enc_waves") {            // 8 = one encoder workgroup per CU (default), 4 = two independent workgroups per CU
-        if (value != 4 && value != 8) return fail(UITK_ERR_INVALID_ARG, "enc_waves: 4 or 8");
+        if (value != 0 && value != 4 && value != 8) return fail(UITK_ERR_INVALID_ARG, "enc_waves: 0 (by batch size), 4 or 8");
         m->enc_waves = value;
     } else if (n == "split_pe") {             // patch embed on split weights: 1 / 0 / -1 = the precision's default
         m->split_pe_env = value < 0 ? -1 : (value != 0);
@@ -450,7 +451,13 @@ int uitk_encode(uitk_model* m, int64_t B, int64_t T, float* probs, float* logits
     a.split_pe = m->split_pe_env >= 0 ? m->split_pe_env : m->cfg.precision == UITK_PREC_F16X2;     // f16x2: the patch embed runs on its split weights too
     // (f16l6 keeps the structurally rounded single weights: same-box, worst sweep seeds 6.0e-4 / 5.1e-4 without vs 6.6e-4 / 4.8e-4 with, +1.2 % time)
     a.attention_full = m->cfg.attention_full; a.act_gelu = m->cfg.act_gelu; a.pooling = m->cfg.pooling;
-    HIP_TRY(launch_encoder(a, m->cfg.precision, m->enc_waves, s));
+    // Workgroup shape.  Large batches: 8 waves (two per SIMD, every weight fragment read once per 16 clips).  A batch that fits ONE
+    // 4-wave workgroup per CU (rows <= 8 per CU) runs on those instead: a lone wave per SIMD finishes its two clips 1.3-1.4x sooner
+    // than a pair sharing the SIMD finishes four (XS: 0.14-0.15 ms against 0.20 ms up to 2048 clips; profiles/round4/occ_test.log),
+    // which is what a small-batch / latency caller wants.  Same arithmetic, same bits (tests: test_pass_distribution_...).
+    // launch_encoder ignores the hint for the variants that only have 8-wave instantiations.
+    const int waves = m->enc_waves ? m->enc_waves : (a.rows <= 8 * m->n_cu ? 4 : 8);
+    HIP_TRY(launch_encoder(a, m->cfg.precision, waves, s));
     if (nc > 1) HIP_TRY(launch_crop_reduce(m->rowprobs, probs, B, nc, a.C, m->cfg.eval_avg, s));
     return UITK_OK;
 }
