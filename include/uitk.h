@@ -233,7 +233,8 @@ int uitk_set_timing_buffers(uitk_model* m, unsigned long long* enc_buf, unsigned
  *                       -1 (default) = the share measured for the batch shape on this device (uitk_tune_frontend / fe_autotune)
  *   "fe_wg_per_cu"      persistent front-end workgroups per CU (0 = default 2)
  *   "enc_waves"         0 (default: by batch size -- 4-wave workgroups while the batch fits one of them per CU, i.e. up to 8 clip rows per
- *                       CU: 1.3-1.4x lower latency for small batches; 8-wave workgroups above), 8 (one 8-wave encoder workgroup per CU)
+ *                       CU: 1.3-1.4x lower latency for small batches; 8-wave workgroups above, and the rows left over after the full
+ *                       8-wave rounds go out as a second, 4-wave launch when they fit one), 8 (one 8-wave encoder workgroup per CU)
  *                       or 4 (two 4-wave workgroups per CU); the uit_* family in f16 / bf16 / fp8 -- other variants always run 8
  *   "split_pe"          1 / 0: patch embed on split (hi + lo) weights; -1 = the precision's default (on for f16x2)
  *   "enc_generic_clamp" 1 = use the generic top_db clamp path even when every init_bn scale is >= 0 (test of that path)

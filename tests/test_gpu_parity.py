@@ -682,7 +682,7 @@ def test_pass_distribution_does_not_change_results():
         assert np.array_equal(p, outs[0][0]) and np.array_equal(mel, outs[0][1])
     # the encoder's workgroup shape follows the batch size (4-wave workgroups up to 8 clip rows per CU): small batches give the bits
     # of either explicit shape, short clips (masked time patches) included
-    for xs in (x[:100], x[:2048], x[:2049], x[:7, :9000]):
+    for xs in (x[:100], x[:2048], x[:2049], x[:7, :9000], x[:4096 + 101], x[:6144]):      # (the last two: full 8-wave rounds + a 4-wave tail launch)
         trio = []
         for waves in (0, 4, 8):
             m, _ = build("uit_xxxs", 31, fe_autotune=False)         # (no pass-split measurement for these shapes: a later test counts them)

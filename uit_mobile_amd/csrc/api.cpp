@@ -454,10 +454,32 @@ int uitk_encode(uitk_model* m, int64_t B, int64_t T, float* probs, float* logits
     // Workgroup shape.  Large batches: 8 waves (two per SIMD, every weight fragment read once per 16 clips).  A batch that fits ONE
     // 4-wave workgroup per CU (rows <= 8 per CU) runs on those instead: a lone wave per SIMD finishes its two clips 1.3-1.4x sooner
     // than a pair sharing the SIMD finishes four (XS: 0.14-0.15 ms against 0.20 ms up to 2048 clips; profiles/round4/occ_test.log),
-    // which is what a small-batch / latency caller wants.  Same arithmetic, same bits (tests: test_pass_distribution_...).
-    // launch_encoder ignores the hint for the variants that only have 8-wave instantiations.
-    const int waves = m->enc_waves ? m->enc_waves : (a.rows <= 8 * m->n_cu ? 4 : 8);
-    HIP_TRY(launch_encoder(a, m->cfg.precision, waves, s));
+    // which is what a small-batch / latency caller wants.  The same holds for the LAST round of a large batch: rows beyond the full
+    // 8-wave rounds (16 per CU each) that fit one 4-wave workgroup per CU go out as a second launch of that shape (rows are
+    // independent; both launches read the same amax slots).  Same arithmetic, same bits (tests: test_pass_distribution_...).
+    // Only the uit_* family in f16 / bf16 / fp8 has 4-wave instantiations; launch_encoder ignores the hint for the others.
+    const bool has_w4 = !a.attention_full && !a.act_gelu && !a.pooling &&
+                        (m->cfg.precision == UITK_PREC_F16 || m->cfg.precision == UITK_PREC_BF16 || m->cfg.precision == UITK_PREC_FP8);
+    const int small = 8 * m->n_cu, round8 = 16 * m->n_cu;
+    auto launch_rows = [&](int row0, int nrows, int waves) {
+        EncoderArgs b = a;
+        b.rows = nrows;
+        b.mel = a.mel + (size_t)row0 * NTOK * 256;
+        b.probs = a.probs + (size_t)row0 * a.C;
+        if (a.logits) b.logits = a.logits + (size_t)row0 * a.C;
+        return launch_encoder(b, m->cfg.precision, waves, s);
+    };
+    const int tail = a.rows % round8;
+    if (m->enc_waves || !has_w4 || a.dbg || a.timing) {
+        HIP_TRY(launch_encoder(a, m->cfg.precision, m->enc_waves ? m->enc_waves : 8, s));
+    } else if (a.rows <= small) {
+        HIP_TRY(launch_encoder(a, m->cfg.precision, 4, s));
+    } else if (a.rows > round8 && tail > 0 && tail <= small) {
+        HIP_TRY(launch_rows(0, a.rows - tail, 8));
+        HIP_TRY(launch_rows(a.rows - tail, tail, 4));
+    } else {
+        HIP_TRY(launch_encoder(a, m->cfg.precision, 8, s));
+    }
     if (nc > 1) HIP_TRY(launch_crop_reduce(m->rowprobs, probs, B, nc, a.C, m->cfg.eval_avg, s));
     return UITK_OK;
 }
