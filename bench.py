@@ -430,7 +430,7 @@ def main():
     enc_ms = [e[2].elapsed_time(e[3]) for e in evs[args.warmup:]]
     period_ms = [a[3].elapsed_time(b[3]) for a, b in zip(evs[args.warmup:-1], evs[args.warmup + 1:])]      # encoder end to encoder end
     assert out.shape == (world * Bl, pay_cols) and (pay_dtype == torch.int32 or bool(torch.isfinite(out.float()).all()))
-    # parity of what was just timed (rank 0; the checker, outside the timed region): 8 rows of the LAST timed step's output against
+    # parity of what was just timed (rank 0; the checker, outside the timed region): 32 rows of the LAST timed step's output against
     # the CPU oracle on the same clips.  The subset holds the batch's loudest clip (found with the product's own mel), so the oracle
     # computes the batch's top_db floor; the loud tones repeat with period 64 in the global clip index, i.e. on every rank.
     parity = None
@@ -441,12 +441,13 @@ def main():
             tones = torch.arange(1, min(Bl, 1024), 8, device=dev)
             with torch.no_grad():
                 loud = int(tones[reps[0].melspec_db(last_x[tones]).amax(dim=(1, 2)).argmax()])
-            rows = sorted({loud, 0, 2, 3, Bl // 3, Bl // 2 + 1, Bl - 2, Bl - 1})
+            rows = sorted({loud, 0, 2, 3, Bl // 3, Bl // 2 + 1, Bl - 2, Bl - 1} | {int(i) for i in np.linspace(5, Bl - 6, 24)})    # 32 rows: both
+            # rounds of encoder workgroups, every wave slot, the loudest clip (sets the top_db floor) and the first / last rows
             sub = last_x[rows].cpu().numpy()
             ref = Oracle(sd).forward(sub)
             got = out[rows].float().cpu().numpy()
             parity = {"max_abs_dprob": float(np.abs(got - ref["probs"]).max()), "rows": rows,
-                      "what": "8 rows of the last timed step's gathered output vs oracle/uit_oracle.c on the same clips"}
+                      "what": f"{len(rows)} rows of the last timed step's gathered output vs oracle/uit_oracle.c on the same clips"}
         except Exception as e:                              # the check is reported, never silently skipped
             parity = {"max_abs_dprob": None, "error": str(e)[:200]}
     t = torch.tensor([el], device=dev, dtype=torch.float64)
