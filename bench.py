@@ -473,7 +473,11 @@ def main():
             try:
                 rec_ = json.loads(pmc.read_text())
                 src_now = kernel_sources_sha16()
-                if rec_.get("kernel_sources_sha16") == src_now and rec_.get("precision", "f16") == args.precision:
+                wl_now = {"model": args.model, "batch_per_gpu": Bl}
+                if rec_.get("workload", {"model": "uit_xs", "batch_per_gpu": 8192}) != wl_now:
+                    traffic_source = (f"not quoted: profiles/pmc_latest.json was measured on "
+                                      f"{rec_.get('workload', {'model': 'uit_xs', 'batch_per_gpu': 8192})}, this run is {wl_now}")
+                elif rec_.get("kernel_sources_sha16") == src_now and rec_.get("precision", "f16") == args.precision:
                     traffic = rec_.get("encoder_hbm_bytes_per_launch")
                     traffic_source = f"profiles/pmc_latest.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, kernel sources {src_now})"
                 else:
