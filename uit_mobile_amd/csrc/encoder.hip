@@ -269,10 +269,10 @@ __device__ __forceinline__ void ln_stats(const f4 (&R)[8][3], int ct, float eps,
 }
 
 // LN + conversion to the MFMA operand of the next linear (its affine is folded into that linear by pack.cpp).
-template <int PREC>
+template <int PREC, int NCT = 3>                     // NCT: live column tiles (2 for pooling 'token': one clip per wave)
 __device__ __forceinline__ void layernorm_to_operand(const f4 (&R)[8][3], float eps, typename Op<PREC>::v8 (&X)[4][3]) {
 #pragma unroll
-    for (int ct = 0; ct < 3; ++ct) {
+    for (int ct = 0; ct < NCT; ++ct) {
         float mean, rstd;
         ln_stats(R, ct, eps, mean, rstd);
         const f4 rs = splat(rstd);
@@ -298,23 +298,24 @@ __device__ constexpr int TI[7] = {0, 0, 1, 1, 1, 2, 2};
 // Attention of one block on 16x16x16 MFMAs (K = head_dim 16 exactly) + the proj linear into the residual stream R.
 //   Qh/Kh[h][ct]: q, k of head h as C/D tiles packed to 16 bits (feature-major);  Vh[ct][h]: V token-major (A operand of P.V)
 //   tvalid / pmask: see the kernel;  proj: the eight 1 KiB proj fragments (K = 32 = (head, d));  bias: this block's bias table
-template <class OP, bool SHORT, bool X2 = false>
+template <class OP, bool SHORT, bool X2 = false, int NCT = 3>
 __device__ __forceinline__ void attention_proj(f4 (&R)[8][3], const typename OP::v4 (&Qh)[2][3], const typename OP::v4 (&Kh)[2][3],
                                                const typename OP::v4 (&Vh)[3][2], const bool (&tvalid)[7], const u2 (&pmask)[7],
                                                const char* proj, const float* bias, int lane, int g) {
     using v8 = typename OP::v8;
     using v4 = typename OP::v4;
+    constexpr int N7 = NCT == 2 ? 4 : 7;                  // one clip in tiles 0 / 1: the four score tiles among them (the first four of TJ / TI)
     f4 O[2][3];
     // both heads advance together phase by phase (scores, maxima, exponentials, P.V): two independent dependency chains
     // in every phase for the scheduler to overlap
     f4 S[2][7];
     float tm[2][7], mx[2][3];
 #pragma unroll
-    for (int i = 0; i < 7; ++i)
+    for (int i = 0; i < N7; ++i)
 #pragma unroll
         for (int h = 0; h < 2; ++h) S[h][i] = OP::mfma16(Kh[h][TJ[i]], Qh[h][TI[i]], splat(0.f));
 #pragma unroll
-    for (int i = 0; i < 7; ++i)
+    for (int i = 0; i < N7; ++i)
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
             if constexpr (SHORT) {
@@ -329,13 +330,15 @@ __device__ __forceinline__ void attention_proj(f4 (&R)[8][3], const typename OP:
         }
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
+#pragma unroll
+        for (int i = N7; i < 7; ++i) tm[h][i] = -INFINITY;
         mx[h][0] = xmax(vmax(tm[h][0], tm[h][1]));
         mx[h][1] = xmax(vmax3(tm[h][2], tm[h][3], tm[h][4]));
         mx[h][2] = xmax(vmax(tm[h][5], tm[h][6]));
     }
     f4 Lsum[2][3];
 #pragma unroll
-    for (int i = 0; i < 7; ++i)
+    for (int i = 0; i < N7; ++i)
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
             f4 p;
@@ -354,19 +357,19 @@ __device__ __forceinline__ void attention_proj(f4 (&R)[8][3], const typename OP:
 #pragma unroll
     for (int h = 0; h < 2; ++h)
 #pragma unroll
-        for (int it = 0; it < 3; ++it) O[h][it] = O[h][it] * splat(__builtin_amdgcn_rcpf(Lsum[h][it][0]));
+        for (int it = 0; it < NCT; ++it) O[h][it] = O[h][it] * splat(__builtin_amdgcn_rcpf(Lsum[h][it][0]));
     // proj: K = 32 = (head, d); slots j<4 head 0, j>=4 head 1 (same universal k-order as pack_frag)
     v8 A[8];
 #pragma unroll
     for (int ft = 0; ft < 8; ++ft) A[ft] = *(const v8*)(proj + ft * FRAG_BYTES + lane * 16);
     v8 OX[3];
 #pragma unroll
-    for (int ct = 0; ct < 3; ++ct) OX[ct] = OP::pack8(O[0][ct], O[1][ct]);
+    for (int ct = 0; ct < NCT; ++ct) OX[ct] = OP::pack8(O[0][ct], O[1][ct]);
 #pragma unroll
     for (int ft = 0; ft < 8; ++ft) {
         const f4 bp = *(const f4*)(bias + BIAS_PROJ + 16 * ft + 4 * g);
 #pragma unroll
-        for (int ct = 0; ct < 3; ++ct) R[ft][ct] = OP::mfma32(A[ft], OX[ct], add4s(R[ft][ct], bp));
+        for (int ct = 0; ct < NCT; ++ct) R[ft][ct] = OP::mfma32(A[ft], OX[ct], add4s(R[ft][ct], bp));
     }
     if constexpr (X2) {                                   // precision f16x2: the low-order proj fragments follow the high-order ones
 #pragma unroll
@@ -374,7 +377,7 @@ __device__ __forceinline__ void attention_proj(f4 (&R)[8][3], const typename OP:
 #pragma unroll
         for (int ft = 0; ft < 8; ++ft)
 #pragma unroll
-            for (int ct = 0; ct < 3; ++ct) R[ft][ct] = OP::mfma32(A[ft], OX[ct], R[ft][ct]);
+            for (int ct = 0; ct < NCT; ++ct) R[ft][ct] = OP::mfma32(A[ft], OX[ct], R[ft][ct]);
     }
 }
 
@@ -557,13 +560,16 @@ __global__ __launch_bounds__(WAVES * 64, 2) void uit_encoder_kernel(EncoderArgs 
     if constexpr (TIMING) tlast = stamp();
     // ---- rows (clip-crops) of this wave, token maps
     constexpr bool TOK = POOL == 2;
+    // pooling 'token': ONE clip per wave = 25 live columns (cls + 24 patches) = column tiles 0 and 1; tile 2 would hold dead columns
+    // only, so every per-tile loop stops at NCT = 2 and attention visits the four score tiles among tiles 0 / 1 (N7 = 4 of the 7)
+    constexpr int NCT = TOK ? 2 : 3, N7 = TOK ? 4 : 7;
     constexpr bool PERKEY = SHORT || TOK;                   // softmax maxima with per-key masks (padding / dead columns exist)
     const int r0 = TOK ? blockIdx.x * WAVES + wave : (blockIdx.x * WAVES + wave) * 2;
     const int row_lo = r0 < a.rows ? r0 : a.rows - 1, row_hi = TOK ? row_lo : (r0 + 1 < a.rows ? r0 + 1 : a.rows - 1);
     int clip_[3], tk_[3], pf_[3], pt_[3];
     bool patch_[3];                                         // the column holds a patch token (TOK: not the cls token, not dead)
 #pragma unroll
-    for (int ct = 0; ct < 3; ++ct) {
+    for (int ct = 0; ct < NCT; ++ct) {
         const int col = 16 * ct + c;
         if constexpr (TOK) {
             clip_[ct] = 0;
@@ -585,7 +591,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void uit_encoder_kernel(EncoderArgs 
     // trip covers the whole patch embed.
     v8 XB[3][8];
 #pragma unroll
-    for (int ct = 0; ct < 3; ++ct) {
+    for (int ct = 0; ct < NCT; ++ct) {
         const unsigned short* src = a.mel + ((int64_t)(clip_[ct] ? row_hi : row_lo) * NTOK + tk_[ct]) * 256 + 8 * g;
 #pragma unroll
         for (int s = 0; s < 8; ++s) XB[ct][s] = *(const v8*)(src + 32 * s);
@@ -642,7 +648,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void uit_encoder_kernel(EncoderArgs 
     f4 R[8][3];
     if constexpr (!PEB_LDS) {
 #pragma unroll
-        for (int ct = 0; ct < 3; ++ct)
+        for (int ct = 0; ct < NCT; ++ct)
 #pragma unroll
             for (int ft = 0; ft < 8; ++ft) R[ft][ct] = *(const f4*)(a.pe_bias + (patch_[ct] ? tk_[ct] : NTOK) * DIM + 16 * ft + 4 * g);   // row 24: cls
     }
@@ -674,7 +680,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void uit_encoder_kernel(EncoderArgs 
         typedef unsigned u4v __attribute__((ext_vector_type(4)));
         typedef _Float16 h2v __attribute__((ext_vector_type(2)));
 #pragma unroll
-        for (int ct = 0; ct < 3; ++ct) {
+        for (int ct = 0; ct < NCT; ++ct) {
             const bool live = patch_[ct] && pt_[ct] < a.nt;               // cls / dead columns carry no patch: operand 0
             const float* trow = clamp_tab + 16 * pf_[ct] + 8 * (g >> 1);
             const f4 th_lo = *(const f4*)trow, th_hi = *(const f4*)(trow + 4);
@@ -692,7 +698,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void uit_encoder_kernel(EncoderArgs 
         }
     } else {
 #pragma unroll
-    for (int ct = 0; ct < 3; ++ct) {
+    for (int ct = 0; ct < NCT; ++ct) {
         const bool live = patch_[ct] && pt_[ct] < a.nt;                   // cls / dead columns carry no patch: operand 0
         const float* trow = clamp_tab + 16 * pf_[ct] + 8 * (g >> 1);
         const f4 th_lo = *(const f4*)trow, th_hi = *(const f4*)(trow + 4);
@@ -713,7 +719,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void uit_encoder_kernel(EncoderArgs 
     TSTAMP(9);                                                            // barrier: slowest wave of the workgroup
     if constexpr (PEB_LDS) {
 #pragma unroll
-        for (int ct = 0; ct < 3; ++ct)
+        for (int ct = 0; ct < NCT; ++ct)
 #pragma unroll
             for (int ft = 0; ft < 8; ++ft) R[ft][ct] = *(const f4*)(peb + (patch_[ct] ? tk_[ct] : NTOK) * PEB_STRIDE + 16 * ft + 4 * g);   // row 24: cls
     }
@@ -728,14 +734,14 @@ __global__ __launch_bounds__(WAVES * 64, 2) void uit_encoder_kernel(EncoderArgs 
 #pragma unroll
         for (int s = 0; s < 8; ++s)
 #pragma unroll
-            for (int ct = 0; ct < 3; ++ct) R[ft][ct] = OP::mfma32(A[s], XB[ct][s], R[ft][ct]);
+            for (int ct = 0; ct < NCT; ++ct) R[ft][ct] = OP::mfma32(A[s], XB[ct][s], R[ft][ct]);
         if (SPLIT_PE && a.split_pe) {
 #pragma unroll
             for (int s = 0; s < 8; ++s) A[s] = lds_frag<OPC>(pelo, ft * 8 + s, lane);
 #pragma unroll
             for (int s = 0; s < 8; ++s)
 #pragma unroll
-                for (int ct = 0; ct < 3; ++ct) R[ft][ct] = OP::mfma32(A[s], XB[ct][s], R[ft][ct]);
+                for (int ct = 0; ct < NCT; ++ct) R[ft][ct] = OP::mfma32(A[s], XB[ct][s], R[ft][ct]);
         }
     }
     TSTAMP(10);                                                           // patch-embed MFMAs
@@ -753,7 +759,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void uit_encoder_kernel(EncoderArgs 
     auto dbg_store = [&](int stage) {                      // (debug path: recomputes its token map from v_mbcnt -- volatile, so that no
         const int dl = lane_id_now();                      //  lane-dependent address is hoisted out of the block loop and spilled there)
 #pragma unroll
-        for (int ct = 0; ct < 3; ++ct) {
+        for (int ct = 0; ct < NCT; ++ct) {
             const int col = 16 * ct + (dl & 15);
             const int dclip = (!TOK && col >= NTOK) ? 1 : 0, dtk = TOK ? (col >= 1 && col <= NTOK ? col - 1 : 0) : col - NTOK * dclip;
             const int row = r0 + dclip;
@@ -773,7 +779,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void uit_encoder_kernel(EncoderArgs 
     bool tvalid[7];
     u2 pmask[7];
 #pragma unroll
-    for (int i = 0; i < 7; ++i) {
+    for (int i = 0; i < N7; ++i) {
         const int qc = (16 * TI[i] + c) >= NTOK ? 1 : 0;
         const int jc = (16 * TJ[i] + 4 * g) >= NTOK ? 1 : 0;
         tvalid[i] = TOK ? true : jc == qc;
@@ -807,7 +813,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void uit_encoder_kernel(EncoderArgs 
         v8 OX[4][3];                                                   // attention output, k-order of proj: k-step 2h + dt/2
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
-            if (h == 1) layernorm_to_operand<OPC>(R, 1e-6f, X);
+            if (h == 1) layernorm_to_operand<OPC, NCT>(R, 1e-6f, X);
             v4 Qp[4][3], Kp[4][3];
 #pragma unroll
             for (int which = 0; which < 2; ++which) {
@@ -823,19 +829,19 @@ __global__ __launch_bounds__(WAVES * 64, 2) void uit_encoder_kernel(EncoderArgs 
                         f4 acc[3];
                         const f4 bq = *(const f4*)(bias + BIASF_QKV + 128 * which + 64 * h + 16 * dt + 4 * g);
 #pragma unroll
-                        for (int ct = 0; ct < 3; ++ct) acc[ct] = bq;
+                        for (int ct = 0; ct < NCT; ++ct) acc[ct] = bq;
 #pragma unroll
                         for (int part = 0; part < KF / 4; ++part) {            // hi k-steps, then (f16x2) the lo k-steps
                             v8 A[4];
 #pragma unroll
                             for (int sk = 0; sk < 4; ++sk) A[sk] = lds_frag<OPC>(slot, dl * KF + 4 * part + sk, lane);
 #pragma unroll
-                            for (int ct = 0; ct < 3; ++ct)
+                            for (int ct = 0; ct < NCT; ++ct)
 #pragma unroll
                                 for (int sk = 0; sk < 4; ++sk) acc[ct] = OP::mfma32(A[sk], X[sk][ct], acc[ct]);
                         }
 #pragma unroll
-                        for (int ct = 0; ct < 3; ++ct) { if (which == 0) Qp[dt][ct] = OP::pack4(acc[ct]); else Kp[dt][ct] = OP::pack4(acc[ct]); }
+                        for (int ct = 0; ct < NCT; ++ct) { if (which == 0) Qp[dt][ct] = OP::pack4(acc[ct]); else Kp[dt][ct] = OP::pack4(acc[ct]); }
                     }
                 }
             }
@@ -843,7 +849,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void uit_encoder_kernel(EncoderArgs 
             f4 S[7];
             float tm[7], mx[3];
 #pragma unroll
-            for (int i = 0; i < 7; ++i) {
+            for (int i = 0; i < N7; ++i) {
                 f4 acc = splat(0.f);
 #pragma unroll
                 for (int dt = 0; dt < 4; ++dt) acc = OP::mfma16(Kp[dt][TJ[i]], Qp[dt][TI[i]], acc);
@@ -858,6 +864,8 @@ __global__ __launch_bounds__(WAVES * 64, 2) void uit_encoder_kernel(EncoderArgs 
                     tm[i] = tvalid[i] ? hm : -INFINITY;
                 }
             }
+#pragma unroll
+            for (int i = N7; i < 7; ++i) tm[i] = -INFINITY;
             mx[0] = xmax(vmax(tm[0], tm[1]));
             mx[1] = xmax(vmax3(tm[2], tm[3], tm[4]));
             mx[2] = xmax(vmax(tm[5], tm[6]));
@@ -874,30 +882,30 @@ __global__ __launch_bounds__(WAVES * 64, 2) void uit_encoder_kernel(EncoderArgs 
                     f4 acc[3];
                     const f4 bv = splat(bias[BIASF_QKV + 256 + 64 * h + 16 * dt + c]);
 #pragma unroll
-                    for (int ct = 0; ct < 3; ++ct) acc[ct] = bv;
+                    for (int ct = 0; ct < NCT; ++ct) acc[ct] = bv;
 #pragma unroll
                     for (int part = 0; part < KF / 4; ++part) {
                         v8 Bw[4];
 #pragma unroll
                         for (int sk = 0; sk < 4; ++sk) Bw[sk] = lds_frag<OPC>(slot, dl * KF + 4 * part + sk, lane);
 #pragma unroll
-                        for (int ct = 0; ct < 3; ++ct)
+                        for (int ct = 0; ct < NCT; ++ct)
 #pragma unroll
                             for (int sk = 0; sk < 4; ++sk) acc[ct] = OP::mfma32(X[sk][ct], Bw[sk], acc[ct]);
                     }
 #pragma unroll
-                    for (int ct = 0; ct < 3; ++ct) Vp[ct][dt] = OP::pack4(acc[ct]);
+                    for (int ct = 0; ct < NCT; ++ct) Vp[ct][dt] = OP::pack4(acc[ct]);
                 }
             }
             f4 O[4][3], Lsum[3];
 #pragma unroll
-            for (int it = 0; it < 3; ++it) {
+            for (int it = 0; it < NCT; ++it) {
                 Lsum[it] = splat(0.f);
 #pragma unroll
                 for (int dt = 0; dt < 4; ++dt) O[dt][it] = splat(0.f);
             }
 #pragma unroll
-            for (int i = 0; i < 7; ++i) {
+            for (int i = 0; i < N7; ++i) {
                 f4 p;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) p[r] = __builtin_amdgcn_exp2f(S[i][r] - mx[TI[i]]);
@@ -908,7 +916,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void uit_encoder_kernel(EncoderArgs 
                 Lsum[TI[i]] = OP::mfma16(OP::ones4(), Pm, Lsum[TI[i]]);
             }
 #pragma unroll
-            for (int it = 0; it < 3; ++it) {
+            for (int it = 0; it < NCT; ++it) {
                 const f4 inv = splat(__builtin_amdgcn_rcpf(Lsum[it][0]));
                 OX[2 * h][it] = OP::pack8(O[0][it] * inv, O[1][it] * inv);
                 OX[2 * h + 1][it] = OP::pack8(O[2][it] * inv, O[3][it] * inv);
@@ -927,19 +935,19 @@ __global__ __launch_bounds__(WAVES * 64, 2) void uit_encoder_kernel(EncoderArgs 
                 const f4 bp = *(const f4*)(bias + BIASF_PROJ + 16 * ft + 4 * g);
                 f4 acc[3];
 #pragma unroll
-                for (int ct = 0; ct < 3; ++ct) acc[ct] = add4s(R[ft][ct], bp);
+                for (int ct = 0; ct < NCT; ++ct) acc[ct] = add4s(R[ft][ct], bp);
 #pragma unroll
                 for (int part = 0; part < KF / 4; ++part) {
                     v8 A[4];
 #pragma unroll
                     for (int sk = 0; sk < 4; ++sk) A[sk] = lds_frag<OPC>(slot, fl * KF + 4 * part + sk, lane);
 #pragma unroll
-                    for (int ct = 0; ct < 3; ++ct)
+                    for (int ct = 0; ct < NCT; ++ct)
 #pragma unroll
                         for (int sk = 0; sk < 4; ++sk) acc[ct] = OP::mfma32(A[sk], OX[sk][ct], acc[ct]);
                 }
 #pragma unroll
-                for (int ct = 0; ct < 3; ++ct) R[ft][ct] = acc[ct];
+                for (int ct = 0; ct < NCT; ++ct) R[ft][ct] = acc[ct];
             }
         }
       };
@@ -961,7 +969,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void uit_encoder_kernel(EncoderArgs 
                 const v8i A = lds_frag8(slot + t * FRAG8_BYTES, lane);
                 const f4 bq = *(const f4*)(bias + BIAS_QKV + 16 * t + 4 * g);
 #pragma unroll
-                for (int ct = 0; ct < 3; ++ct) {
+                for (int ct = 0; ct < NCT; ++ct) {
                     const f4 acc = mfma8_wa_sel(t, A, X8[ct], bq, sq0);
                     if (t < 2) Qh[t][ct] = OP::pack4(acc); else Kh[t - 2][ct] = OP::pack4(acc);
                 }
@@ -971,7 +979,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void uit_encoder_kernel(EncoderArgs 
                 const v8i Bw = lds_frag8(slot + (4 + h) * FRAG8_BYTES, lane);
                 const f4 bv = splat(bias[BIAS_QKV + 64 + 16 * h + c]);
 #pragma unroll
-                for (int ct = 0; ct < 3; ++ct)
+                for (int ct = 0; ct < NCT; ++ct)
                     Vh[ct][h] = OP::pack4(h == 0 ? mfma8_wb<0>(X8[ct], Bw, bv, sq1) : mfma8_wb<1>(X8[ct], Bw, bv, sq1));
             }
         }
@@ -985,7 +993,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void uit_encoder_kernel(EncoderArgs 
                 s1[d] = *(const int*)(slot + FP8_MLP_SCALES + d * 256 + lane * 4);
                 s2[d] = *(const int*)(slot + FP8_MLP_SCALES + (6 + d) * 256 + lane * 4);
             }
-            attention_proj<OP, PERKEY>(R, Qh, Kh, Vh, tvalid, pmask, slot, bias, lane, g);
+            attention_proj<OP, PERKEY, false, NCT>(R, Qh, Kh, Vh, tvalid, pmask, slot, bias, lane, g);
         }
         // ----- MLP: three k-groups of 128 hidden features: fc1 tiles 8q..8q+7 -> relu -> e4m3 -> fc2 k-group q
         layernorm_to_fp8(R, 1e-6f, X8);
@@ -1000,7 +1008,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void uit_encoder_kernel(EncoderArgs 
                     const v8i A = lds_frag8(slot + i * FRAG8_BYTES, lane);
                     const f4 b1 = *(const f4*)(bias + BIAS_FC1 + 16 * (8 * q + i) + 4 * g);
 #pragma unroll
-                    for (int ct = 0; ct < 3; ++ct) HX8[ct][i] = relu_cvt4_fp8(mfma8_wa_sel(i, A, X8[ct], b1, s1[2 * q + (i >> 2)]));
+                    for (int ct = 0; ct < NCT; ++ct) HX8[ct][i] = relu_cvt4_fp8(mfma8_wa_sel(i, A, X8[ct], b1, s1[2 * q + (i >> 2)]));
                 }
             }
             ring_step<WAVES>(a.wstream, ring, tb + 3 + 2 * q, wave, lane);
@@ -1010,7 +1018,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void uit_encoder_kernel(EncoderArgs 
                 for (int ft = 0; ft < 8; ++ft) {
                     const v8i A = lds_frag8(slot + ft * FRAG8_BYTES, lane);
 #pragma unroll
-                    for (int ct = 0; ct < 3; ++ct) R[ft][ct] = mfma8_wa_sel(ft, A, HX8[ct], R[ft][ct], s2[2 * q + (ft >> 2)]);
+                    for (int ct = 0; ct < NCT; ++ct) R[ft][ct] = mfma8_wa_sel(ft, A, HX8[ct], R[ft][ct], s2[2 * q + (ft >> 2)]);
                 }
             }
         }
@@ -1018,7 +1026,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void uit_encoder_kernel(EncoderArgs 
         for (int ft = 0; ft < 8; ++ft) {
             const f4 b2 = *(const f4*)(bias + BIAS_FC2 + 16 * ft + 4 * g);
 #pragma unroll
-            for (int ct = 0; ct < 3; ++ct) R[ft][ct] = add4s(R[ft][ct], b2);
+            for (int ct = 0; ct < NCT; ++ct) R[ft][ct] = add4s(R[ft][ct], b2);
         }
         if (a.dbg != nullptr) {
             dbg_store(blk + 1);
@@ -1034,7 +1042,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void uit_encoder_kernel(EncoderArgs 
         const int tb = PE_STAGES + blk * BLK_ST;
         const float* bias = (const float*)(breg + (blk & 1) * BIAS_FLOATS * 4);
         v8 X[4][3];
-        layernorm_to_operand<OPC>(R, 1e-6f, X);
+        layernorm_to_operand<OPC, NCT>(R, 1e-6f, X);
         if constexpr (ATT) {
         full_attention(std::true_type{}, tb, bias, X);
         } else {
@@ -1051,7 +1059,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void uit_encoder_kernel(EncoderArgs 
                 for (int f = 0; f < 8; ++f) A[f] = lds_frag<OPC>(slot, 8 * i + f, lane);
                 const f4 bq = *(const f4*)(bias + BIAS_QKV + 16 * (2 * half + i) + 4 * g);
 #pragma unroll
-                for (int ct = 0; ct < 3; ++ct) {
+                for (int ct = 0; ct < NCT; ++ct) {
                     f4 acc = bq;
 #pragma unroll
                     for (int s = 0; s < 8; ++s) acc = OP::mfma32(A[s], X[s & 3][ct], acc);
@@ -1069,7 +1077,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void uit_encoder_kernel(EncoderArgs 
                 for (int f = 0; f < 8; ++f) Bw[f] = lds_frag<OPC>(slot, 8 * h + f, lane);
                 const f4 bv = splat(bias[BIAS_QKV + 64 + 16 * h + c]);
 #pragma unroll
-                for (int ct = 0; ct < 3; ++ct) {
+                for (int ct = 0; ct < NCT; ++ct) {
                     f4 acc = bv;
 #pragma unroll
                     for (int s = 0; s < 8; ++s) acc = OP::mfma32(X[s & 3][ct], Bw[s], acc);
@@ -1078,9 +1086,9 @@ __global__ __launch_bounds__(WAVES * 64, 2) void uit_encoder_kernel(EncoderArgs 
             }
         }
         ring_step<WAVES>(a.wstream, ring, tb + 3, wave, lane);             // stage 3: attention + proj (hi, lo)
-        attention_proj<OP, PERKEY, true>(R, Qh, Kh, Vh, tvalid, pmask, ring + ((tb + 3) & (RING_SLOTS - 1)) * STAGE_BYTES, bias, lane, g);
+        attention_proj<OP, PERKEY, true, NCT>(R, Qh, Kh, Vh, tvalid, pmask, ring + ((tb + 3) & (RING_SLOTS - 1)) * STAGE_BYTES, bias, lane, g);
         }
-        layernorm_to_operand<OPC>(R, 1e-6f, X);
+        layernorm_to_operand<OPC, NCT>(R, 1e-6f, X);
 #pragma unroll 1
         for (int ch = 0; ch < 12; ++ch) {
             v8 HX[3];
@@ -1095,14 +1103,14 @@ __global__ __launch_bounds__(WAVES * 64, 2) void uit_encoder_kernel(EncoderArgs 
                     for (int f = 0; f < 8; ++f) A[f] = lds_frag<OPC>(slot, 8 * i + f, lane);
                     const f4 b1 = *(const f4*)(bias + B_FC1 + 32 * ch + 16 * i + 4 * g);
 #pragma unroll
-                    for (int ct = 0; ct < 3; ++ct) {
+                    for (int ct = 0; ct < NCT; ++ct) {
                         H[i][ct] = b1;
 #pragma unroll
                         for (int s = 0; s < 8; ++s) H[i][ct] = OP::mfma32(A[s], X[s & 3][ct], H[i][ct]);
                     }
                 }
 #pragma unroll
-                for (int ct = 0; ct < 3; ++ct) {
+                for (int ct = 0; ct < NCT; ++ct) {
                     if constexpr (ACT == 1) HX[ct] = OP::pack8(gelu4(H[0][ct]), gelu4(H[1][ct]));
                     else HX[ct] = OP::relu_pack8(H[0][ct], H[1][ct]);
                 }
@@ -1118,7 +1126,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void uit_encoder_kernel(EncoderArgs 
 #pragma unroll
                     for (int ft = 0; ft < 8; ++ft)
 #pragma unroll
-                        for (int ct = 0; ct < 3; ++ct) R[ft][ct] = OP::mfma32(A2[ft], HX[ct], R[ft][ct]);
+                        for (int ct = 0; ct < NCT; ++ct) R[ft][ct] = OP::mfma32(A2[ft], HX[ct], R[ft][ct]);
                 }
             }
         }
@@ -1126,7 +1134,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void uit_encoder_kernel(EncoderArgs 
         for (int ft = 0; ft < 8; ++ft) {
             const f4 b2 = *(const f4*)(bias + B_FC2 + 16 * ft + 4 * g);
 #pragma unroll
-            for (int ct = 0; ct < 3; ++ct) R[ft][ct] = add4s(R[ft][ct], b2);
+            for (int ct = 0; ct < NCT; ++ct) R[ft][ct] = add4s(R[ft][ct], b2);
         }
         if (a.dbg != nullptr) {
             dbg_store(blk + 1);
@@ -1145,7 +1153,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void uit_encoder_kernel(EncoderArgs 
         const float* bias = (const float*)(breg + (blk & 1) * BIAS_FLOATS * 4);
         const int* sct = (const int*)(bias + L6_SCALES) + c;              // row-scale dwords [quad][row = c]
         v8 X[4][3];
-        layernorm_to_operand<OPC>(R, 1e-6f, X);
+        layernorm_to_operand<OPC, NCT>(R, 1e-6f, X);
         // ===== stage QK (issue MLP stage 0; younger stages VP + M).  qkv keeps single fp16 weights: its rounding is the smallest of the
         // four weight terms and the stage has no register room for a second operand set
         l6_step<2, l6_dma_count<1>() + l6_dma_count<2>()>(wblk + l6_mlp_offset(0), slot_of(2), wave, lane);
@@ -1164,7 +1172,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void uit_encoder_kernel(EncoderArgs 
                 }
                 const f4 bq = *(const f4*)(bias + BIAS_QKV + 16 * ft + 4 * g);
 #pragma unroll
-                for (int ct = 0; ct < 3; ++ct) {
+                for (int ct = 0; ct < NCT; ++ct) {
                     f4 acc = bq;
 #pragma unroll
                     for (int s = 0; s < 4; ++s) acc = OP::mfma32(A[ft * 4 + s], X[s][ct], acc);
@@ -1185,7 +1193,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void uit_encoder_kernel(EncoderArgs 
                 for (int h = 0; h < 2; ++h) {
                     const f4 bv = splat(bias[BIAS_QKV + 64 + 16 * h + c]);
 #pragma unroll
-                    for (int ct = 0; ct < 3; ++ct) {
+                    for (int ct = 0; ct < NCT; ++ct) {
                         f4 acc = bv;
 #pragma unroll
                         for (int s = 0; s < 4; ++s) acc = OP::mfma32(X[s][ct], Bw[h * 4 + s], acc);
@@ -1194,7 +1202,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void uit_encoder_kernel(EncoderArgs 
                 }
             }
             if constexpr (PERKEY) {
-                attention_proj<OP, PERKEY, !(L6_ABL & 4)>(R, Qh, Kh, Vh, tvalid, pmask, slot + 8 * FRAG_BYTES, bias, lane, g);
+                attention_proj<OP, PERKEY, !(L6_ABL & 4), NCT>(R, Qh, Kh, Vh, tvalid, pmask, slot + 8 * FRAG_BYTES, bias, lane, g);
             } else {
                 // full clips: a lane's four keys of a tile are all valid or all foreign, so the probability masks follow from tvalid --
                 // rebuilt per block (14 selects) instead of living in 14 registers through the MLP loop, which has none to spare
@@ -1202,22 +1210,23 @@ __global__ __launch_bounds__(WAVES * 64, 2) void uit_encoder_kernel(EncoderArgs 
                 unsigned ones = ~0u;
                 asm volatile("" : "+v"(ones));                        // (keeps the selects inside the block loop: hoisted, they are 14 live registers again)
 #pragma unroll
-                for (int i = 0; i < 7; ++i) pm[i] = tvalid[i] ? u2{ones, ones} : u2{0u, 0u};
-                attention_proj<OP, PERKEY, !(L6_ABL & 4)>(R, Qh, Kh, Vh, tvalid, pm, slot + 8 * FRAG_BYTES, bias, lane, g);
+                for (int i = 0; i < N7; ++i) pm[i] = tvalid[i] ? u2{ones, ones} : u2{0u, 0u};
+                attention_proj<OP, PERKEY, !(L6_ABL & 4), NCT>(R, Qh, Kh, Vh, tvalid, pm, slot + 8 * FRAG_BYTES, bias, lane, g);
             }
         }
         // ===== MLP: 12 stages in three k-groups of four.  fc1: four fp16 k-steps + ONE fp6 MFMA per accumulator; fc2: the fp16 k-step of
         // the chunk, and at the last stage of a group (MB) the group's low-order term on the fp4 copy of its 128 hidden activations.
         // fc2 runs in its own chunk's stage (not under the next chunk's fragment reads as in precision f16): carrying its fragments
         // across the barrier costs 44 registers this mode does not have -- any spill inside the loop would drain the counted vmcnt.
-        layernorm_to_operand<OPC>(R, 1e-6f, X);
+        layernorm_to_operand<OPC, NCT>(R, 1e-6f, X);
         u4 HX4[3];
         // the fp6 copy of the LayerNorm operand is converted ONCE per block and held (18 registers): converting it per chunk instead
         // (3 v_cvt_scalef32_pk32_fp6_f16 of ~16 issue cycles each) was measured at +5 % encoder time
         u6 X6[3];
 #pragma unroll
-        for (int ct = 0; ct < 3; ++ct) X6[ct] = operand_to_fp6(X[0][ct], X[1][ct], X[2][ct], X[3][ct]);
-        asm volatile("" : "+v"(X6[0]), "+v"(X6[1]), "+v"(X6[2]));        // converted HERE, once per block (not re-materialised per chunk)
+        for (int ct = 0; ct < NCT; ++ct) X6[ct] = operand_to_fp6(X[0][ct], X[1][ct], X[2][ct], X[3][ct]);
+        if constexpr (NCT == 3) asm volatile("" : "+v"(X6[0]), "+v"(X6[1]), "+v"(X6[2]));        // converted HERE, once per block (not re-materialised per chunk)
+        else asm volatile("" : "+v"(X6[0]), "+v"(X6[1]));
 #pragma unroll 1
         for (int q = 0; q < 3; ++q) {
 #pragma unroll
@@ -1254,7 +1263,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void uit_encoder_kernel(EncoderArgs 
 #pragma unroll
                         for (int tt = 0; tt < NT; ++tt)
 #pragma unroll
-                            for (int ct = 0; ct < 3; ++ct) {
+                            for (int ct = 0; ct < NCT; ++ct) {
                                 H[tt][ct] = t0 + tt == 0 ? b10 : b11;
 #if !(L6_ABL & 1)
                                 H[tt][ct] = mfma6_wa_sel(2 * j + t0 + tt, t0 + tt == 0 ? W6a : W6b, X6[ct], H[tt][ct], s1);
@@ -1265,17 +1274,17 @@ __global__ __launch_bounds__(WAVES * 64, 2) void uit_encoder_kernel(EncoderArgs 
 #pragma unroll
                             for (int tt = 0; tt < NT; ++tt)
 #pragma unroll
-                                for (int ct = 0; ct < 3; ++ct) H[tt][ct] = OP::mfma32(A[(t0 + tt) * 4 + s], X[s][ct], H[tt][ct]);
+                                for (int ct = 0; ct < NCT; ++ct) H[tt][ct] = OP::mfma32(A[(t0 + tt) * 4 + s], X[s][ct], H[tt][ct]);
 #pragma unroll
                         for (int tt = 0; tt < NT; ++tt)
 #pragma unroll
-                            for (int ct = 0; ct < 3; ++ct) {
+                            for (int ct = 0; ct < NCT; ++ct) {
                                 P[t0 + tt][ct] = __builtin_elementwise_max(OP::pack4(H[tt][ct]), v4{0, 0, 0, 0});
                                 if (NT == 1 && t0 == 0) asm volatile("" : "+v"(P[0][ct]));
                             }
                     }
 #pragma unroll
-                    for (int ct = 0; ct < 3; ++ct) {
+                    for (int ct = 0; ct < NCT; ++ct) {
                         HX[ct] = __builtin_shufflevector(P[0][ct], P[1][ct], 0, 1, 2, 3, 4, 5, 6, 7);
                         unsigned w4 = (L6_ABL & 2) ? 0u : operand_to_fp4(HX[ct]);
                         asm volatile("" : "+v"(w4));                  // convert HERE: the scheduler must not keep four chunks of f16 operands alive instead
@@ -1289,7 +1298,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void uit_encoder_kernel(EncoderArgs 
 #pragma unroll
                     for (int ft = 0; ft < 8; ++ft)
 #pragma unroll
-                        for (int ct = 0; ct < 3; ++ct) R[ft][ct] = OP::mfma32(A2[ft], HX[ct], R[ft][ct]);
+                        for (int ct = 0; ct < NCT; ++ct) R[ft][ct] = OP::mfma32(A2[ft], HX[ct], R[ft][ct]);
                 }
                 if (j == 3 && !(L6_ABL & 2)) {                        // fc2 low-order term of k-group q
                     const int s2a = sct[(6 + 2 * q) * 16], s2b = sct[(7 + 2 * q) * 16];
@@ -1297,7 +1306,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void uit_encoder_kernel(EncoderArgs 
                     for (int ft = 0; ft < 8; ++ft) {
                         const u6 W6 = lds_frag6(slot + L6_M_BYTES + ft * FRAG6_BYTES, lane);
 #pragma unroll
-                        for (int ct = 0; ct < 3; ++ct) R[ft][ct] = mfma64_wa_sel(ft, W6, HX4[ct], R[ft][ct], ft < 4 ? s2a : s2b);
+                        for (int ct = 0; ct < NCT; ++ct) R[ft][ct] = mfma64_wa_sel(ft, W6, HX4[ct], R[ft][ct], ft < 4 ? s2a : s2b);
                     }
                 }
             }
@@ -1306,7 +1315,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void uit_encoder_kernel(EncoderArgs 
         for (int ft = 0; ft < 8; ++ft) {
             const f4 b2 = *(const f4*)(bias + BIAS_FC2 + 16 * ft + 4 * g);
 #pragma unroll
-            for (int ct = 0; ct < 3; ++ct) R[ft][ct] = add4s(R[ft][ct], b2);
+            for (int ct = 0; ct < NCT; ++ct) R[ft][ct] = add4s(R[ft][ct], b2);
         }
         if (a.dbg != nullptr) {
             dbg_store(blk + 1);
@@ -1318,7 +1327,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void uit_encoder_kernel(EncoderArgs 
         const int tb = PE_STAGES + blk * BLK_ST;
         const float* bias = (const float*)(breg + (blk & 1) * BIAS_FLOATS * 4);
         v8 X[4][3];
-        layernorm_to_operand<OPC>(R, 1e-6f, X);
+        layernorm_to_operand<OPC, NCT>(R, 1e-6f, X);
         TSTAMP(0);                                                     // LN1
 
         if constexpr (ATT) {
@@ -1342,7 +1351,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void uit_encoder_kernel(EncoderArgs 
                 }
                 const f4 bq = *(const f4*)(bias + BIAS_QKV + 16 * ft + 4 * g);
 #pragma unroll
-                for (int ct = 0; ct < 3; ++ct) {
+                for (int ct = 0; ct < NCT; ++ct) {
                     f4 acc = bq;
 #pragma unroll
                     for (int s = 0; s < 4; ++s) acc = OP::mfma32(A[ft * 4 + s], X[s][ct], acc);
@@ -1366,7 +1375,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void uit_encoder_kernel(EncoderArgs 
                 for (int h = 0; h < 2; ++h) {
                     const f4 bv = splat(bias[BIAS_QKV + 64 + 16 * h + c]);
 #pragma unroll
-                    for (int ct = 0; ct < 3; ++ct) {
+                    for (int ct = 0; ct < NCT; ++ct) {
                         f4 acc = bv;
 #pragma unroll
                         for (int s = 0; s < 4; ++s) acc = OP::mfma32(X[s][ct], Bw[h * 4 + s], acc);
@@ -1374,14 +1383,14 @@ __global__ __launch_bounds__(WAVES * 64, 2) void uit_encoder_kernel(EncoderArgs 
                     }
                 }
             }
-            attention_proj<OP, PERKEY>(R, Qh, Kh, Vh, tvalid, pmask, slot + 8 * FRAG_BYTES, bias, lane, g);
+            attention_proj<OP, PERKEY, false, NCT>(R, Qh, Kh, Vh, tvalid, pmask, slot + 8 * FRAG_BYTES, bias, lane, g);
         }
 
         }
 
         TSTAMP(4);                                                     // V + attention + proj
         // ===== MLP: 12 stages; stage ch = fc1 rows 32ch..32ch+31 (frags j*4+s) and fc2 k-step ch (frags 8+ft)
-        layernorm_to_operand<OPC>(R, 1e-6f, X);
+        layernorm_to_operand<OPC, NCT>(R, 1e-6f, X);
         TSTAMP(5);                                                     // LN2
         // Software-pipelined over the 12 stages: at stage ch the fc1 fragment reads are issued first, then the fc2
         // MFMAs of chunk ch-1 run from registers (A2/HX carried across the barrier) and cover the LDS latency; the
@@ -1396,7 +1405,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void uit_encoder_kernel(EncoderArgs 
             // consumes the tiles in the same order.  (Measured no better: one VALU instruction pinned behind each MFMA with
             // sched_group_barrier; the last tile's conversion deferred behind the next ring step.)
 #pragma unroll
-            for (int ct = 0; ct < 3; ++ct) {
+            for (int ct = 0; ct < NCT; ++ct) {
                 f4 H0 = b10, H1 = b11;
 #pragma unroll
                 for (int s = 0; s < 4; ++s) { H0 = OP::mfma32(A[s], X[s][ct], H0); H1 = OP::mfma32(A[4 + s], X[s][ct], H1); }
@@ -1424,21 +1433,21 @@ __global__ __launch_bounds__(WAVES * 64, 2) void uit_encoder_kernel(EncoderArgs 
 #pragma unroll
             for (int f = 0; f < 8; ++f) A[f] = lds_frag<OPC>(slot, f, lane);   // fc1 fragments: in flight ...
 #pragma unroll
-            for (int ct = 0; ct < 3; ++ct)                                              // ... under chunk ch-1's fc2, token tile by token tile
+            for (int ct = 0; ct < NCT; ++ct)                                              // ... under chunk ch-1's fc2, token tile by token tile
 #pragma unroll
                 for (int ft = 0; ft < 8; ++ft) R[ft][ct] = OP::mfma32(A2[ft], HX[ct], R[ft][ct]);
             fc1_chunk(slot, ch, A);
             TSTAMP(7);                                                 // MLP chunk compute (sum of 12)
         }
 #pragma unroll
-        for (int ct = 0; ct < 3; ++ct)
+        for (int ct = 0; ct < NCT; ++ct)
 #pragma unroll
             for (int ft = 0; ft < 8; ++ft) R[ft][ct] = OP::mfma32(A2[ft], HX[ct], R[ft][ct]);
 #pragma unroll
         for (int ft = 0; ft < 8; ++ft) {
             const f4 b2 = *(const f4*)(bias + B_FC2 + 16 * ft + 4 * g);
 #pragma unroll
-            for (int ct = 0; ct < 3; ++ct) R[ft][ct] = add4s(R[ft][ct], b2);
+            for (int ct = 0; ct < NCT; ++ct) R[ft][ct] = add4s(R[ft][ct], b2);
         }
         if (a.dbg != nullptr) {
             dbg_store(blk + 1);
@@ -1455,7 +1464,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void uit_encoder_kernel(EncoderArgs 
         constexpr int HEAD_PRE = 5;                       // class tiles per wave (5 x 8 waves covers C <= 640; pack.cpp enforces it)
         float rstd[3], mean3[3];
 #pragma unroll
-        for (int ct = 0; ct < 3; ++ct) ln_stats(R, ct, 1e-6f, mean3[ct], rstd[ct]);
+        for (int ct = 0; ct < NCT; ++ct) ln_stats(R, ct, 1e-6f, mean3[ct], rstd[ct]);
         f4 pacc[HEAD_PRE];
 #pragma unroll
         for (int i = 0; i < HEAD_PRE; ++i) pacc[i] = splat(0.f);
@@ -1645,7 +1654,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void uit_encoder_kernel(EncoderArgs 
     {
         float mean[3], rstd[3];
 #pragma unroll
-        for (int ct = 0; ct < 3; ++ct) {
+        for (int ct = 0; ct < NCT; ++ct) {
             ln_stats(R, ct, 1e-6f, mean[ct], rstd[ct]);
             if (pt_[ct] >= a.nt) rstd[ct] = 0.f;          // masked token contributes 0 to the pool
         }
