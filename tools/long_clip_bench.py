@@ -10,7 +10,7 @@ from bench import synth_batch
 sd = make_state_dict("uit_xs", 13)
 m = models.uit_xs(outputdim=537, target_length=102); m.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()}); m = m.cuda().eval()
 ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
-for B, T in ((8192, 16000), (820, 160000), (2048, 64000)):
+for B, T in ((8192, 16000), (819, 160000), (820, 160000), (2048, 64000)):      # 819 x 10 crops = 8190 rows: two full encoder rounds; 820: + an 8-row tail launch
     x = synth_batch(B, T, 0, "cuda", False)
     for _ in range(5): m(x)
     fe, en = [], []
