@@ -6,7 +6,7 @@ from uit_mobile_amd import models
 x = synth_batch(4096, 16000, 0, torch.device("cuda", 0), False)
 for name, att in (("uit_xs", "bneck"), ("audio_transformer_h128_d4_m3", "full")):
     sd = make_trained_like_state_dict(name, 200, attention=att)
-    for pooling in ("mean", "token"):
+    for pooling in ("mean", "token", "dm"):
         for prec in ("f16c", "f16l6" if att == "bneck" else "f16x2"):
             m = getattr(models, name)(outputdim=537, target_length=102, pooling=pooling, precision=prec)
             m.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()}); m = m.cuda().eval()

@@ -1458,20 +1458,23 @@ __global__ __launch_bounds__(WAVES * 64, 2) void uit_encoder_kernel(EncoderArgs 
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // drain the dummy tail stages before the LDS can be re-used
     if constexpr (POOL == 1) {
         // ===== pooling 'dm' (models/uit.py:405-412): for every time patch t the mean over the four frequency patches goes through
-        // outputlayer (LayerNorm 1e-5 + Linear) and the sigmoid; the output is the mean over the nt time patches.  The mean-pool
-        // machinery below runs once per time patch with the token mask (pt == t); probabilities accumulate in registers.
+        // outputlayer (LayerNorm 1e-5 + Linear) and the sigmoid; the output is the mean over the nt time patches.
+        // Two phases (round 4; was: pool -> barrier -> head -> barrier per time patch, the classifier re-fetched from L2 six times):
+        //   1. while the residual stream is alive: the pooled, normalised z of ALL time patches -> LDS (the weight ring is idle now:
+        //      8 KiB per time patch = 16 clip slots x 128 x (hi, lo) 16-bit);
+        //   2. the stream is dead: this wave's classifier fragments go to registers ONCE, then one pass over the time patches.
         const int ntiles = (a.C + 15) / 16;
         constexpr int HEAD_PRE = 5;                       // class tiles per wave (5 x 8 waves covers C <= 640; pack.cpp enforces it)
+        constexpr int ZB = 2 * 16 * DIM * 2;              // bytes of one time patch's z operands
         float rstd[3], mean3[3];
 #pragma unroll
         for (int ct = 0; ct < NCT; ++ct) ln_stats(R, ct, 1e-6f, mean3[ct], rstd[ct]);
-        f4 pacc[HEAD_PRE];
-#pragma unroll
-        for (int i = 0; i < HEAD_PRE; ++i) pacc[i] = splat(0.f);
         const bool lo = c < 8;
         const int row0 = blockIdx.x * WAVES * 2 + 4 * g;
+        __syncthreads();                                  // every wave has read its last fragments and drained its dummy-stage DMAs: the ring is free
 #pragma unroll 1
         for (int tsel = 0; tsel < a.nt; ++tsel) {
+            char* zb = ring + tsel * ZB;
             f4 pooled[8];
             const float r0 = pt_[0] == tsel ? rstd[0] : 0.f, r1 = pt_[1] == tsel ? rstd[1] : 0.f, r2 = pt_[2] == tsel ? rstd[2] : 0.f;
 #pragma unroll
@@ -1492,65 +1495,76 @@ __global__ __launch_bounds__(WAVES * 64, 2) void uit_encoder_kernel(EncoderArgs 
                 }
                 pooled[ft] = v;
             }
-            {
-                f4 acc = splat(0.f);
+            f4 acc = splat(0.f);
 #pragma unroll
-                for (int ft = 0; ft < 8; ++ft) {
-                    const f4 gw = *(const f4*)(a.fin + 0 * DIM + 16 * ft + 4 * g);
-                    const f4 gb = *(const f4*)(a.fin + 1 * DIM + 16 * ft + 4 * g);
-                    pooled[ft] = pooled[ft] * splat(1.0f / (float)GF) * gw + gb;
-                    acc = acc + pooled[ft];
-                }
-                const float mean = xsum(hsum(acc)) * (1.0f / DIM);
-                f4 q = splat(0.f);
+            for (int ft = 0; ft < 8; ++ft) {
+                const f4 gw = *(const f4*)(a.fin + 0 * DIM + 16 * ft + 4 * g);
+                const f4 gb = *(const f4*)(a.fin + 1 * DIM + 16 * ft + 4 * g);
+                pooled[ft] = pooled[ft] * splat(1.0f / (float)GF) * gw + gb;
+                acc = acc + pooled[ft];
+            }
+            const float mean = xsum(hsum(acc)) * (1.0f / DIM);
+            f4 q = splat(0.f);
 #pragma unroll
-                for (int ft = 0; ft < 8; ++ft) { const f4 d = pooled[ft] - splat(mean); q = q + d * d; }
-                const float rs = __builtin_amdgcn_rsqf(xsum(hsum(q)) * (1.0f / DIM) + 1e-5f);
-                const int slot_clip = 2 * wave + (c >= 8 ? 1 : 0);
+            for (int ft = 0; ft < 8; ++ft) { const f4 d = pooled[ft] - splat(mean); q = q + d * d; }
+            const float rs = __builtin_amdgcn_rsqf(xsum(hsum(q)) * (1.0f / DIM) + 1e-5f);
+            const int slot_clip = 2 * wave + (c >= 8 ? 1 : 0);
 #pragma unroll
-                for (int ft = 0; ft < 8; ++ft) {
-                    const f4 gw = *(const f4*)(a.fin + 2 * DIM + 16 * ft + 4 * g);
-                    const f4 gb = *(const f4*)(a.fin + 3 * DIM + 16 * ft + 4 * g);
-                    const f4 z = (pooled[ft] - splat(mean)) * splat(rs) * gw + gb;
-                    if ((c & 7) == 0) {
-                        const v4 zh = OP::pack4(z);
-                        *(v4*)(zbuf + (slot_clip * DIM + 16 * ft + 4 * g) * 2) = zh;
-                        *(v4*)(zbuf + 16 * DIM * 2 + (slot_clip * DIM + 16 * ft + 4 * g) * 2) = OP::pack4(z - OP::unpack4(zh));
-                    }
+            for (int ft = 0; ft < 8; ++ft) {
+                const f4 gw = *(const f4*)(a.fin + 2 * DIM + 16 * ft + 4 * g);
+                const f4 gb = *(const f4*)(a.fin + 3 * DIM + 16 * ft + 4 * g);
+                const f4 z = (pooled[ft] - splat(mean)) * splat(rs) * gw + gb;
+                if ((c & 7) == 0) {
+                    const v4 zh = OP::pack4(z);
+                    *(v4*)(zb + (slot_clip * DIM + 16 * ft + 4 * g) * 2) = zh;
+                    *(v4*)(zb + 16 * DIM * 2 + (slot_clip * DIM + 16 * ft + 4 * g) * 2) = OP::pack4(z - OP::unpack4(zh));
                 }
             }
-            __syncthreads();
-            {
-                const int cz = c < 2 * WAVES ? c : 0;
-                v8 Bz[4], Bzl[4];
+        }
+        __syncthreads();
+        v8 Hc[HEAD_PRE][4], Hl[HEAD_PRE][4];
+        f4 pacc[HEAD_PRE], hb[HEAD_PRE];
+#pragma unroll
+        for (int i = 0; i < HEAD_PRE; ++i) {
+            const int ot = wave + i * WAVES;
+            pacc[i] = splat(0.f);
+            if (ot < ntiles) {
+                hb[i] = splat(a.head_b[16 * ot + c]);
 #pragma unroll
                 for (int s = 0; s < 4; ++s) {
-                    const v4 l0 = *(const v4*)(zbuf + (cz * DIM + 32 * s + 4 * g) * 2);
-                    const v4 h0 = *(const v4*)(zbuf + (cz * DIM + 32 * s + 16 + 4 * g) * 2);
-                    Bz[s] = v8{l0[0], l0[1], l0[2], l0[3], h0[0], h0[1], h0[2], h0[3]};
-                    const v4 l1 = *(const v4*)(zbuf + 16 * DIM * 2 + (cz * DIM + 32 * s + 4 * g) * 2);
-                    const v4 h1 = *(const v4*)(zbuf + 16 * DIM * 2 + (cz * DIM + 32 * s + 16 + 4 * g) * 2);
-                    Bzl[s] = v8{l1[0], l1[1], l1[2], l1[3], h1[0], h1[1], h1[2], h1[3]};
-                }
-#pragma unroll
-                for (int i = 0; i < HEAD_PRE; ++i) {
-                    const int ot = wave + i * WAVES;
-                    if (ot < ntiles) {
-                        f4 acc = splat(a.head_b[16 * ot + c]);
-#pragma unroll
-                        for (int s = 0; s < 4; ++s) {
-                            const v8 Hc = *(const v8*)(a.head_w + (size_t)(ot * 4 + s) * 2 * FRAG_BYTES + lane * 16);
-                            const v8 Hlo = *(const v8*)(a.head_w + ((size_t)(ot * 4 + s) * 2 + 1) * FRAG_BYTES + lane * 16);
-                            acc = OP::mfma32(Bz[s], Hlo, acc);
-                            acc = OP::mfma32(Bzl[s], Hc, acc);
-                            acc = OP::mfma32(Bz[s], Hc, acc);
-                        }
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) pacc[i][r] += __builtin_amdgcn_rcpf(1.0f + __expf(-acc[r]));
-                    }
+                    Hc[i][s] = *(const v8*)(a.head_w + (size_t)(ot * 4 + s) * 2 * FRAG_BYTES + lane * 16);
+                    Hl[i][s] = *(const v8*)(a.head_w + ((size_t)(ot * 4 + s) * 2 + 1) * FRAG_BYTES + lane * 16);
                 }
             }
-            __syncthreads();                              // zbuf is rewritten for the next time patch
+        }
+        const int cz = c < 2 * WAVES ? c : 0;
+#pragma unroll 1
+        for (int tsel = 0; tsel < a.nt; ++tsel) {
+            const char* zb = ring + tsel * ZB;
+            v8 Bz[4], Bzl[4];
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                const v4 l0 = *(const v4*)(zb + (cz * DIM + 32 * s + 4 * g) * 2);
+                const v4 h0 = *(const v4*)(zb + (cz * DIM + 32 * s + 16 + 4 * g) * 2);
+                Bz[s] = v8{l0[0], l0[1], l0[2], l0[3], h0[0], h0[1], h0[2], h0[3]};
+                const v4 l1 = *(const v4*)(zb + 16 * DIM * 2 + (cz * DIM + 32 * s + 4 * g) * 2);
+                const v4 h1 = *(const v4*)(zb + 16 * DIM * 2 + (cz * DIM + 32 * s + 16 + 4 * g) * 2);
+                Bzl[s] = v8{l1[0], l1[1], l1[2], l1[3], h1[0], h1[1], h1[2], h1[3]};
+            }
+#pragma unroll
+            for (int i = 0; i < HEAD_PRE; ++i) {
+                if (wave + i * WAVES < ntiles) {
+                    f4 acc = hb[i];
+#pragma unroll
+                    for (int s = 0; s < 4; ++s) {
+                        acc = OP::mfma32(Bz[s], Hl[i][s], acc);
+                        acc = OP::mfma32(Bzl[s], Hc[i][s], acc);
+                        acc = OP::mfma32(Bz[s], Hc[i][s], acc);
+                    }
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) pacc[i][r] += __builtin_amdgcn_rcpf(1.0f + __expf(-acc[r]));
+                }
+            }
         }
         const float inv_nt = 1.0f / (float)a.nt;
 #pragma unroll
