@@ -29,11 +29,16 @@ def _find(kernels, prefix):
 
 @pytest.mark.parametrize("inst,max_spill", [("<0, 8, false, false, 0, 0, 0>", 0),      # f16 / f16c, full clips, mean pooling: THE bench kernel
                                             ("<4, 8, false, false, 0, 0, 0>", 16),     # f16l6 (round 3's parity mode): spills in prologue / epilogue only
-                                            ("<3, 8, false, false, 0, 0, 0>", 8)])     # f16x2
+                                            ("<3, 8, false, false, 0, 0, 0>", 8),      # f16x2
+                                            # the full-width-attention factories (round 4: head 0's attention output waits in LDS, the
+                                            # probabilities are packed before the V stage: 117 spilled registers -> none in the block loop)
+                                            ("<0, 8, false, false, 1, 0, 0>", 0),      # audio_transformer_h128_*_relu, f16 / f16c
+                                            ("<0, 8, false, false, 1, 1, 0>", 8),      # audio_transformer_h128_* (GELU)
+                                            ("<0, 4, false, false, 0, 0, 0>", 64)])    # the small-batch shape (4-wave workgroups): loop scratch-free
 def test_default_encoder_loops_are_scratch_free(kernels, inst, max_spill):
     k = _find(kernels, f"void uitk::uit_encoder_kernel{inst}")
     s = kernel_isa.summary(k)
-    assert s["mfma"] > 600 and s["vgpr"] <= 256
+    assert s["mfma"] > 450 and s["vgpr"] <= 256
     assert s["vgpr_spill"] <= max_spill, s
     # the block loop = the loop that holds most of the kernel's MFMAs (the epilogue's head-tile loop and the prologue may spill)
     mf = lambda lo, hi: sum(1 for a, t in k["insts"] if lo <= a <= hi and t.startswith("v_mfma"))

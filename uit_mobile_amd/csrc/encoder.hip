@@ -952,7 +952,20 @@ __global__ __launch_bounds__(WAVES * 64, 2) void uit_encoder_kernel(EncoderArgs 
                     OX[2 * h + 1][it] = OP::pack8(O[2][it] * inv, O[3][it] * inv);
                 }
             }
+            // head 0's output is not needed before proj: it waits in LDS -- the region of the prologue's low-order patch-embed weights,
+            // idle in the block loop; 6 KiB per wave -- instead of in 24 registers through head 1 (the compiler spilled exactly these to
+            // scratch, and a scratch reload is a vector-memory load: its wait drains the weight ring's DMAs in flight)
+            if (h == 0) {
+#pragma unroll
+                for (int sk = 0; sk < 2; ++sk)
+#pragma unroll
+                    for (int ct = 0; ct < NCT; ++ct) *(v8*)(pelo + ((wave * 6 + sk * 3 + ct) * 64 + lane) * 16) = OX[sk][ct];
+            }
         }
+#pragma unroll
+        for (int sk = 0; sk < 2; ++sk)
+#pragma unroll
+            for (int ct = 0; ct < NCT; ++ct) OX[sk][ct] = *(const v8*)(pelo + ((wave * 6 + sk * 3 + ct) * 64 + lane) * 16);
         // proj 128 -> 128: output tiles ft, four k-steps each (+ the lo k-steps): 2 stages of 4 tiles, or (f16x2) 4 stages of 2 tiles
         constexpr int PST = 2 * NSUB, FTS = 8 / PST;
 #pragma unroll
