@@ -873,14 +873,15 @@ __global__ __launch_bounds__(WAVES * 64, 2) void uit_encoder_kernel(EncoderArgs 
             // live through it), masked by tile validity -- a lane's four keys of a tile are all its clip's or all foreign -- which
             // is a wave mask in scalar registers where the per-element masks are 14 vector registers
             v4 Pq[7];
-            if constexpr (!PERKEY) {
+            {
 #pragma unroll
                 for (int i = 0; i < N7; ++i) {
                     f4 p;
 #pragma unroll
                     for (int r = 0; r < 4; ++r) p[r] = __builtin_amdgcn_exp2f(S[i][r] - mx[TI[i]]);
                     const u2 bits = __builtin_bit_cast(u2, OP::pack4(p));
-                    Pq[i] = __builtin_bit_cast(v4, tvalid[i] ? bits : u2{0u, 0u});
+                    if constexpr (PERKEY) Pq[i] = __builtin_bit_cast(v4, bits & pmask[i]);
+                    else Pq[i] = __builtin_bit_cast(v4, tvalid[i] ? bits : u2{0u, 0u});
                 }
             }
             // v_h token-major (operand roles swapped: tokens are the rows)
@@ -920,33 +921,14 @@ __global__ __launch_bounds__(WAVES * 64, 2) void uit_encoder_kernel(EncoderArgs 
             }
 #pragma unroll
             for (int i = 0; i < N7; ++i) {
-                v4 Pm;
-                if constexpr (PERKEY) {
-                    f4 p;
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) p[r] = __builtin_amdgcn_exp2f(S[i][r] - mx[TI[i]]);
-                    const u2 bits = __builtin_bit_cast(u2, OP::pack4(p)) & pmask[i];
-                    Pm = __builtin_bit_cast(v4, bits);
-                } else {
-                    Pm = Pq[i];
-                }
+                const v4 Pm = Pq[i];
 #pragma unroll
                 for (int dt = 0; dt < 4; ++dt) O[dt][TI[i]] = OP::mfma16(Vp[TJ[i]][dt], Pm, O[dt][TI[i]]);
                 Lsum[TI[i]] = OP::mfma16(OP::ones4(), Pm, Lsum[TI[i]]);
                 // a query tile's output is scaled and packed as soon as its last key tile is in (TI is sorted): its sixteen fp32
                 // accumulators become eight operand registers before the next query tile's accumulate (48 -> 16 live accumulators)
-                // (full clips only: the per-key-mask instantiations -- short clips, pooling 'token' -- allocate better with the
-                // scaling behind the loop: 71 vs 102 spilled registers, 0 vs 6)
-                if (!PERKEY && (i + 1 == N7 || TI[i + 1 < 7 ? i + 1 : 6] != TI[i])) {
+                if (i + 1 == N7 || TI[i + 1 < 7 ? i + 1 : 6] != TI[i]) {
                     const int it = TI[i];
-                    const f4 inv = splat(__builtin_amdgcn_rcpf(Lsum[it][0]));
-                    OX[2 * h][it] = OP::pack8(O[0][it] * inv, O[1][it] * inv);
-                    OX[2 * h + 1][it] = OP::pack8(O[2][it] * inv, O[3][it] * inv);
-                }
-            }
-            if constexpr (PERKEY) {
-#pragma unroll
-                for (int it = 0; it < NCT; ++it) {
                     const f4 inv = splat(__builtin_amdgcn_rcpf(Lsum[it][0]));
                     OX[2 * h][it] = OP::pack8(O[0][it] * inv, O[1][it] * inv);
                     OX[2 * h + 1][it] = OP::pack8(O[2][it] * inv, O[3][it] * inv);
