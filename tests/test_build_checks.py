@@ -33,19 +33,23 @@ def _find(kernels, prefix):
                                             # the full-width-attention factories (round 4: head 0's attention output waits in LDS, the
                                             # probabilities are packed before the V stage: 117 spilled registers -> none in the block loop)
                                             ("<0, 8, false, false, 1, 0, 0>", 0),      # audio_transformer_h128_*_relu, f16 / f16c
-                                            ("<0, 8, false, false, 1, 1, 0>", 8),      # audio_transformer_h128_* (GELU)
+                                            ("<0, 8, false, false, 1, 1, 0>", -16),    # audio_transformer_h128_* (GELU): <= 16 spilled; the packed-f32
+                                            # erf polynomial (-7 % encoder time) leaves two loop-invariant 64-bit values that are RELOADED
+                                            # inside the loop (no stores): negative = allow up to two scratch loads there
                                             ("<0, 4, false, false, 0, 0, 0>", 64)])    # the small-batch shape (4-wave workgroups): loop scratch-free
 def test_default_encoder_loops_are_scratch_free(kernels, inst, max_spill):
     k = _find(kernels, f"void uitk::uit_encoder_kernel{inst}")
     s = kernel_isa.summary(k)
     assert s["mfma"] > 450 and s["vgpr"] <= 256
+    loop_loads_ok = 2 if max_spill < 0 else 0
+    max_spill = abs(max_spill)
     assert s["vgpr_spill"] <= max_spill, s
     # the block loop = the loop that holds most of the kernel's MFMAs (the epilogue's head-tile loop and the prologue may spill)
     mf = lambda lo, hi: sum(1 for a, t in k["insts"] if lo <= a <= hi and t.startswith("v_mfma"))
     lo, hi = max(kernel_isa.loops(k["insts"]), key=lambda sp: (mf(*sp), sp[1] - sp[0]))
     assert mf(lo, hi) >= 200, mf(lo, hi)
     in_loop = [(hex(a), t) for a, t in k["insts"] if t.startswith("scratch_") and lo <= a <= hi]
-    assert not in_loop, in_loop
+    assert len(in_loop) <= loop_loads_ok and not [t for _, t in in_loop if t.startswith("scratch_store")], in_loop
     if max_spill == 0:
         assert s["scratch_insts"] == 0 and s["scratch_bytes"] == 0, s
 

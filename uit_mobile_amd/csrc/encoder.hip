@@ -443,7 +443,27 @@ __device__ __forceinline__ float gelu1(float x) {
     const float y = p * t * __builtin_amdgcn_exp2f(-1.4426950408889634f * z * z);       // 1 - erf(z)
     return 0.5f * x * (x >= 0.f ? 2.0f - y : y);                                       // 1 + erf(x / sqrt 2) = 2 - y | y
 }
-__device__ __forceinline__ f4 gelu4(f4 x) { return f4{gelu1(x[0]), gelu1(x[1]), gelu1(x[2]), gelu1(x[3])}; }
+// The same on register pairs (round 4): the polynomial, the products and the final combination are packed-f32 instructions (two
+// elements each); 1 + erf(x / sqrt 2) = 2 - y for x >= 0 and y for x < 0 folds into  gelu = 0.5 (x + |x| - |x| y)  -- no select.
+typedef float f2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f2 gelu2(f2 x) {
+    const f2 a = f2{fabsf(x[0]), fabsf(x[1])};
+    const f2 z = a * f2{0.70710678118654752f, 0.70710678118654752f};
+    const f2 d = __builtin_elementwise_fma(f2{0.3275911f, 0.3275911f}, z, f2{1.0f, 1.0f});
+    const f2 t = f2{__builtin_amdgcn_rcpf(d[0]), __builtin_amdgcn_rcpf(d[1])};
+    f2 p = __builtin_elementwise_fma(f2{1.061405429f, 1.061405429f}, t, f2{-1.453152027f, -1.453152027f});
+    p = __builtin_elementwise_fma(p, t, f2{1.421413741f, 1.421413741f});
+    p = __builtin_elementwise_fma(p, t, f2{-0.284496736f, -0.284496736f});
+    p = __builtin_elementwise_fma(p, t, f2{0.254829592f, 0.254829592f});
+    const f2 e = (z * f2{-1.4426950408889634f, -1.4426950408889634f}) * z;
+    const f2 y = (p * t) * f2{__builtin_amdgcn_exp2f(e[0]), __builtin_amdgcn_exp2f(e[1])};            // 1 - erf(z)
+    const f2 h = f2{0.5f, 0.5f};
+    return __builtin_elementwise_fma(a * h, f2{1.0f, 1.0f} - y, x * h);                               // 0.5 x + 0.5 |x| (1 - y)
+}
+__device__ __forceinline__ f4 gelu4(f4 x) {
+    const f2 lo = gelu2(f2{x[0], x[1]}), hi = gelu2(f2{x[2], x[3]});
+    return f4{lo[0], lo[1], hi[0], hi[1]};
+}
 
 // ---- precision f16l6 (round 3): the low-order weight term W - f16(W) as MX-fp6 (e2m3) operands of v_mfma_scale_f32_16x16x128_f8f6f4
 // against fp6 / fp4 copies of the activations: one MFMA at the cost of one f16 k-step covers K = 128 (tools/probe/mx6_layout.hip:
