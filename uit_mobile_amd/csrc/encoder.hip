@@ -347,7 +347,10 @@ __device__ __forceinline__ void attention_proj(f4 (&R)[8][3], const typename OP:
             // full clips: the diagonal tiles (0,0) and (2,2) hold one clip's keys and queries only -- every probability counts
             // (their masks are all-ones by construction: 4 packed ANDs per block less)
             const bool all_valid = !SHORT && (i == 0 || i == 6);
-            const u2 bits = all_valid ? __builtin_bit_cast(u2, OP::pack4(p)) : (__builtin_bit_cast(u2, OP::pack4(p)) & pmask[i]);
+            // off-diagonal tiles of full clips: a lane's four keys are all its query's clip's or all foreign, so the mask is the tile
+            // validity -- a wave mask in scalar registers, where the per-element masks are 10 vector registers alive through the MLP loop
+            const u2 pk = __builtin_bit_cast(u2, OP::pack4(p));
+            const u2 bits = all_valid ? pk : (SHORT ? (pk & pmask[i]) : (tvalid[i] ? pk : u2{0u, 0u}));
             const v4 Pm = __builtin_bit_cast(v4, bits);
             // the first tile of a query tile starts its accumulators from the literal 0 (an inline constant of the MFMA: no v_mov per register)
             const bool first = i == 0 || i == 2 || i == 5;
