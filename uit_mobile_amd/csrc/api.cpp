@@ -458,7 +458,9 @@ int uitk_encode(uitk_model* m, int64_t B, int64_t T, float* probs, float* logits
     // 8-wave rounds (16 per CU each) that fit one 4-wave workgroup per CU go out as a second launch of that shape (rows are
     // independent; both launches read the same amax slots).  Same arithmetic, same bits (tests: test_pass_distribution_...).
     // Only the uit_* family in f16 / bf16 / fp8 has 4-wave instantiations; launch_encoder ignores the hint for the others.
-    const bool has_w4 = !a.attention_full && !a.act_gelu && !a.pooling &&
+    // (not with the split patch embed switched on: only 8-wave workgroups have the LDS for its low-order fragments, and a batch must
+    // not change its arithmetic with its size)
+    const bool has_w4 = !a.attention_full && !a.act_gelu && !a.pooling && !a.split_pe &&
                         (m->cfg.precision == UITK_PREC_F16 || m->cfg.precision == UITK_PREC_BF16 || m->cfg.precision == UITK_PREC_FP8);
     const int small = 8 * m->n_cu, round8 = 16 * m->n_cu;
     auto launch_rows = [&](int row0, int nrows, int waves) {
