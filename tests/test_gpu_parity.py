@@ -695,6 +695,14 @@ def test_pass_distribution_does_not_change_results():
             with torch.no_grad():
                 trio.append(m(xs).cpu().numpy())
         assert np.array_equal(trio[0], trio[1]) and np.array_equal(trio[0], trio[2])
+    for prec in ("bf16", "fp8"):                        # the other precisions that have both shapes
+        trio = []
+        for waves in (0, 4, 8):
+            m, _ = build("uit_xxxs", 31, prec=prec, fe_autotune=False)
+            m.set_option("enc_waves", waves)
+            with torch.no_grad():
+                trio.append(m(x[:100]).cpu().numpy())
+        assert np.array_equal(trio[0], trio[1]) and np.array_equal(trio[0], trio[2]), prec
     m, _ = build("uit_xxxs", 31)
     with pytest.raises(ValueError):                     # unknown option: UITK_ERR_UNSUPPORTED when the handle is created
         m.set_option("no_such_option", 1)
