@@ -9,6 +9,7 @@ runs on split hi+lo operands): `build()` / `build_trained()` take the factory's 
 subject.  The bf16-operand and fp8 modes are measured, non-parity modes: their tests assert measured bounds and say so.
 """
 import os
+from pathlib import Path
 
 import numpy as np
 import pytest
@@ -21,6 +22,7 @@ from uit_mobile_amd import models
 
 pytestmark = pytest.mark.gpu
 TOL = 1e-3
+ROOT = Path(__file__).resolve().parents[1]
 
 
 def build(name, seed, scale=1.0, prec=None, outputdim=537, **kw):      # prec=None: the factory's own default = the product / bench mode
@@ -947,6 +949,46 @@ def test_calibration_acceptance_check(golden):
         print(f"{name} pooling {pooling}: {rep}")
         assert rep is not None and 0 < rep["max_calibrated"] < 1e-3 and 0 < rep["max_nearest"] < 3e-3
         assert (mm.get_option("weights_calibrated")[0] == 1) == rep["accepted"]
+
+
+def test_c_abi_consumer_in_plain_c(tmp_path):
+    """The drop-in boundary is a C ABI (include/uitk.h): a consumer written in plain C99 (tests/native/cabi_consumer.c: gcc, no C++, no
+    Python, no torch; the HIP runtime API only for its device buffers) creates a model from raw float arrays, calibrates, runs
+    uitk_forward on int16 clips -- and writes, bit for bit, what the Python wrapper returns for the same checkpoint and clips."""
+    import shutil
+    import subprocess
+    if shutil.which("gcc") is None:
+        pytest.skip("no gcc on this box")
+    sd = make_trained_like_state_dict("uit_xxxs", 205)
+    pcm = synth_pcm_i16(6, 16000, seed=77)
+    order = ["front_end.0.spectrogram.window", "front_end.0.mel_scale.fb", "init_bn.1.weight", "init_bn.1.bias", "init_bn.1.running_mean",
+             "init_bn.1.running_var", "patch_embed.proj.weight", "patch_embed.proj.bias", "time_pos_embed", "freq_pos_embed", "norm.weight",
+             "norm.bias", "outputlayer.0.weight", "outputlayer.0.bias", "outputlayer.1.weight", "outputlayer.1.bias", "cls_token", "token_pos_embed"]
+    for b in range(4):
+        order += [f"blocks.{b}.{k}" for k in ("norm1.weight", "norm1.bias", "attn.qkv.weight", "attn.qkv.bias", "attn.proj.weight", "attn.proj.bias",
+                                              "norm2.weight", "norm2.bias", "mlp.fc1.weight", "mlp.fc1.bias", "mlp.fc2.weight", "mlp.fc2.bias")]
+    blob = tmp_path / "ckpt.bin"
+    with open(blob, "wb") as f:
+        f.write(np.array([4, 537, pcm.shape[0], pcm.shape[1]], np.int32).tobytes())
+        for k in order:
+            f.write(np.ascontiguousarray(np.asarray(sd[k]), dtype=np.float32).tobytes())
+        f.write(np.ascontiguousarray(pcm).tobytes())
+    exe = tmp_path / "cabi_consumer"
+    lib = ROOT / "uit_mobile_amd"
+    subprocess.run(["gcc", "-std=c99", "-Wall", "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include", f"-I{ROOT / 'include'}",
+                    str(ROOT / "tests" / "native" / "cabi_consumer.c"), "-o", str(exe), f"-L{lib}", "-luitk", "-L/opt/rocm/lib", "-lamdhip64",
+                    f"-Wl,-rpath,{lib}", "-Wl,-rpath,/opt/rocm/lib"], check=True)
+    r = subprocess.run([str(exe), str(blob), str(tmp_path / "out.bin")], capture_output=True, text=True, timeout=300)
+    print(r.stdout.strip(), r.stderr.strip())
+    assert r.returncode == 0, r.stderr
+    out = np.fromfile(tmp_path / "out.bin", np.float32)
+    n = pcm.shape[0] * 537
+    m, _ = build_trained("uit_xxxs", 205)
+    with torch.no_grad():
+        p, l = m(torch.from_numpy(pcm).cuda(), return_logits=True)
+    assert np.array_equal(out[:n].reshape(-1, 537), p.cpu().numpy()) and np.array_equal(out[n:2 * n].reshape(-1, 537), l.cpu().numpy().reshape(-1, 537))
+    rep = m.calibration_report()
+    assert out[2 * n + 4] == 1.0 and np.isclose(out[2 * n + 1], rep["max_calibrated"], rtol=0, atol=0)
 
 
 def test_inference_cli_counterpart_config1(golden, tmp_path, capsys):
