@@ -49,6 +49,10 @@ typedef enum uitk_precision {
                            activations fp16 as in UITK_PREC_F16: the reference point for what weight splitting can buy, at ~1.7x the
                            encoder time.  Any attention / activation / pooling (round 3): it is the parity mode of the
                            full-width-attention / GELU factories (audio_transformer_*), which have no UITK_PREC_F16L6 build */
+    UITK_PREC_FP8W = 5, /* round 5: BASELINE config #5 read literally -- "fp8 WEIGHTS": the qkv / fc1 / fc2 weights on the OCP e4m3 grid with MX
+                           block scales (32 consecutive k per scale), expanded to fp16 fragments at pack time: the UITK_PREC_F16 kernel,
+                           fp16 activations, any family / pooling.  With uitk_calibrate_weights the grid rounding is GPTQ (as for
+                           UITK_PREC_FP8).  A measured mode (weight error ~2^-4 relative), not a parity mode */
     UITK_PREC_F16L6 = 4 /* round 3's parity mode (kept built and tested): fp16 operands as UITK_PREC_F16 plus the LOW-ORDER weight term on the cheap pipe:
                            W = f16(W) + 2^e(row) . e2m3(W - f16(W)), the second term as OCP fp6 on
                            v_mfma_scale_f32_16x16x128_f8f6f4 (one MFMA at the cost of one f16 k-step covers K = 128) against fp6
@@ -136,7 +140,8 @@ int uitk_destroy(uitk_model* m);
  * layout tests).  *needed receives the byte size; out may be NULL to query. */
 int uitk_pack_weights(const uitk_config* cfg, const uitk_weights* w, void* out, size_t cap, size_t* needed);
 
-/* ---- Calibrated rounding (round 4).  The single-weight precisions (UITK_PREC_F16, UITK_PREC_BF16) round every weight matrix
+/* ---- Calibrated rounding (round 4; round 5: also UITK_PREC_FP8 / UITK_PREC_FP8W, whose qkv / fc1 / fc2 weights are then rounded on the
+ * MX e4m3 grid by the same algorithm).  The single-weight precisions (UITK_PREC_F16, UITK_PREC_BF16) round every weight matrix
  * against the second moments E[x x^T] of the operand it multiplies, measured on a calibration batch (GPTQ on the fp16 grid,
  * csrc/pack.cpp: round_gptq): same kernel, same speed, and the weight-rounding term of the logit error -- which dominates plain
  * round-to-nearest at trained-checkpoint magnitudes -- drops to the floor set by the fp16 activations (the accuracy of
@@ -149,12 +154,20 @@ int uitk_pack_weights(const uitk_config* cfg, const uitk_weights* w, void* out, 
  * synchronises the device.  Clips must cover target_length frames; at most the first 1024 clips are used.
  *
  * Acceptance check (option "calib_accept_pct", default 105): before the calibrated image is installed, it and the image uitk_create
- * packed (every weight rounded to nearest) both run the PRODUCT kernels on sixteen HELD-OUT clips of the library (a second signal family,
- * never the calibration clips), and are compared with what the unrounded network answers there (the fp32 forward of calibrate.hip
- * finished in double on the host).  The calibrated image is kept only if its largest logit deviation is at most calib_accept_pct per
- * cent of the nearest image's (default: 5 % slack for ties); otherwise the handle keeps the nearest image and
- * get_option("weights_calibrated") stays 0 -- a calibration on unrepresentative clips falls back to precision f16 instead of
- * installing a rounding that is worse than nearest where it was not fitted.  uitk_get_calib_check reports the four numbers. */
+ * packed (every weight rounded to nearest) both run the PRODUCT kernels on sixteen HELD-OUT clips of the library -- round 5: a
+ * different signal FAMILY from the calibration clips (impulse train, single click, DC offsets, hard clipping, +-1 LSB dither, Nyquist
+ * alternation, AM/FM stacks at -40 / -12 dBFS, clipped noise, square wave, silence + burst, exponential sweep, bin-edge tone pair,
+ * decaying resonances) -- and are compared with what the unrounded network answers there (the fp32 forward of calibrate.hip finished in
+ * double on the host).  The calibrated image is kept only if its largest logit deviation is at most calib_accept_pct per cent of the
+ * nearest image's (default: 5 % slack for ties); otherwise the handle keeps the nearest image and get_option("weights_calibrated")
+ * stays 0.  uitk_get_calib_check reports the four numbers.
+ *
+ * Absolute budget (round 5; option "calib_budget_e6", default 600 = 6e-4 on logits, a quarter of that on the probabilities of pooling
+ * 'dm'): the image that STAYS on the handle -- calibrated, or nearest after a refusal -- must itself be inside the budget on the held-out
+ * clips.  If it is not (or the check failed), get_option("parity_escalate_to") names the precision the caller must rebuild the handle
+ * with to stay a parity mode: UITK_PREC_F16L6 for BNeckAttention + ReLU, UITK_PREC_F16X2 for the other families (-1: inside the
+ * budget).  The Python wrapper's precision 'auto' (the factories' default) does exactly that and reports it; tests/native/
+ * cabi_consumer.c shows the same four calls in C.  Not callable under stream capture (it allocates and synchronises). */
 int uitk_calibrate_weights(uitk_model* m, const uitk_weights* w, const void* pcm, int in_dtype, int64_t B, int64_t T, void* stream);
 /* Number of doubles of a statistics block for this config: patch embed [256][256], then per block LayerNorm-1 output [128][128],
  * attention output [inner][inner] (inner = 32, or 128 with attention_full), LayerNorm-2 output [128][128], activation output [384][384]. */
@@ -168,7 +181,14 @@ int uitk_get_calib_stats(const uitk_model* m, double* out, size_t cap_doubles);
  * front-end: the numbers measure the encoder's arithmetic (weight + activation rounding), not the front-end's.
  * All -1: no check has run (option calib_accept_pct 0, or no calibration). */
 int uitk_get_calib_check(const uitk_model* m, float* out5);
-/* Host-only (no GPU): uitk_pack_weights with calibrated rounding against caller-supplied statistics (layout tests, offline packing). */
+/* The oracle-free estimate of a handle's own parity margin, for ANY precision: the held-out clips of the acceptance check through the
+ * product kernels on the parameter image the handle holds now, against the fp32 forward of the unrounded network built from `w` (the
+ * weights the handle was created from).  out2[0] = max |d|, out2[1] = rms (pre-sigmoid logits; probabilities for pooling 'dm'); both -1
+ * when no single-crop clip length covers target_length.  A pack-time operation like uitk_calibrate_weights: allocates, synchronises,
+ * overwrites the workspace of a pending uitk_frontend; not under stream capture. */
+int uitk_self_check(uitk_model* m, const uitk_weights* w, void* stream, float* out2);
+/* Host-only (no GPU): uitk_pack_weights with calibrated rounding against caller-supplied statistics (layout tests, offline packing).
+ * Statistics with a non-finite or negative diagonal entry are rejected (UITK_ERR_INVALID_ARG). */
 int uitk_pack_weights_calibrated(const uitk_config* cfg, const uitk_weights* w, const double* stats, void* out, size_t cap, size_t* needed);
 
 /* Frames and crops the reference makes for a T-sample clip: 1 + T/hop frames (center=True); more than
@@ -243,11 +263,14 @@ int uitk_set_timing_buffers(uitk_model* m, unsigned long long* enc_buf, unsigned
  *                       skip their FFT when a Parseval bound shows they cannot raise it; 0 transforms every frame (test of the skip)
  *   "calib_accept_pct"  0..1000 (default 105): uitk_calibrate_weights installs its image only if its largest deviation on the library's
  *                       held-out clips is at most this many per cent of the nearest-rounded image's (see there); 0 = no check, install
- *                       unconditionally; 1 = refuse in practice (test of the fallback) */
+ *                       unconditionally; 1 = refuse in practice (test of the fallback)
+ *   "calib_budget_e6"   0..1000000 (default 600): absolute budget, in 1e-6 units, for the largest deviation of the image that stays
+ *                       installed after uitk_calibrate_weights on the held-out clips (see there); 0 = no budget */
 int uitk_set_option(uitk_model* m, const char* name, int value);
 /* Current value of an option ("fe_asym_pm": the explicit setting, else the share the latest front-end launch used, -1 = the
  * built-in 590 because nothing was measured for its shape); also "weights_calibrated" (read-only: 1 when the
- * handle runs an image uitk_calibrate_weights built AND its acceptance check kept). */
+ * handle runs an image uitk_calibrate_weights built AND its acceptance check kept) and "parity_escalate_to" (read-only: -1, or the
+ * uitk_precision to rebuild the handle with because the installed image is over the budget -- see uitk_calibrate_weights). */
 int uitk_get_option(const uitk_model* m, const char* name, int* value);
 
 /* ---- Step after the path: post-processing of the probability rows on the device, so that only

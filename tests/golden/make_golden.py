@@ -245,7 +245,41 @@ def main_kwargs():
     np.savez_compressed(HERE / "win400_uit_xxxs.npz", seed=35, **out)
 
 
+def main_heldout():
+    """Round-5 fixture: the WIDE held-out set under the imported reference.  All eleven recordings of the
+    reference's samples/ (native length: one or two crops, each its own forward call as inference.py does) and one member of every
+    adversarial family of uit_mobile_amd.synth (impulses, clicks, DC, clipping, LSB dither, Nyquist alternation, quiet speech-like
+    stacks ... as ONE batch: batch-global top_db floor), through three trained-like checkpoints: uit_xs seed 207 (the sweep's worst
+    checkpoint for nearest-rounded fp16 weights), uit_xxxs seed 203 and the full-attention GELU factory d4 seed 206 (the checkpoint
+    that sat at the gate in round 4)."""
+    from uit_mobile_amd.synth import adversarial_pcm_i16
+    wavs = sorted(p.name for p in (REF / "samples").glob("*.wav"))
+    assert len(wavs) == 11, wavs
+    adv, names = adversarial_pcm_i16(0, 1)
+    out = {"adv_pcm": adv, "adv_names": np.array(len(names)), "wav_count": np.array(len(wavs))}
+    for i, wv in enumerate(wavs):
+        out[f"wav{i:02d}_pcm"] = read_wav_i16(REF / "samples" / wv)
+    for tag, name, seed, att in (("xs207", "uit_xs", 207, "bneck"), ("xxxs203", "uit_xxxs", 203, "bneck"),
+                                 ("d4gelu206", "audio_transformer_h128_d4_m3", 206, "full")):
+        m = getattr(uit, name)(outputdim=537, target_length=102)
+        sd = {k: torch.from_numpy(np.asarray(v)) for k, v in make_trained_like_state_dict(name, seed, attention=att).items()}
+        assert not (set(m.state_dict().keys()) ^ set(sd.keys()))
+        m.load_state_dict(sd, strict=True)
+        m.eval()
+        for i in range(len(wavs)):
+            r = run_ref(m, out[f"wav{i:02d}_pcm"][None])
+            out[f"{tag}_wav{i:02d}_probs"], out[f"{tag}_wav{i:02d}_logits"] = r["probs"][0], r["logits"][0]
+        r = run_ref(m, adv)
+        out[f"{tag}_adv_probs"], out[f"{tag}_adv_logits"] = r["probs"], r["logits"]
+        print("heldout", tag, "wav logit range", min(out[f"{tag}_wav{i:02d}_logits"].min() for i in range(11)),
+              max(out[f"{tag}_wav{i:02d}_logits"].max() for i in range(11)), "adv", r["logits"].min(), r["logits"].max())
+    np.savez_compressed(HERE / "heldout_wide.npz", **out)
+    print("wavs:", wavs, "adversarial:", names)
+
+
 def main():
+    if "--heldout" in sys.argv:
+        return main_heldout()
     if "--kwargs" in sys.argv:
         return main_kwargs()
     if "--token" in sys.argv:
@@ -324,6 +358,7 @@ def main():
     main_dm()
     main_token()
     main_kwargs()
+    main_heldout()
     print("done")
 
 

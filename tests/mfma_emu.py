@@ -107,7 +107,7 @@ class EncoderEmu:
         self.h = parse_header(img)
         assert self.h["magic"] == 0x4B544955
         self.l6 = self.h["precision"] == 4                                # f16 operands + MX-fp6 low-order weight term
-        self.prec = 0 if self.l6 else self.h["precision"]
+        self.prec = 0 if self.l6 or self.h["precision"] == 5 else self.h["precision"]      # 5 = fp8w: fp8-grid weights in fp16 fragments (the f16 kernel)
         self.depth = self.h["depth"]
         self.C = self.h["outputdim"]
 

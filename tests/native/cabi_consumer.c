@@ -2,7 +2,7 @@
  * tests/test_gpu_parity.py::test_c_abi_consumer_in_plain_c builds it with gcc, hands it a checkpoint + clips as one binary blob and
  * compares what it writes, bit for bit, with the Python wrapper's output for the same weights and clips.
  *
- *   cabi_consumer <blob in> <out>
+ *   cabi_consumer <blob in> <out> [calib_budget_e6]
  * blob: int32 depth, outputdim, B, T; then float32 tensors in the order of `take` calls below (reference state_dict layouts,
  * include/uitk.h); then int16 PCM [B][T].   out: float32 probs [B][outputdim], logits [B][outputdim], calibration check [5].
  *
@@ -32,7 +32,7 @@ static const float* take(size_t n) { const float* p = cursor; cursor += n; retur
     } while (0)
 
 int main(int argc, char** argv) {
-    if (argc != 3) { fprintf(stderr, "usage: %s blob out\n", argv[0]); return 1; }
+    if (argc != 3 && argc != 4) { fprintf(stderr, "usage: %s blob out [calib_budget_e6]\n", argv[0]); return 1; }
     FILE* f = fopen(argv[1], "rb");
     if (!f) { perror(argv[1]); return 1; }
     fseek(f, 0, SEEK_END);
@@ -76,11 +76,25 @@ int main(int argc, char** argv) {
     cfg.eval_avg = UITK_AVG_MEAN; cfg.precision = UITK_PREC_F16; cfg.top_db = 120.0f;
     cfg.attention_full = 0; cfg.act_gelu = 0; cfg.pooling = 0; cfg.fe_autotune = 0;
 
+    /* THE PARITY MODE as a C consumer builds it (what the Python wrapper's precision 'auto' does): create in f16, calibrate on the library's
+     * own signals, then ask the handle whether the image it kept is inside the absolute budget on the held-out clips -- if not, rebuild in
+     * the split-weight precision it names.  argv[3] (optional): a calib_budget_e6 value, e.g. 1 = a budget nobody meets (the escalation path). */
     uitk_model* m = NULL;
     CHECK_UITK(uitk_create(&cfg, &w, &m));
-    CHECK_UITK(uitk_calibrate_weights(m, &w, NULL, UITK_IN_I16, 0, 0, NULL));      /* the parity mode: calibrated rounding, library's own signals */
+    if (argc > 3) CHECK_UITK(uitk_set_option(m, "calib_budget_e6", atoi(argv[3])));
+    CHECK_UITK(uitk_calibrate_weights(m, &w, NULL, UITK_IN_I16, 0, 0, NULL));
     float check[5];
     CHECK_UITK(uitk_get_calib_check(m, check));
+    int escalate_to = -1;
+    CHECK_UITK(uitk_get_option(m, "parity_escalate_to", &escalate_to));
+    if (escalate_to >= 0) {
+        float self[2];
+        CHECK_UITK(uitk_destroy(m));
+        cfg.precision = escalate_to;
+        CHECK_UITK(uitk_create(&cfg, &w, &m));
+        CHECK_UITK(uitk_self_check(m, &w, NULL, self));
+        printf("over budget (or refused): rebuilt in precision %d, self check max %.2e rms %.2e\n", escalate_to, self[0], self[1]);
+    }
 
     void *d_pcm = NULL, *d_probs = NULL, *d_logits = NULL;
     const size_t n_out = (size_t)B * C;

@@ -77,15 +77,15 @@ def test_other_factories_match_reference_layout(name, depth, gelu):
         assert tuple(mine[k].shape) == tuple(np.asarray(sd[k]).shape), k
     assert tuple(mine["blocks.0.attn.qkv.weight"].shape) == (384, 128) and tuple(mine["blocks.0.attn.proj.weight"].shape) == (128, 128)
     assert m.depth == depth and m.attention_full and m.act_gelu == gelu and m.pooling == "mean"
-    assert m.precision == "f16c"                    # the default of every factory (round 4): single fp16 weights, calibrated rounding
+    assert m.precision == "auto"                    # the default of every factory (round 5): 'f16c' held to the library's budget, else split weights
     m16 = getattr(models, name)(outputdim=537, target_length=102, precision="f16").eval()
     assert (8 + 40 * depth) * 16384 > len(m16.packed_image()) > (8 + 20 * depth) * 16384       # the 20-stage single-weight layout
-    assert len(m.eval().packed_image()) == len(m16.packed_image())                             # f16c: the same layout, other roundings
+    assert len(m.eval().packed_image()) == len(m16.packed_image())                             # auto / f16c: the same layout, other roundings
     img = getattr(models, name)(outputdim=537, target_length=102, precision="f16x2").eval().packed_image()      # split weights (round 3)
     assert len(img) > (8 + 40 * depth) * 16384      # host-only packing works without a GPU
     with pytest.raises(NotImplementedError):        # built for the uit_* family only
         getattr(models, name)(outputdim=537, target_length=102, precision="fp8")
-    assert getattr(models, name)(outputdim=537, target_length=102, pooling="token").precision == "f16c"       # any pooling
+    assert getattr(models, name)(outputdim=537, target_length=102, pooling="token").precision == "auto"       # any pooling
     assert len(getattr(models, name)(outputdim=537, target_length=102, pooling="dm", precision="f16x2").eval().packed_image()) == len(img)
 
 
@@ -202,7 +202,7 @@ def test_uploaded_image_follows_the_weights(monkeypatch):
     """Round 4: every call compares a CHEAP stamp of the weights (sum of the tensors' version counters + two storage
     pointers, one pass over a cached tensor list) with the one the uploaded image was packed from -- in-place edits under no_grad,
     nn.init.*, a sub-module's load_state_dict are seen; load_state_dict, .to()/.float() (= _apply) and refresh() drop the handles
-    outright.  UITK_CHECK_WEIGHTS=0 (benchmark loops) returns the cached handle without looking."""
+    outright.  check_weights=False (a constructor kwarg since round 5; benchmark loops) returns the cached handle without looking."""
     from uit_mobile_amd.models import uit as U
     m = models.uit_xxxs(outputdim=537, target_length=102).eval()
 
@@ -210,7 +210,7 @@ def test_uploaded_image_follows_the_weights(monkeypatch):
         ptr = 1234
 
     dev = torch.device("cuda", 0)
-    assert U._CHECK_WEIGHTS                             # the default
+    assert m.check_weights and not hasattr(U, "_CHECK_WEIGHTS")     # the default; no environment variable is read any more
     m._handles[0] = (H(), m._stamp())
     assert m._handle(dev) == 1234                       # unchanged weights: the cached handle
     for edit in (lambda: m.norm.weight.mul_(2.0), lambda: torch.nn.init.zeros_(m.blocks[1].mlp.fc2.bias),
@@ -230,10 +230,11 @@ def test_uploaded_image_follows_the_weights(monkeypatch):
     m.refresh()
     assert m._handles == {}
     m._handles[0] = (H(), ())                           # a stale stamp ...
-    monkeypatch.setattr(U, "_CHECK_WEIGHTS", False)
+    m.check_weights = False
     calls = []
     monkeypatch.setattr(m, "_stamp", lambda: calls.append(1) or ())
-    assert m._handle(dev) == 1234 and calls == []       # ... is not even looked at with UITK_CHECK_WEIGHTS=0
+    assert m._handle(dev) == 1234 and calls == []       # ... is not even looked at with check_weights=False
+    assert models.uit_xxxs(outputdim=537, target_length=102, check_weights=False).check_weights is False
     with pytest.raises(ValueError):                     # option names are validated without a live handle (no leak, no poisoned state)
         m.set_option("no_such_option", 1)
     assert "no_such_option" not in m._options

@@ -6,7 +6,7 @@ import pytest
 import torch
 
 from conftest import centred
-from mfma_emu import EncoderEmu
+from mfma_emu import EncoderEmu, parse_header
 from oracle.oracle import Oracle
 from uit_mobile_amd.synth import make_state_dict, synth_pcm_i16
 from uit_mobile_amd import models
@@ -412,3 +412,57 @@ def test_calibrated_packing_rejects_bad_statistics_and_other_precisions():
     m2, _ = _model("uit_xxxs", 3, "f16l6")
     with pytest.raises(ValueError):
         m2.packed_image(calib_stats=np.zeros(L.uitk_calib_stats_doubles(ctypes.byref(m2._config()))))
+
+
+def test_fp8_grid_weights_with_and_without_gptq_in_the_emulated_f16_kernel():
+    """Round 5: precision 'fp8w' = qkv / fc1 / fc2 weights on the MX e4m3 grid (32 consecutive k per power-of-two
+    scale), expanded to fp16 fragments -> the f16 kernel.  (a) Every weight of an MLP stage decodes to an e4m3 value times a power of two
+    (<= 4 significant bits).  (b) With the operand statistics the grid rounding is GPTQ (pack.cpp: round_fp8_grid): on a held-out clip
+    pair the emulated kernel's logit error drops against nearest-on-the-grid.  (c) The fp8 KERNEL's stream ('fp8c') takes the same
+    statistics: its image differs from nearest in the fp8 bytes, on the grid the exact weights' MX scales define.  (d) Statistics with a
+    NaN or negative diagonal are refused (ADVICE r4) instead of reaching std::stable_sort."""
+    from calib_ref import calib_stats
+    from uit_mobile_amd.synth import make_trained_like_state_dict
+    sd = make_trained_like_state_dict("uit_xxxs", 203)
+    stats = calib_stats(sd, synth_pcm_i16(16, 16000, seed=4242), depth=4)
+    pcm = synth_pcm_i16(2, 16000, seed=7)
+    o = Oracle(sd)
+    ref = o.forward(pcm)
+    mel_raw, amax = o.melspec_db(pcm)
+    mel2 = np.ascontiguousarray(mel_raw.transpose(0, 2, 1))
+    m = models.uit_xxxs(outputdim=537, target_length=102, precision="fp8w")
+    m.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()}, strict=True)
+    imgs = {"nearest": m.eval().packed_image(), "gptq": m.packed_image(calib_stats=stats)}
+    err = {}
+    for kind, img in imgs.items():
+        emu = EncoderEmu(img)
+        assert emu.h["precision"] == 5
+        logits, _ = emu.run_wave(mel2, amax - 120.0, nt=6)
+        err[kind] = (float(np.abs(logits - ref["logits"][:, 0]).max()), float(np.sqrt(np.mean((logits - ref["logits"][:, 0]) ** 2))))
+        # (a) MLP stage of block 0 (stage 8 + 2): fc1 + fc2 fragments -- every value has at most 4 significant bits
+        w = np.concatenate([emu.frag(8 + 2, f).ravel() for f in range(16)]).astype(np.float64)
+        mant, _ = np.frexp(w[w != 0])
+        assert np.all(np.abs(mant) * 16 == np.round(np.abs(mant) * 16)), kind
+    print("fp8w emulated, (max, rms) logit error vs oracle:", err)
+    assert err["gptq"][1] < 0.8 * err["nearest"][1] and err["nearest"][0] < 0.3
+    # (c)
+    m8 = models.uit_xxxs(outputdim=537, target_length=102, precision="fp8c")
+    m8.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()}, strict=True)
+    a, b = m8.eval().packed_image(), m8.packed_image(calib_stats=stats)
+    h = EncoderEmu.__new__(EncoderEmu); h = parse_header(a)
+    assert h["precision"] == 2 and len(a) == len(b)
+    s1 = h["off_wstream"] + (8 + 1) * 16384                                  # block 0, stage 1: proj + the MLP's MX scale bytes
+    sa = np.frombuffer(a, np.uint8, 12 * 256, s1 + 8192).astype(int); sb = np.frombuffer(b, np.uint8, 12 * 256, s1 + 8192).astype(int)
+    # the grid is that of the exact weights' scales; a block whose largest element the error feedback moved below half its range is
+    # re-expressed one binade lower (the same values, exactly)
+    assert np.all((sb == sa) | (sb == sa - 1)) and np.mean(sb == sa) > 0.9
+    st2 = h["off_wstream"] + (8 + 2) * 16384
+    da = np.frombuffer(a, np.uint8, 16384, st2); db = np.frombuffer(b, np.uint8, 16384, st2)
+    assert 0.02 < np.mean(da != db) < 0.9                                    # rounding-sized moves on the grid
+    # (d)
+    bad = stats.copy(); bad[0] = np.nan
+    with pytest.raises(ValueError):
+        m.packed_image(calib_stats=bad)
+    bad = stats.copy(); bad[256 * 256 + 5 * 129] = -1.0
+    with pytest.raises(ValueError):
+        m.packed_image(calib_stats=bad)

@@ -12,7 +12,7 @@ LIB_PATH = Path(os.environ["UITK_LIB_PATH"]) if os.environ.get("UITK_LIB_PATH") 
 UITK_OK = 0
 ERR_INVALID_ARG, ERR_UNSUPPORTED, ERR_NO_DEVICE, ERR_HIP, ERR_TOO_SHORT, ERR_WORKSPACE = -1, -2, -3, -4, -5, -6
 IN_F32, IN_I16 = 0, 1
-PREC_F16, PREC_BF16, PREC_FP8, PREC_F16X2, PREC_F16L6 = 0, 1, 2, 3, 4
+PREC_F16, PREC_BF16, PREC_FP8, PREC_F16X2, PREC_F16L6, PREC_FP8W = 0, 1, 2, 3, 4, 5
 AVG_MEAN, AVG_MAX = 0, 1
 AMAX_SLOTS = 64
 
@@ -20,7 +20,7 @@ EXPORTS = ["uitk_create", "uitk_destroy", "uitk_pack_weights", "uitk_num_frames"
            "uitk_reserve", "uitk_forward", "uitk_frontend", "uitk_amax_ptr", "uitk_encode", "uitk_mel_db",
            "uitk_set_debug_tokens", "uitk_set_timing_buffers", "uitk_set_option", "uitk_get_option", "uitk_topk", "uitk_kws_transform", "uitk_last_error",
            "uitk_version", "uitk_calibrate_weights", "uitk_calib_stats_doubles", "uitk_get_calib_stats", "uitk_pack_weights_calibrated",
-           "uitk_tune_frontend", "uitk_get_calib_check"]
+           "uitk_tune_frontend", "uitk_get_calib_check", "uitk_self_check"]
 
 
 class Config(Structure):
@@ -83,6 +83,7 @@ def load():
     L.uitk_get_calib_stats.argtypes = [c_void_p, c_void_p, c_size_t]
     L.uitk_get_calib_check.argtypes = [c_void_p, c_void_p]
     L.uitk_pack_weights_calibrated.argtypes = [POINTER(Config), POINTER(Weights), c_void_p, c_void_p, c_size_t, POINTER(c_size_t)]
+    L.uitk_self_check.argtypes = [c_void_p, POINTER(Weights), c_void_p, c_void_p]
     L.uitk_tune_frontend.argtypes = [c_void_p, c_void_p, c_int, c_int64, c_int64, c_void_p]
     for name in EXPORTS:                      # every entry point include/uitk.h declares must be exported
         getattr(L, name)

@@ -144,9 +144,10 @@ static bool chol_lower(std::vector<double>& A, int n) {          // in place, lo
     return true;
 }
 
-static std::vector<uint16_t> round_gptq(int rows, int K, const std::function<double(int, int)>& W, int prec, const double* H, double damp = 0.01) {
-    std::vector<uint16_t> q((size_t)rows * K);
-    std::vector<int> perm(K);
+// the column order (decreasing H_jj) and the upper-triangular factor U with (H_perm + damping)^-1 = U^T U; false = statistics unusable
+static bool gptq_factor(int K, const double* H, double damp, std::vector<int>* perm_out, std::vector<double>* U_out) {
+    std::vector<int>& perm = *perm_out;
+    perm.resize(K);
     std::iota(perm.begin(), perm.end(), 0);
     std::stable_sort(perm.begin(), perm.end(), [&](int a, int b) { return H[(size_t)a * K + a] > H[(size_t)b * K + b]; });
     std::vector<double> A((size_t)K * K);
@@ -158,7 +159,8 @@ static std::vector<uint16_t> round_gptq(int rows, int K, const std::function<dou
     }
     bool ok = std::isfinite(tr);
     for (int i = 0; i < K; ++i) A[(size_t)i * K + i] += damp * tr / K;
-    std::vector<double> U((size_t)K * K, 0.0);                   // upper triangular, (H + damping)^-1 = U^T U
+    std::vector<double>& U = *U_out;
+    U.assign((size_t)K * K, 0.0);                                // upper triangular, (H + damping)^-1 = U^T U
     if (ok) ok = chol_lower(A, K);
     if (ok) {
         // Linv (lower) by forward substitution, column by column; Hinv = Linv^T Linv
@@ -185,6 +187,16 @@ static std::vector<uint16_t> round_gptq(int rows, int K, const std::function<dou
         ok = chol_lower(Hi, K);
         if (ok) for (int i = 0; i < K; ++i) for (int j = 0; j <= i; ++j) U[(size_t)j * K + i] = Hi[(size_t)i * K + j];
     }
+    return ok;
+}
+
+// (the error feedback may move a later column by MORE than half a step from its own nearest value -- that is the point: what bounds the
+// deviation from the exact weights is the damping, not a per-element half-step rule)
+static std::vector<uint16_t> round_gptq(int rows, int K, const std::function<double(int, int)>& W, int prec, const double* H, double damp = 0.01) {
+    std::vector<uint16_t> q((size_t)rows * K);
+    std::vector<int> perm;
+    std::vector<double> U;
+    const bool ok = gptq_factor(K, H, damp, &perm, &U);
     std::vector<double> wr(K);
     for (int r = 0; r < rows; ++r) {
         for (int k = 0; k < K; ++k) wr[k] = W(r, perm[k]);
@@ -218,6 +230,56 @@ static uint8_t f32_to_e4m3(double x) {
     if (E > 8 || (E == 8 && r > 14.0)) return (uint8_t)(s | 0x7e);
     if (r < 8.0) return (uint8_t)(s | (uint8_t)r);                     // subnormal (exponent field 0)
     return (uint8_t)(s | ((E + 7) << 3) | ((int)r - 8));
+}
+
+static double e4m3_value(uint8_t u) {
+    const int e = (u >> 3) & 15, m = u & 7;
+    const double v = e == 0 ? std::ldexp((double)m, -9) : std::ldexp((double)(m | 8), e - 10);
+    return (u & 0x80) ? -v : v;
+}
+
+// Weights on the MX e4m3 grid (round 5): every row is cut into 32-element scale blocks (block_of(k): the hardware's interleaved blocks
+// of a fragment8 for precision fp8, contiguous ones for the weights-only variant); a block's scale is the smallest power of two that
+// brings its largest |w| inside e4m3's 448 (as pack_frag8 chooses it), its elements are e4m3 values times that scale.  Returns the
+// VALUES (doubles, exactly representable).  H = nullptr: every element to nearest.  With the operand's second moments H: GPTQ
+// (round_gptq above) on this grid -- the rounding error of a column is pushed onto the columns not yet rounded, saturating at the
+// block's 448 * scale; the scales stay those of the exact weights.
+static std::vector<double> round_fp8_grid(int rows, int K, const std::function<double(int, int)>& W, const std::function<int(int)>& block_of,
+                                          int nblocks, const double* H, double damp = 0.01) {
+    std::vector<double> q((size_t)rows * K);
+    std::vector<int> perm;
+    std::vector<double> U;
+    bool ok = false;
+    if (H) ok = gptq_factor(K, H, damp, &perm, &U);
+    if (!ok) { perm.resize(K); std::iota(perm.begin(), perm.end(), 0); }
+    std::vector<double> wr(K), sc(nblocks);
+    for (int r = 0; r < rows; ++r) {
+        std::fill(sc.begin(), sc.end(), 0.0);
+        for (int k = 0; k < K; ++k) sc[block_of(k)] = std::fmax(sc[block_of(k)], std::fabs(W(r, k)));
+        for (int b = 0; b < nblocks; ++b) {
+            const double m = sc[b];
+            int e = 0;
+            if (m > 0.0) {                                             // smallest e with m / 2^e <= 448 (pack_frag8's rule)
+                e = (int)std::ceil(std::log2(m / 448.0));
+                while (m / std::ldexp(1.0, e) > 448.0) ++e;
+                while (m / std::ldexp(1.0, e - 1) <= 448.0) --e;
+            }
+            if (e < -126) e = -126;
+            if (e > 126) e = 126;
+            sc[b] = std::ldexp(1.0, e);
+        }
+        for (int k = 0; k < K; ++k) wr[k] = W(r, perm[k]);
+        for (int j = 0; j < K; ++j) {
+            const double s_ = sc[block_of(perm[j])];
+            const double v = e4m3_value(f32_to_e4m3(wr[j] / s_)) * s_;
+            q[(size_t)r * K + perm[j]] = v;
+            if (!ok) continue;
+            const double e = (wr[j] - v) / U[(size_t)j * K + j];
+            const double* uj = &U[(size_t)j * K];
+            for (int k = j + 1; k < K; ++k) wr[k] -= e * uj[k];
+        }
+    }
+    return q;
 }
 
 // one 2 KiB fragment8 (see uitk_dev.h) of rows 16*tile .. +15, k = kbase + [0, 128) from an accessor W(row, k) -> double, plus the
@@ -318,13 +380,13 @@ int validate_config(const uitk_config* c, const char** why) {
     if (c->depth < 1 || c->depth > 64) return bad("depth out of range");
     if (c->outputdim < 1 || c->outputdim > 65536) return bad("outputdim out of range");
     if (c->eval_avg != UITK_AVG_MEAN && c->eval_avg != UITK_AVG_MAX) return bad("unknown eval_avg");
-    if (c->precision != UITK_PREC_F16 && c->precision != UITK_PREC_BF16 && c->precision != UITK_PREC_FP8 && c->precision != UITK_PREC_F16X2 && c->precision != UITK_PREC_F16L6) return bad("unknown precision");
+    if (c->precision != UITK_PREC_F16 && c->precision != UITK_PREC_BF16 && c->precision != UITK_PREC_FP8 && c->precision != UITK_PREC_F16X2 && c->precision != UITK_PREC_F16L6 && c->precision != UITK_PREC_FP8W) return bad("unknown precision");
 
     if (c->precision == UITK_PREC_F16L6 && (c->attention_full || c->act_gelu)) return bad("precision f16l6 is built for BNeckAttention + ReLU (any pooling)");
     if ((c->attention_full != 0 && c->attention_full != 1) || (c->act_gelu != 0 && c->act_gelu != 1)) return bad("attention_full / act_gelu must be 0 or 1");
     if ((c->attention_full || c->act_gelu || c->pooling) && c->precision == UITK_PREC_FP8) return bad("precision fp8 is built for the uit_* family (BNeckAttention, ReLU, mean pooling) only");
     if (c->pooling < 0 || c->pooling > 2) return bad("pooling must be 0 (mean), 1 (dm) or 2 (token)");
-    if (c->pooling && c->precision != UITK_PREC_F16 && c->precision != UITK_PREC_F16L6 && c->precision != UITK_PREC_F16X2) return bad("pooling 'dm' / 'token' are built for precision f16 / f16l6 / f16x2");
+    if (c->pooling && c->precision != UITK_PREC_F16 && c->precision != UITK_PREC_F16L6 && c->precision != UITK_PREC_F16X2 && c->precision != UITK_PREC_FP8W) return bad("pooling 'dm' / 'token' are built for precision f16 / f16l6 / f16x2");
     if (c->pooling == 1 && c->outputdim > 640) return bad("pooling 'dm' is built for outputdim <= 640");
     return UITK_OK;
 }
@@ -429,7 +491,8 @@ void fold_model(const uitk_config* c, const uitk_weights* w, Folded* F) {
 
 int pack_image(const uitk_config* c, const uitk_weights* w, const double* calib, std::vector<char>* out, ImageHeader* hdr_out) {
     const bool l6 = c->precision == UITK_PREC_F16L6;                     // f16 operands + fp6 low-order weight term
-    const int prec = (c->precision == UITK_PREC_F16X2 || l6) ? UITK_PREC_F16 : c->precision, depth = c->depth, C = c->outputdim;
+    const bool w8 = c->precision == UITK_PREC_FP8W;                      // f16 operands (the f16 kernel) holding weights on the MX e4m3 grid
+    const int prec = (c->precision == UITK_PREC_F16X2 || l6 || w8) ? UITK_PREC_F16 : c->precision, depth = c->depth, C = c->outputdim;
     const int ntiles = (C + 15) / 16;
     const int nb = c->n_fft / 2 + 1;
     // ---- mel filterbank as banded B operands of v_mfma_f32_4x4x1 (16 independent 4x4 blocks): block g owns mels
@@ -573,14 +636,37 @@ int pack_image(const uitk_config* c, const uitk_weights* w, const double* calib,
     structured = std::getenv("UITK_PACK_RTN") == nullptr;       // lab A/B: UITK_PACK_RTN=1 -> plain round-to-nearest
 #endif
     auto Wpe = [&](int r, int k) { return F.pe_w[(size_t)r * 256 + k]; };
-    // CALIBRATED ROUNDING (round_gptq) of every single-weight linear when calibration statistics are given: the single-term 16-bit
-    // modes only (the split modes f16x2 / f16l6 carry the rounding residual as a second term; fp8 quantises the exact values).
+    // CALIBRATED ROUNDING (round_gptq) of every single-weight linear when calibration statistics are given: the single-term modes (the
+    // split modes f16x2 / f16l6 carry the rounding residual as a second term).  Round 5: the fp8 modes too -- qkv / fc1 / fc2 are
+    // rounded on THEIR grid (MX e4m3: round_fp8_grid), the patch embed and proj, which stay fp16 there, on the fp16 grid.
     // One task per matrix (1 + 4 per block, independent), spread over host threads: ~0.1 s for UiT-XS.
-    const bool calibrated = calib != nullptr && !x2 && !l6 && prec != UITK_PREC_FP8;
+    const bool calibrated = calib != nullptr && !x2 && !l6;
+    const bool grid8 = w8 || (prec == UITK_PREC_FP8 && calibrated);     // qkv / fc1 / fc2 as VALUES on the MX e4m3 grid (Q8_*)
+    // scale blocks: precision fp8 = the hardware's 32-element blocks of a fragment8 (uitk_dev.h: per 128 k, block 2 (kk >> 6) + ((kk >> 3) & 1));
+    // the weights-only variant = 32 consecutive k
+    const std::function<int(int)> block_of = w8 ? std::function<int(int)>([](int k) { return k >> 5; })
+                                                : std::function<int(int)>([](int k) { const int kk = k & 127; return 4 * (k >> 7) + 2 * (kk >> 6) + ((kk >> 3) & 1); });
     std::vector<uint16_t> pe_q;
     std::vector<std::vector<uint16_t>> cq_qkv(depth), cq_proj(depth), cq_fc1(depth), cq_fc2(depth);
+    std::vector<std::vector<double>> Q8_qkv(depth), Q8_fc1(depth), Q8_fc2(depth);
+    auto grid8_block = [&](int b, const double* base, const CalibOffsets* co) {       // base == nullptr: every element to nearest
+        const FoldedBlock& fb = F.blocks[b];
+        Q8_qkv[b] = round_fp8_grid(3 * inner, DIM, [&](int r, int k) { return fb.qkv_w[(size_t)r * DIM + k]; }, block_of, DIM / 32, base ? base + co->ln1 : nullptr);
+        Q8_fc1[b] = round_fp8_grid(HID, DIM, [&](int r, int k) { return fb.fc1_w[(size_t)r * DIM + k]; }, block_of, DIM / 32, base ? base + co->ln2 : nullptr);
+        Q8_fc2[b] = round_fp8_grid(DIM, HID, [&](int r, int k) { return fb.fc2_w[(size_t)r * HID + k]; }, block_of, HID / 32, base ? base + co->hid : nullptr);
+    };
     if (calibrated) {
         const CalibOffsets co = calib_offsets(c);
+        {   // a NaN on a diagonal makes round_gptq's column order comparator a non-strict-weak ordering (undefined behaviour in
+            // std::stable_sort) and a negative one is no second moment: reject instead of sorting
+            auto diag_ok = [&](const double* H, int n) { for (int i = 0; i < n; ++i) { const double d = H[(size_t)i * n + i]; if (!std::isfinite(d) || d < 0.0) return false; } return true; };
+            bool ok = diag_ok(calib + co.pe, 256);
+            for (int b = 0; b < depth && ok; ++b) {
+                const double* base = calib + (size_t)b * co.per_block;
+                ok = diag_ok(base + co.ln1, DIM) && diag_ok(base + co.att, inner) && diag_ok(base + co.ln2, DIM) && diag_ok(base + co.hid, HID);
+            }
+            if (!ok) return UITK_ERR_INVALID_ARG;
+        }
         const int ntask = 1 + 4 * depth;
         std::atomic<int> next{0};
         auto worker = [&]() {
@@ -589,20 +675,32 @@ int pack_image(const uitk_config* c, const uitk_weights* w, const double* calib,
                 const int b = (t - 1) / 4, which = (t - 1) % 4;
                 const FoldedBlock& fb = F.blocks[b];
                 const double* base = calib + (size_t)b * co.per_block;
+                if (which == 1) { cq_proj[b] = round_gptq(DIM, inner, [&](int r, int k) { return fb.proj_w[(size_t)r * inner + k]; }, prec, base + co.att); continue; }
+                if (grid8) {                                 // one of the three tasks does the block's three grid roundings
+                    if (which == 0) grid8_block(b, base, &co);
+                    continue;
+                }
                 if (which == 0) cq_qkv[b] = round_gptq(3 * inner, DIM, [&](int r, int k) { return fb.qkv_w[(size_t)r * DIM + k]; }, prec, base + co.ln1);
-                else if (which == 1) cq_proj[b] = round_gptq(DIM, inner, [&](int r, int k) { return fb.proj_w[(size_t)r * inner + k]; }, prec, base + co.att);
                 else if (which == 2) cq_fc1[b] = round_gptq(HID, DIM, [&](int r, int k) { return fb.fc1_w[(size_t)r * DIM + k]; }, prec, base + co.ln2);
                 else cq_fc2[b] = round_gptq(DIM, HID, [&](int r, int k) { return fb.fc2_w[(size_t)r * HID + k]; }, prec, base + co.hid);
             }
         };
         unsigned nth = std::thread::hardware_concurrency();
         nth = nth == 0 ? 4 : nth > 16 ? 16 : nth;
+        // no exception may cross the extern "C" boundary above: a thread that cannot be created (std::system_error) just means
+        // fewer workers -- this thread drains the task counter anyway; an allocation failure inside a task is reported as an error code
         std::vector<std::thread> pool;
-        for (unsigned i = 1; i < nth; ++i) pool.emplace_back(worker);
-        worker();
+        std::atomic<bool> failed{false};
+        auto guarded = [&]() { try { worker(); } catch (...) { failed.store(true); } };
+        try {
+            for (unsigned i = 1; i < nth; ++i) pool.emplace_back(guarded);
+        } catch (...) {}
+        guarded();
         for (auto& th : pool) th.join();
+        if (failed.load()) return UITK_ERR_INVALID_ARG;
     } else {
         pe_q = round_structured(DIM, 256, Wpe, prec, structured ? 16 : 1);
+        if (grid8) for (int b = 0; b < depth; ++b) grid8_block(b, nullptr, nullptr);      // fp8w without statistics: nearest on the grid
     }
     for (int i = 0; i < PE_HI_STAGES; ++i)
         for (int f = 0; f < STAGE_FRAGS; ++f) {
@@ -623,16 +721,17 @@ int pack_image(const uitk_config* c, const uitk_weights* w, const double* calib,
         float* bb = bias + (size_t)b * BIAS_FLOATS;
         // the folded weights; with calibration statistics: their calibrated 16-bit values (exactly representable, so the
         // conversions below reproduce them)
-        auto Wqkv = [&](int r, int k) { return calibrated ? op16_value(cq_qkv[b][(size_t)r * DIM + k], prec) : fb.qkv_w[(size_t)r * DIM + k]; };
+        auto Wqkv = [&](int r, int k) { return grid8 ? Q8_qkv[b][(size_t)r * DIM + k] : calibrated ? op16_value(cq_qkv[b][(size_t)r * DIM + k], prec) : fb.qkv_w[(size_t)r * DIM + k]; };
         auto Wproj = [&](int r, int k) { return calibrated ? op16_value(cq_proj[b][(size_t)r * inner + k], prec) : fb.proj_w[(size_t)r * inner + k]; };
-        auto Wfc1 = [&](int r, int k) { return calibrated ? op16_value(cq_fc1[b][(size_t)r * DIM + k], prec) : fb.fc1_w[(size_t)r * DIM + k]; };
+        auto Wfc1 = [&](int r, int k) { return grid8 ? Q8_fc1[b][(size_t)r * DIM + k] : calibrated ? op16_value(cq_fc1[b][(size_t)r * DIM + k], prec) : fb.fc1_w[(size_t)r * DIM + k]; };
         auto Wfc2_exact = [&](int r, int k) { return fb.fc2_w[(size_t)r * HID + k]; };
         // fc2 consumes ReLU / GELU outputs (a common non-negative level): structured rounding over each 32-wide k-step; the fp8
         // stream quantises the exact values itself
         std::vector<uint16_t> fc2_q;
-        if (calibrated) fc2_q = cq_fc2[b];
+        if (grid8) {}                                                    // (values on the e4m3 grid: Q8_fc2)
+        else if (calibrated && prec != UITK_PREC_FP8) fc2_q = cq_fc2[b];
         else if (prec != UITK_PREC_FP8) fc2_q = round_structured(DIM, HID, Wfc2_exact, prec, structured ? 32 : 1);
-        auto Wfc2 = [&](int r, int k) { return prec == UITK_PREC_FP8 ? Wfc2_exact(r, k) : op16_value(fc2_q[(size_t)r * HID + k], prec); };
+        auto Wfc2 = [&](int r, int k) { return grid8 ? Q8_fc2[b][(size_t)r * HID + k] : prec == UITK_PREC_FP8 ? Wfc2_exact(r, k) : op16_value(fc2_q[(size_t)r * HID + k], prec); };
         for (int r = 0; r < 3 * inner; ++r) bb[BIAS_QKV + r] = (float)fb.qkv_b[r];
         for (int r = 0; r < DIM; ++r) bb[b_proj + r] = (float)fb.proj_b[r];
         for (int r = 0; r < HID; ++r) bb[b_fc1 + r] = (float)fb.fc1_b[r];

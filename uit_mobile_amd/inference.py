@@ -47,7 +47,8 @@ def build_model(model_arg, device="cuda", precision=None):
             model = getattr(models, name)(outputdim=dump["outputlayer.1.weight"].shape[0], target_length=102,
                                           precision=precision)
             model.load_state_dict(dump, strict=True)
-    return model.to(device).eval()
+    # prepare(): the set-up a first forward would otherwise hide -- parameter image incl. weight calibration and its budget check (round 5)
+    return model.to(device).eval().prepare(device)
 
 
 def topk_lines(probs, label_maps, k):
@@ -74,8 +75,9 @@ def main(argv=None):
     ap.add_argument("-m", "--model", type=str, nargs="?", default="uit_xs",
                     metavar=f"Public Checkpoint [{','.join(PRETRAINED_CHECKPOINTS)}] or Experiment Path")
     ap.add_argument("-k", "--topk", type=int, default=3, help="Print top-k results")
-    ap.add_argument("--precision", default=None, choices=["f16c", "f16l6", "f16", "f16x2", "bf16", "fp8"],
-                    help="default: f16c, the parity mode of every factory (the fp16 kernels on weights with calibrated rounding)")
+    ap.add_argument("--precision", default=None, choices=["auto", "f16c", "f16l6", "f16", "f16x2", "bf16", "fp8", "fp8c", "fp8w"],
+                    help="default: auto, the parity mode of every factory (the fp16 kernels on weights with calibrated rounding, held to the "
+                         "library's deviation budget, else split weights)")
     args = ap.parse_args(argv)
     label_maps = load_label_map()
     model = build_model(args.model, precision=args.precision)

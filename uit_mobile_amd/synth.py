@@ -187,3 +187,121 @@ def make_kwargs_variant_state_dict(name="uit_xxxs", seed=0, scale=2.0, outputdim
         sd[f"blocks.{b}.ls1.gamma"] = (0.2 + rng.random(128)).astype(np.float32)
         sd[f"blocks.{b}.ls2.gamma"] = (0.2 + rng.random(128)).astype(np.float32)
     return sd
+
+
+# ---------------------------------------------------------------------------------------------- adversarial held-out signals
+# Round 5: the signal families a calibration fit on noise / tones / chirps / harmonic stacks leaves
+# unconstrained.  Every family is a function (rng, T) -> float64 [T] in full-scale units; adversarial_pcm_i16 draws `per_family`
+# members of each (a fixed seed = the fixed held-out set of the parity tests; the random search of the GPU tests walks other seeds).
+# Deliberately NOT the library's own acceptance clips (csrc/api.cpp: builtin_heldout_set) -- same kinds, other parameters.
+_LSB = 1.0 / 32768.0
+
+
+def _speechlike(rng, T, level):
+    t = np.arange(T) / 16000.0
+    f0 = rng.uniform(90.0, 260.0)
+    ph = 2 * np.pi * (f0 * t + rng.uniform(0.3, 1.5) * np.sin(2 * np.pi * rng.uniform(3.0, 7.0) * t))
+    formants = [(rng.uniform(300, 900), 250.0, 1.0), (rng.uniform(1100, 2500), 450.0, 0.6), (rng.uniform(2600, 3600), 650.0, 0.3)]
+    acc = np.zeros(T)
+    for h in range(1, 22):
+        fh = h * f0
+        if fh > 7600:
+            break
+        g = 0.1 + sum(a * np.exp(-0.5 * ((fh - c) / w) ** 2) for c, w, a in formants)
+        acc += g / h * np.sin(h * ph)
+    env = (0.5 + 0.5 * np.sin(2 * np.pi * rng.uniform(2.5, 5.5) * t + rng.uniform(0, 6.28))) ** 2
+    return level * env * acc / max(1e-9, np.abs(acc).max())
+
+
+def _family_impulse_train(rng, T):
+    x = np.zeros(T)
+    per = int(rng.integers(40, 900))
+    idx = np.arange(int(rng.integers(0, per)), T, per)
+    x[idx] = rng.uniform(0.2, 1.0) * np.where(np.arange(len(idx)) % 2 == 0, 1.0, rng.choice([-1.0, 1.0]))
+    return x
+
+
+def _family_single_click(rng, T):
+    x = np.zeros(T)
+    x[int(rng.integers(0, T))] = rng.choice([-1.0, 1.0]) * rng.choice([1.0, 0.5, 8 * _LSB, _LSB])
+    return x
+
+
+def _family_dc_offset(rng, T):
+    t = np.arange(T) / 16000.0
+    return rng.choice([-0.5, 0.5]) + rng.uniform(0.0, 0.3) * np.sin(2 * np.pi * rng.uniform(80, 4000) * t) + rng.uniform(0.0, 0.02) * rng.standard_normal(T)
+
+
+def _family_hard_clipped(rng, T):
+    t = np.arange(T) / 16000.0
+    return np.clip(rng.uniform(1.5, 8.0) * np.sin(2 * np.pi * rng.uniform(60, 2500) * t + rng.uniform(0, 6.28)), -1.0, 1.0)
+
+
+def _family_lsb_dither(rng, T):
+    return rng.integers(-1, 2, T) * _LSB * rng.choice([1, 1, 2])
+
+
+def _family_nyquist(rng, T):
+    a = rng.choice([0.5, 0.9, 0.05, _LSB, 3 * _LSB])
+    return a * np.where(np.arange(T) % 2 == 0, 1.0, -1.0) + (rng.integers(-1, 2, T) * _LSB if a < 1e-3 else 0.0)
+
+
+def _family_speechlike_quiet(rng, T):
+    return _speechlike(rng, T, 0.01)                                     # -40 dBFS
+
+
+def _family_speechlike(rng, T):
+    return _speechlike(rng, T, rng.uniform(0.1, 0.7))
+
+
+def _family_clipped_noise(rng, T):
+    return np.clip(rng.uniform(1.0, 4.0) * rng.standard_normal(T) * 0.5, -1.0, 1.0)
+
+
+def _family_square(rng, T):
+    t = np.arange(T) / 16000.0
+    return rng.uniform(0.2, 0.95) * np.sign(np.sin(2 * np.pi * rng.uniform(30, 1500) * t + 1e-3))
+
+
+def _family_silence_then_burst(rng, T):
+    x = np.zeros(T)
+    on = int(T * rng.uniform(0.55, 0.97))
+    x[on:] = rng.uniform(0.3, 0.95) * (rng.random(T - on) - 0.5) * 2
+    return x if rng.random() < 0.5 else x[::-1].copy()
+
+
+def _family_exp_sweep(rng, T):
+    t = np.arange(T) / 16000.0
+    f0, f1 = sorted(rng.uniform(20, 7900, 2))
+    k = np.log(max(f1, f0 + 1.0) / f0) / t[-1]
+    return rng.uniform(0.05, 0.9) * np.sin(2 * np.pi * f0 * (np.exp(k * t) - 1.0) / k)
+
+
+def _family_bin_edge_tones(rng, T):
+    t = np.arange(T) / 16000.0
+    k = int(rng.integers(2, 250))
+    return 0.45 * np.sin(2 * np.pi * (k + 0.5) * 31.25 * t) + 0.45 * np.sin(2 * np.pi * (k + 0.5 + rng.choice([0.5, 1.0, 8.0])) * 31.25 * t + rng.uniform(0, 6.28))
+
+
+def _family_resonances(rng, T):
+    t = np.arange(T) / 16000.0
+    tt = np.mod(t, rng.uniform(0.08, 0.4))
+    return 0.6 * sum(np.exp(-rng.uniform(5, 40) * tt) * np.sin(2 * np.pi * rng.uniform(150, 5000) * tt) / (r + 1) for r in range(3))
+
+
+ADVERSARIAL_FAMILIES = [("impulse_train", _family_impulse_train), ("single_click", _family_single_click), ("dc_offset", _family_dc_offset),
+                        ("hard_clipped", _family_hard_clipped), ("lsb_dither", _family_lsb_dither), ("nyquist", _family_nyquist),
+                        ("speechlike_-40dBFS", _family_speechlike_quiet), ("speechlike", _family_speechlike), ("clipped_noise", _family_clipped_noise),
+                        ("square", _family_square), ("silence_then_burst", _family_silence_then_burst), ("exp_sweep", _family_exp_sweep),
+                        ("bin_edge_tones", _family_bin_edge_tones), ("resonances", _family_resonances)]
+
+
+def adversarial_pcm_i16(seed=0, per_family=1, T=16000):
+    """-> (pcm int16 [len(ADVERSARIAL_FAMILIES) * per_family, T], names): `per_family` seeded members of every family, family-major."""
+    rng = np.random.default_rng(31000 + seed)
+    rows, names = [], []
+    for name, fn in ADVERSARIAL_FAMILIES:
+        for j in range(per_family):
+            rows.append(np.clip(np.round(np.asarray(fn(rng, T), np.float64) * 32768.0), -32768, 32767).astype(np.int16))
+            names.append(f"{name}#{seed}.{j}")
+    return np.stack(rows), names
