@@ -352,7 +352,8 @@ def supervise(ranks, world, worker_argv, env_for, setup_timeout, run_timeout, ga
         for th in threads:
             th.join(timeout=5)
         rec = {"gather": g, "seconds": round(time.perf_counter() - t_start, 1), "error": why,
-               "last_phase": {str(r): last[r][0] + (" (its own watchdog fired)" if last[r][2] else "") for r, _ in procs}}
+               "last_phase": {str(r): last[r][0] + (" (its own watchdog fired)" if last[r][2] else "") for r, _ in procs},
+               "last_phase_at_s": {str(r): round(last[r][1], 1) for r, _ in procs}}
         attempts.append(rec)
         if why is None:
             if is_printer:
@@ -711,7 +712,7 @@ def main():
             "max_abs_dprob": None if parity is None else parity.get("max_abs_dprob"), "parity_check": parity,
             # what the library's own acceptance check measured when it calibrated this handle's weights (logits, held-out clips of the
             # library, against the unrounded network; include/uitk.h: uitk_get_calib_check) -- None for the uncalibrated precisions
-            "calibration_check": (lambda r: None if r is None else {k: (v if isinstance(v, bool) else float(f"{v:.3e}")) for k, v in r.items()})(
+            "calibration_check": (lambda r: None if r is None else {k: (float(f"{v:.3e}") if isinstance(v, float) else v) for k, v in r.items()})(
                 reps[0].calibration_report() if args.precision in ("auto", "f16c") else None),
             "step_ms_median": round(float(np.median(period_ms)), 4) if period_ms else None,
             "rccl_ranks": dist.get_world_size() if world > 1 else 1, "rank_devices": devices,

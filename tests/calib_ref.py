@@ -2,7 +2,8 @@
 
 What the library measures (csrc/calibrate.hip, layout of include/uitk.h: uitk_calib_stats_doubles): the uncentred second moments
 E[x x^T] of the operand of every single-weight linear of the path -- the clamped init_bn(log-mel) patches (patch embed), the
-LayerNorm-1 output (qkv), the attention output (proj), the LayerNorm-2 output (fc1), the activation output (fc2) -- restated here
+LayerNorm-1 output (qkv), the attention output (proj), the LayerNorm-2 output (fc1), the activation output (fc2), and behind them the
+per-block MEAN of the LayerNorm-1 output (the operand centring of the attention, pack.cpp) -- restated here
 from the reference's arithmetic (models/uit.py:89-122, 181-248, 379-395) on the oracle's mel.  Used (1) on CPU to drive
 uitk_pack_weights_calibrated, (2) on the GPU box as the reference for uitk_get_calib_stats.
 """
@@ -37,7 +38,7 @@ def calib_stats(sd, pcm, depth, inner=32, act="relu", cls=False):
     g = lambda k: np.asarray(sd[k], np.float64)
     x = patches(sd, pcm)
     B = x.shape[0]
-    out = []
+    out, means = [], []
 
     def second_moment(a):
         a = _f16(a.reshape(-1, a.shape[-1]))
@@ -55,6 +56,7 @@ def calib_stats(sd, pcm, depth, inner=32, act="relu", cls=False):
         p = f"blocks.{b}."
         xn = _ln(tok, 1e-6)
         out.append(second_moment(xn))
+        means.append(xn.reshape(-1, 128).mean(0))                      # round 5: E[LayerNorm-1 output] per block (operand centring)
         qkv = (xn * g(p + "norm1.weight") + g(p + "norm1.bias")) @ g(p + "attn.qkv.weight").T + g(p + "attn.qkv.bias")
         qkv = qkv.reshape(B, N, 3, 2, hd).transpose(2, 0, 3, 1, 4)
         q, k, v = qkv[0], qkv[1], qkv[2]
@@ -69,4 +71,4 @@ def calib_stats(sd, pcm, depth, inner=32, act="relu", cls=False):
         h = np.maximum(h, 0.0) if act == "relu" else 0.5 * h * (1.0 + erf(h / np.sqrt(2.0)))
         out.append(second_moment(h))
         tok = tok + h @ g(p + "mlp.fc2.weight").T + g(p + "mlp.fc2.bias")
-    return np.concatenate(out)
+    return np.concatenate(out + means)

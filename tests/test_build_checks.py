@@ -58,3 +58,37 @@ def test_frontend_kernel_has_no_vector_spills(kernels):
     for inst in ("<false, true, false>", "<true, true, false>"):           # f32 / int16 input, patch layout: what uitk_frontend launches
         s = kernel_isa.summary(_find(kernels, f"void uitk::mel_frontend_kernel{inst}"))
         assert s["vgpr_spill"] == 0 and s["scratch_insts"] == 0 and s["mfma"] >= 52, s
+
+
+def _block_loop(k):
+    """the loop that holds most of the kernel's MFMAs (the epilogue's head-tile loop and the prologue are other loops)"""
+    mf = lambda lo, hi: sum(1 for a, t in k["insts"] if lo <= a <= hi and t.startswith("v_mfma"))
+    lo, hi = max(kernel_isa.loops(k["insts"]), key=lambda sp: (mf(*sp), sp[1] - sp[0]))
+    return lo, hi, mf(lo, hi)
+
+
+def test_every_encoder_instantiation_has_a_scratch_free_block_loop(kernels):
+    """Round 5: EVERY uit_encoder_kernel instantiation the product can launch -- short clips, GELU, full-width
+    attention, the poolings, bf16 / fp8 / f16x2 / f16l6, 4-wave workgroups: all of the library's encoder kernels -- keeps its block
+    loop free of scratch instructions (round 4 checked six full-clip shapes; the default family on SHORT clips had two in-loop
+    reloads, the short-clip GELU / full-attention builds 13-41).  What did it: the short-clip key masks became the score MFMAs'
+    start values rebuilt per block from a 48-bit scalar column mask (-14 vector registers), the GELU constants moved into scalar
+    register pairs, the register-starved builds issue their DMAs in the scalar-base form and re-derive lane indices at their uses."""
+    enc = {n: k for n, k in kernels.items() if n.startswith("void uitk::uit_encoder_kernel<")}
+    assert len(enc) >= 60, len(enc)
+    bad, spills = [], {}
+    for name, k in sorted(enc.items()):
+        lo, hi, n_mfma = _block_loop(k)
+        assert n_mfma >= 150, (name, n_mfma)
+        in_loop = [(hex(a), t) for a, t in k["insts"] if t.startswith("scratch_") and lo <= a <= hi]
+        if in_loop:
+            bad.append((name, in_loop))
+        s = kernel_isa.summary(k)
+        assert s["vgpr"] <= 256, name
+        spills[name.split("uit_encoder_kernel")[1].split("(")[0]] = s["vgpr_spill"]
+    assert not bad, bad
+    # vector spills outside the loop (prologue / epilogue): none in the 8-wave default family; bounded everywhere
+    worst = max(spills.items(), key=lambda kv: kv[1])
+    print("vector registers spilled outside the block loop:", {k: v for k, v in spills.items() if v})
+    assert spills["<0, 8, false, false, 0, 0, 0>"] == 0 and spills["<0, 8, true, false, 0, 0, 0>"] == 0
+    assert worst[1] <= 16, worst

@@ -217,9 +217,10 @@ def test_full_attention_factories_parity_mode_all_sweep_seeds(golden, name, act)
         worst_p = max(worst_p, float(np.abs(p.cpu().numpy() - r["probs"]).max()))
         del m
     print(f"f16c {name}: worst max|dlogit| {worst_l:.2e}, worst max|dprob| {worst_p:.2e} over {len(SWEEP_SEEDS)} checkpoints")
-    # the gate itself: one d4-GELU checkpoint (seed 206) sits at 9.1e-4 on the reference's recordings in f16c AND at 8.7e-4 on split
-    # weights (f16x2, profiles/round4/calib_check_d4gelu_gpu.log) -- that is the fp16 ACTIVATION floor of this family, not the weights
-    assert worst_l < TOL and worst_p < 2.5e-4
+    # round 4: one d4-GELU checkpoint (seed 206) sat at 9.7e-4 -- the fp16 ACTIVATION floor of this family (split weights: 8.7e-4).  Round 5:
+    # operand centring (the calibration mean of LayerNorm-1's output leaves the operand before it is rounded; k - E[k], v - E[v] by
+    # bias algebra) took that floor away: measured 6.1e-4 / 6.6e-4 / 5.7e-4 -- asserted at 8e-4
+    assert worst_l < 8e-4 and worst_p < 2.5e-4
 
 
 @pytest.mark.parametrize("name", ["uit_xs", "uit_xxxs"])
@@ -425,7 +426,8 @@ def test_golden_pooling_token(golden):
         m = m.to("cuda").eval()
         p, l = run(m, g["pcm"])
         dl, dp = np.abs(l - g[f"{tag}_logits"]).max(), np.abs(p - g[f"{tag}_probs"]).max()
-        print(f"pooling token {name} ({prec}): |logit|max {np.abs(g[f'{tag}_logits']).max():.1f} max|dlogit| {dl:.2e} max|dprob| {dp:.2e}")
+        print(f"pooling token {name} ({prec} -> {m.effective_precision()}): |logit|max {np.abs(g[f'{tag}_logits']).max():.1f} max|dlogit| {dl:.2e} max|dprob| {dp:.2e}; "
+              f"report {m.calibration_report()}")
         assert dl < TOL and dp < TOL
         if tag == "xxxs":
             p, l = run(m, g["xxxs_short_pcm"])
@@ -459,7 +461,7 @@ def test_full_attention_factory_pooling_at_trained_magnitudes(pooling):
                 worst = max(worst, float(np.abs(out[1].cpu().numpy().reshape(ref["logits"].shape) - ref["logits"]).max()))
         res[prec] = worst
     print(f"full attention + GELU, pooling {pooling}, trained-like: f16c {res['f16c']:.2e}, f16x2 {res['f16x2']:.2e}, f16 {res['f16']:.2e}")
-    assert res["f16x2"] < TOL and res["f16c"] < TOL
+    assert res["f16x2"] < 8e-4 and res["f16c"] < 8e-4         # round 4: f16c 8.2e-4 (token); round 5 with operand centring: 6.2e-4
 
 
 @pytest.mark.parametrize("avg", ["mean", "max"])
@@ -877,6 +879,8 @@ def test_calibration_statistics_match_the_restatement():
             g_, w_ = got[off:off + n * n], want[off:off + n * n]
             worst = max(worst, float(np.linalg.norm(g_ - w_) / np.linalg.norm(w_)))
             off += n * n
+        assert got.size - off == 4 * 128                                # round 5: the LayerNorm-1 means behind the second moments
+        worst = max(worst, float(np.abs(got[off:] - want[off:]).max() / np.abs(want[off:]).max()))
         print(f"{name}: worst relative Frobenius error of the 17 statistics matrices {worst:.2e}")
         assert worst < 2e-3
 
@@ -999,7 +1003,8 @@ def test_calibration_acceptance_check(golden):
         rep = mm.calibration_report()
         print(f"{name} pooling {pooling}: {rep}")
         assert rep is not None and 0 < rep["max_calibrated"] < 1e-3 and 0 < rep["max_nearest"] < 3e-3
-        assert (mm.get_option("weights_calibrated")[0] == 1) == rep["accepted"]
+        if not rep["escalated"]:
+            assert (mm.get_option("weights_calibrated")[0] == 1) == rep["accepted"]
 
 
 HELDOUT_MODELS = (("xs207", "uit_xs", 207, "bneck", "relu"), ("xxxs203", "uit_xxxs", 203, "bneck", "relu"),
@@ -1069,7 +1074,8 @@ def test_auto_escalates_instead_of_falling_back_to_nearest(golden):
     SABOTAGED calibration (calib_accept_pct = 1: the acceptance check refuses every calibrated image) no longer leaves the handle on
     the nearest image: the installed image is over the 6e-4 budget, 'auto' rebuilds the handle as 'f16l6', warns, reports it -- and
     the result is parity-grade, while an explicit 'f16c' under the same sabotage warns and answers bit for bit like 'f16'.  (c) A
-    budget nobody can meet escalates an accepted calibration too; the full-attention GELU family escalates to 'f16x2'.  (d) At init
+    budget nobody can meet makes 'auto' MEASURE the split-weight build too and keep whichever is better (here the calibrated image: the
+    rest is activation rounding); the full-attention GELU family escalates to 'f16x2'.  (d) At init
     scale a refused calibration is harmless (nearest is inside the budget): no escalation."""
     import warnings
     from uit_mobile_amd.models.uit import UitkParityWarning
@@ -1113,11 +1119,14 @@ def test_auto_escalates_instead_of_falling_back_to_nearest(golden):
         m = make("f16c", calib_accept_pct=1)
         e_c, p_c = err_of(m)
     assert m.effective_precision() == "f16" and torch.equal(p_c, p_near) and e_c == e_near
-    # (c)
-    with pytest.warns(UitkParityWarning):
+    # (c) a budget nobody can meet: the accepted calibrated image is over it, the split-weight build is measured on the same clips -- and,
+    # being no better than the calibrated image (what is left is activation rounding), is NOT taken: the report says so
+    with pytest.warns(UitkParityWarning, match="no better"):
         m = make("auto", calib_budget_e6=1)
         err_of(m)
-    assert m.effective_precision() == "f16l6" and m.calibration_report()["accepted"] and m.calibration_report()["escalated"]
+    rep = m.calibration_report()
+    assert m.effective_precision() == "f16c" and rep["accepted"] and not rep["escalated"] and rep["within_budget"] is False
+    assert rep["self_check_split"][0] >= rep["max_calibrated"]
     sdg = make_trained_like_state_dict("audio_transformer_h128_d4_m3", 206, attention="full")
     with pytest.warns(UitkParityWarning, match="f16x2"):
         m = make("auto", models.audio_transformer_h128_d4_m3, {k: torch.from_numpy(np.asarray(v)) for k, v in sdg.items()}, calib_accept_pct=1)
@@ -1773,8 +1782,11 @@ def test_bench_watchdog_falls_back_to_rccl_when_the_peer_self_test_stalls():
     import time
     from pathlib import Path
     root = Path(__file__).resolve().parents[1]
+    # (uit_xxxs in precision f16: no calibration, a 4-block pack -- what is tested here is the watchdog, and eight ranks that share one
+    # GPU and one host take long enough over their set-up as it is)
     cmd = [sys.executable, str(root / "bench.py"), "--gpus", "8", "--steps", "4", "--warmup", "2", "--batch-per-gpu", "256", "--backend", "gloo",
-           "--all-ranks-on-device0", "--gather", "auto", "--inject-stall", "peer_gather:3", "--setup-timeout", "75", "--run-timeout", "120"]
+           "--model", "uit_xxxs", "--precision", "f16", "--all-ranks-on-device0", "--gather", "auto", "--inject-stall", "peer_gather:3",
+           "--setup-timeout", "100", "--run-timeout", "120"]
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
     t0 = time.time()
     out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=str(root), env=env)
@@ -1785,6 +1797,7 @@ def test_bench_watchdog_falls_back_to_rccl_when_the_peer_self_test_stalls():
     d = json.loads(lines[0])
     att = d["watchdog"]["attempts"]
     assert [a["gather"] for a in att] == ["auto", "rccl"] and att[0]["error"] and att[1]["error"] is None
-    assert att[0]["last_phase"]["3"].startswith("peer_gather") and att[0]["seconds"] < 75 + 25
+    print("attempts:", att)
+    assert att[0]["last_phase"]["3"].startswith("peer_gather") and att[0]["seconds"] < 100 + 25
     assert d["gather"] == "rccl" and d["n_gpus"] == 8 and d["value"] > 0 and d["max_abs_dprob"] < TOL
-    assert len(d["rank_devices"]) == 8 and all(r["effective_precision"] == "f16c" for r in d["rank_devices"])
+    assert len(d["rank_devices"]) == 8 and all(r["effective_precision"] == "f16" for r in d["rank_devices"])

@@ -23,6 +23,9 @@ using namespace uitk;
 static thread_local std::string g_err;
 // precisions whose weights are ONE term each (calibrated rounding applies); fp8w runs the f16 kernels on weights of the e4m3 grid
 static bool single_weight_precision(int p) { return p == UITK_PREC_F16 || p == UITK_PREC_BF16 || p == UITK_PREC_FP8 || p == UITK_PREC_FP8W; }
+// uitk_calibrate_weights also serves the split-weight precisions: their weights are not re-rounded, but the statistics install the
+// operand centring of the attention (pack.cpp) -- what an escalated 'auto' handle keeps of its calibration
+static bool calibratable_precision(int p) { return single_weight_precision(p) || p == UITK_PREC_F16X2 || p == UITK_PREC_F16L6; }
 static int kernel_precision(int p) { return p == UITK_PREC_FP8W ? UITK_PREC_F16 : p; }
 static int fail(int code, const std::string& msg) { g_err = msg; return code; }
 #define HIP_TRY(expr)                                                                                   \
@@ -103,8 +106,8 @@ int uitk_pack_weights_calibrated(const uitk_config* cfg, const uitk_weights* w, 
     if (!cfg || !w || !needed || !stats) return fail(UITK_ERR_INVALID_ARG, "null argument");
     const char* why = "";
     if (int rc = validate_config(cfg, &why)) return fail(rc, why);
-    if (!single_weight_precision(cfg->precision))
-        return fail(UITK_ERR_UNSUPPORTED, "calibrated rounding applies to the single-weight precisions (f16, bf16, fp8, fp8w)");
+    if (!calibratable_precision(cfg->precision))
+        return fail(UITK_ERR_UNSUPPORTED, "unknown precision");
     std::vector<char> img;
     ImageHeader h;
     if (int rc = pack_image(cfg, w, stats, &img, &h)) return fail(rc, "pack failed (statistics with a non-finite / negative diagonal, or out of memory)");
@@ -127,7 +130,7 @@ int uitk_create(const uitk_config* cfg, const uitk_weights* w, uitk_model** out)
     m->cfg = *cfg;
     std::vector<char> img;
     if (int rc = pack_image(cfg, w, nullptr, &img, &m->hdr)) { delete m; return fail(rc, "pack failed"); }
-    if (single_weight_precision(cfg->precision)) m->img_nearest = img;
+    m->img_nearest = img;
     hipDeviceProp_t prop;
     if (hipGetDevice(&m->device) != hipSuccess || hipGetDeviceProperties(&prop, m->device) != hipSuccess) {
         delete m; return fail(UITK_ERR_NO_DEVICE, "cannot query HIP device");
@@ -238,6 +241,9 @@ static std::mutex g_fe_mu;
 static std::map<std::tuple<int, int, int>, int> g_fe_split;      // (device, workgroups per CU, bucket) -> per-mille share
 
 static bool fe_split_key(const uitk_model* m, int64_t B, int64_t T, std::tuple<int, int, int>* key) {
+    // (the split is MEASURED on at most 8192 clips: larger batches share that measurement, and its key -- ADVICE r4: the key used to be
+    // derived from the full batch while the tuning ran on the capped one)
+    if (B > 8192) B = 8192;
     const int nF = uitk_num_frames(m, T), rem = nF & 15;
     const int64_t npass = B * (int64_t)(nF >> 4) + (rem ? (B + 16 / rem - 1) / (16 / rem) : 0);
     const int wg = m->fe_wg_per_cu > 0 ? m->fe_wg_per_cu : 2;
@@ -852,8 +858,8 @@ int uitk_self_check(uitk_model* m, const uitk_weights* w, void* stream, float* o
 
 int uitk_calibrate_weights(uitk_model* m, const uitk_weights* w, const void* pcm, int in_dtype, int64_t B, int64_t T, void* stream) {
     if (!m || !w) return fail(UITK_ERR_INVALID_ARG, "null argument");
-    if (!single_weight_precision(m->cfg.precision))
-        return fail(UITK_ERR_UNSUPPORTED, "calibrated rounding applies to the single-weight precisions (f16, bf16, fp8, fp8w)");
+    if (!calibratable_precision(m->cfg.precision))
+        return fail(UITK_ERR_UNSUPPORTED, "unknown precision");
     hipStream_t s = (hipStream_t)stream;
     {                                                            // a pack-time operation (allocates, synchronises): never inside a capture
         hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
@@ -889,7 +895,7 @@ int uitk_calibrate_weights(uitk_model* m, const uitk_weights* w, const void* pcm
     const size_t n_stats = calib_stats_doubles(&m->cfg);
     if (int rc = naive_net_bind(m, &nn, rows, n_stats)) return rc;
     CalibArgs& a = nn.a;
-    a.off_pe = co.pe; a.off_ln1 = co.ln1; a.off_att = co.att; a.off_ln2 = co.ln2; a.off_hid = co.hid; a.per_block = co.per_block;
+    a.off_pe = co.pe; a.off_ln1 = co.ln1; a.off_att = co.att; a.off_ln2 = co.ln2; a.off_hid = co.hid; a.per_block = co.per_block; a.off_mu1 = co.mu1;
     HIP_TRY(launch_calibration(a, s));
     std::vector<float> stats_f(n_stats);
     HIP_TRY(hipMemcpyAsync(stats_f.data(), a.stats, n_stats * 4, hipMemcpyDeviceToHost, s));

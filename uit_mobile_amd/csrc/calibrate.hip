@@ -149,6 +149,18 @@ __global__ void cal_gram_kernel(const float* __restrict__ X, float* __restrict__
     G[(int64_t)(i0 + ty) * K + j0 + tx] = acc * scale;
 }
 
+// mu[k] = scale * sum_m X[m][k]  (the fp32 values, not the rounded operands: what the kernel subtracts BEFORE it rounds)
+__global__ void cal_colmean_kernel(const float* __restrict__ X, float* __restrict__ mu, int M, int K, float scale) {
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= K) return;
+    float acc = 0.f, comp = 0.f;
+    for (int m = 0; m < M; ++m) {                                           // Kahan: M is up to ~25 000 rows
+        const float y = X[(int64_t)m * K + k] - comp, t = acc + y;
+        comp = (t - acc) - y; acc = t;
+    }
+    mu[k] = acc * scale;
+}
+
 static hipError_t linear(const float* X, const float* W, const float* b, float* Y, int M, int K, int O, int act, int accumulate, hipStream_t s) {
     hipLaunchKernelGGL(cal_linear_kernel, dim3((O + TS - 1) / TS, (M + TS - 1) / TS), dim3(TS, TS), 0, s, X, W, b, Y, M, K, O, act, accumulate);
     return hipGetLastError();
@@ -175,6 +187,10 @@ hipError_t launch_calibration(const CalibArgs& a, hipStream_t s) {
         hipLaunchKernelGGL(cal_layernorm_kernel, dim3((M + 3) / 4), dim3(256), 0, s, a.R, a.Xn, M, 1e-6f);
         CAL_TRY(hipGetLastError());
         if (st) CAL_TRY(gram(a.Xn, st + a.off_ln1, M, DIM, inv_m, a.op_bf16, s));
+        if (st) {
+            hipLaunchKernelGGL(cal_colmean_kernel, dim3(DIM / 64), dim3(64), 0, s, a.Xn, a.stats + a.off_mu1 + (size_t)b * DIM, M, DIM, inv_m);
+            CAL_TRY(hipGetLastError());
+        }
         CAL_TRY(linear(a.Xn, wb + a.o_qkv_w, wb + a.o_qkv_b, a.QKV, M, DIM, 3 * inner, 0, 0, s));
         hipLaunchKernelGGL(cal_attention_kernel, dim3(a.rows, 2), dim3(32), 0, s, a.QKV, a.O, a.ntok, inner);
         CAL_TRY(hipGetLastError());

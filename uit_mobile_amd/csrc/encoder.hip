@@ -133,22 +133,30 @@ constexpr int ENC_LDS_W8 = ENC_LDS_SPLIT_PE + LDS_PEB;        // 8-wave workgrou
 // The stream is padded with PREFETCH dummy stages (pack.cpp) so the issue and the vmcnt immediate never vary.
 // (The scalar-base asm form of the DMA -- dma_b128 below, one lane-offset VGPR instead of a v_lshl_add_u64 + VGPR pair per piece --
 // was measured here too in round 4: 36 VALU instructions less per block, but an s_mov m0 + s_nop per piece more, same time.)
-template <int WAVES>
+__device__ __forceinline__ int lane_id_now();
+__device__ __forceinline__ void dma_b128(const char* gsrc, unsigned lane16, char* ldst);
+// SB (round 5): the scalar-base form of the DMA (dma_b128: uniform 64-bit base in scalar registers + ONE 32-bit lane offset, re-derived
+// from v_mbcnt at the point of use) for the instantiations that have no vector register to spare -- GELU / full-width attention /
+// pooling 'dm': the builtin's per-lane 64-bit addresses were the values those kernels spilled and RELOADED inside the block loop.
+template <int WAVES, bool SB = false>
 __device__ __forceinline__ void ring_issue(const char* wstream, char* ring, int stage, int wave, int lane) {
     constexpr int PER_WAVE = STAGE_FRAGS / WAVES;
     const char* src = wstream + (size_t)stage * STAGE_BYTES;
     char* dst = ring + (stage & (RING_SLOTS - 1)) * STAGE_BYTES;
+    unsigned lane16 = 0;
+    if constexpr (SB) lane16 = (unsigned)lane_id_now() * 16u;
 #pragma unroll
     for (int i = 0; i < PER_WAVE; ++i) {
         const int piece = wave * PER_WAVE + i;
-        __builtin_amdgcn_global_load_lds(GPTR(src + piece * FRAG_BYTES + lane * 16), LPTR(dst + piece * FRAG_BYTES), 16, 0, 0);
+        if constexpr (SB) dma_b128(src + piece * FRAG_BYTES, lane16, dst + piece * FRAG_BYTES);
+        else __builtin_amdgcn_global_load_lds(GPTR(src + piece * FRAG_BYTES + lane * 16), LPTR(dst + piece * FRAG_BYTES), 16, 0, 0);
     }
 }
 
-template <int WAVES>
+template <int WAVES, bool SB = false>
 __device__ __forceinline__ void ring_step(const char* wstream, char* ring, int t, int wave, int lane) {
     constexpr int PER_WAVE = STAGE_FRAGS / WAVES;
-    ring_issue<WAVES>(wstream, ring, t + PREFETCH, wave, lane);
+    ring_issue<WAVES, SB>(wstream, ring, t + PREFETCH, wave, lane);
     // all but the PREFETCH*PER_WAVE youngest LDS-DMAs (stages t+1 .. t+PREFETCH) have landed => this wave's share of stage t
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PREFETCH * PER_WAVE) : "memory");
     __builtin_amdgcn_s_barrier();
@@ -180,7 +188,7 @@ __device__ __forceinline__ void bias_issue(const float* bias, char* breg, int bl
     char* dst = breg + (blk & 1) * BIAS_FLOATS * 4 + wave * PER_WAVE_BYTES;
 #pragma unroll
     for (int i = 0; i < N; ++i) {
-        if constexpr (SCALAR_BASE) dma_b32(src + i * 256, (unsigned)lane * 4u, dst + i * 256);
+        if constexpr (SCALAR_BASE) dma_b32(src + i * 256, (unsigned)lane_id_now() * 4u, dst + i * 256);
         else __builtin_amdgcn_global_load_lds(GPTR(src + i * 256 + lane * 4), LPTR(dst + i * 256), 4, 0, 0);
     }
 }
@@ -269,8 +277,26 @@ __device__ __forceinline__ void ln_stats(const f4 (&R)[8][3], int ct, float eps,
 }
 
 // LN + conversion to the MFMA operand of the next linear (its affine is folded into that linear by pack.cpp).
-template <int PREC, int NCT = 3>                     // NCT: live column tiles (2 for pooling 'token': one clip per wave)
-__device__ __forceinline__ void layernorm_to_operand(const f4 (&R)[8][3], float eps, typename Op<PREC>::v8 (&X)[4][3]) {
+// CEN (round 5): operand centring -- the calibration mean mu of this LayerNorm's output is subtracted BEFORE the rounding (negmu = the
+// block's -mu[128] in LDS; pack.cpp adds W mu to the linear's bias: exact for any mu).  A massive-activation channel is nearly the same
+// in every token of every clip: rounded as it is, its fp16 error (half a unit of 2^-7 at |x| ~ 10) is the same in every token and
+// survives the pooling; rounded as x - mu it is 10-100x smaller.  One packed fma instead of one packed mul per register pair.
+template <int PREC, int NCT = 3, bool CEN = false>                     // NCT: live column tiles (2 for pooling 'token': one clip per wave)
+__device__ __forceinline__ void layernorm_to_operand(const f4 (&R)[8][3], float eps, typename Op<PREC>::v8 (&X)[4][3], const float* negmu = nullptr) {
+    if constexpr (CEN) {
+        float rstd[3];
+#pragma unroll
+        for (int ct = 0; ct < NCT; ++ct) { float mean; ln_stats(R, ct, eps, mean, rstd[ct]); }
+        const float* nm = negmu + 4 * (lane_id_now() >> 4);
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const f4 m0 = *(const f4*)(nm + 32 * s), m1 = *(const f4*)(nm + 32 * s + 16);
+#pragma unroll
+            for (int ct = 0; ct < NCT; ++ct)
+                X[s][ct] = Op<PREC>::pack8(__builtin_elementwise_fma(R[2 * s][ct], splat(rstd[ct]), m0), __builtin_elementwise_fma(R[2 * s + 1][ct], splat(rstd[ct]), m1));
+        }
+        return;
+    }
 #pragma unroll
     for (int ct = 0; ct < NCT; ++ct) {
         float mean, rstd;
@@ -297,10 +323,10 @@ __device__ constexpr int TI[7] = {0, 0, 1, 1, 1, 2, 2};
 
 // Attention of one block on 16x16x16 MFMAs (K = head_dim 16 exactly) + the proj linear into the residual stream R.
 //   Qh/Kh[h][ct]: q, k of head h as C/D tiles packed to 16 bits (feature-major);  Vh[ct][h]: V token-major (A operand of P.V)
-//   tvalid / pmask: see the kernel;  proj: the eight 1 KiB proj fragments (K = 32 = (head, d));  bias: this block's bias table
+//   tvalid / kinit: see the kernel;  proj: the eight 1 KiB proj fragments (K = 32 = (head, d));  bias: this block's bias table
 template <class OP, bool SHORT, bool X2 = false, int NCT = 3>
 __device__ __forceinline__ void attention_proj(f4 (&R)[8][3], const typename OP::v4 (&Qh)[2][3], const typename OP::v4 (&Kh)[2][3],
-                                               const typename OP::v4 (&Vh)[3][2], const bool (&tvalid)[7], const u2 (&pmask)[7],
+                                               const typename OP::v4 (&Vh)[3][2], const bool (&tvalid)[7], const f4 (&kinit)[3],
                                                const char* proj, const float* bias, int lane, int g) {
     using v8 = typename OP::v8;
     using v4 = typename OP::v4;
@@ -311,22 +337,25 @@ __device__ __forceinline__ void attention_proj(f4 (&R)[8][3], const typename OP:
     f4 S[2][7];
     float tm[2][7], mx[2][3];
 #pragma unroll
-    for (int i = 0; i < N7; ++i)
+    for (int i = 0; i < N7; ++i) {
+        // SHORT (padding / dead key columns exist; round 5): the score accumulators START from 0 for a valid key of the query's clip and
+        // from -1e30 for every other one (kinit: per key tile, rebuilt per block from a 48-bit column mask in scalar registers -- see the
+        // kernel), so the masked scores never win a maximum and their exponentials are exactly 0: no per-element mask registers alive
+        // through the block, no select in the softmax (the valid entries see 0 + the same products: the same bits as before)
+        f4 init = splat(0.f);
+        if constexpr (SHORT) {
+            init = kinit[TJ[i]];
+            if (NCT == 3 && i != 0 && i != 6) init = tvalid[i] ? init : splat(-1e30f);
+        }
 #pragma unroll
-        for (int h = 0; h < 2; ++h) S[h][i] = OP::mfma16(Kh[h][TJ[i]], Qh[h][TI[i]], splat(0.f));
+        for (int h = 0; h < 2; ++h) S[h][i] = OP::mfma16(Kh[h][TJ[i]], Qh[h][TI[i]], init);
+    }
 #pragma unroll
     for (int i = 0; i < N7; ++i)
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
-            if constexpr (SHORT) {
-                f4 sv;
-#pragma unroll
-                for (int r = 0; r < 4; ++r) sv[r] = ((r < 2 ? pmask[i][0] : pmask[i][1]) >> (16 * (r & 1))) & 1u ? S[h][i][r] : -INFINITY;
-                tm[h][i] = hmax(sv);
-            } else {
-                const float hm = hmax(S[h][i]);                        // unconditional + select: the conditional form became a divergent branch
-                tm[h][i] = tvalid[i] ? hm : -INFINITY;
-            }
+            const float hm = hmax(S[h][i]);                            // unconditional + select: the conditional form became a divergent branch
+            tm[h][i] = (SHORT || tvalid[i]) ? hm : -INFINITY;
         }
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
@@ -350,7 +379,7 @@ __device__ __forceinline__ void attention_proj(f4 (&R)[8][3], const typename OP:
             // off-diagonal tiles of full clips: a lane's four keys are all its query's clip's or all foreign, so the mask is the tile
             // validity -- a wave mask in scalar registers, where the per-element masks are 10 vector registers alive through the MLP loop
             const u2 pk = __builtin_bit_cast(u2, OP::pack4(p));
-            const u2 bits = all_valid ? pk : (SHORT ? (pk & pmask[i]) : (tvalid[i] ? pk : u2{0u, 0u}));
+            const u2 bits = (all_valid || SHORT) ? pk : (tvalid[i] ? pk : u2{0u, 0u});     // (SHORT: a masked key's exponential is already 0)
             const v4 Pm = __builtin_bit_cast(v4, bits);
             // the first tile of a query tile starts its accumulators from the literal 0 (an inline constant of the MFMA: no v_mov per register)
             const bool first = i == 0 || i == 2 || i == 5;
@@ -448,20 +477,46 @@ __device__ __forceinline__ float gelu1(float x) {
 }
 // The same on register pairs (round 4): the polynomial, the products and the final combination are packed-f32 instructions (two
 // elements each); 1 + erf(x / sqrt 2) = 2 - y for x >= 0 and y for x < 0 folds into  gelu = 0.5 (x + |x| - |x| y)  -- no select.
+// Round 5: a packed-f32 instruction cannot take a literal, and the compiler kept the nine constant PAIRS in vector registers across
+// the MLP loop -- the registers the GELU instantiations spilled inside the block loop (a scratch reload drains the weight ring).  The
+// constants now live in SCALAR register pairs (both halves the constant; one scalar operand per instruction is allowed) and the
+// instructions that take them are written out; 0.70710678 is folded into its two users (k1 = 0.3275911 / sqrt 2, k2 = -log2(e) / 2),
+// so z = |x| / sqrt 2 is never formed.  Every asm operand is a VALU result (never an MFMA accumulator: DESIGN_LOG.md 2.2).
 typedef float f2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned long long sc2(float c) {                   // {c, c} as a 64-bit scalar
+    const unsigned long long b = __float_as_uint(c);
+    return b | (b << 32);
+}
+__device__ __forceinline__ f2 pk_fma_vvs(f2 a, f2 b, unsigned long long c) {   // a * b + c
+    f2 r;
+    asm("v_pk_fma_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "s"(c));
+    return r;
+}
+__device__ __forceinline__ f2 pk_mul_vs(f2 a, unsigned long long c) {          // a * c
+    f2 r;
+    asm("v_pk_mul_f32 %0, %1, %2" : "=v"(r) : "v"(a), "s"(c));
+    return r;
+}
+// the same for an operand that a TRANSCENDENTAL instruction (v_rcp_f32) has just written: gfx950 wants a wait state between such a
+// write and a VALU read of it, the compiler's hazard recogniser pads only the reads it can see -- not an asm operand -- so the wait
+// state is part of the statement (without it: stale reciprocals in some lanes, GELU outputs off by 1e-2; round 5, first GPU run)
+__device__ __forceinline__ f2 pk_mul_vs_after_trans(f2 a, unsigned long long c) {
+    f2 r;
+    asm("s_nop 1\n\tv_pk_mul_f32 %0, %1, %2" : "=v"(r) : "v"(a), "s"(c));
+    return r;
+}
 __device__ __forceinline__ f2 gelu2(f2 x) {
-    const f2 a = f2{fabsf(x[0]), fabsf(x[1])};
-    const f2 z = a * f2{0.70710678118654752f, 0.70710678118654752f};
-    const f2 d = __builtin_elementwise_fma(f2{0.3275911f, 0.3275911f}, z, f2{1.0f, 1.0f});
+    const f2 a = f2{fabsf(x[0]), fabsf(x[1])};                                  // (compiler-visible first uses of the accumulators)
+    const f2 xh = x * f2{0.5f, 0.5f};
+    const f2 d = pk_mul_vs(a, sc2(0.3275911f * 0.70710678118654752f)) + f2{1.0f, 1.0f};              // 1 + p z
     const f2 t = f2{__builtin_amdgcn_rcpf(d[0]), __builtin_amdgcn_rcpf(d[1])};
-    f2 p = __builtin_elementwise_fma(f2{1.061405429f, 1.061405429f}, t, f2{-1.453152027f, -1.453152027f});
-    p = __builtin_elementwise_fma(p, t, f2{1.421413741f, 1.421413741f});
-    p = __builtin_elementwise_fma(p, t, f2{-0.284496736f, -0.284496736f});
-    p = __builtin_elementwise_fma(p, t, f2{0.254829592f, 0.254829592f});
-    const f2 e = (z * f2{-1.4426950408889634f, -1.4426950408889634f}) * z;
+    f2 p = pk_fma_vvs(pk_mul_vs_after_trans(t, sc2(1.061405429f)), f2{1.0f, 1.0f}, sc2(-1.453152027f));
+    p = pk_fma_vvs(p, t, sc2(1.421413741f));
+    p = pk_fma_vvs(p, t, sc2(-0.284496736f));
+    p = pk_fma_vvs(p, t, sc2(0.254829592f));
+    const f2 e = pk_mul_vs(a, sc2(-0.5f * 1.4426950408889634f)) * a;           // -log2(e) z^2, z = |x| / sqrt 2
     const f2 y = (p * t) * f2{__builtin_amdgcn_exp2f(e[0]), __builtin_amdgcn_exp2f(e[1])};            // 1 - erf(z)
-    const f2 h = f2{0.5f, 0.5f};
-    return __builtin_elementwise_fma(a * h, f2{1.0f, 1.0f} - y, x * h);                               // 0.5 x + 0.5 |x| (1 - y)
+    return __builtin_elementwise_fma(a * f2{0.5f, 0.5f}, f2{1.0f, 1.0f} - y, xh);                     // 0.5 x + 0.5 |x| (1 - y)
 }
 __device__ __forceinline__ f4 gelu4(f4 x) {
     const f2 lo = gelu2(f2{x[0], x[1]}), hi = gelu2(f2{x[2], x[3]});
@@ -569,6 +624,11 @@ __global__ __launch_bounds__(WAVES * 64, 2) void uit_encoder_kernel(EncoderArgs 
     extern __shared__ __attribute__((aligned(16))) char smem[];
     // precision f16l6: four 32 KiB ring slots (the low-order patch-embed weights use the upper half of the ring during the prologue)
     constexpr bool L6 = PREC == 4;
+    // instantiations without a vector register to spare issue their weight / bias DMAs in the scalar-base form (see ring_issue)
+    constexpr bool SB = PREC <= 1 && (ATT != 0 || ACT != 0 || POOL == 1);
+    // operand centring of LayerNorm-1 (uitk_dev.h: operand_centring; pack.cpp folds the same way): -mu[128] of a block in its bias table
+    constexpr bool CEN = operand_centring(ATT, ACT, POOL, PREC);
+    constexpr int NEGMU_AT = ATT ? BIASF_QKV + 128 : BIAS_NEGMU;
     constexpr int RING_BYTES = L6 ? 4 * L6_SLOT_BYTES : LDS_RING;
     static_assert(!L6 || (WAVES == 8 && RING_BYTES + LDS_BIAS + LDS_ZBUF + LDS_PEB <= ENC_LDS_W8), "f16l6: 8-wave workgroups, LDS budget");
     char* ring = smem;
@@ -622,9 +682,9 @@ __global__ __launch_bounds__(WAVES * 64, 2) void uit_encoder_kernel(EncoderArgs 
     // The patch operands come from HBM (the slowest trip of the prologue): their loads are issued FIRST, the L2-resident weight /
     // table DMAs behind them.
     // ---- kick the weight stream: block-0 biases + the whole patch-embed weight set (4 stages = the whole ring)
-    if (a.depth > 0) bias_issue<WAVES>(a.bias, breg, 0, wave, lane);
+    if (a.depth > 0) bias_issue<WAVES, SB>(a.bias, breg, 0, wave, lane);
 #pragma unroll
-    for (int i = 0; i < PE_HI_STAGES; ++i) ring_issue<WAVES>(a.wstream, ring, i, wave, lane);
+    for (int i = 0; i < PE_HI_STAGES; ++i) ring_issue<WAVES, SB>(a.wstream, ring, i, wave, lane);
     // split patch embed (W = hi + lo): the low-order fragments go to their own 64 KiB behind the ring; 8-wave workgroups only
     // (a 4-wave workgroup shares its CU's LDS with a second one and runs the single-term patch embed)
     constexpr bool SPLIT_PE = WAVES == 8;
@@ -667,14 +727,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void uit_encoder_kernel(EncoderArgs 
     };
     TSTAMP(12);                                                           // weight-stream kick
 
-    // accumulator init (conv bias + positional embeddings) rides the same memory round trip
     f4 R[8][3];
-    if constexpr (!PEB_LDS) {
-#pragma unroll
-        for (int ct = 0; ct < NCT; ++ct)
-#pragma unroll
-            for (int ft = 0; ft < 8; ++ft) R[ft][ct] = *(const f4*)(a.pe_bias + (patch_[ct] ? tk_[ct] : NTOK) * DIM + 16 * ft + 4 * g);   // row 24: cls
-    }
     // init_bn scale / shift of mel bin `lane`: two coalesced dword loads per wave; the 24 (token tile, k-step) clamp
     // thresholds of a lane are then handed out through a wave-private 512-byte LDS table (zbuf is idle until the head)
     const float my_sc = a.bn_sc[lane], my_sh = a.bn_sh[lane];
@@ -735,6 +788,16 @@ __global__ __launch_bounds__(WAVES * 64, 2) void uit_encoder_kernel(EncoderArgs 
         }
     }
     }
+    // accumulator init (conv bias + positional embeddings), 4-wave workgroups (no LDS copy of the table): loaded HERE, behind the clamp
+    // -- issued up front (round 4) the 96 accumulator registers were alive next to the 96 operand registers and the clamp's temporaries,
+    // and the 4-wave instantiations spilled 57-68 vector registers around the prologue (36-57 scratch instructions, each a memory round
+    // trip of its own); the table is L2-resident and its trip overlaps the wait for the patch-embed weights below
+    if constexpr (!PEB_LDS) {
+#pragma unroll
+        for (int ct = 0; ct < NCT; ++ct)
+#pragma unroll
+            for (int ft = 0; ft < 8; ++ft) R[ft][ct] = *(const f4*)(a.pe_bias + (patch_[ct] ? tk_[ct] : NTOK) * DIM + 16 * ft + 4 * g);   // row 24: cls
+    }
     TSTAMP(14);                                                           // clamp (+ its init_bn table loads)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                      // patch-embed weights landed ...
     __builtin_amdgcn_s_barrier();                                         // ... for every wave
@@ -768,6 +831,9 @@ __global__ __launch_bounds__(WAVES * 64, 2) void uit_encoder_kernel(EncoderArgs 
         }
     }
     TSTAMP(10);                                                           // patch-embed MFMAs
+#if defined(UITK_LAB) && defined(ENC_DYNPRIO)
+    if (tid < 4) ((unsigned*)(zbuf + 4096))[tid] = 0u;                    // the per-SIMD arrival counters of the lab variant
+#endif
     __builtin_amdgcn_s_barrier();                                         // every wave is done with the PE weights
     asm volatile("" ::: "memory");
     if constexpr (L6) {
@@ -776,7 +842,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void uit_encoder_kernel(EncoderArgs 
         l6_issue<1>(w0 + L6_QK_BYTES, ring + L6_SLOT_BYTES, wave, lane);
     } else {
 #pragma unroll
-        for (int i = 0; i < PREFETCH; ++i) ring_issue<WAVES>(a.wstream, ring, PE_STAGES + i, wave, lane);
+        for (int i = 0; i < PREFETCH; ++i) ring_issue<WAVES, SB>(a.wstream, ring, PE_STAGES + i, wave, lane);
     }
 
     auto dbg_store = [&](int stage) {                      // (debug path: recomputes its token map from v_mbcnt -- volatile, so that no
@@ -797,28 +863,38 @@ __global__ __launch_bounds__(WAVES * 64, 2) void uit_encoder_kernel(EncoderArgs 
 
     // ---- attention masks (constant over blocks).  Score tiles (jt,it): S^T[j = 16jt+4g+r][i = 16it+c].
     //   tvalid[i]: this lane's 4 keys of tile i belong to the query's clip (uniform over r: 24 = 16 + 8 and the
-    //              key index is 4g+r) -> used for the row max;
-    //   pmask[i] : per-element AND mask on the packed probabilities (clip membership AND key time-patch < nt).
+    //              key index is 4g+r): wave masks in scalar registers;
+    //   colmask  : (PERKEY: short clips / pooling 'token') bit j = key column j of the wave is a real token -- a patch token with
+    //              time patch < nt, or the cls token -- as ONE 48-bit scalar.  Round 5: the per-element probability masks (14 vector
+    //              registers alive through every block: what the short-clip instantiations spilled inside the block loop) are gone;
+    //              a block rebuilds, from colmask and its lane id, the score accumulators' START values kinit[key tile][r] = 0 for a
+    //              real key, -1e30 for padding (make_kinit; attention_proj / full_attention start their score MFMAs from them).
     bool tvalid[7];
-    u2 pmask[7];
 #pragma unroll
     for (int i = 0; i < N7; ++i) {
         const int qc = (16 * TI[i] + c) >= NTOK ? 1 : 0;
         const int jc = (16 * TJ[i] + 4 * g) >= NTOK ? 1 : 0;
         tvalid[i] = TOK ? true : jc == qc;
-        unsigned m[4];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int j = 16 * TJ[i] + 4 * g + r;
-            if constexpr (TOK) {                           // one clip: key column j is the cls token, a valid patch token, or dead
-                m[r] = (j == 0 || (j <= NTOK && ((j - 1) % GT) < a.nt)) ? 0xFFFFu : 0u;
-            } else {
-                const int jt = (j - NTOK * jc) % GT;
-                m[r] = (jc == qc && jt < a.nt) ? 0xFFFFu : 0u;
-            }
-        }
-        pmask[i] = u2{m[0] | (m[1] << 16), m[2] | (m[3] << 16)};
     }
+    unsigned long long colmask = ~0ull;
+    if constexpr (PERKEY) {
+        const unsigned nt6 = (1u << a.nt) - 1u;                                  // time patches 0 .. nt-1 of one frequency row
+        const unsigned long long clip24 = (unsigned long long)(nt6 * 0x41041u);  // x (1 + 2^6 + 2^12 + 2^18): the clip's 4 x 6 tokens
+        colmask = TOK ? ((clip24 << 1) | 1ull) : (clip24 | (clip24 << NTOK));    // TOK: column 0 = cls, 1..24 patches, the rest dead
+    }
+    auto make_kinit = [&](f4 (&kinit)[3]) {
+        if constexpr (PERKEY) {
+            const int gl = lane_id_now() >> 4;                                   // (volatile: re-derived per block, never a live register)
+            const unsigned long long x = colmask >> (4 * gl);
+#pragma unroll
+            for (int tj = 0; tj < 3; ++tj)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) kinit[tj][r] = ((x >> (16 * tj + r)) & 1ull) ? 0.f : -1e30f;
+        } else {
+#pragma unroll
+            for (int tj = 0; tj < 3; ++tj) kinit[tj] = splat(0.f);
+        }
+    };
 
     // ---- transformer blocks
 #pragma unroll 1
@@ -832,25 +908,28 @@ __global__ __launch_bounds__(WAVES * 64, 2) void uit_encoder_kernel(EncoderArgs 
       auto full_attention = [&](auto xs2_tag, int tb, const float* bias, v8 (&X)[4][3]) {
         constexpr bool XS2 = decltype(xs2_tag)::value;
         constexpr int NSUB = XS2 ? 2 : 1, DTS = 4 / NSUB, KF = XS2 ? 8 : 4;      // stages per group, d-tiles per stage, fragments per tile
-        const int g = lane >> 4, c = lane & 15;
+        // SB instantiations re-derive the lane's (c, g) from v_mbcnt where they are used (a bias-table offset): held across the block
+        // they were spilled and reloaded behind a ring barrier
+        auto lane_now = [&]() { if constexpr (SB) return lane_id_now(); else return lane; };
         v8 OX[4][3];                                                   // attention output, k-order of proj: k-step 2h + dt/2
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
-            if (h == 1) layernorm_to_operand<OPC, NCT>(R, 1e-6f, X);
+            if (h == 1) layernorm_to_operand<OPC, NCT, CEN>(R, 1e-6f, X, bias + NEGMU_AT);
             v4 Qp[4][3], Kp[4][3];
 #pragma unroll
             for (int which = 0; which < 2; ++which) {
 #pragma unroll
                 for (int sub = 0; sub < NSUB; ++sub) {
                     const int t = tb + (3 * h + which) * NSUB + sub;
-                    ring_step<WAVES>(a.wstream, ring, t, wave, lane);
-                    if (h == 0 && which == 0 && sub == 0 && blk + 1 < a.depth) bias_issue<WAVES>(a.bias, breg, blk + 1, wave, lane);
+                    ring_step<WAVES, SB>(a.wstream, ring, t, wave, lane);
+                    if (h == 0 && which == 0 && sub == 0 && blk + 1 < a.depth) bias_issue<WAVES, SB>(a.bias, breg, blk + 1, wave, lane);
                     const char* slot = ring + (t & (RING_SLOTS - 1)) * STAGE_BYTES;
 #pragma unroll
                     for (int dl = 0; dl < DTS; ++dl) {
                         const int dt = sub * DTS + dl;
                         f4 acc[3];
-                        const f4 bq = *(const f4*)(bias + BIASF_QKV + 128 * which + 64 * h + 16 * dt + 4 * g);
+                        // (CEN: the K rows' bias is exactly zero -- its slot carries -mu)
+                        const f4 bq = (CEN && which == 1) ? splat(0.f) : *(const f4*)(bias + BIASF_QKV + 128 * which + 64 * h + 16 * dt + 4 * (lane_now() >> 4));
 #pragma unroll
                         for (int ct = 0; ct < NCT; ++ct) acc[ct] = bq;
 #pragma unroll
@@ -871,21 +950,20 @@ __global__ __launch_bounds__(WAVES * 64, 2) void uit_encoder_kernel(EncoderArgs 
             // S^T = K.Q^T over the 64-wide head: four chained K = 16 MFMAs per score tile (log2 domain, scale folded into Wq)
             f4 S[7];
             float tm[7], mx[3];
+            f4 kinit[3];
+            make_kinit(kinit);                                 // PERKEY: 0 for a real key, -1e30 for padding (see the kernel's mask section)
 #pragma unroll
             for (int i = 0; i < N7; ++i) {
                 f4 acc = splat(0.f);
+                if constexpr (PERKEY) {
+                    acc = kinit[TJ[i]];
+                    if (NCT == 3 && i != 0 && i != 6) acc = tvalid[i] ? acc : splat(-1e30f);
+                }
 #pragma unroll
                 for (int dt = 0; dt < 4; ++dt) acc = OP::mfma16(Kp[dt][TJ[i]], Qp[dt][TI[i]], acc);
                 S[i] = acc;
-                if constexpr (PERKEY) {
-                    f4 sv;
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) sv[r] = ((r < 2 ? pmask[i][0] : pmask[i][1]) >> (16 * (r & 1))) & 1u ? S[i][r] : -INFINITY;
-                    tm[i] = hmax(sv);
-                } else {
-                    const float hm = hmax(S[i]);
-                    tm[i] = tvalid[i] ? hm : -INFINITY;
-                }
+                const float hm = hmax(S[i]);
+                tm[i] = (PERKEY || tvalid[i]) ? hm : -INFINITY;
             }
 #pragma unroll
             for (int i = N7; i < 7; ++i) tm[i] = -INFINITY;
@@ -903,7 +981,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void uit_encoder_kernel(EncoderArgs 
 #pragma unroll
                     for (int r = 0; r < 4; ++r) p[r] = __builtin_amdgcn_exp2f(S[i][r] - mx[TI[i]]);
                     const u2 bits = __builtin_bit_cast(u2, OP::pack4(p));
-                    if constexpr (PERKEY) Pq[i] = __builtin_bit_cast(v4, bits & pmask[i]);
+                    if constexpr (PERKEY) Pq[i] = __builtin_bit_cast(v4, bits);             // (a masked key's exponential is already 0)
                     else Pq[i] = __builtin_bit_cast(v4, tvalid[i] ? bits : u2{0u, 0u});
                 }
             }
@@ -912,13 +990,13 @@ __global__ __launch_bounds__(WAVES * 64, 2) void uit_encoder_kernel(EncoderArgs 
 #pragma unroll
             for (int sub = 0; sub < NSUB; ++sub) {
                 const int t = tb + (3 * h + 2) * NSUB + sub;
-                ring_step<WAVES>(a.wstream, ring, t, wave, lane);
+                ring_step<WAVES, SB>(a.wstream, ring, t, wave, lane);
                 const char* slot = ring + (t & (RING_SLOTS - 1)) * STAGE_BYTES;
 #pragma unroll
                 for (int dl = 0; dl < DTS; ++dl) {
                     const int dt = sub * DTS + dl;
                     f4 acc[3];
-                    const f4 bv = splat(bias[BIASF_QKV + 256 + 64 * h + 16 * dt + c]);
+                    const f4 bv = splat(bias[BIASF_QKV + 256 + 64 * h + 16 * dt + (lane_now() & 15)]);
 #pragma unroll
                     for (int ct = 0; ct < NCT; ++ct) acc[ct] = bv;
 #pragma unroll
@@ -976,12 +1054,12 @@ __global__ __launch_bounds__(WAVES * 64, 2) void uit_encoder_kernel(EncoderArgs 
 #pragma unroll
         for (int ps = 0; ps < PST; ++ps) {
             const int t = tb + 6 * NSUB + ps;
-            ring_step<WAVES>(a.wstream, ring, t, wave, lane);
+            ring_step<WAVES, SB>(a.wstream, ring, t, wave, lane);
             const char* slot = ring + (t & (RING_SLOTS - 1)) * STAGE_BYTES;
 #pragma unroll
             for (int fl = 0; fl < FTS; ++fl) {
                 const int ft = FTS * ps + fl;
-                const f4 bp = *(const f4*)(bias + BIASF_PROJ + 16 * ft + 4 * g);
+                const f4 bp = *(const f4*)(bias + BIASF_PROJ + 16 * ft + 4 * (lane_now() >> 4));
                 f4 acc[3];
 #pragma unroll
                 for (int ct = 0; ct < NCT; ++ct) acc[ct] = add4s(R[ft][ct], bp);
@@ -1007,8 +1085,8 @@ __global__ __launch_bounds__(WAVES * 64, 2) void uit_encoder_kernel(EncoderArgs 
         v8i X8[3];
         layernorm_to_fp8(R, 1e-6f, X8);
         // ----- stage 0: q (h0, h1), k (h0, h1) with the weights as A; v (h0, h1) token-major with the weights as B
-        ring_step<WAVES>(a.wstream, ring, tb, wave, lane);
-        if (blk + 1 < a.depth) bias_issue<WAVES>(a.bias, breg, blk + 1, wave, lane);
+        ring_step<WAVES, SB>(a.wstream, ring, tb, wave, lane);
+        if (blk + 1 < a.depth) bias_issue<WAVES, SB>(a.bias, breg, blk + 1, wave, lane);
         v4 Qh[2][3], Kh[2][3], Vh[3][2];
         {
             const char* slot = ring + (tb & (RING_SLOTS - 1)) * STAGE_BYTES;
@@ -1033,7 +1111,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void uit_encoder_kernel(EncoderArgs 
             }
         }
         // ----- stage 1: attention (f16, as in the 16-bit modes) + proj (f16 fragments); MLP scale dwords
-        ring_step<WAVES>(a.wstream, ring, tb + 1, wave, lane);
+        ring_step<WAVES, SB>(a.wstream, ring, tb + 1, wave, lane);
         int s1[6], s2[6];
         {
             const char* slot = ring + ((tb + 1) & (RING_SLOTS - 1)) * STAGE_BYTES;
@@ -1042,13 +1120,15 @@ __global__ __launch_bounds__(WAVES * 64, 2) void uit_encoder_kernel(EncoderArgs 
                 s1[d] = *(const int*)(slot + FP8_MLP_SCALES + d * 256 + lane * 4);
                 s2[d] = *(const int*)(slot + FP8_MLP_SCALES + (6 + d) * 256 + lane * 4);
             }
-            attention_proj<OP, PERKEY, false, NCT>(R, Qh, Kh, Vh, tvalid, pmask, slot, bias, lane, g);
+            f4 kinit[3];
+            make_kinit(kinit);
+            attention_proj<OP, PERKEY, false, NCT>(R, Qh, Kh, Vh, tvalid, kinit, slot, bias, lane, g);
         }
         // ----- MLP: three k-groups of 128 hidden features: fc1 tiles 8q..8q+7 -> relu -> e4m3 -> fc2 k-group q
         layernorm_to_fp8(R, 1e-6f, X8);
 #pragma unroll
         for (int q = 0; q < 3; ++q) {
-            ring_step<WAVES>(a.wstream, ring, tb + 2 + 2 * q, wave, lane);
+            ring_step<WAVES, SB>(a.wstream, ring, tb + 2 + 2 * q, wave, lane);
             v8i HX8[3];
             {
                 const char* slot = ring + ((tb + 2 + 2 * q) & (RING_SLOTS - 1)) * STAGE_BYTES;
@@ -1060,7 +1140,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void uit_encoder_kernel(EncoderArgs 
                     for (int ct = 0; ct < NCT; ++ct) HX8[ct][i] = relu_cvt4_fp8(mfma8_wa_sel(i, A, X8[ct], b1, s1[2 * q + (i >> 2)]));
                 }
             }
-            ring_step<WAVES>(a.wstream, ring, tb + 3 + 2 * q, wave, lane);
+            ring_step<WAVES, SB>(a.wstream, ring, tb + 3 + 2 * q, wave, lane);
             {
                 const char* slot = ring + ((tb + 3 + 2 * q) & (RING_SLOTS - 1)) * STAGE_BYTES;
 #pragma unroll
@@ -1091,15 +1171,15 @@ __global__ __launch_bounds__(WAVES * 64, 2) void uit_encoder_kernel(EncoderArgs 
         const int tb = PE_STAGES + blk * BLK_ST;
         const float* bias = (const float*)(breg + (blk & 1) * BIAS_FLOATS * 4);
         v8 X[4][3];
-        layernorm_to_operand<OPC, NCT>(R, 1e-6f, X);
+        layernorm_to_operand<OPC, NCT, CEN>(R, 1e-6f, X, bias + NEGMU_AT);
         if constexpr (ATT) {
         full_attention(std::true_type{}, tb, bias, X);
         } else {
         v4 Qh[2][3], Kh[2][3], Vh[3][2];
 #pragma unroll
         for (int half = 0; half < 2; ++half) {                             // stage 0: q h0, q h1; stage 1: k h0, k h1
-            ring_step<WAVES>(a.wstream, ring, tb + half, wave, lane);
-            if (half == 0 && blk + 1 < a.depth) bias_issue<WAVES>(a.bias, breg, blk + 1, wave, lane);
+            ring_step<WAVES, SB>(a.wstream, ring, tb + half, wave, lane);
+            if (half == 0 && blk + 1 < a.depth) bias_issue<WAVES, SB>(a.bias, breg, blk + 1, wave, lane);
             const char* slot = ring + ((tb + half) & (RING_SLOTS - 1)) * STAGE_BYTES;
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
@@ -1116,7 +1196,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void uit_encoder_kernel(EncoderArgs 
                 }
             }
         }
-        ring_step<WAVES>(a.wstream, ring, tb + 2, wave, lane);             // stage 2: V (weights as the B operand: V token-major)
+        ring_step<WAVES, SB>(a.wstream, ring, tb + 2, wave, lane);             // stage 2: V (weights as the B operand: V token-major)
         {
             const char* slot = ring + ((tb + 2) & (RING_SLOTS - 1)) * STAGE_BYTES;
 #pragma unroll
@@ -1134,14 +1214,16 @@ __global__ __launch_bounds__(WAVES * 64, 2) void uit_encoder_kernel(EncoderArgs 
                 }
             }
         }
-        ring_step<WAVES>(a.wstream, ring, tb + 3, wave, lane);             // stage 3: attention + proj (hi, lo)
-        attention_proj<OP, PERKEY, true, NCT>(R, Qh, Kh, Vh, tvalid, pmask, ring + ((tb + 3) & (RING_SLOTS - 1)) * STAGE_BYTES, bias, lane, g);
+        ring_step<WAVES, SB>(a.wstream, ring, tb + 3, wave, lane);             // stage 3: attention + proj (hi, lo)
+        f4 kinit[3];
+        make_kinit(kinit);
+        attention_proj<OP, PERKEY, true, NCT>(R, Qh, Kh, Vh, tvalid, kinit, ring + ((tb + 3) & (RING_SLOTS - 1)) * STAGE_BYTES, bias, lane, g);
         }
         layernorm_to_operand<OPC, NCT>(R, 1e-6f, X);
 #pragma unroll 1
         for (int ch = 0; ch < 12; ++ch) {
             v8 HX[3];
-            ring_step<WAVES>(a.wstream, ring, tb + MLP0 + 2 * ch, wave, lane);  // fc1 rows 32ch .. 32ch+31
+            ring_step<WAVES, SB>(a.wstream, ring, tb + MLP0 + 2 * ch, wave, lane);  // fc1 rows 32ch .. 32ch+31
             {
                 const char* slot = ring + ((tb + MLP0 + 2 * ch) & (RING_SLOTS - 1)) * STAGE_BYTES;
                 f4 H[2][3];
@@ -1164,7 +1246,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void uit_encoder_kernel(EncoderArgs 
                     else HX[ct] = OP::relu_pack8(H[0][ct], H[1][ct]);
                 }
             }
-            ring_step<WAVES>(a.wstream, ring, tb + MLP0 + 1 + 2 * ch, wave, lane);     // fc2 k-step ch
+            ring_step<WAVES, SB>(a.wstream, ring, tb + MLP0 + 1 + 2 * ch, wave, lane);     // fc2 k-step ch
             {
                 const char* slot = ring + ((tb + MLP0 + 1 + 2 * ch) & (RING_SLOTS - 1)) * STAGE_BYTES;
 #pragma unroll
@@ -1250,18 +1332,9 @@ __global__ __launch_bounds__(WAVES * 64, 2) void uit_encoder_kernel(EncoderArgs 
                     }
                 }
             }
-            if constexpr (PERKEY) {
-                attention_proj<OP, PERKEY, !(L6_ABL & 4), NCT>(R, Qh, Kh, Vh, tvalid, pmask, slot + 8 * FRAG_BYTES, bias, lane, g);
-            } else {
-                // full clips: a lane's four keys of a tile are all valid or all foreign, so the probability masks follow from tvalid --
-                // rebuilt per block (14 selects) instead of living in 14 registers through the MLP loop, which has none to spare
-                u2 pm[7];
-                unsigned ones = ~0u;
-                asm volatile("" : "+v"(ones));                        // (keeps the selects inside the block loop: hoisted, they are 14 live registers again)
-#pragma unroll
-                for (int i = 0; i < N7; ++i) pm[i] = tvalid[i] ? u2{ones, ones} : u2{0u, 0u};
-                attention_proj<OP, PERKEY, !(L6_ABL & 4), NCT>(R, Qh, Kh, Vh, tvalid, pm, slot + 8 * FRAG_BYTES, bias, lane, g);
-            }
+            f4 kinit[3];
+            make_kinit(kinit);
+            attention_proj<OP, PERKEY, !(L6_ABL & 4), NCT>(R, Qh, Kh, Vh, tvalid, kinit, slot + 8 * FRAG_BYTES, bias, lane, g);
         }
         // ===== MLP: 12 stages in three k-groups of four.  fc1: four fp16 k-steps + ONE fp6 MFMA per accumulator; fc2: the fp16 k-step of
         // the chunk, and at the last stage of a group (MB) the group's low-order term on the fp4 copy of its 128 hidden activations.
@@ -1376,16 +1449,16 @@ __global__ __launch_bounds__(WAVES * 64, 2) void uit_encoder_kernel(EncoderArgs 
         const int tb = PE_STAGES + blk * BLK_ST;
         const float* bias = (const float*)(breg + (blk & 1) * BIAS_FLOATS * 4);
         v8 X[4][3];
-        layernorm_to_operand<OPC, NCT>(R, 1e-6f, X);
+        layernorm_to_operand<OPC, NCT, CEN>(R, 1e-6f, X, bias + NEGMU_AT);
         TSTAMP(0);                                                     // LN1
 
         if constexpr (ATT) {
         full_attention(std::false_type{}, tb, bias, X);
         } else {
         // ===== stage QK: fragments (ft = f/4 in {q h0, q h1, k h0, k h1}, s = f%4)
-        ring_step<WAVES>(a.wstream, ring, tb, wave, lane);
+        ring_step<WAVES, SB>(a.wstream, ring, tb, wave, lane);
         TSTAMP(1);                                                     // ring wait QK
-        if (blk + 1 < a.depth) bias_issue<WAVES>(a.bias, breg, blk + 1, wave, lane);
+        if (blk + 1 < a.depth) bias_issue<WAVES, SB>(a.bias, breg, blk + 1, wave, lane);
         v4 Qh[2][3], Kh[2][3];
         {
             const char* slot = ring + (tb & (RING_SLOTS - 1)) * STAGE_BYTES;
@@ -1411,7 +1484,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void uit_encoder_kernel(EncoderArgs 
 
         TSTAMP(2);                                                     // QK compute
         // ===== stage VP: fragments 0..7 = V (h = f/4, s = f%4) used as the B operand; 8..15 = proj (ft = f-8)
-        ring_step<WAVES>(a.wstream, ring, tb + 1, wave, lane);
+        ring_step<WAVES, SB>(a.wstream, ring, tb + 1, wave, lane);
         TSTAMP(3);                                                     // ring wait VP
         {
             const char* slot = ring + ((tb + 1) & (RING_SLOTS - 1)) * STAGE_BYTES;
@@ -1432,7 +1505,9 @@ __global__ __launch_bounds__(WAVES * 64, 2) void uit_encoder_kernel(EncoderArgs 
                     }
                 }
             }
-            attention_proj<OP, PERKEY, false, NCT>(R, Qh, Kh, Vh, tvalid, pmask, slot + 8 * FRAG_BYTES, bias, lane, g);
+            f4 kinit[3];
+            make_kinit(kinit);
+            attention_proj<OP, PERKEY, false, NCT>(R, Qh, Kh, Vh, tvalid, kinit, slot + 8 * FRAG_BYTES, bias, lane, g);
         }
 
         }
@@ -1463,7 +1538,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void uit_encoder_kernel(EncoderArgs 
             }
         };
         {   // chunk 0 (peeled: defines A2 / HX before the steady-state loop)
-            ring_step<WAVES>(a.wstream, ring, tb + MLP0, wave, lane);
+            ring_step<WAVES, SB>(a.wstream, ring, tb + MLP0, wave, lane);
             TSTAMP(6);
             const char* slot = ring + ((tb + MLP0) & (RING_SLOTS - 1)) * STAGE_BYTES;
             v8 A[8];
@@ -1475,7 +1550,21 @@ __global__ __launch_bounds__(WAVES * 64, 2) void uit_encoder_kernel(EncoderArgs 
 #pragma unroll 1
         for (int ch = 1; ch < 12; ++ch) {
             const int t = tb + MLP0 + ch;
-            ring_step<WAVES>(a.wstream, ring, t, wave, lane);
+#if defined(UITK_LAB) && defined(ENC_DYNPRIO)
+            // Lab variant (round 5): at every MLP barrier the two waves of a SIMD (wave, wave ^ 4) take a ticket from a
+            // per-SIMD LDS counter; the one that arrives SECOND -- the sibling that was behind -- runs the next stage at raised priority.
+            unsigned ticket = 0;
+            if constexpr (WAVES == 8) {
+                unsigned* cnt = (unsigned*)(zbuf + 4096) + (wave & 3);
+                if (lane == 0) ticket = __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
+#endif
+            ring_step<WAVES, SB>(a.wstream, ring, t, wave, lane);
+#if defined(UITK_LAB) && defined(ENC_DYNPRIO)
+            if constexpr (WAVES == 8) {
+                if (__builtin_amdgcn_readfirstlane(ticket) & 1u) __builtin_amdgcn_s_setprio(2); else __builtin_amdgcn_s_setprio(0);
+            }
+#endif
             TSTAMP(6);                                                 // ring wait MLP (sum of 12)
             const char* slot = ring + (t & (RING_SLOTS - 1)) * STAGE_BYTES;
             v8 A[8];
@@ -1505,6 +1594,23 @@ __global__ __launch_bounds__(WAVES * 64, 2) void uit_encoder_kernel(EncoderArgs 
       }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // drain the dummy tail stages before the LDS can be re-used
+    if constexpr (SB || (L6 && POOL == 1) || WAVES == 4) {
+        // the epilogue's time-patch index of each column, re-derived here from v_mbcnt: alive from the prologue it was one of the values
+        // the register-starved instantiations spilled and reloaded inside the block loop
+        const int ce = lane_id_now() & 15;
+#pragma unroll
+        for (int ct = 0; ct < NCT; ++ct) {
+            const int col = 16 * ct + ce;
+            if constexpr (TOK) {
+                const bool pch = col >= 1 && col <= NTOK;
+                const int tk = pch ? col - 1 : 0;
+                pt_[ct] = pch ? tk - GT * (tk / GT) : (col == 0 ? 0 : 99);
+            } else {
+                const int tk = col - NTOK * (col >= NTOK ? 1 : 0);
+                pt_[ct] = tk - GT * (tk / GT);
+            }
+        }
+    }
     if constexpr (POOL == 1) {
         // ===== pooling 'dm' (models/uit.py:405-412): for every time patch t the mean over the four frequency patches goes through
         // outputlayer (LayerNorm 1e-5 + Linear) and the sigmoid; the output is the mean over the nt time patches.

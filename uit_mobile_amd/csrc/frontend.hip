@@ -34,6 +34,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <atomic>
+#include <type_traits>
 #include "uitk_dev.h"
 
 namespace uitk {
@@ -278,6 +279,47 @@ __global__ __launch_bounds__(FE_WAVES * 64, FE_OCC) void mel_frontend_kernel(Fro
 #pragma unroll
         for (int m1 = 0; m1 < 16; ++m1) v[m1] = v[m1] * win_(m1);
         fft16(v);                                        // over m1 -> k1 (at FPOS), for m2 = p
+#if defined(UITK_LAB) && defined(FE_XPOSE_DPP)
+        // Lab variant (round 5, VERDICT r4 item 3: "replace the 16x16 transpose between the two radix-16 stages with in-register exchanges"):
+        // the frame's 16 lanes are one DPP row, so the (register k1) x (lane m2) transpose is four butterfly stages on lane bits 3, 2, 1, 0:
+        // stage b swaps w[r | b] of the lanes with bit b clear against w[r] of the lanes with bit b set (partner = lane ^ b).  Bits 3 and 2 take
+        // ONE v_mov_b32_dpp per 32-bit value (row_ror:8 / row_shr:4 + row_shl:4, the receiving lanes chosen by the DPP bank mask, the rest keep
+        // `old`); bits 1 and 0 live inside a bank: quad_perm fetch + v_cndmask.  No LDS instruction, no wave barrier: 16 KB of LDS traffic per
+        // wave-pass become ~190 VALU instructions.
+        {
+            c32 w[16];
+#pragma unroll
+            for (int k1 = 0; k1 < 16; ++k1) w[k1] = k1 == 0 ? v[FPOS(0)] : cmul(v[FPOS(k1)], tw_(k1));
+            FSTAMP(1);
+            auto dppf = [](float old, float src, auto ctrl, auto bank) {
+                return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(old), __float_as_int(src), decltype(ctrl)::value, 0xF, decltype(bank)::value, false));
+            };
+            using I = std::integral_constant<int, 0>;
+            (void)sizeof(I);
+#define FE_XB(A, B, CA, BA, CB, BB) do { const c32 a0_ = A;                                                                                   \
+                A.x = dppf(A.x, B.x, std::integral_constant<int, CA>{}, std::integral_constant<int, BA>{});                                    \
+                A.y = dppf(A.y, B.y, std::integral_constant<int, CA>{}, std::integral_constant<int, BA>{});                                    \
+                B.x = dppf(B.x, a0_.x, std::integral_constant<int, CB>{}, std::integral_constant<int, BB>{});                                  \
+                B.y = dppf(B.y, a0_.y, std::integral_constant<int, CB>{}, std::integral_constant<int, BB>{}); } while (0)
+#pragma unroll
+            for (int r = 0; r < 8; ++r) FE_XB(w[r], w[r | 8], 0x128, 0xC, 0x128, 0x3);                     // bit 3: row_ror:8; banks 2,3 receive into w[r], banks 0,1 into w[r|8]
+#pragma unroll
+            for (int r = 0; r < 16; ++r) if (!(r & 4)) FE_XB(w[r], w[r | 4], 0x114, 0xA, 0x104, 0x5);      // bit 2: row_shr:4 into banks 1,3; row_shl:4 into banks 0,2
+#undef FE_XB
+            const bool b1 = (lane & 2) != 0, b0 = (lane & 1) != 0;
+            auto qx = [](float src, auto ctrl) { return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(src), decltype(ctrl)::value, 0xF, 0xF, true)); };
+#define FE_XQ(A, B, QP, BIT) do { const c32 ta_ = c32{qx(B.x, std::integral_constant<int, QP>{}), qx(B.y, std::integral_constant<int, QP>{})};   \
+                const c32 tb_ = c32{qx(A.x, std::integral_constant<int, QP>{}), qx(A.y, std::integral_constant<int, QP>{})};                     \
+                A = BIT ? ta_ : A; B = BIT ? B : tb_; } while (0)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) if (!(r & 2)) FE_XQ(w[r], w[r | 2], 0x4E, b1);                     // bit 1: quad_perm [2,3,0,1]
+#pragma unroll
+            for (int r = 0; r < 16; ++r) if (!(r & 1)) FE_XQ(w[r], w[r | 1], 0xB1, b0);                     // bit 0: quad_perm [1,0,3,2]
+#undef FE_XQ
+#pragma unroll
+            for (int m2 = 0; m2 < 16; ++m2) v[m2] = w[m2];
+        }
+#else
 #pragma unroll
         for (int k1 = 0; k1 < 16; ++k1) {                // twiddle + transpose write E[q][k1][m2 = p]
             const c32 y = k1 == 0 ? v[FPOS(0)] : cmul(v[FPOS(k1)], tw_(k1));
@@ -288,6 +330,7 @@ __global__ __launch_bounds__(FE_WAVES * 64, FE_OCC) void mel_frontend_kernel(Fro
         asm volatile("" ::: "memory");
 #pragma unroll
         for (int m2 = 0; m2 < 16; ++m2) v[m2] = E[(q * 16 + p) * FE_ROW + m2];   // lane k1 = p gathers its row
+#endif
         fft16(v);                                        // over m2 -> Z[k1 + 16 k2], k1 = p, k2 at FPOS
         __builtin_amdgcn_wave_barrier();                 // every lane has read its E row: the tile may be reused
         asm volatile("" ::: "memory");

@@ -406,9 +406,10 @@ CalibOffsets calib_offsets(const uitk_config* c) {
     CalibOffsets o;
     o.pe = 0; o.ln1 = 256 * 256; o.att = o.ln1 + DIM * DIM; o.ln2 = o.att + inner * inner; o.hid = o.ln2 + DIM * DIM;
     o.per_block = 2 * DIM * DIM + inner * inner + (size_t)HID * HID;
+    o.mu1 = 256 * 256 + (size_t)c->depth * o.per_block;
     return o;
 }
-size_t calib_stats_doubles(const uitk_config* c) { return 256 * 256 + (size_t)c->depth * calib_offsets(c).per_block; }
+size_t calib_stats_doubles(const uitk_config* c) { return calib_offsets(c).mu1 + (size_t)c->depth * DIM; }
 
 void fold_model(const uitk_config* c, const uitk_weights* w, Folded* F) {
     const int depth = c->depth, inner = c->attention_full ? DIM : INNER;
@@ -641,6 +642,32 @@ int pack_image(const uitk_config* c, const uitk_weights* w, const double* calib,
     // rounded on THEIR grid (MX e4m3: round_fp8_grid), the patch embed and proj, which stay fp16 there, on the fp16 grid.
     // One task per matrix (1 + 4 per block, independent), spread over host threads: ~0.1 s for UiT-XS.
     const bool calibrated = calib != nullptr && !x2 && !l6;
+    // OPERAND CENTRING of the attention (round 5), whenever calibration statistics are given (any fp16-operand precision,
+    // split weights included -- the means are what matters here, not the rounding):
+    //   * k - c_k leaves the softmax unchanged for ANY constant c_k, v - c_v moves Wp c_v into the proj bias: with c = the calibration
+    //     mean of k / v the fp16 roundings of k, v and of the attention output act on the small centred values instead of on a large
+    //     common part (a massive-activation channel of LayerNorm-1 is ~ the same in every token) -- exact algebra, free at run time;
+    //   * the builds named by operand_centring() also subtract mu = E[LayerNorm-1 output] from the operand before it is rounded
+    //     (W (x - mu) + (b + W mu), exact for any mu): then the k / v biases are exactly 0 and -mu rides in the block's bias table.
+    // tools/err_attrib_full.py, d4-GELU seed 206 (the round-4 gate case): fp16 activation floor 9.8e-4 -> 2.1e-4.
+    const int kprec = (c->precision == UITK_PREC_FP8W) ? UITK_PREC_F16 : c->precision;
+    // (a build with the runtime centring ALWAYS reads -mu from its bias table -- for full-width attention from the K rows' bias slot -- so
+    // its images are folded this way with mu = 0 when there are no statistics)
+    const bool centre_rt = operand_centring(c->attention_full, c->act_gelu, c->pooling, kprec);
+    const bool centre = centre_rt || (calib != nullptr && (kprec == UITK_PREC_F16 || kprec == UITK_PREC_F16X2 || kprec == UITK_PREC_F16L6));
+    const std::vector<double> mu_zero(DIM, 0.0);
+    // the qkv operand's second moment with the runtime centring: E[(x - mu)(x - mu)^T] = H - mu mu^T
+    std::vector<std::vector<double>> Hc(centre_rt && calib ? depth : 0);
+    if (centre_rt && calib) {
+        const CalibOffsets co = calib_offsets(c);
+        for (int b = 0; b < depth; ++b) {
+            const double* H = calib + (size_t)b * co.per_block + co.ln1;
+            const double* mu = calib + co.mu1 + (size_t)b * DIM;
+            Hc[b].resize((size_t)DIM * DIM);
+            for (int i = 0; i < DIM; ++i)
+                for (int j = 0; j < DIM; ++j) Hc[b][(size_t)i * DIM + j] = H[(size_t)i * DIM + j] - mu[i] * mu[j];
+        }
+    }
     const bool grid8 = w8 || (prec == UITK_PREC_FP8 && calibrated);     // qkv / fc1 / fc2 as VALUES on the MX e4m3 grid (Q8_*)
     // scale blocks: precision fp8 = the hardware's 32-element blocks of a fragment8 (uitk_dev.h: per 128 k, block 2 (kk >> 6) + ((kk >> 3) & 1));
     // the weights-only variant = 32 consecutive k
@@ -651,7 +678,8 @@ int pack_image(const uitk_config* c, const uitk_weights* w, const double* calib,
     std::vector<std::vector<double>> Q8_qkv(depth), Q8_fc1(depth), Q8_fc2(depth);
     auto grid8_block = [&](int b, const double* base, const CalibOffsets* co) {       // base == nullptr: every element to nearest
         const FoldedBlock& fb = F.blocks[b];
-        Q8_qkv[b] = round_fp8_grid(3 * inner, DIM, [&](int r, int k) { return fb.qkv_w[(size_t)r * DIM + k]; }, block_of, DIM / 32, base ? base + co->ln1 : nullptr);
+        Q8_qkv[b] = round_fp8_grid(3 * inner, DIM, [&](int r, int k) { return fb.qkv_w[(size_t)r * DIM + k]; }, block_of, DIM / 32,
+                                   base ? (centre_rt ? Hc[b].data() : base + co->ln1) : nullptr);
         Q8_fc1[b] = round_fp8_grid(HID, DIM, [&](int r, int k) { return fb.fc1_w[(size_t)r * DIM + k]; }, block_of, DIM / 32, base ? base + co->ln2 : nullptr);
         Q8_fc2[b] = round_fp8_grid(DIM, HID, [&](int r, int k) { return fb.fc2_w[(size_t)r * HID + k]; }, block_of, HID / 32, base ? base + co->hid : nullptr);
     };
@@ -680,7 +708,7 @@ int pack_image(const uitk_config* c, const uitk_weights* w, const double* calib,
                     if (which == 0) grid8_block(b, base, &co);
                     continue;
                 }
-                if (which == 0) cq_qkv[b] = round_gptq(3 * inner, DIM, [&](int r, int k) { return fb.qkv_w[(size_t)r * DIM + k]; }, prec, base + co.ln1);
+                if (which == 0) cq_qkv[b] = round_gptq(3 * inner, DIM, [&](int r, int k) { return fb.qkv_w[(size_t)r * DIM + k]; }, prec, centre_rt ? Hc[b].data() : base + co.ln1);
                 else if (which == 2) cq_fc1[b] = round_gptq(HID, DIM, [&](int r, int k) { return fb.fc1_w[(size_t)r * DIM + k]; }, prec, base + co.ln2);
                 else cq_fc2[b] = round_gptq(DIM, HID, [&](int r, int k) { return fb.fc2_w[(size_t)r * HID + k]; }, prec, base + co.hid);
             }
@@ -732,8 +760,28 @@ int pack_image(const uitk_config* c, const uitk_weights* w, const double* calib,
         else if (calibrated && prec != UITK_PREC_FP8) fc2_q = cq_fc2[b];
         else if (prec != UITK_PREC_FP8) fc2_q = round_structured(DIM, HID, Wfc2_exact, prec, structured ? 32 : 1);
         auto Wfc2 = [&](int r, int k) { return grid8 ? Q8_fc2[b][(size_t)r * HID + k] : prec == UITK_PREC_FP8 ? Wfc2_exact(r, k) : op16_value(fc2_q[(size_t)r * HID + k], prec); };
-        for (int r = 0; r < 3 * inner; ++r) bb[BIAS_QKV + r] = (float)fb.qkv_b[r];
-        for (int r = 0; r < DIM; ++r) bb[b_proj + r] = (float)fb.proj_b[r];
+        if (!centre) {
+            for (int r = 0; r < 3 * inner; ++r) bb[BIAS_QKV + r] = (float)fb.qkv_b[r];
+            for (int r = 0; r < DIM; ++r) bb[b_proj + r] = (float)fb.proj_b[r];
+        } else {
+            // (the weights the kernel multiplies with: the calibrated / grid values where there are any, else the exact ones -- a split
+            // mode's hi + lo is the exact weight to 22 bits)
+            const double* mu = calib ? calib + calib_offsets(c).mu1 + (size_t)b * DIM : mu_zero.data();
+            std::vector<double> wmu(3 * inner), cv(inner);
+            for (int r = 0; r < 3 * inner; ++r) { double a = 0.0; for (int k = 0; k < DIM; ++k) a += Wqkv(r, k) * mu[k]; wmu[r] = a; }
+            for (int r = 0; r < inner; ++r) bb[BIAS_QKV + r] = (float)(fb.qkv_b[r] + (centre_rt ? wmu[r] : 0.0));            // q
+            for (int r = inner; r < 3 * inner; ++r) bb[BIAS_QKV + r] = (float)(centre_rt ? 0.0 : -wmu[r]);                   // k - c_k, v - c_v
+            for (int j = 0; j < inner; ++j) cv[j] = wmu[2 * inner + j] + fb.qkv_b[2 * inner + j];                           // c_v = E[v]
+            for (int r = 0; r < DIM; ++r) {
+                double a = fb.proj_b[r];
+                for (int j = 0; j < inner; ++j) a += Wproj(r, j) * cv[j];
+                bb[b_proj + r] = (float)a;
+            }
+            if (centre_rt) {
+                float* nm = bb + (full ? BIASF_QKV + 128 : BIAS_NEGMU);      // full-width attention: the K rows' (zero) bias slot
+                for (int k = 0; k < DIM; ++k) nm[k] = (float)-mu[k];
+            }
+        }
         for (int r = 0; r < HID; ++r) bb[b_fc1 + r] = (float)fb.fc1_b[r];
         for (int r = 0; r < DIM; ++r) bb[b_fc2 + r] = (float)fb.fc2_b[r];
         if (prec == UITK_PREC_FP8) {

@@ -40,9 +40,10 @@ void fold_model(const uitk_config* c, const uitk_weights* w, Folded* out);
 
 // Calibration statistics (uitk_calibrate / uitk_pack_weights_calibrated): UNCENTRED second moments E[x x^T] of the operand of every
 // single-weight linear, doubles, in this order: patch embed [256][256]; then per block LayerNorm-1 output [128][128] (qkv),
-// attention output [inner][inner] (proj), LayerNorm-2 output [128][128] (fc1), activation output [384][384] (fc2).
+// attention output [inner][inner] (proj), LayerNorm-2 output [128][128] (fc1), activation output [384][384] (fc2).  Round 5: behind
+// them the MEAN of the LayerNorm-1 output per block, [depth][128] (operand centring, pack.cpp: centre_attention_operands).
 size_t calib_stats_doubles(const uitk_config* c);
-struct CalibOffsets { size_t pe, ln1, att, ln2, hid, per_block; };          // doubles; block b: ln1 + b * per_block, ...
+struct CalibOffsets { size_t pe, ln1, att, ln2, hid, per_block, mu1; };     // doubles; block b: ln1 + b * per_block, ...; mu1 + b * 128
 CalibOffsets calib_offsets(const uitk_config* c);
 
 int validate_config(const uitk_config* c, const char** why);

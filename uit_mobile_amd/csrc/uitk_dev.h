@@ -79,6 +79,16 @@ constexpr int FP8_QKV_SCALES = 6 * FRAG8_BYTES;                 // 2 dwords per 
 constexpr int FP8_MLP_SCALES = 8 * FRAG_BYTES;                  // stage 1: 6 dwords per lane for fc1 tiles, then 6 for fc2 (q*8 + ft)
 constexpr int BIAS_FLOATS = 1024;       // per block: qkv 96 | proj 128 | fc1 384 | fc2 128 (padded to 4 KiB)
 constexpr int BIAS_QKV = 0, BIAS_PROJ = 96, BIAS_FC1 = 224, BIAS_FC2 = 608;
+// ---- operand centring of LayerNorm-1 (round 5): instantiations that subtract the calibration mean mu of the LayerNorm-1
+// output from it BEFORE the fp16 rounding (the linear is exact for any mu: W (x - mu) + (b + W mu)) find -mu[128] in their block's
+// bias table: BNeckAttention at BIAS_NEGMU (the table's spare tail), full-width attention in the K rows' bias slot BIASF_QKV + 128 (with
+// the centring the K and V biases are exactly zero: k - E[k] leaves the softmax unchanged, v - E[v] moves into the proj bias).
+constexpr int BIAS_NEGMU = 736;
+// which (attention, activation, pooling, kernel precision) builds carry the runtime centring: the variants whose fp16 ACTIVATION floor sat
+// at the gate in round 4 (full-width attention, GELU, pooling 'token'), on fp16 operands with single or split weights
+constexpr bool operand_centring(int att, int act, int pool, int kernel_prec) {
+    return (kernel_prec == 0 || kernel_prec == 3) && (att != 0 || act != 0 || pool == 2);
+}
 
 struct FrontendArgs {
     const void* pcm;        // [B][T] f32 or i16
@@ -151,6 +161,7 @@ struct CalibArgs {
     float* X0; float* R; float* Xn; float* QKV; float* O; float* Hd;      // work buffers [rows*ntok][256 | 128 | 128 | 3 inner | inner | 384]
     float* stats;
     size_t off_pe, off_ln1, off_att, off_ln2, off_hid, per_block;
+    size_t off_mu1;             // [depth][128] column means of the LayerNorm-1 output (fp32 values, before operand rounding)
 };
 hipError_t launch_calibration(const CalibArgs& a, hipStream_t stream);
 

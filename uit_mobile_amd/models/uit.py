@@ -505,7 +505,7 @@ class UITBase(nn.Module):
                 _lib.check(L.uitk_get_option(handle.ptr, b"calib_budget_e6", ctypes.byref(budget)), "uitk_get_option")
                 check = None if rep[4] < 0 else {"max_nearest": rep[0], "max_calibrated": rep[1], "rms_nearest": rep[2], "rms_calibrated": rep[3],
                                                  "accepted": rep[4] > 0}
-                handle.mode.update(check=check, budget=budget.value * 1e-6 * (0.25 if self.pooling == 'dm' else 1.0))
+                handle.mode.update(check=check, budget=budget.value * 1e-6 * (0.25 if self.pooling == 'dm' else 1.0), within_budget=esc.value < 0)
                 refused = check is not None and not check["accepted"]
                 if refused:                               # the nearest-rounded image stayed
                     handle.mode["precision"] = {'auto': 'f16', 'f16c': 'f16', 'fp8c': 'fp8'}.get(self.precision, self.precision + ' (nearest on its grid)')
@@ -518,14 +518,30 @@ class UITBase(nn.Module):
                     handle.mode["reason"] = why
                     if self.precision == 'auto' and esc.value >= 0:
                         to = _PRECISION_NAMES[esc.value]
-                        warnings.warn(f"uit_mobile_amd: precision='auto' on cuda:{idx}: {why} -> rebuilding the handle in precision '{to}' "
-                                      "(split weights: parity-grade, slower)", UitkParityWarning, stacklevel=4)
-                        mode = dict(handle.mode)
-                        handle = self._create(L, w, to)   # (the f16c handle is destroyed when its last reference goes)
+                        # the split-weight build of the same weights; the SAME calibration statistics give it the operand centring of the
+                        # attention (its weights are not re-rounded), and its own deviation on the held-out clips decides whether it stays
+                        split = self._create(L, w, to)
+                        if x is None:
+                            _lib.check(L.uitk_calibrate_weights(split.ptr, ctypes.byref(w), None, _lib.IN_I16, 0, 0, stream), "uitk_calibrate_weights")
+                        else:
+                            _lib.check(L.uitk_calibrate_weights(split.ptr, ctypes.byref(w), ctypes.c_void_p(x.data_ptr()),
+                                                                _lib.IN_I16 if x.dtype == torch.int16 else _lib.IN_F32, x.shape[0], x.shape[1], stream),
+                                       "uitk_calibrate_weights")
                         out2 = (ctypes.c_float * 2)()
-                        _lib.check(L.uitk_self_check(handle.ptr, ctypes.byref(w), stream, out2), "uitk_self_check")
-                        handle.mode.update(check=mode["check"], budget=mode["budget"], reason=why, escalated=True,
-                                           self_check=None if out2[0] < 0 else (float(out2[0]), float(out2[1])))
+                        _lib.check(L.uitk_self_check(split.ptr, ctypes.byref(w), stream, out2), "uitk_self_check")
+                        sc = None if out2[0] < 0 else (float(out2[0]), float(out2[1]))
+                        if sc is not None and dev_now is not None and sc[0] >= dev_now:
+                            # split weights do not help here: what is over budget is fp16 ACTIVATION rounding (pooling 'token' reads one
+                            # row instead of a mean over 24), not weight rounding -- the faster image stays, and the report says so
+                            why += "; the split-weight build '%s' measures %.2e there (no better): kept" % (to, sc[0])
+                            handle.mode.update(reason=why, within_budget=False, self_check_split=sc)
+                            warnings.warn(f"uit_mobile_amd: precision='auto' on cuda:{idx}: {why}", UitkParityWarning, stacklevel=4)
+                        else:
+                            warnings.warn(f"uit_mobile_amd: precision='auto' on cuda:{idx}: {why} -> rebuilding the handle in precision '{to}' "
+                                          "(split weights: parity-grade, slower)", UitkParityWarning, stacklevel=4)
+                            split.mode.update(check=handle.mode["check"], budget=handle.mode["budget"], reason=why, escalated=True, self_check=sc,
+                                              within_budget=sc is None or sc[0] <= handle.mode["budget"])
+                            handle = split                # (the f16c handle is destroyed when its last reference goes)
                     elif self.precision == 'f16c':
                         warnings.warn(f"uit_mobile_amd: precision='f16c' on cuda:{idx}: {why}; an explicit 'f16c' does not escalate"
                                       + (" and now runs the NEAREST-rounded fp16 image (= precision 'f16')" if refused else "")
