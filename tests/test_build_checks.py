@@ -92,3 +92,14 @@ def test_every_encoder_instantiation_has_a_scratch_free_block_loop(kernels):
     print("vector registers spilled outside the block loop:", {k: v for k, v in spills.items() if v})
     assert spills["<0, 8, false, false, 0, 0, 0>"] == 0 and spills["<0, 8, true, false, 0, 0, 0>"] == 0
     assert worst[1] <= 16, worst
+
+
+def test_design_md_kernel_table_matches_the_binary():
+    """Round 5: the kernel table of DESIGN.md is GENERATED from the built library (tools/design_tables.py) and must
+    be the one the current binary gives -- registers, spills, MFMA and scratch counts cannot drift from the document again."""
+    import design_tables
+    text = (ROOT / "DESIGN.md").read_text()
+    assert design_tables.BEGIN in text and design_tables.END in text
+    have = text[text.index(design_tables.BEGIN):text.index(design_tables.END) + len(design_tables.END)]
+    want = design_tables.isa_half()
+    assert have == want, "DESIGN.md's generated kernel table is stale: run `python tools/design_tables.py --write`"

@@ -429,6 +429,13 @@ def test_golden_pooling_token(golden):
         print(f"pooling token {name} ({prec} -> {m.effective_precision()}): |logit|max {np.abs(g[f'{tag}_logits']).max():.1f} max|dlogit| {dl:.2e} max|dprob| {dp:.2e}; "
               f"report {m.calibration_report()}")
         assert dl < TOL and dp < TOL
+        if trained:
+            # round 5: with pooling 'token' the head reads ONE row -- what is over the library's budget there is fp16 ACTIVATION rounding
+            # (ln2 / hidden operands of the cls row), which split weights do not touch: 'auto' escalates to 'f16a' (those two operands of
+            # the cls tile as hi + lo terms): 7.8e-4 (round 4, f16c) -> asserted at 7e-4
+            assert m.effective_precision() in ("f16c", "f16a")
+            if m.effective_precision() == "f16a":
+                assert dl < 7e-4
         if tag == "xxxs":
             p, l = run(m, g["xxxs_short_pcm"])
             assert np.abs(l - g["xxxs_short_logits"]).max() < TOL
@@ -447,7 +454,7 @@ def test_full_attention_factory_pooling_at_trained_magnitudes(pooling):
     sd = dict(make_trained_like_state_dict(name, 205, attention="full"))
     o = Oracle(sd, act="gelu", pooling=pooling)
     res = {}
-    for prec in ("f16c", "f16x2", "f16"):
+    for prec in ("f16c", "f16x2", "f16") + (("f16a", "auto") if pooling == "token" else ("auto",)):
         m = getattr(models, name)(outputdim=537, target_length=102, pooling=pooling, precision=prec)
         m.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()}, strict=True)
         m = m.to("cuda").eval()
@@ -460,7 +467,8 @@ def test_full_attention_factory_pooling_at_trained_magnitudes(pooling):
             if pooling == "token":
                 worst = max(worst, float(np.abs(out[1].cpu().numpy().reshape(ref["logits"].shape) - ref["logits"]).max()))
         res[prec] = worst
-    print(f"full attention + GELU, pooling {pooling}, trained-like: f16c {res['f16c']:.2e}, f16x2 {res['f16x2']:.2e}, f16 {res['f16']:.2e}")
+    print(f"full attention + GELU, pooling {pooling}, trained-like: " + ", ".join(f"{k} {v:.2e}" for k, v in res.items()) + f"; auto ran {m.effective_precision()}")
+    assert res["auto"] < 7e-4
     assert res["f16x2"] < 8e-4 and res["f16c"] < 8e-4         # round 4: f16c 8.2e-4 (token); round 5 with operand centring: 6.2e-4
 
 

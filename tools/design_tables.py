@@ -111,8 +111,9 @@ def measured_half():
         if tail:
             lines.append(f"* `profiles/round5/pytest_gpu.log`: {tail[-1].strip()}")
         for l in lg.read_text().splitlines():
-            if re.match(r"^(auto|f16l6|f16c) (uit_|audio_)\S+: worst", l.strip()):
-                lines.append(f"  * {l.strip()}")
+            m = re.match(r"^[.Fs]*((auto|f16l6|f16c) (uit_|audio_)\S+: worst.*)$", l.strip())
+            if m:
+                lines.append(f"  * {m.group(1)}")
     lines.append(MEND)
     return "\n".join(lines)
 

@@ -9,6 +9,11 @@ single-stream order?  Same kernels, same batches; only the streams and their pri
              ENC(n) -> FE(n + R), the workspace reuse of the replica)
  fe-high     the other way round
 Each with R = 2 and 3 replicas.  Prints ms per step (median of 5 repeats of `steps` steps, wall clock around a synchronize).
+
+    python tools/stream_overlap.py [steps] coresident
+Round 5: the same variants with kernels that CAN share a CU -- encoder on 4-wave workgroups (half a CU's registers and LDS each) and the
+front-end on ONE workgroup per CU (the other half): a front-end wave and an encoder wave per SIMD, the matrix pipe and the VALU / LDS
+path used by different instruction streams at the same time.  (Round 4 measured the 8-wave encoder, which owns its CU.)
 """
 import statistics
 import sys
@@ -25,7 +30,8 @@ from uit_mobile_amd import models  # noqa: E402
 
 
 def main():
-    steps = int(sys.argv[1]) if len(sys.argv) > 1 else 60
+    steps = int(sys.argv[1]) if len(sys.argv) > 1 and sys.argv[1].isdigit() else 60
+    coresident = "coresident" in sys.argv
     dev = torch.device("cuda", 0)
     B, T = 8192, 16000
     sd = make_state_dict("uit_xs", 13)
@@ -42,6 +48,11 @@ def main():
             r.reserve(B, T, dev)
             r(x[:64])
         reps[0].tune_frontend(x)
+        if coresident:
+            for r in reps:
+                r.set_option("enc_waves", 4)
+                r.set_option("fe_wg_per_cu", 1)
+            print("co-resident shapes: encoder 4-wave workgroups, front-end one workgroup per CU", flush=True)
 
         def serial(R, n):
             st = reps[0].frontend(x)
@@ -92,7 +103,7 @@ def main():
                     ("split streams, equal priority", make_streamed(0, 0, True)),
                     ("FE stream + ENC stream, equal", make_streamed(0, 0, 2)), ("FE stream low + ENC stream high", make_streamed(lo, hi, 2)),
                     ("FE stream high + ENC stream low", make_streamed(hi, lo, 2))]
-        for R in (2, 3, 4):
+        for R in ((2, 3) if coresident else (2, 3, 4)):
             for name, fn in variants:
                 fn(R, 20)
                 torch.cuda.synchronize()

@@ -22,7 +22,7 @@ if mode == "attention":
     cases = [(n, "full", "mean", p) for n in ("audio_transformer_h128_d4_m3", "audio_transformer_h128_d6_m3_relu") for p in ("f16c", "f16x2")]
 else:
     cases = [(n, att, pooling, p) for n, att in (("uit_xs", "bneck"), ("audio_transformer_h128_d4_m3", "full")) for pooling in ("mean", "token", "dm")
-             for p in ("f16c", "f16l6" if att == "bneck" else "f16x2")]
+             for p in ("f16c", "f16l6" if att == "bneck" else "f16x2") + (("f16a",) if pooling == "token" else ())]
 for name, att, pooling, prec in cases:
     sd = make_trained_like_state_dict(name, 200, attention=att)
     m = getattr(models, name)(outputdim=537, target_length=102, pooling=pooling, precision=prec)

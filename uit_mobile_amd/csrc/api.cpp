@@ -22,11 +22,12 @@ using namespace uitk;
 
 static thread_local std::string g_err;
 // precisions whose weights are ONE term each (calibrated rounding applies); fp8w runs the f16 kernels on weights of the e4m3 grid
-static bool single_weight_precision(int p) { return p == UITK_PREC_F16 || p == UITK_PREC_BF16 || p == UITK_PREC_FP8 || p == UITK_PREC_FP8W; }
+static bool single_weight_precision(int p) { return p == UITK_PREC_F16 || p == UITK_PREC_BF16 || p == UITK_PREC_FP8 || p == UITK_PREC_FP8W || p == UITK_PREC_F16A; }
 // uitk_calibrate_weights also serves the split-weight precisions: their weights are not re-rounded, but the statistics install the
 // operand centring of the attention (pack.cpp) -- what an escalated 'auto' handle keeps of its calibration
 static bool calibratable_precision(int p) { return single_weight_precision(p) || p == UITK_PREC_F16X2 || p == UITK_PREC_F16L6; }
-static int kernel_precision(int p) { return p == UITK_PREC_FP8W ? UITK_PREC_F16 : p; }
+// what launch_encoder is told: fp8w runs the f16 kernels; f16a = 5, the f16 kernel with split activation operands in the cls tile
+static int kernel_precision(int p) { return p == UITK_PREC_FP8W ? UITK_PREC_F16 : p == UITK_PREC_F16A ? 5 : p; }
 static int fail(int code, const std::string& msg) { g_err = msg; return code; }
 #define HIP_TRY(expr)                                                                                   \
     do {                                                                                                \
@@ -805,7 +806,12 @@ int heldout_score(uitk_model* m, HeldOut* ho, hipStream_t s, double* mx, double*
 // the budget a deviation on the held-out clips is compared with (option calib_budget_e6; pooling 'dm' is compared on probabilities,
 // whose slope against the logit is at most 1/4)
 double parity_budget(const uitk_model* m) { return m->calib_budget_e6 * 1e-6 * (m->cfg.pooling == 1 ? 0.25 : 1.0); }
-int parity_fallback_precision(const uitk_model* m) { return (m->cfg.attention_full || m->cfg.act_gelu) ? UITK_PREC_F16X2 : UITK_PREC_F16L6; }
+// over budget: pooling 'token' reads ONE row, what is left there is activation rounding -> split activation operands (f16a); the
+// other poolings: split weights (f16l6 for BNeckAttention + ReLU, f16x2 otherwise)
+int parity_fallback_precision(const uitk_model* m) {
+    if (m->cfg.pooling == 2) return UITK_PREC_F16A;
+    return (m->cfg.attention_full || m->cfg.act_gelu) ? UITK_PREC_F16X2 : UITK_PREC_F16L6;
+}
 }  // namespace
 
 // The acceptance check of uitk_calibrate_weights: both candidate images -- rounded to nearest (uitk_create's) and calibrated -- run the

@@ -625,7 +625,11 @@ __global__ __launch_bounds__(WAVES * 64, 2) void uit_encoder_kernel(EncoderArgs 
     // precision f16l6: four 32 KiB ring slots (the low-order patch-embed weights use the upper half of the ring during the prologue)
     constexpr bool L6 = PREC == 4;
     // instantiations without a vector register to spare issue their weight / bias DMAs in the scalar-base form (see ring_issue)
-    constexpr bool SB = PREC <= 1 && (ATT != 0 || ACT != 0 || POOL == 1);
+    constexpr bool SB = (PREC <= 1 || PREC == 5) && (ATT != 0 || ACT != 0 || POOL == 1);
+    // PREC 5 (precision f16a, pooling 'token'): the f16 kernel with the MLP's two activation operands of column tile 0 -- the tile of the
+    // cls token, the one row the head reads -- as hi + lo fp16 terms (include/uitk.h: UITK_PREC_F16A)
+    constexpr bool ASPLIT = PREC == 5;
+    static_assert(!ASPLIT || POOL == 2, "precision f16a is built for pooling 'token'");
     // operand centring of LayerNorm-1 (uitk_dev.h: operand_centring; pack.cpp folds the same way): -mu[128] of a block in its bias table
     constexpr bool CEN = operand_centring(ATT, ACT, POOL, PREC);
     constexpr int NEGMU_AT = ATT ? BIASF_QKV + 128 : BIAS_NEGMU;
@@ -1515,6 +1519,18 @@ __global__ __launch_bounds__(WAVES * 64, 2) void uit_encoder_kernel(EncoderArgs 
         TSTAMP(4);                                                     // V + attention + proj
         // ===== MLP: 12 stages; stage ch = fc1 rows 32ch..32ch+31 (frags j*4+s) and fc2 k-step ch (frags 8+ft)
         layernorm_to_operand<OPC, NCT>(R, 1e-6f, X);
+        v8 Xlo[4], HXlo = OP::zero8();                                 // ASPLIT: the low-order terms of tile 0's two MLP operands
+        if constexpr (ASPLIT) {
+            float mean, rstd;
+            ln_stats(R, 0, 1e-6f, mean, rstd);
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {                              // lo = x - float(hi): what the fp16 rounding of the operand dropped
+                const h8 hi = __builtin_bit_cast(h8, X[s][0]);
+                const f4 l0 = R[2 * s][0] * splat(rstd) - f4{(float)hi[0], (float)hi[1], (float)hi[2], (float)hi[3]};
+                const f4 l1 = R[2 * s + 1][0] * splat(rstd) - f4{(float)hi[4], (float)hi[5], (float)hi[6], (float)hi[7]};
+                Xlo[s] = OP::pack8(l0, l1);
+            }
+        }
         TSTAMP(5);                                                     // LN2
         // Software-pipelined over the 12 stages: at stage ch the fc1 fragment reads are issued first, then the fc2
         // MFMAs of chunk ch-1 run from registers (A2/HX carried across the barrier) and cover the LDS latency; the
@@ -1533,8 +1549,28 @@ __global__ __launch_bounds__(WAVES * 64, 2) void uit_encoder_kernel(EncoderArgs 
                 f4 H0 = b10, H1 = b11;
 #pragma unroll
                 for (int s = 0; s < 4; ++s) { H0 = OP::mfma32(A[s], X[s][ct], H0); H1 = OP::mfma32(A[4 + s], X[s][ct], H1); }
+                if constexpr (ASPLIT) {
+                    if (ct == 0) {                                     // tile 0: + W . Xlo, and the activation as hi + lo
+#pragma unroll
+                        for (int s = 0; s < 4; ++s) { H0 = OP::mfma32(A[s], Xlo[s], H0); H1 = OP::mfma32(A[4 + s], Xlo[s], H1); }
+                        f4 a0, a1;
+                        if constexpr (ACT == 1) { a0 = gelu4(H0); a1 = gelu4(H1); }
+                        else { a0 = f4{fmaxf(H0[0], 0.f), fmaxf(H0[1], 0.f), fmaxf(H0[2], 0.f), fmaxf(H0[3], 0.f)};
+                               a1 = f4{fmaxf(H1[0], 0.f), fmaxf(H1[1], 0.f), fmaxf(H1[2], 0.f), fmaxf(H1[3], 0.f)}; }
+                        HX[0] = OP::pack8(a0, a1);
+                        const h8 hi = __builtin_bit_cast(h8, HX[0]);
+                        HXlo = OP::pack8(a0 - f4{(float)hi[0], (float)hi[1], (float)hi[2], (float)hi[3]}, a1 - f4{(float)hi[4], (float)hi[5], (float)hi[6], (float)hi[7]});
+                        continue;
+                    }
+                }
                 if constexpr (ACT == 1) HX[ct] = OP::pack8(gelu4(H0), gelu4(H1));
                 else HX[ct] = OP::relu_pack8(H0, H1);
+            }
+        };
+        auto fc2_lo = [&]() {                                          // ASPLIT: tile 0's low-order activation term through fc2
+            if constexpr (ASPLIT) {
+#pragma unroll
+                for (int ft = 0; ft < 8; ++ft) R[ft][0] = OP::mfma32(A2[ft], HXlo, R[ft][0]);
             }
         };
         {   // chunk 0 (peeled: defines A2 / HX before the steady-state loop)
@@ -1574,6 +1610,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void uit_encoder_kernel(EncoderArgs 
             for (int ct = 0; ct < NCT; ++ct)                                              // ... under chunk ch-1's fc2, token tile by token tile
 #pragma unroll
                 for (int ft = 0; ft < 8; ++ft) R[ft][ct] = OP::mfma32(A2[ft], HX[ct], R[ft][ct]);
+            fc2_lo();
             fc1_chunk(slot, ch, A);
             TSTAMP(7);                                                 // MLP chunk compute (sum of 12)
         }
@@ -1581,6 +1618,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void uit_encoder_kernel(EncoderArgs 
         for (int ct = 0; ct < NCT; ++ct)
 #pragma unroll
             for (int ft = 0; ft < 8; ++ft) R[ft][ct] = OP::mfma32(A2[ft], HX[ct], R[ft][ct]);
+        fc2_lo();
 #pragma unroll
         for (int ft = 0; ft < 8; ++ft) {
             const f4 b2 = *(const f4*)(bias + B_FC2 + 16 * ft + 4 * g);
@@ -2000,13 +2038,15 @@ hipError_t launch_encoder(const EncoderArgs& a, int precision, int waves, hipStr
         return a.nt < GT ? launch_enc<4, 8, true, false, 0, 0, 1>(a, stream) : launch_enc<4, 8, false, false, 0, 0, 1>(a, stream);
     }
     if (a.pooling) {                                      // pooling 'dm' / 'token' (f16 / f16x2, 8-wave workgroups), any attention / activation
-        if ((precision != 0 && precision != 3) || a.timing != nullptr) return hipErrorInvalidValue;
+        if ((precision != 0 && precision != 3 && precision != 5) || a.timing != nullptr) return hipErrorInvalidValue;
+        if (precision == 5 && a.pooling != 2) return hipErrorInvalidValue;
 #define UITK_POOL(P, SH, PL) (a.attention_full ? (a.act_gelu ? launch_enc<P, 8, SH, false, 1, 1, PL>(a, stream) : launch_enc<P, 8, SH, false, 1, 0, PL>(a, stream)) \
                                                : (a.act_gelu ? launch_enc<P, 8, SH, false, 0, 1, PL>(a, stream) : launch_enc<P, 8, SH, false, 0, 0, PL>(a, stream)))
         if (precision == 3) {                             // split weights (round 3): the parity mode of the full-width-attention factories
             if (a.pooling == 2) return UITK_POOL(3, true, 2);
             return a.nt < GT ? UITK_POOL(3, true, 1) : UITK_POOL(3, false, 1);
         }
+        if (precision == 5) return UITK_POOL(5, true, 2);  // precision f16a: split activation operands in the cls tile
         if (a.pooling == 2) return UITK_POOL(0, true, 2);  // per-key softmax masks always (dead columns)
         return a.nt < GT ? UITK_POOL(0, true, 1) : UITK_POOL(0, false, 1);
 #undef UITK_POOL

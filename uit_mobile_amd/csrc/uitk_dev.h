@@ -87,7 +87,7 @@ constexpr int BIAS_NEGMU = 736;
 // which (attention, activation, pooling, kernel precision) builds carry the runtime centring: the variants whose fp16 ACTIVATION floor sat
 // at the gate in round 4 (full-width attention, GELU, pooling 'token'), on fp16 operands with single or split weights
 constexpr bool operand_centring(int att, int act, int pool, int kernel_prec) {
-    return (kernel_prec == 0 || kernel_prec == 3) && (att != 0 || act != 0 || pool == 2);
+    return (kernel_prec == 0 || kernel_prec == 3 || kernel_prec == 5) && (att != 0 || act != 0 || pool == 2);
 }
 
 struct FrontendArgs {

@@ -32,9 +32,11 @@ _CALIB_OPTIONS = ('calib_accept_pct', 'calib_budget_e6')            # (meaningfu
 # 'fp8c' / 'fp8w' (round 5, BASELINE config #5): the fp8 kernel on weights GPTQ-rounded to the MX e4m3 grid / the f16 kernel on fp8-grid weights
 # ("fp8 weights" read literally), both calibrated like 'f16c'; 'fp8' keeps its weights rounded to nearest (the reference point)
 _PRECISIONS = {'auto': _lib.PREC_F16, 'f16': _lib.PREC_F16, 'f16c': _lib.PREC_F16, 'bf16': _lib.PREC_BF16, 'fp8': _lib.PREC_FP8, 'fp8c': _lib.PREC_FP8,
-               'fp8w': _lib.PREC_FP8W, 'f16x2': _lib.PREC_F16X2, 'f16l6': _lib.PREC_F16L6}
-_PRECISION_NAMES = {_lib.PREC_F16: 'f16', _lib.PREC_BF16: 'bf16', _lib.PREC_FP8: 'fp8', _lib.PREC_F16X2: 'f16x2', _lib.PREC_F16L6: 'f16l6'}
-_CALIBRATING = ('auto', 'f16c', 'fp8c', 'fp8w')                     # precisions whose handle is built with uitk_calibrate_weights
+               'fp8w': _lib.PREC_FP8W, 'f16x2': _lib.PREC_F16X2, 'f16l6': _lib.PREC_F16L6, 'f16a': _lib.PREC_F16A}
+_PRECISION_NAMES = {_lib.PREC_F16: 'f16', _lib.PREC_BF16: 'bf16', _lib.PREC_FP8: 'fp8', _lib.PREC_F16X2: 'f16x2', _lib.PREC_F16L6: 'f16l6', _lib.PREC_F16A: 'f16a'}
+# 'f16a' (round 5, pooling 'token' only): 'f16c' + the MLP's activation operands of the cls column tile as hi + lo terms -- what 'auto' escalates
+# to there (the cls row is read without a mean over tokens: activation rounding, not weight rounding, is what is over budget)
+_CALIBRATING = ('auto', 'f16c', 'fp8c', 'fp8w', 'f16a')             # precisions whose handle is built with uitk_calibrate_weights
 
 __all__ = ["UITBase", "UitkSetupWarning", "UitkParityWarning", "uit_xs", "uit_xxs", "uit_xxxs", "PRETRAINED_CHECKPOINTS",
            "audio_transformer_h128_d4_m3", "audio_transformer_h128_d4_m3_relu",
@@ -216,7 +218,9 @@ class UITBase(nn.Module):
             raise NotImplementedError("precision='fp8' / 'fp8c' are built for the uit_* family (BNeckAttention + ReLU, mean pooling) only")
         if precision == 'f16l6' and (self.attention_full or self.act_gelu):
             raise NotImplementedError("precision='f16l6' is built for BNeckAttention + ReLU (any pooling)")
-        if pooling != 'mean' and precision not in ('auto', 'f16', 'f16c', 'f16l6', 'f16x2', 'fp8w'):
+        if precision == 'f16a' and pooling != 'token':
+            raise NotImplementedError("precision='f16a' (split activation operands of the cls tile) is built for pooling='token'")
+        if pooling != 'mean' and precision not in ('auto', 'f16', 'f16c', 'f16l6', 'f16x2', 'fp8w', 'f16a'):
             raise NotImplementedError("pooling='dm' / 'token' are built for precision='auto' / 'f16' / 'f16c' / 'f16l6' / 'f16x2' / 'fp8w'")
 
         self.front_end = nn.Sequential(
