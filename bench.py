@@ -312,7 +312,7 @@ def supervise(ranks, world, worker_argv, env_for, setup_timeout, run_timeout, ga
 
         threads = []
         for r, lr in ranks:
-            pr = subprocess.Popen(worker_argv(g), env=env_for(r, lr, attempt), stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True,
+            pr = subprocess.Popen(worker_argv(g, attempt), env=env_for(r, lr, attempt), stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True,
                                   start_new_session=True)
             procs.append((r, pr))
             last[r] = ("spawned", 0.0, False)
@@ -332,11 +332,14 @@ def supervise(ranks, world, worker_argv, env_for, setup_timeout, run_timeout, ga
                 break
             now = time.perf_counter() - t_start
             in_setup = any(last[r][0] in PHASES_SETUP + ("spawned",) for r, _ in procs)
-            if in_setup and now > setup_timeout + grace:
-                why = f"set-up still running after {now:.0f} s (budget {setup_timeout:.0f} s)"
+            # (a retry's set-up budget is doubled: under an external torchrun the supervisors of the ranks do not talk to each other, and
+            # the ones whose first worker died early must wait for the ones whose first worker ran into its deadline)
+            st = setup_timeout * (attempt + 1)
+            if in_setup and now > st + grace:
+                why = f"set-up still running after {now:.0f} s (budget {st:.0f} s)"
                 break
-            if now > setup_timeout + run_timeout + 2.0 * grace:
-                why = f"run still going after {now:.0f} s (budget {setup_timeout:.0f} + {run_timeout:.0f} s)"
+            if now > st + run_timeout + 2.0 * grace:
+                why = f"run still going after {now:.0f} s (budget {st:.0f} + {run_timeout:.0f} s)"
                 break
         if why is not None:                                  # end the attempt: whole process groups, nothing of it may linger on the GPU
             for _, pr in procs:
@@ -398,19 +401,19 @@ def supervise_from_args(args):
             port0 = sk.getsockname()[1]
     argv_base = [a for a in sys.argv[1:]]
 
-    def worker_argv(g):
+    def worker_argv(g, attempt):
         out, skip = [], False
-        for a in argv_base:                                  # replace --gather with this attempt's
+        for a in argv_base:                                  # replace --gather / --setup-timeout with this attempt's
             if skip:
                 skip = False
                 continue
-            if a == "--gather":
+            if a in ("--gather", "--setup-timeout"):
                 skip = True
                 continue
-            if a.startswith("--gather="):
+            if a.startswith("--gather=") or a.startswith("--setup-timeout="):
                 continue
             out.append(a)
-        return [sys.executable, str(Path(__file__).resolve()), "--worker", "--gather", g] + out
+        return [sys.executable, str(Path(__file__).resolve()), "--worker", "--gather", g, "--setup-timeout", str(args.setup_timeout * (attempt + 1))] + out
 
     def env_for(r, lr, attempt):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(lr), WORLD_SIZE=str(world), LOCAL_WORLD_SIZE=str(world),
@@ -607,7 +610,7 @@ def main():
         for r in reps:
             # model.prepare (round 5): the handle (auto / f16c: weight calibration + acceptance check + a possible escalation), the
             # workspace, the front-end's pass split for this shape (measured once per process) and one warm-up forward
-            r.prepare(dev, (Bl, T), dtype=torch.int16 if args.pcm16 else torch.float32)
+            r.prepare(dev, sample=x)                          # (tuned and warmed up on the benchmark's own batch)
         if world > 1:
             phase("collectives")
             amax_allreduce_finish(amax_allreduce_async(torch.zeros(64, device=dev)))
@@ -740,7 +743,7 @@ def main():
                          "algorithmic_flops_per_launch": Bl * GEMM_FLOP[args.model],
                          # the WHOLE step (front-end + encoder + gaps) against the same peak: GEMM FLOPs / ms_per_step / peak
                          "step_frac": round(Bl * GEMM_FLOP[args.model] / (ms * 1e-3) / 1e12 / peak, 5)},
-            "frontend": {"kernel": "mel_frontend_kernel", "launch_ms": round(fe, 4),
+            "frontend": {"kernel": "mel_frontend_kernel", "launch_ms": round(fe, 4), "pass_split_pm": reps[0].get_option("fe_asym_pm").get(dev.index),
                          # algorithmic bytes: PCM in + 24 patches x 256 16-bit operands out per clip
                          "hbm_GBs": round(Bl * (T * in_bytes + 24 * 256 * 2) / (fe * 1e-3) / 1e9, 1),
                          "hbm_frac": round(Bl * (T * in_bytes + 24 * 256 * 2) / (fe * 1e-3) / 1e9 / PEAK_HBM_GBS, 5),

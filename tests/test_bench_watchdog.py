@@ -36,7 +36,7 @@ def _run(tmp_path, capsys, mode, gather="auto"):
     script.write_text(WORKER)
     log = io.StringIO()
     t0 = time.time()
-    rc = bench.supervise([(0, 0), (1, 1)], 2, lambda g: [sys.executable, str(script), g],
+    rc = bench.supervise([(0, 0), (1, 1)], 2, lambda g, attempt: [sys.executable, str(script), g],
                          lambda r, lr, attempt: dict(os.environ, RANK=str(r), FAKE_MODE=mode), setup_timeout=2.0, run_timeout=5.0,
                          gather=gather, is_printer=True, log=log, grace=0.5)
     out = [l for l in capsys.readouterr().out.splitlines() if l.startswith("{")]

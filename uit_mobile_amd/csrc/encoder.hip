@@ -681,7 +681,13 @@ __global__ __launch_bounds__(WAVES * 64, 2) void uit_encoder_kernel(EncoderArgs 
     for (int ct = 0; ct < NCT; ++ct) {
         const unsigned short* src = a.mel + ((int64_t)(clip_[ct] ? row_hi : row_lo) * NTOK + tk_[ct]) * 256 + 8 * g;
 #pragma unroll
-        for (int s = 0; s < 8; ++s) XB[ct][s] = *(const v8*)(src + 32 * s);
+        for (int s = 0; s < 8; ++s) {
+#if defined(UITK_LAB) && defined(ENC_NT_LOADS)
+            XB[ct][s] = __builtin_nontemporal_load((const v8*)(src + 32 * s));      // lab: streaming hint for the once-read operands
+#else
+            XB[ct][s] = *(const v8*)(src + 32 * s);
+#endif
+        }
     }
     // The patch operands come from HBM (the slowest trip of the prologue): their loads are issued FIRST, the L2-resident weight /
     // table DMAs behind them.

@@ -294,8 +294,6 @@ __global__ __launch_bounds__(FE_WAVES * 64, FE_OCC) void mel_frontend_kernel(Fro
             auto dppf = [](float old, float src, auto ctrl, auto bank) {
                 return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(old), __float_as_int(src), decltype(ctrl)::value, 0xF, decltype(bank)::value, false));
             };
-            using I = std::integral_constant<int, 0>;
-            (void)sizeof(I);
 #define FE_XB(A, B, CA, BA, CB, BB) do { const c32 a0_ = A;                                                                                   \
                 A.x = dppf(A.x, B.x, std::integral_constant<int, CA>{}, std::integral_constant<int, BA>{});                                    \
                 A.y = dppf(A.y, B.y, std::integral_constant<int, CA>{}, std::integral_constant<int, BA>{});                                    \

@@ -603,13 +603,16 @@ class UITBase(nn.Module):
                                       ctypes.c_void_p(probs.data_ptr()), lp, stream), "uitk_forward")
         return (probs, logits) if return_logits else probs
 
-    def prepare(self, device="cuda", batch_shape=None, dtype=torch.float32):
+    def prepare(self, device="cuda", batch_shape=None, dtype=torch.float32, sample=None):
         """THE set-up call (round 5): everything a first forward would otherwise do on the caller's time, now -- build the parameter
         image on `device` (for 'auto' / 'f16c': weight calibration, acceptance check, a possible escalation; ~0.15 s, device-synchronous),
         and, given batch_shape = (B, T): reserve the workspace for it, measure the front-end's pass split for that shape
         (uitk_tune_frontend, on a scratch buffer of `dtype` float32 / int16) and run one warm-up forward, so that every later forward of
-        that shape is enqueue-only -- and may be captured into a HIP graph.  Stands in for `.to(DEVICE).eval()` + the first batch of
-        inference.py:39-55 / evaluate.py:34-65.  Returns self."""
+        that shape is enqueue-only -- and may be captured into a HIP graph.  `sample`: a representative [B, T] device batch to tune and
+        warm up on instead of the scratch noise (its shape and dtype then stand for batch_shape / dtype): the split is a property of the
+        device and the pass count, but the leftover-frame skip makes a pass's cost mildly data-dependent, and a caller that has its real
+        data at hand gets the split measured on it.  Stands in for `.to(DEVICE).eval()` + the first batch of inference.py:39-55 /
+        evaluate.py:34-65.  Returns self."""
         device = torch.device(device)
         if device.type != "cuda":
             raise RuntimeError("uit_mobile_amd runs on a HIP device only (no CPU path)")
@@ -619,14 +622,20 @@ class UITBase(nn.Module):
             raise RuntimeError("uit_mobile_amd implements inference only: call model.eval() first")
         self._warned_setup = True                         # the caller did the right thing
         self._handle_obj(device)
+        if sample is not None:
+            sample, _ = self._prep_input(sample)
+            batch_shape = tuple(sample.shape)
         if batch_shape is not None:
             B, T = int(batch_shape[0]), int(batch_shape[1])
             self.reserve(B, T, device)
             with torch.cuda.device(device):
-                g = torch.Generator(device=device).manual_seed(1)
-                x = torch.randn((B, T), device=device, generator=g) * 0.1        # (contents irrelevant for the timing; noise keeps every frame live)
-                if dtype == torch.int16:
-                    x = (x * 32768.0).round().clamp(-32768, 32767).to(torch.int16)
+                if sample is not None:
+                    x = sample.to(device)
+                else:
+                    g = torch.Generator(device=device).manual_seed(1)
+                    x = torch.randn((B, T), device=device, generator=g) * 0.1    # (noise keeps every frame live)
+                    if dtype == torch.int16:
+                        x = (x * 32768.0).round().clamp(-32768, 32767).to(torch.int16)
                 if self.fe_autotune:
                     self.tune_frontend(x)
                 with torch.no_grad():
