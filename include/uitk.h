@@ -175,7 +175,9 @@ int uitk_pack_weights(const uitk_config* cfg, const uitk_weights* w, void* out, 
  * cabi_consumer.c shows the same four calls in C.  Not callable under stream capture (it allocates and synchronises). */
 int uitk_calibrate_weights(uitk_model* m, const uitk_weights* w, const void* pcm, int in_dtype, int64_t B, int64_t T, void* stream);
 /* Number of doubles of a statistics block for this config: patch embed [256][256], then per block LayerNorm-1 output [128][128],
- * attention output [inner][inner] (inner = 32, or 128 with attention_full), LayerNorm-2 output [128][128], activation output [384][384]. */
+ * attention output [inner][inner] (inner = 32, or 128 with attention_full), LayerNorm-2 output [128][128], activation output [384][384];
+ * behind them (round 5) the per-block MEAN of the LayerNorm-1 output, [depth][128].  Configurations whose kernels centre that operand
+ * at run time (attention_full, act_gelu or pooling 'token' on fp16 operands) hold the LayerNorm-1 moment of the centred operand. */
 size_t uitk_calib_stats_doubles(const uitk_config* cfg);
 /* The statistics the latest uitk_calibrate_weights of this handle measured (host buffer of uitk_calib_stats_doubles doubles). */
 int uitk_get_calib_stats(const uitk_model* m, double* out, size_t cap_doubles);

@@ -33,12 +33,14 @@ def patches(sd, pcm):
     return x[:, :, :96].reshape(B, 4, 16, 6, 16).transpose(0, 1, 3, 2, 4).reshape(B, 24, 256)
 
 
-def calib_stats(sd, pcm, depth, inner=32, act="relu", cls=False):
+def calib_stats(sd, pcm, depth, inner=32, act="relu", cls=False, centre=None):
     """-> (stats float64 [uitk_calib_stats_doubles], logits-free): the layout of include/uitk.h"""
     g = lambda k: np.asarray(sd[k], np.float64)
     x = patches(sd, pcm)
     B = x.shape[0]
     out, means = [], []
+    if centre is None:                                                 # uitk_dev.h: operand_centring() -- full attention, GELU or pooling 'token'
+        centre = inner != 32 or act != "relu" or cls
 
     def second_moment(a):
         a = _f16(a.reshape(-1, a.shape[-1]))
@@ -55,8 +57,9 @@ def calib_stats(sd, pcm, depth, inner=32, act="relu", cls=False):
     for b in range(depth):
         p = f"blocks.{b}."
         xn = _ln(tok, 1e-6)
-        out.append(second_moment(xn))
         means.append(xn.reshape(-1, 128).mean(0))                      # round 5: E[LayerNorm-1 output] per block (operand centring)
+        # builds that centre this operand at run time multiply round16(x - mu): that operand's moment
+        out.append(second_moment(xn - (np.float32(means[-1]).astype(np.float64) if centre else 0.0)))
         qkv = (xn * g(p + "norm1.weight") + g(p + "norm1.bias")) @ g(p + "attn.qkv.weight").T + g(p + "attn.qkv.bias")
         qkv = qkv.reshape(B, N, 3, 2, hd).transpose(2, 0, 3, 1, 4)
         q, k, v = qkv[0], qkv[1], qkv[2]

@@ -902,6 +902,7 @@ int uitk_calibrate_weights(uitk_model* m, const uitk_weights* w, const void* pcm
     if (int rc = naive_net_bind(m, &nn, rows, n_stats)) return rc;
     CalibArgs& a = nn.a;
     a.off_pe = co.pe; a.off_ln1 = co.ln1; a.off_att = co.att; a.off_ln2 = co.ln2; a.off_hid = co.hid; a.per_block = co.per_block; a.off_mu1 = co.mu1;
+    a.centre_ln1 = operand_centring(m->cfg.attention_full, m->cfg.act_gelu, m->cfg.pooling, kernel_precision(m->cfg.precision)) ? 1 : 0;
     HIP_TRY(launch_calibration(a, s));
     std::vector<float> stats_f(n_stats);
     HIP_TRY(hipMemcpyAsync(stats_f.data(), a.stats, n_stats * 4, hipMemcpyDeviceToHost, s));

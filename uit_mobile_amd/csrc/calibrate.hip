@@ -131,16 +131,16 @@ __global__ void cal_attention_kernel(const float* __restrict__ QKV, float* __res
     }
 }
 
-// G[i][j] = scale * sum_m x[m][i] x[m][j], x = the 16-bit operand value of X;  K multiple of 16
-__global__ void cal_gram_kernel(const float* __restrict__ X, float* __restrict__ G, int M, int K, float scale, int bf16) {
+// G[i][j] = scale * sum_m x[m][i] x[m][j], x = the 16-bit operand value of X (of X - mu when mu is given: the centred operand);  K multiple of 16
+__global__ void cal_gram_kernel(const float* __restrict__ X, float* __restrict__ G, int M, int K, float scale, int bf16, const float* __restrict__ mu) {
     __shared__ float xi[TS][TS + 1], xj[TS][TS + 1];
     const int tx = threadIdx.x, ty = threadIdx.y;
     const int i0 = blockIdx.y * TS, j0 = blockIdx.x * TS;
     float acc = 0.f;
     for (int m0 = 0; m0 < M; m0 += TS) {
         const int m = m0 + ty;
-        xi[ty][tx] = m < M ? round_op16(X[(int64_t)m * K + i0 + tx], bf16) : 0.f;
-        xj[ty][tx] = m < M ? round_op16(X[(int64_t)m * K + j0 + tx], bf16) : 0.f;
+        xi[ty][tx] = m < M ? round_op16(X[(int64_t)m * K + i0 + tx] - (mu ? mu[i0 + tx] : 0.f), bf16) : 0.f;
+        xj[ty][tx] = m < M ? round_op16(X[(int64_t)m * K + j0 + tx] - (mu ? mu[j0 + tx] : 0.f), bf16) : 0.f;
         __syncthreads();
 #pragma unroll
         for (int mm = 0; mm < TS; ++mm) acc += xi[mm][ty] * xj[mm][tx];
@@ -165,8 +165,8 @@ static hipError_t linear(const float* X, const float* W, const float* b, float* 
     hipLaunchKernelGGL(cal_linear_kernel, dim3((O + TS - 1) / TS, (M + TS - 1) / TS), dim3(TS, TS), 0, s, X, W, b, Y, M, K, O, act, accumulate);
     return hipGetLastError();
 }
-static hipError_t gram(const float* X, float* G, int M, int K, float scale, int bf16, hipStream_t s) {
-    hipLaunchKernelGGL(cal_gram_kernel, dim3(K / TS, K / TS), dim3(TS, TS), 0, s, X, G, M, K, scale, bf16);
+static hipError_t gram(const float* X, float* G, int M, int K, float scale, int bf16, hipStream_t s, const float* mu = nullptr) {
+    hipLaunchKernelGGL(cal_gram_kernel, dim3(K / TS, K / TS), dim3(TS, TS), 0, s, X, G, M, K, scale, bf16, mu);
     return hipGetLastError();
 }
 
@@ -186,10 +186,11 @@ hipError_t launch_calibration(const CalibArgs& a, hipStream_t s) {
         float* st = a.stats ? a.stats + (size_t)b * a.per_block : nullptr;      // nullptr: forward only (the acceptance check)
         hipLaunchKernelGGL(cal_layernorm_kernel, dim3((M + 3) / 4), dim3(256), 0, s, a.R, a.Xn, M, 1e-6f);
         CAL_TRY(hipGetLastError());
-        if (st) CAL_TRY(gram(a.Xn, st + a.off_ln1, M, DIM, inv_m, a.op_bf16, s));
         if (st) {
-            hipLaunchKernelGGL(cal_colmean_kernel, dim3(DIM / 64), dim3(64), 0, s, a.Xn, a.stats + a.off_mu1 + (size_t)b * DIM, M, DIM, inv_m);
+            float* mu = a.stats + a.off_mu1 + (size_t)b * DIM;
+            hipLaunchKernelGGL(cal_colmean_kernel, dim3(DIM / 64), dim3(64), 0, s, a.Xn, mu, M, DIM, inv_m);
             CAL_TRY(hipGetLastError());
+            CAL_TRY(gram(a.Xn, st + a.off_ln1, M, DIM, inv_m, a.op_bf16, s, a.centre_ln1 ? mu : nullptr));
         }
         CAL_TRY(linear(a.Xn, wb + a.o_qkv_w, wb + a.o_qkv_b, a.QKV, M, DIM, 3 * inner, 0, 0, s));
         hipLaunchKernelGGL(cal_attention_kernel, dim3(a.rows, 2), dim3(32), 0, s, a.QKV, a.O, a.ntok, inner);

@@ -658,18 +658,8 @@ int pack_image(const uitk_config* c, const uitk_weights* w, const double* calib,
     const bool centre_rt = operand_centring(c->attention_full, c->act_gelu, c->pooling, kprec);
     const bool centre = centre_rt || (calib != nullptr && (kprec == UITK_PREC_F16 || kprec == UITK_PREC_F16X2 || kprec == UITK_PREC_F16L6));
     const std::vector<double> mu_zero(DIM, 0.0);
-    // the qkv operand's second moment with the runtime centring: E[(x - mu)(x - mu)^T] = H - mu mu^T
-    std::vector<std::vector<double>> Hc(centre_rt && calib ? depth : 0);
-    if (centre_rt && calib) {
-        const CalibOffsets co = calib_offsets(c);
-        for (int b = 0; b < depth; ++b) {
-            const double* H = calib + (size_t)b * co.per_block + co.ln1;
-            const double* mu = calib + co.mu1 + (size_t)b * DIM;
-            Hc[b].resize((size_t)DIM * DIM);
-            for (int i = 0; i < DIM; ++i)
-                for (int j = 0; j < DIM; ++j) Hc[b][(size_t)i * DIM + j] = H[(size_t)i * DIM + j] - mu[i] * mu[j];
-        }
-    }
+    // (with the runtime centring the statistics block holds the LayerNorm-1 moment of the CENTRED operand, round16(x - mu): what qkv
+    // multiplies -- calibrate.hip / tests/calib_ref.py form it that way for these configurations)
     const bool grid8 = w8 || (prec == UITK_PREC_FP8 && calibrated);     // qkv / fc1 / fc2 as VALUES on the MX e4m3 grid (Q8_*)
     // scale blocks: precision fp8 = the hardware's 32-element blocks of a fragment8 (uitk_dev.h: per 128 k, block 2 (kk >> 6) + ((kk >> 3) & 1));
     // the weights-only variant = 32 consecutive k
@@ -681,7 +671,7 @@ int pack_image(const uitk_config* c, const uitk_weights* w, const double* calib,
     auto grid8_block = [&](int b, const double* base, const CalibOffsets* co) {       // base == nullptr: every element to nearest
         const FoldedBlock& fb = F.blocks[b];
         Q8_qkv[b] = round_fp8_grid(3 * inner, DIM, [&](int r, int k) { return fb.qkv_w[(size_t)r * DIM + k]; }, block_of, DIM / 32,
-                                   base ? (centre_rt ? Hc[b].data() : base + co->ln1) : nullptr);
+                                   base ? base + co->ln1 : nullptr);
         Q8_fc1[b] = round_fp8_grid(HID, DIM, [&](int r, int k) { return fb.fc1_w[(size_t)r * DIM + k]; }, block_of, DIM / 32, base ? base + co->ln2 : nullptr);
         Q8_fc2[b] = round_fp8_grid(DIM, HID, [&](int r, int k) { return fb.fc2_w[(size_t)r * HID + k]; }, block_of, HID / 32, base ? base + co->hid : nullptr);
     };
@@ -710,7 +700,7 @@ int pack_image(const uitk_config* c, const uitk_weights* w, const double* calib,
                     if (which == 0) grid8_block(b, base, &co);
                     continue;
                 }
-                if (which == 0) cq_qkv[b] = round_gptq(3 * inner, DIM, [&](int r, int k) { return fb.qkv_w[(size_t)r * DIM + k]; }, prec, centre_rt ? Hc[b].data() : base + co.ln1);
+                if (which == 0) cq_qkv[b] = round_gptq(3 * inner, DIM, [&](int r, int k) { return fb.qkv_w[(size_t)r * DIM + k]; }, prec, base + co.ln1);
                 else if (which == 2) cq_fc1[b] = round_gptq(HID, DIM, [&](int r, int k) { return fb.fc1_w[(size_t)r * DIM + k]; }, prec, base + co.ln2);
                 else cq_fc2[b] = round_gptq(DIM, HID, [&](int r, int k) { return fb.fc2_w[(size_t)r * HID + k]; }, prec, base + co.hid);
             }

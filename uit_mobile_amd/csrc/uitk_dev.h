@@ -162,6 +162,8 @@ struct CalibArgs {
     float* stats;
     size_t off_pe, off_ln1, off_att, off_ln2, off_hid, per_block;
     size_t off_mu1;             // [depth][128] column means of the LayerNorm-1 output (fp32 values, before operand rounding)
+    int centre_ln1;             // builds with the runtime operand centring (operand_centring()): the LayerNorm-1 moment is that of the operand the
+                                // kernel forms, round16(x - mu), not of round16(x)
 };
 hipError_t launch_calibration(const CalibArgs& a, hipStream_t stream);
 
