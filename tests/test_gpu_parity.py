@@ -1047,6 +1047,32 @@ def test_wide_held_out_set_against_the_imported_reference(golden, tag, name, see
     assert worst_wav[0] < 8e-4 and d.max() < 8e-4 and worst_p < 2.5e-4
 
 
+@pytest.mark.parametrize("tag,name,seed,att,act", HELDOUT_MODELS)
+def test_wide_held_out_set_on_short_and_long_clips(golden, tag, name, seed, att, act):
+    """The other clip shapes of the path on the wide held-out signals at trained magnitudes (default mode vs the C oracle): SHORT clips
+    (0.5 s: 51 frames -> 3 time patches, masked padding tokens -- the instantiations whose masks became accumulator start values in
+    round 5; the calibration means were measured on full clips) and LONG clips (4 s: 4 crops with the re-cropped tail, mean over crops)."""
+    from uit_mobile_amd.synth import adversarial_pcm_i16
+    g = golden("heldout_wide")
+    sd = make_trained_like_state_dict(name, seed, attention=att)
+    m = getattr(models, name)(outputdim=537, target_length=102)
+    m.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()}, strict=True)
+    m = m.cuda().eval().prepare("cuda")
+    o = Oracle(sd, act=act)
+    adv, names = adversarial_pcm_i16(3, 1)
+    wavs = np.stack([np.pad(g[f"wav{i:02d}_pcm"], (0, max(0, 16384 - len(g[f"wav{i:02d}_pcm"]))))[:16384] for i in range(int(g["wav_count"]))])
+    res = {}
+    for label, x in (("short 0.5 s", np.concatenate([adv[:, 4000:12000], wavs[:, 2000:10000]])),
+                     ("long 4 s", np.concatenate([np.tile(adv, (1, 4))[:, :64000], np.tile(wavs, (1, 4))[:, :64000]]))):
+        p, l = run(m, x)
+        r = o.forward(x)
+        assert l.shape == r["logits"].shape
+        d = np.abs(l - r["logits"]).reshape(len(x), -1).max(1)
+        res[label] = (float(d.max()), (names + [f"wav{i:02d}" for i in range(len(wavs))])[int(d.argmax())], float(np.abs(p - r["probs"]).max()))
+    print(f"{tag} ({m.effective_precision()}): " + "; ".join(f"{k}: worst max|dlogit| {v[0]:.2e} on {v[1]}, max|dprob| {v[2]:.2e}" for k, v in res.items()))
+    assert all(v[0] < 8e-4 and v[2] < 2.5e-4 for v in res.values())
+
+
 @pytest.mark.parametrize("tag,name,seed,att,act", HELDOUT_MODELS + (("xs205", "uit_xs", 205, "bneck", "relu"),))
 def test_random_search_over_adversarial_families(tag, name, seed, att, act):
     """Round 5: a seeded random search (~12 s per checkpoint) over the adversarial families -- every round draws
