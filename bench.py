@@ -293,6 +293,18 @@ def supervise(ranks, world, worker_argv, env_for, setup_timeout, run_timeout, ga
     import threading
     attempts = []
     gathers = [gather] + (["rccl"] if gather != "rccl" else [])
+    live = []                                               # worker processes of the running attempt (each its own session / process group)
+
+    def on_term(signum, frame):                             # torchrun (or a user) ends the supervisor: its workers must not outlive it on the GPU
+        for pr in live:
+            try:
+                os.killpg(pr.pid, signal.SIGKILL)
+            except (ProcessLookupError, PermissionError):
+                pass
+        os._exit(128 + signum)
+    if threading.current_thread() is threading.main_thread():
+        for sg in (signal.SIGTERM, signal.SIGINT, signal.SIGHUP):
+            signal.signal(sg, on_term)
     for attempt, g in enumerate(gathers):
         procs, last, out_lines, timed_out = [], {}, [], []
         t_start = time.perf_counter()
@@ -315,6 +327,7 @@ def supervise(ranks, world, worker_argv, env_for, setup_timeout, run_timeout, ga
             pr = subprocess.Popen(worker_argv(g, attempt), env=env_for(r, lr, attempt), stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True,
                                   start_new_session=True)
             procs.append((r, pr))
+            live.append(pr)
             last[r] = ("spawned", 0.0, False)
             for fn, a in ((pump_err, (pr, r)), (pump_out, (pr, r == ranks[0][0]))):
                 th = threading.Thread(target=fn, args=a, daemon=True)
@@ -354,6 +367,7 @@ def supervise(ranks, world, worker_argv, env_for, setup_timeout, run_timeout, ga
                     pass
         for th in threads:
             th.join(timeout=5)
+        del live[:]
         rec = {"gather": g, "seconds": round(time.perf_counter() - t_start, 1), "error": why,
                "last_phase": {str(r): last[r][0] + (" (its own watchdog fired)" if last[r][2] else "") for r, _ in procs},
                "last_phase_at_s": {str(r): round(last[r][1], 1) for r, _ in procs}}

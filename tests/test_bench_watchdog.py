@@ -71,3 +71,44 @@ def test_supervisor_reports_an_error_line_when_the_fallback_fails_too(tmp_path, 
     # nothing of a failed attempt lingers: the stand-in workers (own sessions) were killed with their process groups
     rc, out, log, _ = _run(tmp_path, capsys, "always_stall", gather="rccl")
     assert rc != 0 and len(json.loads(out[0])["watchdog"]["attempts"]) == 1      # already rccl: one attempt only
+
+
+def test_supervisor_takes_its_workers_with_it_when_it_is_terminated(tmp_path):
+    """torchrun ends a failed job by SIGTERM to the processes it started -- the supervisors.  Their workers live in sessions of their own
+    (so that a whole attempt can be killed as process groups) and must not outlive the supervisor on the GPU."""
+    import signal
+    import subprocess
+    script = tmp_path / "worker.py"
+    script.write_text(WORKER)
+    pidfile = tmp_path / "pids"
+    driver = tmp_path / "driver.py"
+    driver.write_text(f"""
+import os, sys, subprocess
+sys.path.insert(0, {str(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))!r})
+import bench
+real = subprocess.Popen
+def spy(*a, **k):
+    p = real(*a, **k)
+    open({str(pidfile)!r}, "a").write(str(p.pid) + "\\n")
+    return p
+subprocess.Popen = spy
+bench.supervise([(0, 0), (1, 1)], 2, lambda g, attempt: [sys.executable, {str(script)!r}, g],
+                lambda r, lr, attempt: dict(os.environ, RANK=str(r), FAKE_MODE="always_stall"), 60.0, 60.0, "auto", True)
+""")
+    sup = subprocess.Popen([sys.executable, str(driver)], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    deadline = time.time() + 20
+    while time.time() < deadline and (not pidfile.exists() or len(pidfile.read_text().split()) < 2):
+        time.sleep(0.1)
+    pids = [int(x) for x in pidfile.read_text().split()]
+    assert len(pids) == 2
+    time.sleep(0.5)
+    sup.send_signal(signal.SIGTERM)
+    sup.wait(timeout=20)
+    time.sleep(0.5)
+    for pid in pids:
+        try:
+            os.kill(pid, 0)
+            alive = open(f"/proc/{pid}/stat").read().split()[2] != "Z"
+        except (ProcessLookupError, FileNotFoundError):
+            alive = False
+        assert not alive, pid
