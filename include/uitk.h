@@ -53,11 +53,12 @@ typedef enum uitk_precision {
                            block scales (32 consecutive k per scale), expanded to fp16 fragments at pack time: the UITK_PREC_F16 kernel,
                            fp16 activations, any family / pooling.  With uitk_calibrate_weights the grid rounding is GPTQ (as for
                            UITK_PREC_FP8).  A measured mode (weight error ~2^-4 relative), not a parity mode */
-    UITK_PREC_F16A = 6, /* round 5, pooling 'token' only: UITK_PREC_F16 (calibrated single fp16 weights) with the two ACTIVATION operands of the MLP
-                           (LayerNorm-2 output, ReLU / GELU output) of the column tile that holds the cls token as hi + lo fp16 terms.  With
-                           pooling 'token' the head reads ONE row -- no mean over 24 tokens averages the fp16 activation rounding away, and
-                           split WEIGHTS do not touch it (tools/err_attrib_centring.py: ln2 5.8e-4, hidden 6.4e-4 of 9.6e-4) -- so this is the
-                           precision get_option("parity_escalate_to") names for pooling 'token'; +16 MFMAs per MLP chunk (~1.3x encoder time) */
+    UITK_PREC_F16A = 6, /* round 5, pooling 'token' only: UITK_PREC_F16 (calibrated single fp16 weights) with EVERY ACTIVATION operand of the
+                           column tile that holds the cls token as hi + lo fp16 terms: the LayerNorm-1 operand (into q, k, v), q, the attention
+                           output, the LayerNorm-2 operand, the ReLU / GELU output.  With pooling 'token' the head reads ONE row -- no mean
+                           over 24 tokens averages the fp16 activation rounding away, and split WEIGHTS do not touch it
+                           (tools/err_attrib_centring.py) -- so this is the parity mode of pooling 'token' (the wrapper's 'auto' starts there) and
+                           what get_option("parity_escalate_to") names for it; 1.2-1.4x the encoder time of UITK_PREC_F16 */
     UITK_PREC_F16L6 = 4 /* round 3's parity mode (kept built and tested): fp16 operands as UITK_PREC_F16 plus the LOW-ORDER weight term on the cheap pipe:
                            W = f16(W) + 2^e(row) . e2m3(W - f16(W)), the second term as OCP fp6 on
                            v_mfma_scale_f32_16x16x128_f8f6f4 (one MFMA at the cost of one f16 k-step covers K = 128) against fp6

@@ -924,7 +924,7 @@ int uitk_calibrate_weights(uitk_model* m, const uitk_weights* w, const void* pcm
             (void)hipDeviceSynchronize();
             (void)hipMemcpy(m->image, m->img_nearest.data(), m->img_nearest.size(), hipMemcpyHostToDevice);
             m->weights_calibrated = 0;
-            if (m->cfg.precision == UITK_PREC_F16) m->parity_escalate_to = parity_fallback_precision(m);
+            if (m->cfg.precision == UITK_PREC_F16 || m->cfg.precision == UITK_PREC_F16A) m->parity_escalate_to = parity_fallback_precision(m);
             return rc;
         }
         if (m->calib_report[4] >= 0.f) {                         // the check applied and left its choice on the device
@@ -933,7 +933,7 @@ int uitk_calibrate_weights(uitk_model* m, const uitk_weights* w, const void* pcm
             // A refused calibration leaves the nearest-rounded image (measured at up to 1.2e-3 on trained-like checkpoints; harmless at init
             // scale): whichever image stays, over budget it is reported as "rebuild with the family's split-weight precision".
             const double dev = m->weights_calibrated ? m->calib_report[1] : m->calib_report[0];
-            if (m->cfg.precision == UITK_PREC_F16 && m->calib_budget_e6 > 0 && !(dev <= parity_budget(m)))       // (bf16 / fp8 / fp8w are
+            if ((m->cfg.precision == UITK_PREC_F16 || m->cfg.precision == UITK_PREC_F16A) && m->calib_budget_e6 > 0 && !(dev <= parity_budget(m)))       // (bf16 / fp8 / fp8w are
                 m->parity_escalate_to = parity_fallback_precision(m);                                                  // measured modes, not parity modes)
             return UITK_OK;
         }

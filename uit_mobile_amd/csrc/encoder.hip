@@ -313,6 +313,29 @@ __device__ __forceinline__ void layernorm_to_operand(const f4 (&R)[8][3], float 
     }
 }
 
+// Precision f16a: the LOW-ORDER term of column tile 0's LayerNorm operand, lo = (the fp32 value the operand was rounded from) - float(hi):
+// what the fp16 rounding of X[.][0] dropped, as a second fp16 operand (hi + lo carries ~22 bits).  Same arithmetic as
+// layernorm_to_operand (the centred form with CEN), recomputed for tile 0 only.
+template <bool CEN>
+__device__ __forceinline__ void layernorm_lo_operand(const f4 (&R)[8][3], float eps, const h8 (&X)[4][3], h8 (&Xlo)[4], const float* negmu) {
+    float mean, rstd;
+    ln_stats(R, 0, eps, mean, rstd);
+    const float* nm = CEN ? negmu + 4 * (lane_id_now() >> 4) : nullptr;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        f4 m0 = splat(0.f), m1 = splat(0.f);
+        if constexpr (CEN) { m0 = *(const f4*)(nm + 32 * s); m1 = *(const f4*)(nm + 32 * s + 16); }
+        const h8 hi = X[s][0];
+        const f4 v0 = __builtin_elementwise_fma(R[2 * s][0], splat(rstd), m0), v1 = __builtin_elementwise_fma(R[2 * s + 1][0], splat(rstd), m1);
+        Xlo[s] = Op<0>::pack8(v0 - f4{(float)hi[0], (float)hi[1], (float)hi[2], (float)hi[3]}, v1 - f4{(float)hi[4], (float)hi[5], (float)hi[6], (float)hi[7]});
+    }
+}
+// lo of a packed fp32 quad / pair of quads: x - float(pack(x))
+__device__ __forceinline__ h4 pack4_lo(f4 x, h4 hi) { return Op<0>::pack4(x - f4{(float)hi[0], (float)hi[1], (float)hi[2], (float)hi[3]}); }
+__device__ __forceinline__ h8 pack8_lo(f4 x0, f4 x1, h8 hi) {
+    return Op<0>::pack8(x0 - f4{(float)hi[0], (float)hi[1], (float)hi[2], (float)hi[3]}, x1 - f4{(float)hi[4], (float)hi[5], (float)hi[6], (float)hi[7]});
+}
+
 typedef unsigned u2 __attribute__((ext_vector_type(2)));
 typedef int v8i __attribute__((ext_vector_type(8)));
 
@@ -324,10 +347,10 @@ __device__ constexpr int TI[7] = {0, 0, 1, 1, 1, 2, 2};
 // Attention of one block on 16x16x16 MFMAs (K = head_dim 16 exactly) + the proj linear into the residual stream R.
 //   Qh/Kh[h][ct]: q, k of head h as C/D tiles packed to 16 bits (feature-major);  Vh[ct][h]: V token-major (A operand of P.V)
 //   tvalid / kinit: see the kernel;  proj: the eight 1 KiB proj fragments (K = 32 = (head, d));  bias: this block's bias table
-template <class OP, bool SHORT, bool X2 = false, int NCT = 3>
+template <class OP, bool SHORT, bool X2 = false, int NCT = 3, bool ASP = false>
 __device__ __forceinline__ void attention_proj(f4 (&R)[8][3], const typename OP::v4 (&Qh)[2][3], const typename OP::v4 (&Kh)[2][3],
                                                const typename OP::v4 (&Vh)[3][2], const bool (&tvalid)[7], const f4 (&kinit)[3],
-                                               const char* proj, const float* bias, int lane, int g) {
+                                               const char* proj, const float* bias, int lane, int g, const typename OP::v4* Qlo = nullptr) {
     using v8 = typename OP::v8;
     using v4 = typename OP::v4;
     constexpr int N7 = NCT == 2 ? 4 : 7;                  // one clip in tiles 0 / 1: the four score tiles among them (the first four of TJ / TI)
@@ -348,7 +371,10 @@ __device__ __forceinline__ void attention_proj(f4 (&R)[8][3], const typename OP:
             if (NCT == 3 && i != 0 && i != 6) init = tvalid[i] ? init : splat(-1e30f);
         }
 #pragma unroll
-        for (int h = 0; h < 2; ++h) S[h][i] = OP::mfma16(Kh[h][TJ[i]], Qh[h][TI[i]], init);
+        for (int h = 0; h < 2; ++h) {
+            S[h][i] = OP::mfma16(Kh[h][TJ[i]], Qh[h][TI[i]], init);
+            if constexpr (ASP) { if (TI[i] == 0) S[h][i] = OP::mfma16(Kh[h][TJ[i]], Qlo[h], S[h][i]); }      // precision f16a: q of tile 0 = hi + lo
+        }
     }
 #pragma unroll
     for (int i = 0; i < N7; ++i)
@@ -402,6 +428,11 @@ __device__ __forceinline__ void attention_proj(f4 (&R)[8][3], const typename OP:
         const f4 bp = *(const f4*)(bias + BIAS_PROJ + 16 * ft + 4 * g);
 #pragma unroll
         for (int ct = 0; ct < NCT; ++ct) R[ft][ct] = OP::mfma32(A[ft], OX[ct], add4s(R[ft][ct], bp));
+    }
+    if constexpr (ASP) {                                  // precision f16a: the attention output of tile 0 = hi + lo
+        const v8 OXlo = pack8_lo(O[0][0], O[1][0], OX[0]);
+#pragma unroll
+        for (int ft = 0; ft < 8; ++ft) R[ft][0] = OP::mfma32(A[ft], OXlo, R[ft][0]);
     }
     if constexpr (X2) {                                   // precision f16x2: the low-order proj fragments follow the high-order ones
 #pragma unroll
@@ -915,17 +946,22 @@ __global__ __launch_bounds__(WAVES * 64, 2) void uit_encoder_kernel(EncoderArgs 
       // the hi AND the lo fragments of HALF a group -- tile slot dl: fragments dl*8 + s (hi k-step s), dl*8 + 4 + s (lo) -- so an
       // accumulator takes its hi chain and its lo chain inside one stage (12 + 4 stages).  The LN1 operand is recomputed for head 1
       // instead of being kept alive across head 0's attention.
-      auto full_attention = [&](auto xs2_tag, int tb, const float* bias, v8 (&X)[4][3]) {
+      auto full_attention = [&](auto xs2_tag, int tb, const float* bias, v8 (&X)[4][3], v8 (&Xlo1)[4]) {
         constexpr bool XS2 = decltype(xs2_tag)::value;
+        static_assert(!(ASPLIT && XS2), "precision f16a rides on the single-weight f16 stream");
         constexpr int NSUB = XS2 ? 2 : 1, DTS = 4 / NSUB, KF = XS2 ? 8 : 4;      // stages per group, d-tiles per stage, fragments per tile
         // SB instantiations re-derive the lane's (c, g) from v_mbcnt where they are used (a bias-table offset): held across the block
         // they were spilled and reloaded behind a ring barrier
         auto lane_now = [&]() { if constexpr (SB) return lane_id_now(); else return lane; };
         v8 OX[4][3];                                                   // attention output, k-order of proj: k-step 2h + dt/2
+        v8 OXlo[4];                                                    // precision f16a: its low-order term for column tile 0
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
-            if (h == 1) layernorm_to_operand<OPC, NCT, CEN>(R, 1e-6f, X, bias + NEGMU_AT);
-            v4 Qp[4][3], Kp[4][3];
+            if (h == 1) {
+                layernorm_to_operand<OPC, NCT, CEN>(R, 1e-6f, X, bias + NEGMU_AT);
+                if constexpr (ASPLIT) layernorm_lo_operand<CEN>(R, 1e-6f, X, Xlo1, bias + NEGMU_AT);
+            }
+            v4 Qp[4][3], Kp[4][3], Qlo[4];
 #pragma unroll
             for (int which = 0; which < 2; ++which) {
 #pragma unroll
@@ -951,9 +987,14 @@ __global__ __launch_bounds__(WAVES * 64, 2) void uit_encoder_kernel(EncoderArgs 
                             for (int ct = 0; ct < NCT; ++ct)
 #pragma unroll
                                 for (int sk = 0; sk < 4; ++sk) acc[ct] = OP::mfma32(A[sk], X[sk][ct], acc[ct]);
+                            if constexpr (ASPLIT) {                    // tile 0: + W . Xlo
+#pragma unroll
+                                for (int sk = 0; sk < 4; ++sk) acc[0] = OP::mfma32(A[sk], Xlo1[sk], acc[0]);
+                            }
                         }
 #pragma unroll
                         for (int ct = 0; ct < NCT; ++ct) { if (which == 0) Qp[dt][ct] = OP::pack4(acc[ct]); else Kp[dt][ct] = OP::pack4(acc[ct]); }
+                        if constexpr (ASPLIT) { if (which == 0) Qlo[dt] = pack4_lo(acc[0], Qp[dt][0]); }
                     }
                 }
             }
@@ -971,6 +1012,12 @@ __global__ __launch_bounds__(WAVES * 64, 2) void uit_encoder_kernel(EncoderArgs 
                 }
 #pragma unroll
                 for (int dt = 0; dt < 4; ++dt) acc = OP::mfma16(Kp[dt][TJ[i]], Qp[dt][TI[i]], acc);
+                if constexpr (ASPLIT) {                                // queries of tile 0: q = hi + lo
+                    if (TI[i] == 0) {
+#pragma unroll
+                        for (int dt = 0; dt < 4; ++dt) acc = OP::mfma16(Kp[dt][TJ[i]], Qlo[dt], acc);
+                    }
+                }
                 S[i] = acc;
                 const float hm = hmax(S[i]);
                 tm[i] = (PERKEY || tvalid[i]) ? hm : -INFINITY;
@@ -1018,6 +1065,10 @@ __global__ __launch_bounds__(WAVES * 64, 2) void uit_encoder_kernel(EncoderArgs 
                         for (int ct = 0; ct < NCT; ++ct)
 #pragma unroll
                             for (int sk = 0; sk < 4; ++sk) acc[ct] = OP::mfma32(X[sk][ct], Bw[sk], acc[ct]);
+                        if constexpr (ASPLIT) {
+#pragma unroll
+                            for (int sk = 0; sk < 4; ++sk) acc[0] = OP::mfma32(Xlo1[sk], Bw[sk], acc[0]);
+                        }
                     }
 #pragma unroll
                     for (int ct = 0; ct < NCT; ++ct) Vp[ct][dt] = OP::pack4(acc[ct]);
@@ -1043,6 +1094,12 @@ __global__ __launch_bounds__(WAVES * 64, 2) void uit_encoder_kernel(EncoderArgs 
                     const f4 inv = splat(__builtin_amdgcn_rcpf(Lsum[it][0]));
                     OX[2 * h][it] = OP::pack8(O[0][it] * inv, O[1][it] * inv);
                     OX[2 * h + 1][it] = OP::pack8(O[2][it] * inv, O[3][it] * inv);
+                    if constexpr (ASPLIT) {
+                        if (it == 0) {
+                            OXlo[2 * h] = pack8_lo(O[0][0] * inv, O[1][0] * inv, OX[2 * h][0]);
+                            OXlo[2 * h + 1] = pack8_lo(O[2][0] * inv, O[3][0] * inv, OX[2 * h + 1][0]);
+                        }
+                    }
                 }
             }
             // head 0's output is not needed before proj: it waits in LDS -- the region of the prologue's low-order patch-embed weights,
@@ -1053,12 +1110,20 @@ __global__ __launch_bounds__(WAVES * 64, 2) void uit_encoder_kernel(EncoderArgs 
                 for (int sk = 0; sk < 2; ++sk)
 #pragma unroll
                     for (int ct = 0; ct < NCT; ++ct) *(v8*)(pelo + ((wave * 6 + sk * 3 + ct) * 64 + lane) * 16) = OX[sk][ct];
+                if constexpr (ASPLIT) {                                // (pooling 'token': NCT = 2, the ct = 2 slots are free)
+#pragma unroll
+                    for (int sk = 0; sk < 2; ++sk) *(v8*)(pelo + ((wave * 6 + sk * 3 + 2) * 64 + lane) * 16) = OXlo[sk];
+                }
             }
         }
 #pragma unroll
         for (int sk = 0; sk < 2; ++sk)
 #pragma unroll
             for (int ct = 0; ct < NCT; ++ct) OX[sk][ct] = *(const v8*)(pelo + ((wave * 6 + sk * 3 + ct) * 64 + lane) * 16);
+        if constexpr (ASPLIT) {
+#pragma unroll
+            for (int sk = 0; sk < 2; ++sk) OXlo[sk] = *(const v8*)(pelo + ((wave * 6 + sk * 3 + 2) * 64 + lane) * 16);
+        }
         // proj 128 -> 128: output tiles ft, four k-steps each (+ the lo k-steps): 2 stages of 4 tiles, or (f16x2) 4 stages of 2 tiles
         constexpr int PST = 2 * NSUB, FTS = 8 / PST;
 #pragma unroll
@@ -1082,6 +1147,10 @@ __global__ __launch_bounds__(WAVES * 64, 2) void uit_encoder_kernel(EncoderArgs 
                     for (int ct = 0; ct < NCT; ++ct)
 #pragma unroll
                         for (int sk = 0; sk < 4; ++sk) acc[ct] = OP::mfma32(A[sk], OX[sk][ct], acc[ct]);
+                    if constexpr (ASPLIT) {
+#pragma unroll
+                        for (int sk = 0; sk < 4; ++sk) acc[0] = OP::mfma32(A[sk], OXlo[sk], acc[0]);
+                    }
                 }
 #pragma unroll
                 for (int ct = 0; ct < NCT; ++ct) R[ft][ct] = acc[ct];
@@ -1183,7 +1252,8 @@ __global__ __launch_bounds__(WAVES * 64, 2) void uit_encoder_kernel(EncoderArgs 
         v8 X[4][3];
         layernorm_to_operand<OPC, NCT, CEN>(R, 1e-6f, X, bias + NEGMU_AT);
         if constexpr (ATT) {
-        full_attention(std::true_type{}, tb, bias, X);
+        v8 Xlo1[4];                                                    // (precision f16a has no split-weight build)
+        full_attention(std::true_type{}, tb, bias, X, Xlo1);
         } else {
         v4 Qh[2][3], Kh[2][3], Vh[3][2];
 #pragma unroll
@@ -1460,16 +1530,21 @@ __global__ __launch_bounds__(WAVES * 64, 2) void uit_encoder_kernel(EncoderArgs 
         const float* bias = (const float*)(breg + (blk & 1) * BIAS_FLOATS * 4);
         v8 X[4][3];
         layernorm_to_operand<OPC, NCT, CEN>(R, 1e-6f, X, bias + NEGMU_AT);
+        // precision f16a (round 5): every activation operand of column tile 0 -- the tile of the cls row, the one row pooling 'token' reads
+        // -- is carried as hi + lo fp16 terms: the LayerNorm-1 operand (Xlo1: into q, k, v), q, the attention output, the LayerNorm-2
+        // operand and the MLP's hidden activations (below)
+        v8 Xlo1[4];
+        if constexpr (ASPLIT) layernorm_lo_operand<CEN>(R, 1e-6f, X, Xlo1, bias + NEGMU_AT);
         TSTAMP(0);                                                     // LN1
 
         if constexpr (ATT) {
-        full_attention(std::false_type{}, tb, bias, X);
+        full_attention(std::false_type{}, tb, bias, X, Xlo1);
         } else {
         // ===== stage QK: fragments (ft = f/4 in {q h0, q h1, k h0, k h1}, s = f%4)
         ring_step<WAVES, SB>(a.wstream, ring, tb, wave, lane);
         TSTAMP(1);                                                     // ring wait QK
         if (blk + 1 < a.depth) bias_issue<WAVES, SB>(a.bias, breg, blk + 1, wave, lane);
-        v4 Qh[2][3], Kh[2][3];
+        v4 Qh[2][3], Kh[2][3], Qlo[2];
         {
             const char* slot = ring + (tb & (RING_SLOTS - 1)) * STAGE_BYTES;
             v8 A[16];
@@ -1487,7 +1562,14 @@ __global__ __launch_bounds__(WAVES * 64, 2) void uit_encoder_kernel(EncoderArgs 
                     f4 acc = bq;
 #pragma unroll
                     for (int s = 0; s < 4; ++s) acc = OP::mfma32(A[ft * 4 + s], X[s][ct], acc);
+                    if constexpr (ASPLIT) {
+                        if (ct == 0) {
+#pragma unroll
+                            for (int s = 0; s < 4; ++s) acc = OP::mfma32(A[ft * 4 + s], Xlo1[s], acc);
+                        }
+                    }
                     if (ft < 2) Qh[ft][ct] = OP::pack4(acc); else Kh[ft - 2][ct] = OP::pack4(acc);
+                    if constexpr (ASPLIT) { if (ct == 0 && ft < 2) Qlo[ft] = pack4_lo(acc, Qh[ft][0]); }
                 }
             }
         }
@@ -1511,13 +1593,19 @@ __global__ __launch_bounds__(WAVES * 64, 2) void uit_encoder_kernel(EncoderArgs 
                         f4 acc = bv;
 #pragma unroll
                         for (int s = 0; s < 4; ++s) acc = OP::mfma32(X[s][ct], Bw[h * 4 + s], acc);
+                        if constexpr (ASPLIT) {
+                            if (ct == 0) {
+#pragma unroll
+                                for (int s = 0; s < 4; ++s) acc = OP::mfma32(Xlo1[s], Bw[h * 4 + s], acc);
+                            }
+                        }
                         Vh[ct][h] = OP::pack4(acc);
                     }
                 }
             }
             f4 kinit[3];
             make_kinit(kinit);
-            attention_proj<OP, PERKEY, false, NCT>(R, Qh, Kh, Vh, tvalid, kinit, slot + 8 * FRAG_BYTES, bias, lane, g);
+            attention_proj<OP, PERKEY, false, NCT, ASPLIT>(R, Qh, Kh, Vh, tvalid, kinit, slot + 8 * FRAG_BYTES, bias, lane, g, Qlo);
         }
 
         }
@@ -1526,17 +1614,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void uit_encoder_kernel(EncoderArgs 
         // ===== MLP: 12 stages; stage ch = fc1 rows 32ch..32ch+31 (frags j*4+s) and fc2 k-step ch (frags 8+ft)
         layernorm_to_operand<OPC, NCT>(R, 1e-6f, X);
         v8 Xlo[4], HXlo = OP::zero8();                                 // ASPLIT: the low-order terms of tile 0's two MLP operands
-        if constexpr (ASPLIT) {
-            float mean, rstd;
-            ln_stats(R, 0, 1e-6f, mean, rstd);
-#pragma unroll
-            for (int s = 0; s < 4; ++s) {                              // lo = x - float(hi): what the fp16 rounding of the operand dropped
-                const h8 hi = __builtin_bit_cast(h8, X[s][0]);
-                const f4 l0 = R[2 * s][0] * splat(rstd) - f4{(float)hi[0], (float)hi[1], (float)hi[2], (float)hi[3]};
-                const f4 l1 = R[2 * s + 1][0] * splat(rstd) - f4{(float)hi[4], (float)hi[5], (float)hi[6], (float)hi[7]};
-                Xlo[s] = OP::pack8(l0, l1);
-            }
-        }
+        if constexpr (ASPLIT) layernorm_lo_operand<false>(R, 1e-6f, X, Xlo, nullptr);
         TSTAMP(5);                                                     // LN2
         // Software-pipelined over the 12 stages: at stage ch the fc1 fragment reads are issued first, then the fc2
         // MFMAs of chunk ch-1 run from registers (A2/HX carried across the barrier) and cover the LDS latency; the

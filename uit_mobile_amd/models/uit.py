@@ -491,7 +491,12 @@ class UITBase(nn.Module):
                           "~0.15 s, device-synchronous; front-end tuning on the first full-size batch): call model.prepare(device, (B, T)) "
                           "once at set-up to keep that out of the first forward (required before stream capture)", UitkSetupWarning, stacklevel=4)
         with torch.cuda.device(idx):
-            handle = self._create(L, w, 'f16c' if self.precision == 'auto' else self.precision)
+            # 'auto' starts as 'f16c' -- except for pooling 'token', whose parity mode is 'f16a' from the start: the head reads ONE row, the
+            # MLP's activation rounding on that row is not averaged over 24 tokens, and the library's sixteen held-out clips cannot bound it
+            # for every input (tools/auto_sweep.py, 24 unseen checkpoints of uit_xxs: 'f16c' inside the library's budget and still 1.08e-3
+            # on one of the reference's recordings; 'f16a': see profiles/round5/auto_sweep_extra_seeds.log)
+            start_as = self.precision if self.precision != 'auto' else ('f16a' if self.pooling == 'token' else 'f16c')
+            handle = self._create(L, w, start_as)
             if calibrating:                               # calibrated rounding: the caller's clips, else the library's own signals
                 x = self._calib_input
                 stream = ctypes.c_void_p(torch.cuda.current_stream(idx).cuda_stream)
@@ -512,7 +517,12 @@ class UITBase(nn.Module):
                 handle.mode.update(check=check, budget=budget.value * 1e-6 * (0.25 if self.pooling == 'dm' else 1.0), within_budget=esc.value < 0)
                 refused = check is not None and not check["accepted"]
                 if refused:                               # the nearest-rounded image stayed
-                    handle.mode["precision"] = {'auto': 'f16', 'f16c': 'f16', 'fp8c': 'fp8'}.get(self.precision, self.precision + ' (nearest on its grid)')
+                    handle.mode["precision"] = {'f16c': 'f16', 'fp8c': 'fp8'}.get(start_as, start_as + ' (nearest on its grid)')
+                if start_as == 'f16a' and esc.value == _lib.PREC_F16A:
+                    esc.value = -1                            # (already the top of this pooling's ladder: over budget is reported, not escalated)
+                    handle.mode.update(within_budget=False, reason="held-out deviation over the budget (%.2e against %.1e) in 'f16a', the top of "
+                                       "the ladder for pooling 'token'" % (check["max_calibrated"] if check and check["accepted"] else check["max_nearest"] if check else float('nan'), handle.mode["budget"]))
+                    warnings.warn(f"uit_mobile_amd: precision='auto' on cuda:{idx}: {handle.mode['reason']}", UitkParityWarning, stacklevel=4)
                 if self.precision in ('auto', 'f16c') and (esc.value >= 0 or refused):
                     dev_now = None if check is None else (check["max_nearest"] if refused else check["max_calibrated"])
                     why = ("calibration refused by the acceptance check (calibrated %.2e vs nearest %.2e on the held-out clips)" % (check["max_calibrated"], check["max_nearest"])
