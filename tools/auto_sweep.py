@@ -24,8 +24,19 @@ families = [(n, "bneck", "relu", "mean") for n in ("uit_xs", "uit_xxs", "uit_xxx
            [("audio_transformer_h128_d4_m3", "full", "gelu", "mean"), ("audio_transformer_h128_d6_m3_relu", "full", "relu", "mean"),
             ("uit_xxs", "bneck", "relu", "token"), ("uit_xs", "bneck", "relu", "token"), ("audio_transformer_h128_d4_m3", "full", "gelu", "token"),
             ("uit_xxs", "bneck", "relu", "dm")]
-only = sys.argv[2] if len(sys.argv) > 2 else None           # e.g. "token": that pooling's rows only
+only = sys.argv[2] if len(sys.argv) > 2 else None           # e.g. "token": that pooling's rows only; "more": the second list
+if only == "more":                                          # the remaining factories / poolings, and the other clip shapes (0.5 s, 4 s)
+    families = [("audio_transformer_h128_d6_m3", "full", "gelu", "mean"), ("audio_transformer_h128_d4_m3_relu", "full", "relu", "mean"),
+                ("uit_xs", "bneck", "relu", "dm"), ("audio_transformer_h128_d4_m3", "full", "gelu", "dm"),
+                ("uit_xs", "bneck", "relu", "mean:short"), ("uit_xs", "bneck", "relu", "mean:long"),
+                ("audio_transformer_h128_d4_m3", "full", "gelu", "mean:short"), ("uit_xxs", "bneck", "relu", "token:short")]
+    only = None
+x_full = x
 for name, att, act, pooling in families:
+    pooling, _, shape = pooling.partition(":")
+    x = x_full[:, 4000:12000] if shape == "short" else np.tile(x_full[:40], (1, 4)) if shape == "long" else x_full
+    xd = torch.from_numpy(np.ascontiguousarray(x)).cuda()
+    names_ = names[:len(x)]
     if only and pooling != only:
         continue
     rows, esc = [], []
@@ -41,11 +52,11 @@ for name, att, act, pooling in families:
             else:
                 d = np.abs(m(xd, return_logits=True)[1].cpu().numpy().reshape(r["logits"].shape) - r["logits"]).reshape(len(x), -1).max(1)
         rep = m.calibration_report()
-        rows.append((float(d.max()), seed, names[int(d.argmax())], rep["max_calibrated"]))
+        rows.append((float(d.max()), seed, names_[int(d.argmax())], rep["max_calibrated"]))
         if m.effective_precision() != ("f16a" if pooling == "token" else "f16c"):
             esc.append((seed, m.effective_precision()))
     w = max(rows)
     e = np.array([r[0] for r in rows])
     what = "max|dprob|" if pooling == "dm" else "max|dlogit|"
-    print(f"{name:34s} pooling {pooling:5s}: {nseeds} checkpoints x {len(x)} clips: worst {what} {w[0]:.2e} (seed {w[1]}, input {w[2]}), median {np.median(e):.2e}; "
+    print(f"{name:34s} pooling {pooling:5s} {shape or '1 s':5s}: {nseeds} checkpoints x {len(x)} clips: worst {what} {w[0]:.2e} (seed {w[1]}, input {w[2]}), median {np.median(e):.2e}; "
           f"library's own held-out estimate: worst {max(r[3] for r in rows):.2e}; not in the starting precision: {esc}", flush=True)
