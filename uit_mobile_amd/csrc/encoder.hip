@@ -656,7 +656,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void uit_encoder_kernel(EncoderArgs 
     // precision f16l6: four 32 KiB ring slots (the low-order patch-embed weights use the upper half of the ring during the prologue)
     constexpr bool L6 = PREC == 4;
     // instantiations without a vector register to spare issue their weight / bias DMAs in the scalar-base form (see ring_issue)
-    constexpr bool SB = (PREC <= 1 || PREC == 5) && (ATT != 0 || ACT != 0 || POOL == 1);
+    constexpr bool SB = (PREC <= 1 || PREC == 5) && ACT != 0;           // (the GELU builds: the ReLU ones keep the builtin form -- it is the faster one where registers allow it)
     // PREC 5 (precision f16a, pooling 'token'): the f16 kernel with the MLP's two activation operands of column tile 0 -- the tile of the
     // cls token, the one row the head reads -- as hi + lo fp16 terms (include/uitk.h: UITK_PREC_F16A)
     constexpr bool ASPLIT = PREC == 5;

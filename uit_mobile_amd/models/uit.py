@@ -474,6 +474,16 @@ class UITBase(nn.Module):
     def _handle(self, device):
         return self._handle_obj(device).ptr
 
+    @staticmethod
+    def _calibrate_handle(L, handle, w, x, stream):
+        """uitk_calibrate_weights on `handle`: the caller's clips `x` (device tensor) or, None, the library's own signals."""
+        if x is None:
+            _lib.check(L.uitk_calibrate_weights(handle.ptr, ctypes.byref(w), None, _lib.IN_I16, 0, 0, stream), "uitk_calibrate_weights")
+        else:
+            _lib.check(L.uitk_calibrate_weights(handle.ptr, ctypes.byref(w), ctypes.c_void_p(x.data_ptr()),
+                                                _lib.IN_I16 if x.dtype == torch.int16 else _lib.IN_F32, x.shape[0], x.shape[1], stream),
+                       "uitk_calibrate_weights")
+
     def _handle_obj(self, device, _from_forward=False):
         if self.eval_avg not in ('mean', 'max'):
             raise ValueError(f'Unknown Eval average function ({self.eval_avg})')      # uit.py:488
@@ -494,19 +504,13 @@ class UITBase(nn.Module):
             # 'auto' starts as 'f16c' -- except for pooling 'token', whose parity mode is 'f16a' from the start: the head reads ONE row, the
             # MLP's activation rounding on that row is not averaged over 24 tokens, and the library's sixteen held-out clips cannot bound it
             # for every input (tools/auto_sweep.py, 24 unseen checkpoints of uit_xxs: 'f16c' inside the library's budget and still 1.08e-3
-            # on one of the reference's recordings; 'f16a': see profiles/round5/auto_sweep_extra_seeds.log)
+            # on one of the reference's recordings; 'f16a': profiles/round5/auto_sweep_token_f16a_v2.log)
             start_as = self.precision if self.precision != 'auto' else ('f16a' if self.pooling == 'token' else 'f16c')
             handle = self._create(L, w, start_as)
             if calibrating:                               # calibrated rounding: the caller's clips, else the library's own signals
-                x = self._calib_input
+                x = self._calib_input if self._calib_input is None else self._calib_input.to(torch.device("cuda", idx))
                 stream = ctypes.c_void_p(torch.cuda.current_stream(idx).cuda_stream)
-                if x is None:
-                    _lib.check(L.uitk_calibrate_weights(handle.ptr, ctypes.byref(w), None, _lib.IN_I16, 0, 0, stream), "uitk_calibrate_weights")
-                else:
-                    x = x.to(torch.device("cuda", idx))
-                    _lib.check(L.uitk_calibrate_weights(handle.ptr, ctypes.byref(w), ctypes.c_void_p(x.data_ptr()),
-                                                        _lib.IN_I16 if x.dtype == torch.int16 else _lib.IN_F32, x.shape[0], x.shape[1], stream),
-                               "uitk_calibrate_weights")
+                self._calibrate_handle(L, handle, w, x, stream)
                 rep = (ctypes.c_float * 5)()
                 _lib.check(L.uitk_get_calib_check(handle.ptr, rep), "uitk_get_calib_check")
                 esc, budget = ctypes.c_int(-1), ctypes.c_int(0)
@@ -535,12 +539,7 @@ class UITBase(nn.Module):
                         # the split-weight build of the same weights; the SAME calibration statistics give it the operand centring of the
                         # attention (its weights are not re-rounded), and its own deviation on the held-out clips decides whether it stays
                         split = self._create(L, w, to)
-                        if x is None:
-                            _lib.check(L.uitk_calibrate_weights(split.ptr, ctypes.byref(w), None, _lib.IN_I16, 0, 0, stream), "uitk_calibrate_weights")
-                        else:
-                            _lib.check(L.uitk_calibrate_weights(split.ptr, ctypes.byref(w), ctypes.c_void_p(x.data_ptr()),
-                                                                _lib.IN_I16 if x.dtype == torch.int16 else _lib.IN_F32, x.shape[0], x.shape[1], stream),
-                                       "uitk_calibrate_weights")
+                        self._calibrate_handle(L, split, w, x, stream)
                         out2 = (ctypes.c_float * 2)()
                         _lib.check(L.uitk_self_check(split.ptr, ctypes.byref(w), stream, out2), "uitk_self_check")
                         sc = None if out2[0] < 0 else (float(out2[0]), float(out2[1]))
