@@ -410,9 +410,16 @@ def supervise_from_args(args):
         ranks, port0 = [(rank, lr)], int(os.environ.get("MASTER_PORT", "29500"))
     else:
         world, ranks = args.gpus, [(r, r) for r in range(args.gpus)]
-        with socket.socket() as sk:
-            sk.bind(("127.0.0.1", 0))
-            port0 = sk.getsockname()[1]
+        # one rendezvous port per attempt (port0 + attempt below): a pair of adjacent ports that are both free right now
+        for _ in range(64):
+            with socket.socket() as sk, socket.socket() as sk2:
+                sk.bind(("127.0.0.1", 0))
+                port0 = sk.getsockname()[1]
+                try:
+                    sk2.bind(("127.0.0.1", port0 + 1))
+                    break
+                except OSError:
+                    continue
     argv_base = [a for a in sys.argv[1:]]
 
     def worker_argv(g, attempt):

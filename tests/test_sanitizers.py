@@ -52,3 +52,20 @@ def test_host_packer_under_sanitizers(tmp_path):
                            str(ROOT / "tests" / "native" / "asan_pack_main.cpp"), str(ROOT / "uit_mobile_amd" / "csrc" / "pack.cpp")])
     out = subprocess.run([str(exe)], env=dict(os.environ, ASAN_OPTIONS="detect_leaks=1"), capture_output=True, text=True, timeout=600)
     assert out.returncode == 0 and "0 failures" in out.stdout, (out.stdout + out.stderr)[-3000:]
+
+
+def _libtsan():
+    if not GCC:
+        return None
+    p = subprocess.run([GCC, "-print-file-name=libtsan.so"], capture_output=True, text=True).stdout.strip()
+    return p if p and os.path.isabs(p) and os.path.exists(p) else None
+
+
+@pytest.mark.skipif(_libtsan() is None or not Path("/opt/rocm/include/hip/hip_runtime.h").exists(), reason="g++ / libtsan / HIP headers not available")
+def test_host_packer_thread_pool_under_thread_sanitizer(tmp_path):
+    """The packer rounds the weight matrices of a calibrated image on worker threads (pack.cpp: the guarded pool of pack_image)."""
+    exe = tmp_path / "tsan_pack"
+    subprocess.check_call(["g++", "-O1", "-g", "-std=c++17", "-fsanitize=thread", "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include", "-pthread",
+                           "-o", str(exe), str(ROOT / "tests" / "native" / "asan_pack_main.cpp"), str(ROOT / "uit_mobile_amd" / "csrc" / "pack.cpp")])
+    out = subprocess.run([str(exe)], capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0 and "0 failures" in out.stdout and "ThreadSanitizer" not in out.stderr, (out.stdout + out.stderr)[-3000:]

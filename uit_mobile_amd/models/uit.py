@@ -526,7 +526,7 @@ class UITBase(nn.Module):
                     esc.value = -1                            # (already the top of this pooling's ladder: over budget is reported, not escalated)
                     handle.mode.update(within_budget=False, reason="held-out deviation over the budget (%.2e against %.1e) in 'f16a', the top of "
                                        "the ladder for pooling 'token'" % (check["max_calibrated"] if check and check["accepted"] else check["max_nearest"] if check else float('nan'), handle.mode["budget"]))
-                    warnings.warn(f"uit_mobile_amd: precision='auto' on cuda:{idx}: {handle.mode['reason']}", UitkParityWarning, stacklevel=4)
+                    warnings.warn(f"uit_mobile_amd: precision='{self.precision}' on cuda:{idx}: {handle.mode['reason']}", UitkParityWarning, stacklevel=4)
                 if self.precision in ('auto', 'f16c') and (esc.value >= 0 or refused):
                     dev_now = None if check is None else (check["max_nearest"] if refused else check["max_calibrated"])
                     why = ("calibration refused by the acceptance check (calibrated %.2e vs nearest %.2e on the held-out clips)" % (check["max_calibrated"], check["max_nearest"])
