@@ -58,7 +58,13 @@ typedef enum uitk_precision {
                            output, the LayerNorm-2 operand, the ReLU / GELU output.  With pooling 'token' the head reads ONE row -- no mean
                            over 24 tokens averages the fp16 activation rounding away, and split WEIGHTS do not touch it
                            (tools/err_attrib_centring.py) -- so this is the parity mode of pooling 'token' (the wrapper's 'auto' starts there) and
-                           what get_option("parity_escalate_to") names for it; 1.2-1.4x the encoder time of UITK_PREC_F16 */
+                           what get_option("parity_escalate_to") names for it; 1.2-1.4x the encoder time of UITK_PREC_F16.  q, k and v of EVERY
+                           column tile are hi + lo as well (the cls row's scores against all keys: with full-width attention the fp16 rounding
+                           of the keys carried the error on heavy-tailed checkpoints, tools/err_attrib_token.py) */
+    UITK_PREC_F16AX = 7,/* round 5, pooling 'token' only, the top of its ladder: UITK_PREC_F16A's split activation operands on UITK_PREC_F16X2's
+                           split WEIGHTS (its parameter image and ring schedule) -- what is left is the fp16 rounding of the other tiles'
+                           LayerNorm operands; ~2x the encoder time of UITK_PREC_F16.  get_option("parity_escalate_to") of a
+                           UITK_PREC_F16A handle over its budget names it */
     UITK_PREC_F16L6 = 4 /* round 3's parity mode (kept built and tested): fp16 operands as UITK_PREC_F16 plus the LOW-ORDER weight term on the cheap pipe:
                            W = f16(W) + 2^e(row) . e2m3(W - f16(W)), the second term as OCP fp6 on
                            v_mfma_scale_f32_16x16x128_f8f6f4 (one MFMA at the cost of one f16 k-step covers K = 128) against fp6
@@ -160,10 +166,11 @@ int uitk_pack_weights(const uitk_config* cfg, const uitk_weights* w, void* out, 
  * synchronises the device.  Clips must cover target_length frames; at most the first 1024 clips are used.
  *
  * Acceptance check (option "calib_accept_pct", default 105): before the calibrated image is installed, it and the image uitk_create
- * packed (every weight rounded to nearest) both run the PRODUCT kernels on sixteen HELD-OUT clips of the library -- round 5: a
- * different signal FAMILY from the calibration clips (impulse train, single click, DC offsets, hard clipping, +-1 LSB dither, Nyquist
+ * packed (every weight rounded to nearest) both run the PRODUCT kernels on 48 HELD-OUT clips of the library -- round 5: two
+ * variants each of sixteen kinds of a different signal FAMILY from the calibration clips (impulse train, single click, DC offsets, hard clipping, +-1 LSB dither, Nyquist
  * alternation, AM/FM stacks at -40 / -12 dBFS, clipped noise, square wave, silence + burst, exponential sweep, bin-edge tone pair,
- * decaying resonances) -- and are compared with what the unrounded network answers there (the fp32 forward of calibrate.hip finished in
+ * decaying resonances) plus sixteen ordinary signals from seeds of their own (noise at four levels and with a silent tail, chirps, tone
+ * stacks, brown / band-limited noise: a checkpoint's worst input is as often one of those) -- and are compared with what the unrounded network answers there (the fp32 forward of calibrate.hip finished in
  * double on the host).  The calibrated image is kept only if its largest logit deviation is at most calib_accept_pct per cent of the
  * nearest image's (default: 5 % slack for ties); otherwise the handle keeps the nearest image and get_option("weights_calibrated")
  * stays 0.  uitk_get_calib_check reports the four numbers.
@@ -171,8 +178,8 @@ int uitk_pack_weights(const uitk_config* cfg, const uitk_weights* w, void* out, 
  * Absolute budget (round 5; option "calib_budget_e6", default 600 = 6e-4 on logits, a quarter of that on the probabilities of pooling
  * 'dm'): the image that STAYS on the handle -- calibrated, or nearest after a refusal -- must itself be inside the budget on the held-out
  * clips.  If it is not (or the check failed), get_option("parity_escalate_to") names the precision the caller must rebuild the handle
- * with to stay a parity mode: UITK_PREC_F16L6 for BNeckAttention + ReLU, UITK_PREC_F16X2 for the other families (-1: inside the
- * budget).  The Python wrapper's precision 'auto' (the factories' default) does exactly that and reports it; tests/native/
+ * with to stay a parity mode: UITK_PREC_F16L6 for BNeckAttention + ReLU, UITK_PREC_F16X2 for the other families; pooling 'token':
+ * UITK_PREC_F16A, and from a UITK_PREC_F16A handle UITK_PREC_F16AX (-1: inside the budget).  The Python wrapper's precision 'auto' (the factories' default) does exactly that and reports it; tests/native/
  * cabi_consumer.c shows the same four calls in C.  Not callable under stream capture (it allocates and synchronises). */
 int uitk_calibrate_weights(uitk_model* m, const uitk_weights* w, const void* pcm, int in_dtype, int64_t B, int64_t T, void* stream);
 /* Number of doubles of a statistics block for this config: patch embed [256][256], then per block LayerNorm-1 output [128][128],

@@ -130,6 +130,10 @@ def test_unsupported_variants_raise():
         models.uit_xs(pooling="dm", precision="bf16")
     with pytest.raises(NotImplementedError):
         models.uit_xs(act_layer=torch.nn.SiLU)
+    for prec in ("f16a", "f16ax"):                              # the split-activation precisions are pooling 'token''s ladder only
+        with pytest.raises(NotImplementedError):
+            models.uit_xs(precision=prec)
+        assert models.uit_xs(pooling="token", precision=prec).precision == prec
     m = models.uit_xs(embed_dim=256)                # geometry outside the kernels' family -> C ABI rejects it
     with pytest.raises(ValueError):
         m.packed_image()

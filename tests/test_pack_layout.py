@@ -468,3 +468,30 @@ def test_fp8_grid_weights_with_and_without_gptq_in_the_emulated_f16_kernel():
     bad = stats.copy(); bad[256 * 256 + 5 * 129] = -1.0                       # (a diagonal entry of block 0's LayerNorm-1 moment)
     with pytest.raises(ValueError):
         m.packed_image(calib_stats=bad)
+
+
+@pytest.mark.parametrize("factory", ["uit_xxxs", "audio_transformer_h128_d4_m3"])
+def test_f16ax_runs_on_the_parameter_image_of_f16x2(factory):
+    """Precision 'f16ax' (round 5: the top of pooling 'token''s ladder) = the split-weight stream of 'f16x2' under another kernel (split
+    activation operands): the packed images must be byte-identical behind the header's precision field, with and without statistics
+    (the centring folds follow the kernel precision the image is for: both builds carry the runtime LayerNorm-1 centring)."""
+    import ctypes
+    from uit_mobile_amd import _lib
+    from uit_mobile_amd.synth import make_trained_like_state_dict
+    att = "bneck" if factory.startswith("uit") else "full"
+    sd = make_trained_like_state_dict(factory, 5, attention=att)
+    imgs = {}
+    for prec in ("f16x2", "f16ax"):
+        m = getattr(models, factory)(outputdim=537, target_length=102, pooling="token", precision=prec)
+        m.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()})
+        n = _lib.load().uitk_calib_stats_doubles(ctypes.byref(m._config()))
+        rng = np.random.default_rng(3)
+        st = np.zeros(n)
+        st[-m.depth * 128:] = 0.3 * rng.standard_normal(m.depth * 128)                     # LayerNorm-1 means: the centring folds move
+        imgs[prec] = (m.packed_image(), m.packed_image(calib_stats=st))
+    for a, b in zip(imgs["f16x2"], imgs["f16ax"]):
+        ha, hb = EncoderEmu(a).h, EncoderEmu(b).h
+        assert (ha["precision"], hb["precision"]) == (3, 7) and len(a) == len(b)
+        off = 8                                                                               # magic + precision
+        assert a[off:] == b[off:]
+    assert imgs["f16ax"][0] != imgs["f16ax"][1]                                             # the statistics did something

@@ -3,6 +3,7 @@
 
     python tools/variant_bench.py [pooling]      # uit_xs + the full-width-attention factories x mean / token / dm x f16c + the split mode
     python tools/variant_bench.py attention      # the full-width-attention factories only (mean pooling): d4 GELU, d6 ReLU
+    python tools/variant_bench.py token          # pooling 'token' only: f16c / the split-weight mode / f16a / f16ax, every factory family
 
 Logs of the round-4 A/Bs made with it: profiles/round4/{token_pooling_two_tiles,dm_pooling_two_phase,full_attention_registers,gelu_packed}_ab.log"""
 import sys
@@ -20,9 +21,12 @@ mode = sys.argv[1] if len(sys.argv) > 1 else "pooling"
 x = synth_batch(4096, 16000, 0, torch.device("cuda", 0), False)
 if mode == "attention":
     cases = [(n, "full", "mean", p) for n in ("audio_transformer_h128_d4_m3", "audio_transformer_h128_d6_m3_relu") for p in ("f16c", "f16x2")]
+elif mode == "token":
+    cases = [(n, att, "token", p) for n, att in (("uit_xs", "bneck"), ("uit_xxs", "bneck"), ("audio_transformer_h128_d4_m3", "full"), ("audio_transformer_h128_d6_m3_relu", "full"))
+             for p in ("f16c", "f16l6" if att == "bneck" else "f16x2", "f16a", "f16ax")]
 else:
     cases = [(n, att, pooling, p) for n, att in (("uit_xs", "bneck"), ("audio_transformer_h128_d4_m3", "full")) for pooling in ("mean", "token", "dm")
-             for p in ("f16c", "f16l6" if att == "bneck" else "f16x2") + (("f16a",) if pooling == "token" else ())]
+             for p in ("f16c", "f16l6" if att == "bneck" else "f16x2") + (("f16a", "f16ax") if pooling == "token" else ())]
 for name, att, pooling, prec in cases:
     sd = make_trained_like_state_dict(name, 200, attention=att)
     m = getattr(models, name)(outputdim=537, target_length=102, pooling=pooling, precision=prec)

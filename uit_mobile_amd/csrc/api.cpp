@@ -25,9 +25,9 @@ static thread_local std::string g_err;
 static bool single_weight_precision(int p) { return p == UITK_PREC_F16 || p == UITK_PREC_BF16 || p == UITK_PREC_FP8 || p == UITK_PREC_FP8W || p == UITK_PREC_F16A; }
 // uitk_calibrate_weights also serves the split-weight precisions: their weights are not re-rounded, but the statistics install the
 // operand centring of the attention (pack.cpp) -- what an escalated 'auto' handle keeps of its calibration
-static bool calibratable_precision(int p) { return single_weight_precision(p) || p == UITK_PREC_F16X2 || p == UITK_PREC_F16L6; }
+static bool calibratable_precision(int p) { return single_weight_precision(p) || p == UITK_PREC_F16X2 || p == UITK_PREC_F16L6 || p == UITK_PREC_F16AX; }
 // what launch_encoder is told: fp8w runs the f16 kernels; f16a = 5, the f16 kernel with split activation operands in the cls tile
-static int kernel_precision(int p) { return p == UITK_PREC_FP8W ? UITK_PREC_F16 : p == UITK_PREC_F16A ? 5 : p; }
+static int kernel_precision(int p) { return p == UITK_PREC_FP8W ? UITK_PREC_F16 : p == UITK_PREC_F16A ? 5 : p == UITK_PREC_F16AX ? 6 : p; }
 static int fail(int code, const std::string& msg) { g_err = msg; return code; }
 #define HIP_TRY(expr)                                                                                   \
     do {                                                                                                \
@@ -468,7 +468,7 @@ int uitk_encode(uitk_model* m, int64_t B, int64_t T, float* probs, float* logits
     a.logits = logits; a.dbg = m->dbg;
     a.timing = m->timing;
     a.bn_nonneg = m->bn_nonneg && !m->force_generic_clamp;
-    a.split_pe = m->split_pe_env >= 0 ? m->split_pe_env : m->cfg.precision == UITK_PREC_F16X2;     // f16x2: the patch embed runs on its split weights too
+    a.split_pe = m->split_pe_env >= 0 ? m->split_pe_env : (m->cfg.precision == UITK_PREC_F16X2 || m->cfg.precision == UITK_PREC_F16AX);     // f16x2 / f16ax: the patch embed runs on its split weights too
     // (f16l6 keeps the structurally rounded single weights: same-box, worst sweep seeds 6.0e-4 / 5.1e-4 without vs 6.6e-4 / 4.8e-4 with, +1.2 % time)
     a.attention_full = m->cfg.attention_full; a.act_gelu = m->cfg.act_gelu; a.pooling = m->cfg.pooling;
     // Workgroup shape.  Large batches: 8 waves (two per SIMD, every weight fragment read once per 16 clips).  A batch that fits ONE
@@ -582,11 +582,11 @@ static void builtin_calibration_set(int n, int64_t T, std::vector<int16_t>* out)
 }
 
 // The HELD-OUT clips of the acceptance / self check (round 5: a DIFFERENT family from the calibration signals above, not the same
-// generator with other parameters -- VERDICT r4 item 1b): sixteen kinds of signal a fit on noise, tones, chirps and harmonic stacks leaves
+// generator with other parameters -- VERDICT r4 item 1b): two variants each of sixteen kinds of signal a fit on noise, tones, chirps and harmonic stacks leaves
 // unconstrained -- impulse train, single full-scale click, DC offsets (+0.5 with -40 dB noise, -0.5 with a tone), hard-clipped tone,
 // +-1 LSB dither, Nyquist alternation (half scale, and at 1 LSB), AM/FM harmonic stacks at -40 and -12 dBFS, full-scale noise driven into
 // clipping, 50 Hz square wave, silence ending in a loud burst, exponential sweep, two tones on a bin edge, re-struck decaying
-// resonances.  Deterministic (own LCG), int16.  One batch: the loud clips set the batch-global top_db floor for the quiet ones, as a
+// resonances -- and, behind them, sixteen ordinary signals (see the loop).  Deterministic (own LCG), int16.  One batch: the loud clips set the batch-global top_db floor for the quiet ones, as a
 // mixed batch of a caller does.
 static void builtin_heldout_set(int n, int64_t T, std::vector<int16_t>* out) {
     out->assign((size_t)n * T, 0);
@@ -595,7 +595,11 @@ static void builtin_heldout_set(int n, int64_t T, std::vector<int16_t>* out) {
     const double sr = 16000.0, lsb = 1.0 / 32768.0;
     std::vector<double> x(T);
     for (int i = 0; i < n; ++i) {
-        const int kind = i & 15, v = i >> 4;
+        // clips 0..31: two variants of the sixteen adversarial kinds; clips 32..: ORDINARY signals (kinds 16..31: noise at several levels and
+        // with a silent tail, chirps, tone stacks, brown / band-limited noise) from this generator's own seeds -- the worst input of a
+        // checkpoint is as often a plain noise clip as an exotic one (tools/auto_sweep.py: sixteen adversarial clips alone estimated 5.3e-4
+        // where a noise clip of the test set measured 9.4e-4), and the estimate is a maximum: it grows with what it is taken over
+        const int kind = i < 32 ? (i & 15) : 16 + ((i - 32) & 15), v = i < 32 ? (i >> 4) : ((i - 32) >> 4);
         std::fill(x.begin(), x.end(), 0.0);
         switch (kind) {
         case 0: { const int64_t per = 173 + 31 * v; int sgn = 1; for (int64_t t = per / 2; t < T; t += per) { x[t] = 0.9 * sgn; sgn = -sgn; } break; }
@@ -604,7 +608,7 @@ static void builtin_heldout_set(int n, int64_t T, std::vector<int16_t>* out) {
         case 3: { for (int64_t t = 0; t < T; ++t) x[t] = -0.5 + 0.3 * std::sin(2.0 * M_PI * (440.0 + 60.0 * v) * t / sr); break; }
         case 4: { for (int64_t t = 0; t < T; ++t) { const double y = 3.0 * std::sin(2.0 * M_PI * (311.0 + 40.0 * v) * t / sr); x[t] = 0.98 * (y > 1.0 ? 1.0 : y < -1.0 ? -1.0 : y); } break; }
         case 5: { for (int64_t t = 0; t < T; ++t) x[t] = std::nearbyint(3.0 * noise()) * lsb; break; }
-        case 6: { for (int64_t t = 0; t < T; ++t) x[t] = (t & 1) ? -0.5 : 0.5; break; }
+        case 6: { const double a6 = v ? 0.06 : 0.5; for (int64_t t = 0; t < T; ++t) x[t] = (t & 1) ? -a6 : a6; break; }
         case 7: { for (int64_t t = 0; t < T; ++t) x[t] = ((t & 1) ? -1.0 : 1.0) * lsb + std::nearbyint(1.2 * noise()) * lsb; break; }
         case 8: case 9: {
             const double lvl = kind == 8 ? 0.01 : 0.25, f0 = kind == 8 ? 131.0 + 17.0 * v : 197.0 + 13.0 * v;
@@ -621,11 +625,30 @@ static void builtin_heldout_set(int n, int64_t T, std::vector<int16_t>* out) {
             break; }
         case 10: { for (int64_t t = 0; t < T; ++t) x[t] = 2.6 * noise(); break; }                                      // clips ~23 % of the samples
         case 11: { for (int64_t t = 0; t < T; ++t) x[t] = std::sin(2.0 * M_PI * (50.0 + 7.0 * v) * t / sr) >= 0.0 ? 0.8 : -0.8; break; }
-        case 12: { const int64_t on = T - T / 10; for (int64_t t = on; t < T; ++t) x[t] = 0.9 * noise() + 0.4 * std::sin(2.0 * M_PI * 1250.0 * t / sr); break; }
+        case 12: { const int64_t on = v ? T / 2 : T - T / 10; for (int64_t t = on; t < T; ++t) x[t] = 0.9 * noise() + 0.4 * std::sin(2.0 * M_PI * 1250.0 * t / sr); break; }
         case 13: { const double dur = (double)T / sr, k = std::log(7900.0 / 20.0) / dur;
-                   for (int64_t t = 0; t < T; ++t) { const double tt = t / sr; x[t] = 0.5 * std::sin(2.0 * M_PI * 20.0 * (std::exp(k * tt) - 1.0) / k); }
+                   for (int64_t t = 0; t < T; ++t) { const double tt = (v ? T - 1 - t : t) / sr; x[t] = (v ? 0.05 : 0.5) * std::sin(2.0 * M_PI * 20.0 * (std::exp(k * tt) - 1.0) / k); }
                    break; }
-        case 14: { for (int64_t t = 0; t < T; ++t) x[t] = 0.4 * std::sin(2.0 * M_PI * 1000.0 * t / sr) + 0.4 * std::sin(2.0 * M_PI * 1015.625 * t / sr + 0.7); break; }
+        case 14: { const double fb = v ? 2500.0 : 1000.0;     // two tones half a bin apart, on a bin edge
+                   for (int64_t t = 0; t < T; ++t) x[t] = 0.4 * std::sin(2.0 * M_PI * fb * t / sr) + 0.4 * std::sin(2.0 * M_PI * (fb + 15.625) * t / sr + 0.7); break; }
+        case 16: case 17: case 18: case 19: { const double g4[4] = {1.0, 0.5, 0.2, 0.04}; for (int64_t t = 0; t < T; ++t) x[t] = g4[kind - 16] * noise(); break; }
+        case 20: case 21: { const int64_t cut = T - T / 4; for (int64_t t = 0; t < cut; ++t) x[t] = (kind == 20 ? 1.0 : 0.3) * noise(); break; }       // silent tail: the dB floor
+        case 22: case 23: { const double f0 = kind == 22 ? 60.0 : 7800.0, f1 = kind == 22 ? 7800.0 : 60.0, dur = (double)T / sr;
+                            for (int64_t t = 0; t < T; ++t) { const double tt = t / sr; x[t] = 0.45 * std::sin(2.0 * M_PI * (f0 + 0.5 * (f1 - f0) * tt / dur) * tt) + 2e-3 * noise(); }
+                            break; }
+        case 24: case 25: case 26: { const double fs[3][3] = {{233.0, 1870.0, 4310.0}, {97.0, 610.0, 3333.0}, {1450.0, 2900.0, 6100.0}};
+                            for (int64_t t = 0; t < T; ++t) { double acc = 0.0; for (int r = 0; r < 3; ++r) acc += std::sin(2.0 * M_PI * fs[kind - 24][r] * t / sr + r); x[t] = 0.28 * acc + 1e-3 * noise(); }
+                            break; }
+        case 27: case 28: { const double a = kind == 27 ? 0.995 : 0.9; double y = 0.0, pk = 1e-9;                                   // brown / low-passed noise
+                            for (int64_t t = 0; t < T; ++t) { y = a * y + noise(); x[t] = y; pk = std::fmax(pk, std::fabs(y)); }
+                            for (int64_t t = 0; t < T; ++t) x[t] *= 0.7 / pk;
+                            break; }
+        case 29: { for (int64_t t = 0; t < T; ++t) { const double e = 0.5 + 0.5 * std::sin(2.0 * M_PI * 7.0 * t / sr); x[t] = 0.9 * e * e * noise(); } break; }
+        case 30: { double y1 = 0.0, y2 = 0.0;                                                                                     // resonant (band-passed) noise around 3 kHz
+                   const double rr = 0.98, th = 2.0 * M_PI * 3000.0 / sr;
+                   for (int64_t t = 0; t < T; ++t) { const double y = 2.0 * rr * std::cos(th) * y1 - rr * rr * y2 + noise(); y2 = y1; y1 = y; x[t] = 0.02 * y; }
+                   break; }
+        case 31: { for (int64_t t = 0; t < T; ++t) x[t] = 0.3 * noise() + 0.3 * std::sin(2.0 * M_PI * 440.0 * t / sr) + (t > T / 2 ? 0.2 * std::sin(2.0 * M_PI * 5200.0 * t / sr) : 0.0); break; }
         default: { const double fr[3] = {330.0 + 20.0 * v, 1240.0, 2750.0}, dec[3] = {9.0, 14.0, 22.0};
                    for (int64_t t = 0; t < T; ++t) {
                        const double tt = std::fmod(t / sr, 0.25);
@@ -748,13 +771,13 @@ void head_reference(const uitk_config& c, const uitk_weights* w, const float* R,
 }
 }  // namespace
 
-// The held-out evaluation shared by the acceptance check of uitk_calibrate_weights and by uitk_self_check: sixteen held-out clips of
+// The held-out evaluation shared by the acceptance check of uitk_calibrate_weights and by uitk_self_check: the 48 held-out clips of
 // the library (builtin_heldout_set) go through the PRODUCT front-end; the plain fp32 forward of calibrate.hip + head_reference give
 // what the unrounded network answers on those 16-bit patch operands; heldout_score runs the product encoder on whatever parameter
 // image the handle holds and returns the largest / root-mean-square deviation (pre-sigmoid logits; probabilities for pooling 'dm').
 namespace {
 struct HeldOut {
-    int Be = 16;
+    int Be = 48;                                                 // (round 5: 16 -> 48 clips, see builtin_heldout_set)
     int64_t Te = 0;                                              // 0: no single-crop clip length covers target_length (check does not apply)
     DevBuf pcm, outb;
     std::vector<double> ref;
@@ -806,10 +829,11 @@ int heldout_score(uitk_model* m, HeldOut* ho, hipStream_t s, double* mx, double*
 // the budget a deviation on the held-out clips is compared with (option calib_budget_e6; pooling 'dm' is compared on probabilities,
 // whose slope against the logit is at most 1/4)
 double parity_budget(const uitk_model* m) { return m->calib_budget_e6 * 1e-6 * (m->cfg.pooling == 1 ? 0.25 : 1.0); }
-// over budget: pooling 'token' reads ONE row, what is left there is activation rounding -> split activation operands (f16a); the
-// other poolings: split weights (f16l6 for BNeckAttention + ReLU, f16x2 otherwise)
+// over budget: pooling 'token' reads ONE row, what is left there is activation rounding -> split activation operands (f16a), and from
+// there split weights as well (f16ax: the top of that ladder); the other poolings: split weights (f16l6 for BNeckAttention + ReLU,
+// f16x2 otherwise)
 int parity_fallback_precision(const uitk_model* m) {
-    if (m->cfg.pooling == 2) return UITK_PREC_F16A;
+    if (m->cfg.pooling == 2) return m->cfg.precision == UITK_PREC_F16A ? UITK_PREC_F16AX : UITK_PREC_F16A;
     return (m->cfg.attention_full || m->cfg.act_gelu) ? UITK_PREC_F16X2 : UITK_PREC_F16L6;
 }
 }  // namespace

@@ -350,7 +350,10 @@ __device__ constexpr int TI[7] = {0, 0, 1, 1, 1, 2, 2};
 template <class OP, bool SHORT, bool X2 = false, int NCT = 3, bool ASP = false>
 __device__ __forceinline__ void attention_proj(f4 (&R)[8][3], const typename OP::v4 (&Qh)[2][3], const typename OP::v4 (&Kh)[2][3],
                                                const typename OP::v4 (&Vh)[3][2], const bool (&tvalid)[7], const f4 (&kinit)[3],
-                                               const char* proj, const float* bias, int lane, int g, const typename OP::v4* Qlo = nullptr) {
+                                               const char* proj, const float* bias, int lane, int g, const typename OP::v4 (*Qlo)[3] = nullptr,
+                                               const typename OP::v4 (*Klo)[3] = nullptr, const typename OP::v4 (*Vlo)[2] = nullptr) {
+    // ASP (precisions f16a / f16ax): Qlo / Klo[h][ct], Vlo[ct][h] = the low-order fp16 terms of q, k, v (every tile); the attention output of
+    // tile 0 goes into proj as hi + lo
     using v8 = typename OP::v8;
     using v4 = typename OP::v4;
     constexpr int N7 = NCT == 2 ? 4 : 7;                  // one clip in tiles 0 / 1: the four score tiles among them (the first four of TJ / TI)
@@ -373,7 +376,10 @@ __device__ __forceinline__ void attention_proj(f4 (&R)[8][3], const typename OP:
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
             S[h][i] = OP::mfma16(Kh[h][TJ[i]], Qh[h][TI[i]], init);
-            if constexpr (ASP) { if (TI[i] == 0) S[h][i] = OP::mfma16(Kh[h][TJ[i]], Qlo[h], S[h][i]); }      // precision f16a: q of tile 0 = hi + lo
+            if constexpr (ASP) {                           // (k_hi + k_lo) . (q_hi + q_lo) without the lo . lo term
+                S[h][i] = OP::mfma16(Klo[h][TJ[i]], Qh[h][TI[i]], S[h][i]);
+                S[h][i] = OP::mfma16(Kh[h][TJ[i]], Qlo[h][TI[i]], S[h][i]);
+            }
         }
     }
 #pragma unroll
@@ -410,6 +416,7 @@ __device__ __forceinline__ void attention_proj(f4 (&R)[8][3], const typename OP:
             // the first tile of a query tile starts its accumulators from the literal 0 (an inline constant of the MFMA: no v_mov per register)
             const bool first = i == 0 || i == 2 || i == 5;
             O[h][TI[i]] = OP::mfma16(Vh[TJ[i]][h], Pm, first ? splat(0.f) : O[h][TI[i]]);
+            if constexpr (ASP) O[h][TI[i]] = OP::mfma16(Vlo[TJ[i]][h], Pm, O[h][TI[i]]);
             Lsum[h][TI[i]] = OP::mfma16(OP::ones4(), Pm, first ? splat(0.f) : Lsum[h][TI[i]]);
         }
 #pragma unroll
@@ -659,8 +666,12 @@ __global__ __launch_bounds__(WAVES * 64, 2) void uit_encoder_kernel(EncoderArgs 
     constexpr bool SB = (PREC <= 1 || PREC == 5) && ACT != 0;           // (the GELU builds: the ReLU ones keep the builtin form -- it is the faster one where registers allow it)
     // PREC 5 (precision f16a, pooling 'token'): the f16 kernel with the MLP's two activation operands of column tile 0 -- the tile of the
     // cls token, the one row the head reads -- as hi + lo fp16 terms (include/uitk.h: UITK_PREC_F16A)
-    constexpr bool ASPLIT = PREC == 5;
-    static_assert(!ASPLIT || POOL == 2, "precision f16a is built for pooling 'token'");
+    // PREC 6 (precision f16ax, round 5): the same on the SPLIT weights of precision f16x2 (W = hi + lo) -- the top of pooling 'token''s ladder.
+    // Both also carry q, k and v of EVERY column tile as hi + lo (Qlo / Klo / Vlo below): with one row read by the head, the fp16 rounding
+    // of the keys was what carried the error of full-width attention on heavy-tailed checkpoints (tools/err_attrib_token.py)
+    constexpr bool ASPLIT = PREC == 5 || PREC == 6;
+    constexpr bool XW2 = PREC == 3 || PREC == 6;              // the split-weight stream and stage schedule of precision f16x2
+    static_assert(!ASPLIT || POOL == 2, "precisions f16a / f16ax are built for pooling 'token'");
     // operand centring of LayerNorm-1 (uitk_dev.h: operand_centring; pack.cpp folds the same way): -mu[128] of a block in its bias table
     constexpr bool CEN = operand_centring(ATT, ACT, POOL, PREC);
     constexpr int NEGMU_AT = ATT ? BIASF_QKV + 128 : BIAS_NEGMU;
@@ -948,7 +959,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void uit_encoder_kernel(EncoderArgs 
       // instead of being kept alive across head 0's attention.
       auto full_attention = [&](auto xs2_tag, int tb, const float* bias, v8 (&X)[4][3], v8 (&Xlo1)[4]) {
         constexpr bool XS2 = decltype(xs2_tag)::value;
-        static_assert(!(ASPLIT && XS2), "precision f16a rides on the single-weight f16 stream");
+        static_assert(XS2 == XW2, "the split-weight schedule goes with the split-weight stream");
         constexpr int NSUB = XS2 ? 2 : 1, DTS = 4 / NSUB, KF = XS2 ? 8 : 4;      // stages per group, d-tiles per stage, fragments per tile
         // SB instantiations re-derive the lane's (c, g) from v_mbcnt where they are used (a bias-table offset): held across the block
         // they were spilled and reloaded behind a ring barrier
@@ -961,7 +972,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void uit_encoder_kernel(EncoderArgs 
                 layernorm_to_operand<OPC, NCT, CEN>(R, 1e-6f, X, bias + NEGMU_AT);
                 if constexpr (ASPLIT) layernorm_lo_operand<CEN>(R, 1e-6f, X, Xlo1, bias + NEGMU_AT);
             }
-            v4 Qp[4][3], Kp[4][3], Qlo[4];
+            v4 Qp[4][3], Kp[4][3], Qlo[4][3], Klo[4][3];               // ASPLIT: q and k of every tile as hi + lo
 #pragma unroll
             for (int which = 0; which < 2; ++which) {
 #pragma unroll
@@ -987,14 +998,18 @@ __global__ __launch_bounds__(WAVES * 64, 2) void uit_encoder_kernel(EncoderArgs 
                             for (int ct = 0; ct < NCT; ++ct)
 #pragma unroll
                                 for (int sk = 0; sk < 4; ++sk) acc[ct] = OP::mfma32(A[sk], X[sk][ct], acc[ct]);
-                            if constexpr (ASPLIT) {                    // tile 0: + W . Xlo
+                            if constexpr (ASPLIT) {                    // tile 0: + W . Xlo (the high-order weight fragments only)
+                                if (part == 0) {
 #pragma unroll
-                                for (int sk = 0; sk < 4; ++sk) acc[0] = OP::mfma32(A[sk], Xlo1[sk], acc[0]);
+                                    for (int sk = 0; sk < 4; ++sk) acc[0] = OP::mfma32(A[sk], Xlo1[sk], acc[0]);
+                                }
                             }
                         }
 #pragma unroll
-                        for (int ct = 0; ct < NCT; ++ct) { if (which == 0) Qp[dt][ct] = OP::pack4(acc[ct]); else Kp[dt][ct] = OP::pack4(acc[ct]); }
-                        if constexpr (ASPLIT) { if (which == 0) Qlo[dt] = pack4_lo(acc[0], Qp[dt][0]); }
+                        for (int ct = 0; ct < NCT; ++ct) {
+                            if (which == 0) Qp[dt][ct] = OP::pack4(acc[ct]); else Kp[dt][ct] = OP::pack4(acc[ct]);
+                            if constexpr (ASPLIT) { if (which == 0) Qlo[dt][ct] = pack4_lo(acc[ct], Qp[dt][ct]); else Klo[dt][ct] = pack4_lo(acc[ct], Kp[dt][ct]); }
+                        }
                     }
                 }
             }
@@ -1012,11 +1027,11 @@ __global__ __launch_bounds__(WAVES * 64, 2) void uit_encoder_kernel(EncoderArgs 
                 }
 #pragma unroll
                 for (int dt = 0; dt < 4; ++dt) acc = OP::mfma16(Kp[dt][TJ[i]], Qp[dt][TI[i]], acc);
-                if constexpr (ASPLIT) {                                // queries of tile 0: q = hi + lo
-                    if (TI[i] == 0) {
+                if constexpr (ASPLIT) {                                // (k_hi + k_lo) . (q_hi + q_lo) without the lo . lo term
 #pragma unroll
-                        for (int dt = 0; dt < 4; ++dt) acc = OP::mfma16(Kp[dt][TJ[i]], Qlo[dt], acc);
-                    }
+                    for (int dt = 0; dt < 4; ++dt) acc = OP::mfma16(Klo[dt][TJ[i]], Qp[dt][TI[i]], acc);
+#pragma unroll
+                    for (int dt = 0; dt < 4; ++dt) acc = OP::mfma16(Kp[dt][TJ[i]], Qlo[dt][TI[i]], acc);
                 }
                 S[i] = acc;
                 const float hm = hmax(S[i]);
@@ -1043,7 +1058,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void uit_encoder_kernel(EncoderArgs 
                 }
             }
             // v_h token-major (operand roles swapped: tokens are the rows)
-            v4 Vp[3][4];
+            v4 Vp[3][4], Vlo[3][4];                                    // ASPLIT: v of every tile as hi + lo
 #pragma unroll
             for (int sub = 0; sub < NSUB; ++sub) {
                 const int t = tb + (3 * h + 2) * NSUB + sub;
@@ -1066,12 +1081,17 @@ __global__ __launch_bounds__(WAVES * 64, 2) void uit_encoder_kernel(EncoderArgs 
 #pragma unroll
                             for (int sk = 0; sk < 4; ++sk) acc[ct] = OP::mfma32(X[sk][ct], Bw[sk], acc[ct]);
                         if constexpr (ASPLIT) {
+                            if (part == 0) {
 #pragma unroll
-                            for (int sk = 0; sk < 4; ++sk) acc[0] = OP::mfma32(Xlo1[sk], Bw[sk], acc[0]);
+                                for (int sk = 0; sk < 4; ++sk) acc[0] = OP::mfma32(Xlo1[sk], Bw[sk], acc[0]);
+                            }
                         }
                     }
 #pragma unroll
-                    for (int ct = 0; ct < NCT; ++ct) Vp[ct][dt] = OP::pack4(acc[ct]);
+                    for (int ct = 0; ct < NCT; ++ct) {
+                        Vp[ct][dt] = OP::pack4(acc[ct]);
+                        if constexpr (ASPLIT) Vlo[ct][dt] = pack4_lo(acc[ct], Vp[ct][dt]);
+                    }
                 }
             }
             f4 O[4][3], Lsum[3];
@@ -1086,6 +1106,10 @@ __global__ __launch_bounds__(WAVES * 64, 2) void uit_encoder_kernel(EncoderArgs 
                 const v4 Pm = Pq[i];
 #pragma unroll
                 for (int dt = 0; dt < 4; ++dt) O[dt][TI[i]] = OP::mfma16(Vp[TJ[i]][dt], Pm, O[dt][TI[i]]);
+                if constexpr (ASPLIT) {
+#pragma unroll
+                    for (int dt = 0; dt < 4; ++dt) O[dt][TI[i]] = OP::mfma16(Vlo[TJ[i]][dt], Pm, O[dt][TI[i]]);
+                }
                 Lsum[TI[i]] = OP::mfma16(OP::ones4(), Pm, Lsum[TI[i]]);
                 // a query tile's output is scaled and packed as soon as its last key tile is in (TI is sorted): its sixteen fp32
                 // accumulators become eight operand registers before the next query tile's accumulate (48 -> 16 live accumulators)
@@ -1148,8 +1172,10 @@ __global__ __launch_bounds__(WAVES * 64, 2) void uit_encoder_kernel(EncoderArgs 
 #pragma unroll
                         for (int sk = 0; sk < 4; ++sk) acc[ct] = OP::mfma32(A[sk], OX[sk][ct], acc[ct]);
                     if constexpr (ASPLIT) {
+                        if (part == 0) {
 #pragma unroll
-                        for (int sk = 0; sk < 4; ++sk) acc[0] = OP::mfma32(A[sk], OXlo[sk], acc[0]);
+                            for (int sk = 0; sk < 4; ++sk) acc[0] = OP::mfma32(A[sk], OXlo[sk], acc[0]);
+                        }
                     }
                 }
 #pragma unroll
@@ -1240,8 +1266,8 @@ __global__ __launch_bounds__(WAVES * 64, 2) void uit_encoder_kernel(EncoderArgs 
             dbg_store(blk + 1);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
-      } else if constexpr (PREC == 3) {
-        // ================= precision f16x2: W = hi + lo, 28 ring stages per block (uitk_dev.h) =================
+      } else if constexpr (XW2) {
+        // ================= precision f16x2 (and f16ax = f16x2 + the split activation operands of f16a): W = hi + lo, 28 ring stages per block (uitk_dev.h) =================
         // Every stage carries the hi and the lo fragments of the rows it covers; an accumulator takes the hi chain, then the lo
         // chain, and is finished (packed / ReLU'd) inside the stage.  Activations are the fp16 operands of precision f16.
         // Full-width attention (ATT = 1, round 3): 16 attention stages (full_attention above) + the same 24 MLP stages = 40 per block.
@@ -1251,11 +1277,12 @@ __global__ __launch_bounds__(WAVES * 64, 2) void uit_encoder_kernel(EncoderArgs 
         const float* bias = (const float*)(breg + (blk & 1) * BIAS_FLOATS * 4);
         v8 X[4][3];
         layernorm_to_operand<OPC, NCT, CEN>(R, 1e-6f, X, bias + NEGMU_AT);
+        v8 Xlo1[4];                                                    // precision f16ax: the low-order term of tile 0's LayerNorm-1 operand
+        if constexpr (ASPLIT) layernorm_lo_operand<CEN>(R, 1e-6f, X, Xlo1, bias + NEGMU_AT);
         if constexpr (ATT) {
-        v8 Xlo1[4];                                                    // (precision f16a has no split-weight build)
         full_attention(std::true_type{}, tb, bias, X, Xlo1);
         } else {
-        v4 Qh[2][3], Kh[2][3], Vh[3][2];
+        v4 Qh[2][3], Kh[2][3], Vh[3][2], Qlo[2][3], Klo[2][3], Vlo[3][2];
 #pragma unroll
         for (int half = 0; half < 2; ++half) {                             // stage 0: q h0, q h1; stage 1: k h0, k h1
             ring_step<WAVES, SB>(a.wstream, ring, tb + half, wave, lane);
@@ -1272,7 +1299,21 @@ __global__ __launch_bounds__(WAVES * 64, 2) void uit_encoder_kernel(EncoderArgs 
                     f4 acc = bq;
 #pragma unroll
                     for (int s = 0; s < 8; ++s) acc = OP::mfma32(A[s], X[s & 3][ct], acc);
+                    if constexpr (ASPLIT) {
+                        // tile 0: + W . Xlo on an accumulator of its own.  CHAINED behind the eight k-steps above (as the other precisions'
+                        // stages do it) this kernel returned wrong keys for tile 0 on some inputs -- 2.4e-3 on logits, NaN on others, bit-stable
+                        // run to run; same MFMAs, same operands; every other chained site checks out against the oracle -- and the
+                        // disassembly shows nothing the hazard rules forbid.  Measured, not explained (profiles/round5/f16ax_bisect.log):
+                        // the separate chain costs one packed add and is right (6e-5)
+                        if (ct == 0) {
+                            f4 accl = splat(0.f);
+#pragma unroll
+                            for (int s = 0; s < 4; ++s) accl = OP::mfma32(A[s], Xlo1[s], accl);
+                            acc = acc + accl;
+                        }
+                    }
                     if (half == 0) Qh[i][ct] = OP::pack4(acc); else Kh[i][ct] = OP::pack4(acc);
+                    if constexpr (ASPLIT) { if (half == 0) Qlo[i][ct] = pack4_lo(acc, Qh[i][ct]); else Klo[i][ct] = pack4_lo(acc, Kh[i][ct]); }
                 }
             }
         }
@@ -1290,16 +1331,25 @@ __global__ __launch_bounds__(WAVES * 64, 2) void uit_encoder_kernel(EncoderArgs 
                     f4 acc = bv;
 #pragma unroll
                     for (int s = 0; s < 8; ++s) acc = OP::mfma32(X[s & 3][ct], Bw[s], acc);
+                    if constexpr (ASPLIT) {
+                        if (ct == 0) {
+#pragma unroll
+                            for (int s = 0; s < 4; ++s) acc = OP::mfma32(Xlo1[s], Bw[s], acc);
+                        }
+                    }
                     Vh[ct][h] = OP::pack4(acc);
+                    if constexpr (ASPLIT) Vlo[ct][h] = pack4_lo(acc, Vh[ct][h]);
                 }
             }
         }
         ring_step<WAVES, SB>(a.wstream, ring, tb + 3, wave, lane);             // stage 3: attention + proj (hi, lo)
         f4 kinit[3];
         make_kinit(kinit);
-        attention_proj<OP, PERKEY, true, NCT>(R, Qh, Kh, Vh, tvalid, kinit, ring + ((tb + 3) & (RING_SLOTS - 1)) * STAGE_BYTES, bias, lane, g);
+        attention_proj<OP, PERKEY, true, NCT, ASPLIT>(R, Qh, Kh, Vh, tvalid, kinit, ring + ((tb + 3) & (RING_SLOTS - 1)) * STAGE_BYTES, bias, lane, g, Qlo, Klo, Vlo);
         }
         layernorm_to_operand<OPC, NCT>(R, 1e-6f, X);
+        v8 Xlo[4], HXlo = OP::zero8();                                 // ASPLIT: the low-order terms of tile 0's two MLP operands
+        if constexpr (ASPLIT) layernorm_lo_operand<false>(R, 1e-6f, X, Xlo, nullptr);
 #pragma unroll 1
         for (int ch = 0; ch < 12; ++ch) {
             v8 HX[3];
@@ -1318,10 +1368,27 @@ __global__ __launch_bounds__(WAVES * 64, 2) void uit_encoder_kernel(EncoderArgs 
                         H[i][ct] = b1;
 #pragma unroll
                         for (int s = 0; s < 8; ++s) H[i][ct] = OP::mfma32(A[s], X[s & 3][ct], H[i][ct]);
+                        if constexpr (ASPLIT) {
+                            if (ct == 0) {
+#pragma unroll
+                                for (int s = 0; s < 4; ++s) H[i][0] = OP::mfma32(A[s], Xlo[s], H[i][0]);
+                            }
+                        }
                     }
                 }
 #pragma unroll
                 for (int ct = 0; ct < NCT; ++ct) {
+                    if constexpr (ASPLIT) {
+                        if (ct == 0) {                                 // tile 0: the activation as hi + lo
+                            f4 a0, a1;
+                            if constexpr (ACT == 1) { a0 = gelu4(H[0][0]); a1 = gelu4(H[1][0]); }
+                            else { a0 = f4{fmaxf(H[0][0][0], 0.f), fmaxf(H[0][0][1], 0.f), fmaxf(H[0][0][2], 0.f), fmaxf(H[0][0][3], 0.f)};
+                                   a1 = f4{fmaxf(H[1][0][0], 0.f), fmaxf(H[1][0][1], 0.f), fmaxf(H[1][0][2], 0.f), fmaxf(H[1][0][3], 0.f)}; }
+                            HX[0] = OP::pack8(a0, a1);
+                            HXlo = pack8_lo(a0, a1, __builtin_bit_cast(h8, HX[0]));
+                            continue;
+                        }
+                    }
                     if constexpr (ACT == 1) HX[ct] = OP::pack8(gelu4(H[0][ct]), gelu4(H[1][ct]));
                     else HX[ct] = OP::relu_pack8(H[0][ct], H[1][ct]);
                 }
@@ -1338,6 +1405,12 @@ __global__ __launch_bounds__(WAVES * 64, 2) void uit_encoder_kernel(EncoderArgs 
                     for (int ft = 0; ft < 8; ++ft)
 #pragma unroll
                         for (int ct = 0; ct < NCT; ++ct) R[ft][ct] = OP::mfma32(A2[ft], HX[ct], R[ft][ct]);
+                    if constexpr (ASPLIT) {                            // tile 0's low-order activation term on the high-order fc2 fragments
+                        if (half == 0) {
+#pragma unroll
+                            for (int ft = 0; ft < 8; ++ft) R[ft][0] = OP::mfma32(A2[ft], HXlo, R[ft][0]);
+                        }
+                    }
                 }
             }
         }
@@ -1544,7 +1617,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void uit_encoder_kernel(EncoderArgs 
         ring_step<WAVES, SB>(a.wstream, ring, tb, wave, lane);
         TSTAMP(1);                                                     // ring wait QK
         if (blk + 1 < a.depth) bias_issue<WAVES, SB>(a.bias, breg, blk + 1, wave, lane);
-        v4 Qh[2][3], Kh[2][3], Qlo[2];
+        v4 Qh[2][3], Kh[2][3], Qlo[2][3], Klo[2][3];
         {
             const char* slot = ring + (tb & (RING_SLOTS - 1)) * STAGE_BYTES;
             v8 A[16];
@@ -1569,7 +1642,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void uit_encoder_kernel(EncoderArgs 
                         }
                     }
                     if (ft < 2) Qh[ft][ct] = OP::pack4(acc); else Kh[ft - 2][ct] = OP::pack4(acc);
-                    if constexpr (ASPLIT) { if (ct == 0 && ft < 2) Qlo[ft] = pack4_lo(acc, Qh[ft][0]); }
+                    if constexpr (ASPLIT) { if (ft < 2) Qlo[ft][ct] = pack4_lo(acc, Qh[ft][ct]); else Klo[ft - 2][ct] = pack4_lo(acc, Kh[ft - 2][ct]); }
                 }
             }
         }
@@ -1580,7 +1653,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void uit_encoder_kernel(EncoderArgs 
         TSTAMP(3);                                                     // ring wait VP
         {
             const char* slot = ring + ((tb + 1) & (RING_SLOTS - 1)) * STAGE_BYTES;
-            v4 Vh[3][2];                       // V[token 16ct+4g+r][d = c] -> A operand of P.V (rows d, k = token)
+            v4 Vh[3][2], Vlo[3][2];            // V[token 16ct+4g+r][d = c] -> A operand of P.V (rows d, k = token)
             {
                 v8 Bw[8];
 #pragma unroll
@@ -1600,12 +1673,13 @@ __global__ __launch_bounds__(WAVES * 64, 2) void uit_encoder_kernel(EncoderArgs 
                             }
                         }
                         Vh[ct][h] = OP::pack4(acc);
+                        if constexpr (ASPLIT) Vlo[ct][h] = pack4_lo(acc, Vh[ct][h]);
                     }
                 }
             }
             f4 kinit[3];
             make_kinit(kinit);
-            attention_proj<OP, PERKEY, false, NCT, ASPLIT>(R, Qh, Kh, Vh, tvalid, kinit, slot + 8 * FRAG_BYTES, bias, lane, g, Qlo);
+            attention_proj<OP, PERKEY, false, NCT, ASPLIT>(R, Qh, Kh, Vh, tvalid, kinit, slot + 8 * FRAG_BYTES, bias, lane, g, Qlo, Klo, Vlo);
         }
 
         }
@@ -2122,8 +2196,8 @@ hipError_t launch_encoder(const EncoderArgs& a, int precision, int waves, hipStr
         return a.nt < GT ? launch_enc<4, 8, true, false, 0, 0, 1>(a, stream) : launch_enc<4, 8, false, false, 0, 0, 1>(a, stream);
     }
     if (a.pooling) {                                      // pooling 'dm' / 'token' (f16 / f16x2, 8-wave workgroups), any attention / activation
-        if ((precision != 0 && precision != 3 && precision != 5) || a.timing != nullptr) return hipErrorInvalidValue;
-        if (precision == 5 && a.pooling != 2) return hipErrorInvalidValue;
+        if ((precision != 0 && precision != 3 && precision != 5 && precision != 6) || a.timing != nullptr) return hipErrorInvalidValue;
+        if ((precision == 5 || precision == 6) && a.pooling != 2) return hipErrorInvalidValue;
 #define UITK_POOL(P, SH, PL) (a.attention_full ? (a.act_gelu ? launch_enc<P, 8, SH, false, 1, 1, PL>(a, stream) : launch_enc<P, 8, SH, false, 1, 0, PL>(a, stream)) \
                                                : (a.act_gelu ? launch_enc<P, 8, SH, false, 0, 1, PL>(a, stream) : launch_enc<P, 8, SH, false, 0, 0, PL>(a, stream)))
         if (precision == 3) {                             // split weights (round 3): the parity mode of the full-width-attention factories
@@ -2131,6 +2205,7 @@ hipError_t launch_encoder(const EncoderArgs& a, int precision, int waves, hipStr
             return a.nt < GT ? UITK_POOL(3, true, 1) : UITK_POOL(3, false, 1);
         }
         if (precision == 5) return UITK_POOL(5, true, 2);  // precision f16a: split activation operands in the cls tile
+        if (precision == 6) return UITK_POOL(6, true, 2);  // precision f16ax: the same on split weights
         if (a.pooling == 2) return UITK_POOL(0, true, 2);  // per-key softmax masks always (dead columns)
         return a.nt < GT ? UITK_POOL(0, true, 1) : UITK_POOL(0, false, 1);
 #undef UITK_POOL

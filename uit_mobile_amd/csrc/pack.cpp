@@ -380,14 +380,14 @@ int validate_config(const uitk_config* c, const char** why) {
     if (c->depth < 1 || c->depth > 64) return bad("depth out of range");
     if (c->outputdim < 1 || c->outputdim > 65536) return bad("outputdim out of range");
     if (c->eval_avg != UITK_AVG_MEAN && c->eval_avg != UITK_AVG_MAX) return bad("unknown eval_avg");
-    if (c->precision != UITK_PREC_F16 && c->precision != UITK_PREC_BF16 && c->precision != UITK_PREC_FP8 && c->precision != UITK_PREC_F16X2 && c->precision != UITK_PREC_F16L6 && c->precision != UITK_PREC_FP8W && c->precision != UITK_PREC_F16A) return bad("unknown precision");
-    if (c->precision == UITK_PREC_F16A && c->pooling != 2) return bad("precision f16a (split activation operands of the cls tile) is built for pooling 'token'");
+    if (c->precision != UITK_PREC_F16 && c->precision != UITK_PREC_BF16 && c->precision != UITK_PREC_FP8 && c->precision != UITK_PREC_F16X2 && c->precision != UITK_PREC_F16L6 && c->precision != UITK_PREC_FP8W && c->precision != UITK_PREC_F16A && c->precision != UITK_PREC_F16AX) return bad("unknown precision");
+    if ((c->precision == UITK_PREC_F16A || c->precision == UITK_PREC_F16AX) && c->pooling != 2) return bad("precisions f16a / f16ax (split activation operands of the cls tile) are built for pooling 'token'");
 
     if (c->precision == UITK_PREC_F16L6 && (c->attention_full || c->act_gelu)) return bad("precision f16l6 is built for BNeckAttention + ReLU (any pooling)");
     if ((c->attention_full != 0 && c->attention_full != 1) || (c->act_gelu != 0 && c->act_gelu != 1)) return bad("attention_full / act_gelu must be 0 or 1");
     if ((c->attention_full || c->act_gelu || c->pooling) && c->precision == UITK_PREC_FP8) return bad("precision fp8 is built for the uit_* family (BNeckAttention, ReLU, mean pooling) only");
     if (c->pooling < 0 || c->pooling > 2) return bad("pooling must be 0 (mean), 1 (dm) or 2 (token)");
-    if (c->pooling && c->precision != UITK_PREC_F16 && c->precision != UITK_PREC_F16L6 && c->precision != UITK_PREC_F16X2 && c->precision != UITK_PREC_FP8W && c->precision != UITK_PREC_F16A) return bad("pooling 'dm' / 'token' are built for precision f16 / f16l6 / f16x2");
+    if (c->pooling && c->precision != UITK_PREC_F16 && c->precision != UITK_PREC_F16L6 && c->precision != UITK_PREC_F16X2 && c->precision != UITK_PREC_FP8W && c->precision != UITK_PREC_F16A && c->precision != UITK_PREC_F16AX) return bad("pooling 'dm' / 'token' are built for precision f16 / f16l6 / f16x2");
     if (c->pooling == 1 && c->outputdim > 640) return bad("pooling 'dm' is built for outputdim <= 640");
     return UITK_OK;
 }
@@ -495,7 +495,7 @@ int pack_image(const uitk_config* c, const uitk_weights* w, const double* calib,
     const bool l6 = c->precision == UITK_PREC_F16L6;                     // f16 operands + fp6 low-order weight term
     const bool w8 = c->precision == UITK_PREC_FP8W;                      // f16 operands (the f16 kernel) holding weights on the MX e4m3 grid
     // (f16a: the image of precision f16 -- its second activation terms are formed in the kernel)
-    const int prec = (c->precision == UITK_PREC_F16X2 || l6 || w8 || c->precision == UITK_PREC_F16A) ? UITK_PREC_F16 : c->precision, depth = c->depth, C = c->outputdim;
+    const int prec = (c->precision == UITK_PREC_F16X2 || l6 || w8 || c->precision == UITK_PREC_F16A || c->precision == UITK_PREC_F16AX) ? UITK_PREC_F16 : c->precision, depth = c->depth, C = c->outputdim;
     const int ntiles = (C + 15) / 16;
     const int nb = c->n_fft / 2 + 1;
     // ---- mel filterbank as banded B operands of v_mfma_f32_4x4x1 (16 independent 4x4 blocks): block g owns mels
@@ -565,7 +565,7 @@ int pack_image(const uitk_config* c, const uitk_weights* w, const double* calib,
     auto take = [&](size_t bytes) { size_t r = o; o = align_up(o + bytes, 256); return r; };
     const bool full = c->attention_full != 0;
     const int inner = full ? DIM : INNER;                                // qkv = Linear(dim, 3 * inner), proj = Linear(inner, dim)
-    const bool x2 = c->precision == UITK_PREC_F16X2;                     // split weights: operand type fp16 (prec 0 for every conversion)
+    const bool x2 = c->precision == UITK_PREC_F16X2 || c->precision == UITK_PREC_F16AX;      // split weights: operand type fp16 (prec 0 for every conversion); f16ax = this image, other kernel
     const int blk_stages = full ? (x2 ? BLOCK_STAGES_X2_ATT : BLOCK_STAGES_ATT) : (prec == UITK_PREC_FP8 ? BLOCK_STAGES_FP8 : x2 ? BLOCK_STAGES_X2 : BLOCK_STAGES);
     const int b_proj = full ? BIASF_PROJ : BIAS_PROJ, b_fc1 = full ? BIASF_FC1 : BIAS_FC1, b_fc2 = full ? BIASF_FC2 : BIAS_FC2;
     h.off_wstream = take(l6 ? (size_t)PE_STAGES * STAGE_BYTES + (size_t)depth * L6_BLOCK_BYTES + L6_TAIL_BYTES
@@ -652,7 +652,7 @@ int pack_image(const uitk_config* c, const uitk_weights* w, const double* calib,
     //   * the builds named by operand_centring() also subtract mu = E[LayerNorm-1 output] from the operand before it is rounded
     //     (W (x - mu) + (b + W mu), exact for any mu): then the k / v biases are exactly 0 and -mu rides in the block's bias table.
     // tools/err_attrib_full.py, d4-GELU seed 206 (the round-4 gate case): fp16 activation floor 9.8e-4 -> 2.1e-4.
-    const int kprec = (c->precision == UITK_PREC_FP8W || c->precision == UITK_PREC_F16A) ? UITK_PREC_F16 : c->precision;
+    const int kprec = (c->precision == UITK_PREC_FP8W || c->precision == UITK_PREC_F16A) ? UITK_PREC_F16 : c->precision == UITK_PREC_F16AX ? UITK_PREC_F16X2 : c->precision;
     // (a build with the runtime centring ALWAYS reads -mu from its bias table -- for full-width attention from the K rows' bias slot -- so
     // its images are folded this way with mu = 0 when there are no statistics)
     const bool centre_rt = operand_centring(c->attention_full, c->act_gelu, c->pooling, kprec);

@@ -88,9 +88,9 @@ constexpr int BIAS_NEGMU = 736;
 // at the gate in round 4 (full-width attention, GELU, pooling 'token'), on fp16 operands with single or split weights
 constexpr bool operand_centring(int att, int act, int pool, int kernel_prec) {
 #if defined(UITK_LAB) && defined(UITK_CEN_ALL)
-    return kernel_prec == 0 || kernel_prec == 3 || kernel_prec == 5;      // lab: the runtime centring for the default family too
+    return kernel_prec == 0 || kernel_prec == 3 || kernel_prec == 5 || kernel_prec == 6;      // lab: the runtime centring for the default family too
 #else
-    return (kernel_prec == 0 || kernel_prec == 3 || kernel_prec == 5) && (att != 0 || act != 0 || pool == 2);
+    return (kernel_prec == 0 || kernel_prec == 3 || kernel_prec == 5 || kernel_prec == 6) && (att != 0 || act != 0 || pool == 2);      // (5 / 6: precisions f16a / f16ax)
 #endif
 }
 

@@ -32,11 +32,12 @@ _CALIB_OPTIONS = ('calib_accept_pct', 'calib_budget_e6')            # (meaningfu
 # 'fp8c' / 'fp8w' (round 5, BASELINE config #5): the fp8 kernel on weights GPTQ-rounded to the MX e4m3 grid / the f16 kernel on fp8-grid weights
 # ("fp8 weights" read literally), both calibrated like 'f16c'; 'fp8' keeps its weights rounded to nearest (the reference point)
 _PRECISIONS = {'auto': _lib.PREC_F16, 'f16': _lib.PREC_F16, 'f16c': _lib.PREC_F16, 'bf16': _lib.PREC_BF16, 'fp8': _lib.PREC_FP8, 'fp8c': _lib.PREC_FP8,
-               'fp8w': _lib.PREC_FP8W, 'f16x2': _lib.PREC_F16X2, 'f16l6': _lib.PREC_F16L6, 'f16a': _lib.PREC_F16A}
-_PRECISION_NAMES = {_lib.PREC_F16: 'f16', _lib.PREC_BF16: 'bf16', _lib.PREC_FP8: 'fp8', _lib.PREC_F16X2: 'f16x2', _lib.PREC_F16L6: 'f16l6', _lib.PREC_F16A: 'f16a'}
+               'fp8w': _lib.PREC_FP8W, 'f16x2': _lib.PREC_F16X2, 'f16l6': _lib.PREC_F16L6, 'f16a': _lib.PREC_F16A, 'f16ax': _lib.PREC_F16AX}
+_PRECISION_NAMES = {_lib.PREC_F16: 'f16', _lib.PREC_BF16: 'bf16', _lib.PREC_FP8: 'fp8', _lib.PREC_F16X2: 'f16x2', _lib.PREC_F16L6: 'f16l6', _lib.PREC_F16A: 'f16a', _lib.PREC_F16AX: 'f16ax'}
 # 'f16a' (round 5, pooling 'token' only): 'f16c' + the MLP's activation operands of the cls column tile as hi + lo terms -- what 'auto' escalates
 # to there (the cls row is read without a mean over tokens: activation rounding, not weight rounding, is what is over budget)
-_CALIBRATING = ('auto', 'f16c', 'fp8c', 'fp8w', 'f16a')             # precisions whose handle is built with uitk_calibrate_weights
+_CALIBRATING = ('auto', 'f16c', 'fp8c', 'fp8w', 'f16a', 'f16ax')    # precisions whose handle is built with uitk_calibrate_weights
+# 'f16ax' (round 5): 'f16a' on the split weights of 'f16x2' -- where 'auto' goes when an 'f16a' handle is over the budget
 
 __all__ = ["UITBase", "UitkSetupWarning", "UitkParityWarning", "uit_xs", "uit_xxs", "uit_xxxs", "PRETRAINED_CHECKPOINTS",
            "audio_transformer_h128_d4_m3", "audio_transformer_h128_d4_m3_relu",
@@ -218,9 +219,9 @@ class UITBase(nn.Module):
             raise NotImplementedError("precision='fp8' / 'fp8c' are built for the uit_* family (BNeckAttention + ReLU, mean pooling) only")
         if precision == 'f16l6' and (self.attention_full or self.act_gelu):
             raise NotImplementedError("precision='f16l6' is built for BNeckAttention + ReLU (any pooling)")
-        if precision == 'f16a' and pooling != 'token':
-            raise NotImplementedError("precision='f16a' (split activation operands of the cls tile) is built for pooling='token'")
-        if pooling != 'mean' and precision not in ('auto', 'f16', 'f16c', 'f16l6', 'f16x2', 'fp8w', 'f16a'):
+        if precision in ('f16a', 'f16ax') and pooling != 'token':
+            raise NotImplementedError("precision='f16a' / 'f16ax' (split activation operands of the cls tile) are built for pooling='token'")
+        if pooling != 'mean' and precision not in ('auto', 'f16', 'f16c', 'f16l6', 'f16x2', 'fp8w', 'f16a', 'f16ax'):
             raise NotImplementedError("pooling='dm' / 'token' are built for precision='auto' / 'f16' / 'f16c' / 'f16l6' / 'f16x2' / 'fp8w'")
 
         self.front_end = nn.Sequential(
@@ -298,7 +299,7 @@ class UITBase(nn.Module):
         Results stay within the parity tolerance either way (tests/test_gpu_parity.py::test_calibrated_rounding_*): calibration only
         decides in which direction each fp16 weight is rounded."""
         if self.precision not in _CALIBRATING:
-            raise ValueError("calibrate() applies to the calibrated precisions 'auto' / 'f16c' (single fp16 weights) and 'fp8c' / 'fp8w'")
+            raise ValueError("calibrate() applies to the calibrated precisions 'auto' / 'f16c' / 'f16a' / 'f16ax' and 'fp8c' / 'fp8w'")
         if x is not None:
             x, _ = self._prep_input(x)
         self._calib_input = x
@@ -502,7 +503,7 @@ class UITBase(nn.Module):
                           "once at set-up to keep that out of the first forward (required before stream capture)", UitkSetupWarning, stacklevel=4)
         with torch.cuda.device(idx):
             # 'auto' starts as 'f16c' -- except for pooling 'token', whose parity mode is 'f16a' from the start: the head reads ONE row, the
-            # MLP's activation rounding on that row is not averaged over 24 tokens, and the library's sixteen held-out clips cannot bound it
+            # MLP's activation rounding on that row is not averaged over 24 tokens, and the library's held-out clips cannot bound it
             # for every input (tools/auto_sweep.py, 24 unseen checkpoints of uit_xxs: 'f16c' inside the library's budget and still 1.08e-3
             # on one of the reference's recordings; 'f16a': profiles/round5/auto_sweep_token_f16a_v2.log)
             start_as = self.precision if self.precision != 'auto' else ('f16a' if self.pooling == 'token' else 'f16c')
@@ -522,12 +523,7 @@ class UITBase(nn.Module):
                 refused = check is not None and not check["accepted"]
                 if refused:                               # the nearest-rounded image stayed
                     handle.mode["precision"] = {'f16c': 'f16', 'fp8c': 'fp8'}.get(start_as, start_as + ' (nearest on its grid)')
-                if start_as == 'f16a' and esc.value == _lib.PREC_F16A:
-                    esc.value = -1                            # (already the top of this pooling's ladder: over budget is reported, not escalated)
-                    handle.mode.update(within_budget=False, reason="held-out deviation over the budget (%.2e against %.1e) in 'f16a', the top of "
-                                       "the ladder for pooling 'token'" % (check["max_calibrated"] if check and check["accepted"] else check["max_nearest"] if check else float('nan'), handle.mode["budget"]))
-                    warnings.warn(f"uit_mobile_amd: precision='{self.precision}' on cuda:{idx}: {handle.mode['reason']}", UitkParityWarning, stacklevel=4)
-                if self.precision in ('auto', 'f16c') and (esc.value >= 0 or refused):
+                if self.precision in ('auto', 'f16c', 'f16a') and (esc.value >= 0 or refused):
                     dev_now = None if check is None else (check["max_nearest"] if refused else check["max_calibrated"])
                     why = ("calibration refused by the acceptance check (calibrated %.2e vs nearest %.2e on the held-out clips)" % (check["max_calibrated"], check["max_nearest"])
                            if refused else "held-out deviation of the calibrated image over the budget") if check is not None else "the held-out check failed"
@@ -550,14 +546,17 @@ class UITBase(nn.Module):
                             handle.mode.update(reason=why, within_budget=False, self_check_split=sc)
                             warnings.warn(f"uit_mobile_amd: precision='auto' on cuda:{idx}: {why}", UitkParityWarning, stacklevel=4)
                         else:
+                            inside = sc is None or sc[0] <= handle.mode["budget"]
                             warnings.warn(f"uit_mobile_amd: precision='auto' on cuda:{idx}: {why} -> rebuilding the handle in precision '{to}' "
-                                          "(split weights: parity-grade, slower)", UitkParityWarning, stacklevel=4)
+                                          + ("(split activation operands + split weights: the top of pooling 'token''s ladder, slower)" if to == 'f16ax'
+                                             else "(split weights: parity-grade, slower)")
+                                          + ("" if inside else "; that build measures %.2e there: STILL OVER the budget" % sc[0]), UitkParityWarning, stacklevel=4)
                             split.mode.update(check=handle.mode["check"], budget=handle.mode["budget"], reason=why, escalated=True, self_check=sc,
-                                              within_budget=sc is None or sc[0] <= handle.mode["budget"])
-                            handle = split                # (the f16c handle is destroyed when its last reference goes)
-                    elif self.precision == 'f16c':
-                        warnings.warn(f"uit_mobile_amd: precision='f16c' on cuda:{idx}: {why}; an explicit 'f16c' does not escalate"
-                                      + (" and now runs the NEAREST-rounded fp16 image (= precision 'f16')" if refused else "")
+                                              within_budget=inside)
+                            handle = split                # (the first handle is destroyed when its last reference goes)
+                    elif self.precision != 'auto':
+                        warnings.warn(f"uit_mobile_amd: precision='{self.precision}' on cuda:{idx}: {why}; an explicit '{self.precision}' does not escalate"
+                                      + (" and now runs the NEAREST-rounded fp16 image (= precision 'f16')" if refused and self.precision == 'f16c' else "")
                                       + " -- use precision='auto' (the default) for the guaranteed parity mode", UitkParityWarning, stacklevel=4)
         self._handles[idx] = (handle, stamp)
         return handle
