@@ -486,6 +486,7 @@ class UITBase(nn.Module):
                        "uitk_calibrate_weights")
 
     def _handle_obj(self, device, _from_forward=False):
+        """The live _Handle for `device`: the cached one while the weights' stamp is unchanged, else a new build (_build_handle)."""
         if self.eval_avg not in ('mean', 'max'):
             raise ValueError(f'Unknown Eval average function ({self.eval_avg})')      # uit.py:488
         idx = device.index if device.index is not None else torch.cuda.current_device()
@@ -493,14 +494,19 @@ class UITBase(nn.Module):
         stamp = self._stamp() if (self.check_weights or h is None) else None
         if h is not None and (stamp is None or h[1] == stamp):
             return h[0]
-        L = _lib.load()
-        w, keep = self._host_weights()
-        calibrating = self.precision in _CALIBRATING
-        if calibrating and _from_forward and not self._warned_setup:
+        if self.precision in _CALIBRATING and _from_forward and not self._warned_setup:
             self._warned_setup = True
             warnings.warn("uit_mobile_amd: this forward call builds the parameter image first (weight calibration + acceptance check, "
-                          "~0.15 s, device-synchronous; front-end tuning on the first full-size batch): call model.prepare(device, (B, T)) "
+                          "~0.2 s, device-synchronous; front-end tuning on the first full-size batch): call model.prepare(device, (B, T)) "
                           "once at set-up to keep that out of the first forward (required before stream capture)", UitkSetupWarning, stacklevel=4)
+        handle = self._build_handle(idx)
+        self._handles[idx] = (handle, stamp)
+        return handle
+
+    def _build_handle(self, idx):
+        """uitk_create (+ uitk_calibrate_weights and the parity ladder for the calibrated precisions) on device `idx` -> _Handle."""
+        L = _lib.load()
+        w, keep = self._host_weights()
         with torch.cuda.device(idx):
             # 'auto' starts as 'f16c' -- except for pooling 'token', whose parity mode is 'f16a' from the start: the head reads ONE row, the
             # MLP's activation rounding on that row is not averaged over 24 tokens, and the library's held-out clips cannot bound it
@@ -508,58 +514,65 @@ class UITBase(nn.Module):
             # on one of the reference's recordings; 'f16a': profiles/round5/auto_sweep_token_f16a_v2.log)
             start_as = self.precision if self.precision != 'auto' else ('f16a' if self.pooling == 'token' else 'f16c')
             handle = self._create(L, w, start_as)
-            if calibrating:                               # calibrated rounding: the caller's clips, else the library's own signals
+            if self.precision in _CALIBRATING:            # calibrated rounding: the caller's clips, else the library's own signals
                 x = self._calib_input if self._calib_input is None else self._calib_input.to(torch.device("cuda", idx))
                 stream = ctypes.c_void_p(torch.cuda.current_stream(idx).cuda_stream)
                 self._calibrate_handle(L, handle, w, x, stream)
-                rep = (ctypes.c_float * 5)()
-                _lib.check(L.uitk_get_calib_check(handle.ptr, rep), "uitk_get_calib_check")
-                esc, budget = ctypes.c_int(-1), ctypes.c_int(0)
-                _lib.check(L.uitk_get_option(handle.ptr, b"parity_escalate_to", ctypes.byref(esc)), "uitk_get_option")
-                _lib.check(L.uitk_get_option(handle.ptr, b"calib_budget_e6", ctypes.byref(budget)), "uitk_get_option")
-                check = None if rep[4] < 0 else {"max_nearest": rep[0], "max_calibrated": rep[1], "rms_nearest": rep[2], "rms_calibrated": rep[3],
-                                                 "accepted": rep[4] > 0}
-                handle.mode.update(check=check, budget=budget.value * 1e-6 * (0.25 if self.pooling == 'dm' else 1.0), within_budget=esc.value < 0)
-                refused = check is not None and not check["accepted"]
-                if refused:                               # the nearest-rounded image stayed
-                    handle.mode["precision"] = {'f16c': 'f16', 'fp8c': 'fp8'}.get(start_as, start_as + ' (nearest on its grid)')
-                if self.precision in ('auto', 'f16c', 'f16a') and (esc.value >= 0 or refused):
-                    dev_now = None if check is None else (check["max_nearest"] if refused else check["max_calibrated"])
-                    why = ("calibration refused by the acceptance check (calibrated %.2e vs nearest %.2e on the held-out clips)" % (check["max_calibrated"], check["max_nearest"])
-                           if refused else "held-out deviation of the calibrated image over the budget") if check is not None else "the held-out check failed"
-                    if dev_now is not None:
-                        why += "; installed image: %.2e against a budget of %.1e" % (dev_now, handle.mode["budget"])
-                    handle.mode["reason"] = why
-                    if self.precision == 'auto' and esc.value >= 0:
-                        to = _PRECISION_NAMES[esc.value]
-                        # the split-weight build of the same weights; the SAME calibration statistics give it the operand centring of the
-                        # attention (its weights are not re-rounded), and its own deviation on the held-out clips decides whether it stays
-                        split = self._create(L, w, to)
-                        self._calibrate_handle(L, split, w, x, stream)
-                        out2 = (ctypes.c_float * 2)()
-                        _lib.check(L.uitk_self_check(split.ptr, ctypes.byref(w), stream, out2), "uitk_self_check")
-                        sc = None if out2[0] < 0 else (float(out2[0]), float(out2[1]))
-                        if sc is not None and dev_now is not None and sc[0] >= dev_now:
-                            # split weights do not help here: what is over budget is fp16 ACTIVATION rounding (pooling 'token' reads one
-                            # row instead of a mean over 24), not weight rounding -- the faster image stays, and the report says so
-                            why += "; the split-weight build '%s' measures %.2e there (no better): kept" % (to, sc[0])
-                            handle.mode.update(reason=why, within_budget=False, self_check_split=sc)
-                            warnings.warn(f"uit_mobile_amd: precision='auto' on cuda:{idx}: {why}", UitkParityWarning, stacklevel=4)
-                        else:
-                            inside = sc is None or sc[0] <= handle.mode["budget"]
-                            warnings.warn(f"uit_mobile_amd: precision='auto' on cuda:{idx}: {why} -> rebuilding the handle in precision '{to}' "
-                                          + ("(split activation operands + split weights: the top of pooling 'token''s ladder, slower)" if to == 'f16ax'
-                                             else "(split weights: parity-grade, slower)")
-                                          + ("" if inside else "; that build measures %.2e there: STILL OVER the budget" % sc[0]), UitkParityWarning, stacklevel=4)
-                            split.mode.update(check=handle.mode["check"], budget=handle.mode["budget"], reason=why, escalated=True, self_check=sc,
-                                              within_budget=inside)
-                            handle = split                # (the first handle is destroyed when its last reference goes)
-                    elif self.precision != 'auto':
-                        warnings.warn(f"uit_mobile_amd: precision='{self.precision}' on cuda:{idx}: {why}; an explicit '{self.precision}' does not escalate"
-                                      + (" and now runs the NEAREST-rounded fp16 image (= precision 'f16')" if refused and self.precision == 'f16c' else "")
-                                      + " -- use precision='auto' (the default) for the guaranteed parity mode", UitkParityWarning, stacklevel=4)
-        self._handles[idx] = (handle, stamp)
+                handle = self._hold_to_budget(L, w, handle, start_as, x, stream, idx)
         return handle
+
+    def _hold_to_budget(self, L, w, handle, start_as, x, stream, idx):
+        """The guarantee of the parity mode (round 5), after uitk_calibrate_weights on `handle`: read what the library measured on its
+        held-out clips and what it asks for (option parity_escalate_to); 'auto' builds the precision named there -- 'f16l6' / 'f16x2';
+        pooling 'token': 'f16a', then 'f16ax' -- calibrates it too (operand centring), measures it on the same clips (uitk_self_check) and
+        keeps the better of the two; an explicit 'f16c' / 'f16a' warns and stays.  Returns the _Handle to install; its .mode is the report."""
+        rep = (ctypes.c_float * 5)()
+        _lib.check(L.uitk_get_calib_check(handle.ptr, rep), "uitk_get_calib_check")
+        esc, budget = ctypes.c_int(-1), ctypes.c_int(0)
+        _lib.check(L.uitk_get_option(handle.ptr, b"parity_escalate_to", ctypes.byref(esc)), "uitk_get_option")
+        _lib.check(L.uitk_get_option(handle.ptr, b"calib_budget_e6", ctypes.byref(budget)), "uitk_get_option")
+        check = None if rep[4] < 0 else {"max_nearest": rep[0], "max_calibrated": rep[1], "rms_nearest": rep[2], "rms_calibrated": rep[3],
+                                         "accepted": rep[4] > 0}
+        handle.mode.update(check=check, budget=budget.value * 1e-6 * (0.25 if self.pooling == 'dm' else 1.0), within_budget=esc.value < 0)
+        refused = check is not None and not check["accepted"]
+        if refused:                                       # the nearest-rounded image stayed
+            handle.mode["precision"] = {'f16c': 'f16', 'fp8c': 'fp8'}.get(start_as, start_as + ' (nearest on its grid)')
+        if self.precision not in ('auto', 'f16c', 'f16a') or not (esc.value >= 0 or refused):
+            return handle
+        dev_now = None if check is None else (check["max_nearest"] if refused else check["max_calibrated"])
+        why = ("calibration refused by the acceptance check (calibrated %.2e vs nearest %.2e on the held-out clips)" % (check["max_calibrated"], check["max_nearest"])
+               if refused else "held-out deviation of the calibrated image over the budget") if check is not None else "the held-out check failed"
+        if dev_now is not None:
+            why += "; installed image: %.2e against a budget of %.1e" % (dev_now, handle.mode["budget"])
+        handle.mode["reason"] = why
+        if self.precision != 'auto':
+            warnings.warn(f"uit_mobile_amd: precision='{self.precision}' on cuda:{idx}: {why}; an explicit '{self.precision}' does not escalate"
+                          + (" and now runs the NEAREST-rounded fp16 image (= precision 'f16')" if refused and self.precision == 'f16c' else "")
+                          + " -- use precision='auto' (the default) for the guaranteed parity mode", UitkParityWarning, stacklevel=6)
+            return handle
+        if esc.value < 0:                                 # refused, yet inside the budget (harmless at init scale): reported, not escalated
+            return handle
+        to = _PRECISION_NAMES[esc.value]
+        # the build the library names, of the same weights; the SAME calibration call gives it the operand centring of the attention (split
+        # weights are not re-rounded), and its own deviation on the held-out clips decides whether it stays
+        split = self._create(L, w, to)
+        self._calibrate_handle(L, split, w, x, stream)
+        out2 = (ctypes.c_float * 2)()
+        _lib.check(L.uitk_self_check(split.ptr, ctypes.byref(w), stream, out2), "uitk_self_check")
+        sc = None if out2[0] < 0 else (float(out2[0]), float(out2[1]))
+        if sc is not None and dev_now is not None and sc[0] >= dev_now:
+            # no better: what is over budget is not what that build splits -- the faster image stays, and the report says so
+            why += "; the build '%s' measures %.2e there (no better): kept" % (to, sc[0])
+            handle.mode.update(reason=why, within_budget=False, self_check_split=sc)
+            warnings.warn(f"uit_mobile_amd: precision='auto' on cuda:{idx}: {why}", UitkParityWarning, stacklevel=6)
+            return handle
+        inside = sc is None or sc[0] <= handle.mode["budget"]
+        warnings.warn(f"uit_mobile_amd: precision='auto' on cuda:{idx}: {why} -> rebuilding the handle in precision '{to}' "
+                      + ("(split activation operands + split weights: the top of pooling 'token''s ladder, slower)" if to == 'f16ax'
+                         else "(split activation operands of the cls tile, slower)" if to == 'f16a' else "(split weights: parity-grade, slower)")
+                      + ("" if inside else "; that build measures %.2e there: STILL OVER the budget" % sc[0]), UitkParityWarning, stacklevel=6)
+        split.mode.update(check=handle.mode["check"], budget=handle.mode["budget"], reason=why, escalated=True, self_check=sc, within_budget=inside)
+        return split                                      # (the first handle is destroyed when its last reference goes)
 
     @staticmethod
     def _prep_input(x):
