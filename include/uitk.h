@@ -65,6 +65,12 @@ typedef enum uitk_precision {
                            split WEIGHTS (its parameter image and ring schedule) -- what is left is the fp16 rounding of the other tiles'
                            LayerNorm operands; ~2x the encoder time of UITK_PREC_F16.  get_option("parity_escalate_to") of a
                            UITK_PREC_F16A handle over its budget names it */
+    UITK_PREC_F32 = 8,  /* round 5: the LAST rung of the parity ladder, any family / pooling: the folded network in fp32 on the vector ALUs (the
+                           plain forward of csrc/calibrate.hip: one simple kernel per operation, sums of the head in double) behind the
+                           product front-end -- ~2 orders of magnitude slower than the MFMA encoder (still above the 64-core CPU port) and
+                           right for every checkpoint, e.g. those with strong attention sinks, whose fp16 activation floor no split
+                           mode brings inside the budget (tools/err_attrib_sink.py).  get_option("parity_escalate_to") of a split-weight
+                           handle (f16l6 / f16x2 / f16ax) that uitk_calibrate_weights measured over its budget names it */
     UITK_PREC_F16L6 = 4 /* round 3's parity mode (kept built and tested): fp16 operands as UITK_PREC_F16 plus the LOW-ORDER weight term on the cheap pipe:
                            W = f16(W) + 2^e(row) . e2m3(W - f16(W)), the second term as OCP fp6 on
                            v_mfma_scale_f32_16x16x128_f8f6f4 (one MFMA at the cost of one f16 k-step covers K = 128) against fp6
@@ -179,7 +185,8 @@ int uitk_pack_weights(const uitk_config* cfg, const uitk_weights* w, void* out, 
  * 'dm'): the image that STAYS on the handle -- calibrated, or nearest after a refusal -- must itself be inside the budget on the held-out
  * clips.  If it is not (or the check failed), get_option("parity_escalate_to") names the precision the caller must rebuild the handle
  * with to stay a parity mode: UITK_PREC_F16L6 for BNeckAttention + ReLU, UITK_PREC_F16X2 for the other families; pooling 'token':
- * UITK_PREC_F16A, and from a UITK_PREC_F16A handle UITK_PREC_F16AX (-1: inside the budget).  The Python wrapper's precision 'auto' (the factories' default) does exactly that and reports it; tests/native/
+ * UITK_PREC_F16A, and from a UITK_PREC_F16A handle UITK_PREC_F16AX; from any of those split builds, measured over the budget by its own
+ * uitk_calibrate_weights call: UITK_PREC_F32 (-1: inside the budget).  The Python wrapper's precision 'auto' (the factories' default) does exactly that and reports it; tests/native/
  * cabi_consumer.c shows the same four calls in C.  Not callable under stream capture (it allocates and synchronises). */
 int uitk_calibrate_weights(uitk_model* m, const uitk_weights* w, const void* pcm, int in_dtype, int64_t B, int64_t T, void* stream);
 /* Number of doubles of a statistics block for this config: patch embed [256][256], then per block LayerNorm-1 output [128][128],

@@ -1153,21 +1153,35 @@ def test_auto_escalates_instead_of_falling_back_to_nearest(golden):
         m = make("f16c", calib_accept_pct=1)
         e_c, p_c = err_of(m)
     assert m.effective_precision() == "f16" and torch.equal(p_c, p_near) and e_c == e_near
-    # (c) a budget nobody can meet: the accepted calibrated image is over it, the split-weight build is measured on the same clips -- and,
-    # being no better than the calibrated image (what is left is activation rounding), is NOT taken: the report says so
+    # (c) a budget no fp16 mode can meet: the accepted calibrated image is over it, the split-weight build is measured on the same clips -- and,
+    # being no better than the calibrated image (what is left is activation rounding), is NOT taken: the report says so.  With the fp32
+    # rung switched off the calibrated image stays; with it (the default) the ladder ends in 'f32', the library's plain fp32 forward
+    def make_nofp32(prec, **opts):
+        m = models.uit_xs(outputdim=537, target_length=102, precision=prec, fp32_fallback=False)
+        m.load_state_dict(tsd, strict=True)
+        m = m.cuda().eval()
+        for k, v in opts.items():
+            m.set_option(k, v)
+        return m
     with pytest.warns(UitkParityWarning, match="no better"):
-        m = make("auto", calib_budget_e6=1)
+        m = make_nofp32("auto", calib_budget_e6=1)
         err_of(m)
     rep = m.calibration_report()
     assert m.effective_precision() == "f16c" and rep["accepted"] and not rep["escalated"] and rep["within_budget"] is False
     assert rep["self_check_split"][0] >= rep["max_calibrated"]
+    with pytest.warns(UitkParityWarning, match="'f32'"):
+        m = make("auto", calib_budget_e6=1)
+        e_f32, _ = err_of(m)
+    rep = m.calibration_report()
+    print(f"a budget of 1e-6: auto -> {m.effective_precision()}: {e_f32:.2e} against the C oracle on the held-out inputs; report {rep}")
+    assert m.effective_precision() == "f32" and rep["escalated"] and rep["self_check"][0] < 5e-5 and e_f32 < 4e-4
     sdg = make_trained_like_state_dict("audio_transformer_h128_d4_m3", 206, attention="full")
     with pytest.warns(UitkParityWarning, match="f16x2"):
         m = make("auto", models.audio_transformer_h128_d4_m3, {k: torch.from_numpy(np.asarray(v)) for k, v in sdg.items()}, calib_accept_pct=1)
         with torch.no_grad():
             p, l = m(xd[:8], return_logits=True)
-    assert m.effective_precision() == "f16x2"
-    rg = Oracle(sdg, act="gelu").forward(x[:8])
+    assert m.effective_precision() in ("f16x2", "f32") and "f16x2" in m.calibration_report()["ladder"]      # (the sabotage also refuses the split build's centring: if
+    rg = Oracle(sdg, act="gelu").forward(x[:8])                                                               #  that leaves it over the budget, the ladder goes on to 'f32')
     assert np.abs(l.cpu().numpy().reshape(rg["logits"].shape) - rg["logits"]).max() < TOL
     # (d)
     with warnings.catch_warnings():
@@ -1890,3 +1904,101 @@ def test_token_ladder_reaches_f16ax_on_heavy_tailed_checkpoints(golden):
     d = np.abs(lg.reshape(ref.shape) - ref).reshape(len(x), -1).max(1)
     print(f"structured seed 234, uit_xxs, pooling token, f16ax without calibration: worst max|dlogit| {d.max():.2e} ({names[int(d.argmax())]})")
     assert np.isfinite(lg).all() and d.max() < 3e-4
+
+
+@pytest.mark.parametrize("pooling", ["mean", "token"])
+def test_degenerate_whole_batches(pooling):
+    """Batches in which EVERY clip is degenerate -- nothing in them sets a top_db floor above the amin clamp, or everything clips: all
+    digital silence (float32 and int16; every mel bin at 10 log10(1e-10) = -100 dB, the batch amax included), one lone silent clip
+    (B = 1), full-scale DC (+1.0: only bin 0 and the window's leakage carry power), full-scale Nyquist alternation, int16 rails
+    (-32768 everywhere).  Against the C oracle at trained-like magnitudes; finite everywhere."""
+    m, sd = build_trained("uit_xxs", 209, pooling=pooling)
+    o = Oracle(sd, pooling=pooling)
+    T_ = 16000
+    alt = np.where(np.arange(T_) % 2 == 0, 1.0, -1.0).astype(np.float32)
+    cases = {"silence f32 x4": np.zeros((4, T_), np.float32), "silence i16 x3": np.zeros((3, T_), np.int16), "silence B=1": np.zeros((1, T_), np.float32),
+             "DC +1.0 x2": np.ones((2, T_), np.float32), "Nyquist +-1.0 x2": np.stack([alt, -alt]), "int16 rail x2": np.full((2, T_), -32768, np.int16)}
+    for what, x in cases.items():
+        p, l = run(m, x)
+        r = o.forward(x)
+        dl, dp = np.abs(l.reshape(r["logits"].shape) - r["logits"]).max(), np.abs(p - r["probs"]).max()
+        print(f"pooling {pooling}, {what}: |logit|max {np.abs(r['logits']).max():.1f} max|dlogit| {dl:.2e} max|dprob| {dp:.2e}")
+        assert np.isfinite(l).all() and np.isfinite(p).all() and dl < 1e-3 and dp < 2.5e-4, what
+
+
+@pytest.mark.parametrize("factory,att,act,pooling", [("uit_xxs", "bneck", "relu", "mean"), ("uit_xxs", "bneck", "relu", "token"), ("uit_xxxs", "bneck", "relu", "dm"),
+                                                      ("audio_transformer_h128_d4_m3", "full", "gelu", "mean"), ("audio_transformer_h128_d4_m3", "full", "gelu", "token")])
+def test_f32_rung_matches_the_oracle(golden, factory, att, act, pooling):
+    """Precision 'f32' (round 5): the plain fp32 forward of the library (csrc/calibrate.hip + a head kernel) behind the product front-end --
+    the last rung of the parity ladder.  Against the C oracle at trained-like magnitudes through every shape of the path: 1 s clips (wide
+    held-out set), 0.5 s clips (masked time patches), 4-crop clips (crop reduction), int16 input; far inside the tolerance (the rung reads
+    the front-end's fp32 dB frames, not its 16-bit operands: what is left are the two fp32 FFTs -- the bin-edge tone pairs)."""
+    x, names = held_out_inputs(golden, with_names=True)
+    sd = make_trained_like_state_dict(factory, 210, attention=att)
+    m = getattr(models, factory)(outputdim=537, target_length=102, pooling=pooling, precision="f32")
+    m.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()}, strict=True)
+    m = m.cuda().eval()
+    o = Oracle(sd, act=act, pooling=pooling)
+    for what, xi in (("1 s", x), ("0.5 s", np.ascontiguousarray(x[:24, 4000:12000])), ("4 s (4 crops)", np.ascontiguousarray(np.tile(x[:6], (1, 4))))):
+        r = o.forward(xi)
+        with torch.no_grad():
+            if pooling == "dm":
+                p = m(torch.from_numpy(xi).cuda()).cpu().numpy()
+                dl = 0.0
+            else:
+                p, l = m(torch.from_numpy(xi).cuda(), return_logits=True)
+                p, dl = p.cpu().numpy(), float(np.abs(l.cpu().numpy().reshape(r["logits"].shape) - r["logits"]).max())
+        dp = float(np.abs(p - r["probs"]).max())
+        print(f"f32 {factory} pooling {pooling}, {what}: max|dlogit| {dl:.2e} max|dprob| {dp:.2e}")
+        assert dl < 3e-4 and dp < 1e-4, what
+    assert m.effective_precision() == "f32" and m.calibration_report() is None
+    sc = m.self_check()
+    assert sc is not None and sc[0] < 5e-5, sc
+
+
+def test_auto_ends_in_f32_on_an_attention_sink_checkpoint(golden):
+    """A third checkpoint family (synth.make_sink_trained_like_state_dict): an attention sink in every block and head -- six outlier keys
+    every query looks for, scores of tens of units.  A sink key's fp16 rounding error q . dk is proportional to the score it produces and
+    centring does not shrink an outlier (tools/err_attrib_sink.py: the activation floor of uit_xs goes 2.4e-4 -> 1.0e-3 at gain 4): no fp16
+    mode of the library is inside the budget (tools/auto_sweep.py ... sink4: every checkpoint flagged).  The ladder goes on: 'auto' ends in
+    'f32' -- slow, warned about, and right: against an fp64 evaluation of the SAME mel spectrogram the rung is at 1e-5, closer than the
+    fp32 oracle is to fp64; what is left against the oracle is the two fp32 FFTs' round-off floors, amplified by this checkpoint
+    (tools/fe_split.py).  With fp32_fallback=False 'auto' stays on the best fp16 build and says so."""
+    import sys
+    from uit_mobile_amd.models.uit import UitkParityWarning
+    from uit_mobile_amd.synth import DEPTH, make_sink_trained_like_state_dict
+    sys.path[:0] = [str(ROOT / "tools")]
+    import err_attrib_centring as E
+    x = held_out_inputs(golden)[:32]
+    xd = torch.from_numpy(x).cuda()
+    sd = make_sink_trained_like_state_dict("uit_xxs", 216, gain=4.0)
+    tsd = {k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()}
+    ref = Oracle(sd).forward(x)["logits"]
+
+    def run_(**kw):
+        m = models.uit_xxs(outputdim=537, target_length=102, **kw)
+        m.load_state_dict(tsd, strict=True)
+        m = m.cuda().eval()
+        with torch.no_grad():
+            l = m(xd, return_logits=True)[1].cpu().numpy().reshape(ref.shape)
+        return m, l, float(np.abs(l - ref).max())
+
+    with pytest.warns(UitkParityWarning, match="'f32'"):
+        m, l, e = run_()
+    rep = m.calibration_report()
+    # the fp64 evaluation of the mel spectrogram the rung itself read
+    with torch.no_grad():
+        mel = m.melspec_db(xd).cpu().numpy().astype(np.float64)
+    sc = np.asarray(sd["init_bn.1.weight"], np.float64) / np.sqrt(np.asarray(sd["init_bn.1.running_var"], np.float64) + 1e-5)
+    mel_bn = torch.from_numpy((mel - np.asarray(sd["init_bn.1.running_mean"], np.float64)[None, :, None]) * sc[None, :, None]
+                              + np.asarray(sd["init_bn.1.bias"], np.float64)[None, :, None])
+    truth = E.forward(sd, mel_bn, DEPTH["uit_xxs"], "relu", "bneck", "mean", ()).numpy()
+    e64 = float(np.abs(l.reshape(truth.shape) - truth).max())
+    print(f"sink checkpoint (uit_xxs seed 216, gain 4): auto -> {m.effective_precision()}, ladder {rep['ladder']}: {e64:.2e} against fp64 on its own mel, "
+          f"{e:.2e} against the C oracle (front-end difference); library: f16c {rep['max_calibrated']:.2e}, self check of the rung {rep['self_check'][0]:.1e}")
+    assert m.effective_precision() == "f32" and rep["escalated"] and rep["within_budget"] and rep["max_calibrated"] > 1e-3
+    assert e64 < 2e-5 and e < 1.5e-3
+    with pytest.warns(UitkParityWarning, match="fp32_fallback=False"):
+        m2, l2, e2 = run_(fp32_fallback=False)
+    print(f"   fp32_fallback=False: stays on {m2.effective_precision()}: {e2:.2e} against the C oracle")
+    assert m2.effective_precision() != "f32" and m2.calibration_report()["within_budget"] is False and e2 > e

@@ -130,6 +130,9 @@ def test_unsupported_variants_raise():
         models.uit_xs(pooling="dm", precision="bf16")
     with pytest.raises(NotImplementedError):
         models.uit_xs(act_layer=torch.nn.SiLU)
+    for pooling in ("mean", "dm", "token"):                     # the fp32 rung: any family, any pooling; its image is the f16 one (front-end tables)
+        mf = models.uit_xxxs(outputdim=537, target_length=102, pooling=pooling, precision="f32")
+        assert len(mf.packed_image()) == len(models.uit_xxxs(outputdim=537, target_length=102, pooling=pooling, precision="f16").packed_image())
     for prec in ("f16a", "f16ax"):                              # the split-activation precisions are pooling 'token''s ladder only
         with pytest.raises(NotImplementedError):
             models.uit_xs(precision=prec)

@@ -1,7 +1,8 @@
 """GPU box: the default mode ('auto') over trained-like checkpoints OUTSIDE the test-suite's sweep (seeds 212 ...), every family, on the
 wide held-out set of tests/test_gpu_parity.py: worst logit deviation from the C oracle per family, the worst input, what the budget
-check decided per checkpoint.     python tools/auto_sweep.py [nseeds=24] [all|token|mean|dm|more] [gaussian|structured]
--> profiles/round5/auto_sweep_*.log      ("structured": synth.make_structured_trained_like_state_dict -- heavy-tailed, low-rank, uneven rows)"""
+check decided per checkpoint.     python tools/auto_sweep.py [nseeds=24] [all|token|mean|dm|more] [gaussian|structured|sink|sink4]
+-> profiles/round5/auto_sweep_*.log      ("structured": synth.make_structured_trained_like_state_dict -- heavy-tailed, low-rank, uneven rows; "sink" / "sink4": an attention sink in
+every block and head, synth.make_sink_trained_like_state_dict at gain 2 / 4)"""
 import sys
 import warnings
 from pathlib import Path
@@ -13,7 +14,7 @@ ROOT = Path(__file__).resolve().parents[1]
 sys.path[:0] = [str(ROOT), str(ROOT / "tests"), str(ROOT / "tests" / "golden")]
 from oracle.oracle import Oracle  # noqa: E402
 from uit_mobile_amd import models  # noqa: E402
-from uit_mobile_amd.synth import make_structured_trained_like_state_dict, make_trained_like_state_dict  # noqa: E402
+from uit_mobile_amd.synth import make_sink_trained_like_state_dict, make_structured_trained_like_state_dict, make_trained_like_state_dict  # noqa: E402
 import test_gpu_parity as T  # noqa: E402
 
 warnings.simplefilter("ignore")
@@ -27,7 +28,8 @@ families = [(n, "bneck", "relu", "mean") for n in ("uit_xs", "uit_xxs", "uit_xxx
             ("uit_xxs", "bneck", "relu", "dm")]
 only = sys.argv[2] if len(sys.argv) > 2 and sys.argv[2] != "all" else None           # e.g. "token": that pooling's rows only; "more": the second list
 style = sys.argv[3] if len(sys.argv) > 3 else "gaussian"
-make_sd = {"gaussian": make_trained_like_state_dict, "structured": make_structured_trained_like_state_dict}[style]
+make_sd = {"gaussian": make_trained_like_state_dict, "structured": make_structured_trained_like_state_dict, "sink": make_sink_trained_like_state_dict,
+           "sink4": lambda *a, **k: make_sink_trained_like_state_dict(*a, gain=4.0, **k)}[style]
 print(f"checkpoint family: {style}", flush=True)
 if only == "more":                                          # the remaining factories / poolings, and the other clip shapes (0.5 s, 4 s)
     families = [("audio_transformer_h128_d6_m3", "full", "gelu", "mean"), ("audio_transformer_h128_d4_m3_relu", "full", "relu", "mean"),

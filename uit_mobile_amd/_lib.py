@@ -12,7 +12,7 @@ LIB_PATH = Path(os.environ["UITK_LIB_PATH"]) if os.environ.get("UITK_LIB_PATH") 
 UITK_OK = 0
 ERR_INVALID_ARG, ERR_UNSUPPORTED, ERR_NO_DEVICE, ERR_HIP, ERR_TOO_SHORT, ERR_WORKSPACE = -1, -2, -3, -4, -5, -6
 IN_F32, IN_I16 = 0, 1
-PREC_F16, PREC_BF16, PREC_FP8, PREC_F16X2, PREC_F16L6, PREC_FP8W, PREC_F16A, PREC_F16AX = 0, 1, 2, 3, 4, 5, 6, 7
+PREC_F16, PREC_BF16, PREC_FP8, PREC_F16X2, PREC_F16L6, PREC_FP8W, PREC_F16A, PREC_F16AX, PREC_F32 = 0, 1, 2, 3, 4, 5, 6, 7, 8
 AVG_MEAN, AVG_MAX = 0, 1
 AMAX_SLOTS = 64
 

@@ -17,6 +17,7 @@
 #include "../../include/uitk.h"
 #include "pack.h"
 #include "uitk_dev.h"
+#include "naive_forward.h"
 
 using namespace uitk;
 
@@ -27,6 +28,9 @@ static bool single_weight_precision(int p) { return p == UITK_PREC_F16 || p == U
 // operand centring of the attention (pack.cpp) -- what an escalated 'auto' handle keeps of its calibration
 static bool calibratable_precision(int p) { return single_weight_precision(p) || p == UITK_PREC_F16X2 || p == UITK_PREC_F16L6 || p == UITK_PREC_F16AX; }
 // what launch_encoder is told: fp8w runs the f16 kernels; f16a = 5, the f16 kernel with split activation operands in the cls tile
+// precision 'f32' (round 5, the last rung of the parity ladder) runs the plain fp32 forward of calibrate.hip: the packer still builds an
+// image for it -- the front-end's tables, init_bn -- in the layout of UITK_PREC_F16
+static uitk_config pack_config(const uitk_config* cfg) { uitk_config c = *cfg; if (c.precision == UITK_PREC_F32) c.precision = UITK_PREC_F16; return c; }
 static int kernel_precision(int p) { return p == UITK_PREC_FP8W ? UITK_PREC_F16 : p == UITK_PREC_F16A ? 5 : p == UITK_PREC_F16AX ? 6 : p; }
 static int fail(int code, const std::string& msg) { g_err = msg; return code; }
 #define HIP_TRY(expr)                                                                                   \
@@ -35,8 +39,10 @@ static int fail(int code, const std::string& msg) { g_err = msg; return code; }
         if (_e != hipSuccess) return fail(UITK_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(_e)); \
     } while (0)
 
+struct F32Path;
 struct uitk_model {
     uitk_config cfg;
+    F32Path* f32 = nullptr;       // precision 'f32': the fp32 network on the device + its work buffers (below)
     ImageHeader hdr;
     char* image = nullptr;        // device copy of the packed parameter image
     float* mel = nullptr;         // patch-major 16-bit operands [B*ncrops][24][16][16]
@@ -77,6 +83,12 @@ struct uitk_model {
     int64_t fe_B = 0, fe_T = 0;   // shape of the latest uitk_frontend call (uitk_encode must match it)
 };
 
+// precision 'f32' (defined behind the naive network's helpers, below)
+static int f32_create(uitk_model* m, const uitk_weights* w);
+static void f32_destroy(uitk_model* m);
+static int f32_reserve(uitk_model* m, int64_t rows);
+static int f32_encode(uitk_model* m, int rows, int nt, int nF, int ncrops, float* rowprobs, float* rowlogits, hipStream_t s);
+
 extern "C" {
 
 const char* uitk_last_error(void) { return g_err.c_str(); }
@@ -85,10 +97,11 @@ const char* uitk_version(void) { return "uitk 0.1 (gfx950)"; }
 int uitk_pack_weights(const uitk_config* cfg, const uitk_weights* w, void* out, size_t cap, size_t* needed) {
     if (!cfg || !w || !needed) return fail(UITK_ERR_INVALID_ARG, "null argument");
     const char* why = "";
-    if (int rc = validate_config(cfg, &why)) return fail(rc, why);
+    const uitk_config pc = pack_config(cfg);
+    if (int rc = validate_config(&pc, &why)) return fail(rc, why);
     std::vector<char> img;
     ImageHeader h;
-    if (int rc = pack_image(cfg, w, nullptr, &img, &h)) return fail(rc, "pack failed");
+    if (int rc = pack_image(&pc, w, nullptr, &img, &h)) return fail(rc, "pack failed");
     *needed = img.size();
     if (out) {
         if (cap < img.size()) return fail(UITK_ERR_INVALID_ARG, "output buffer too small");
@@ -123,14 +136,15 @@ int uitk_pack_weights_calibrated(const uitk_config* cfg, const uitk_weights* w, 
 int uitk_create(const uitk_config* cfg, const uitk_weights* w, uitk_model** out) {
     if (!cfg || !w || !out) return fail(UITK_ERR_INVALID_ARG, "null argument");
     const char* why = "";
-    if (int rc = validate_config(cfg, &why)) return fail(rc, why);
+    const uitk_config pc = pack_config(cfg);
+    if (int rc = validate_config(&pc, &why)) return fail(rc, why);
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
         return fail(UITK_ERR_NO_DEVICE, "no HIP device: libuitk has no CPU path");
     uitk_model* m = new uitk_model();
     m->cfg = *cfg;
     std::vector<char> img;
-    if (int rc = pack_image(cfg, w, nullptr, &img, &m->hdr)) { delete m; return fail(rc, "pack failed"); }
+    if (int rc = pack_image(&pc, w, nullptr, &img, &m->hdr)) { delete m; return fail(rc, "pack failed"); }
     m->img_nearest = img;
     hipDeviceProp_t prop;
     if (hipGetDevice(&m->device) != hipSuccess || hipGetDeviceProperties(&prop, m->device) != hipSuccess) {
@@ -166,6 +180,9 @@ int uitk_create(const uitk_config* cfg, const uitk_weights* w, uitk_model** out)
         hipMemcpy(m->amax, armed, sizeof armed, hipMemcpyHostToDevice) != hipSuccess) {
         uitk_destroy(m); return fail(UITK_ERR_HIP, "parameter upload failed");
     }
+    if (cfg->precision == UITK_PREC_F32) {
+        if (int rc = f32_create(m, w)) { uitk_destroy(m); return rc; }
+    }
     *out = m;
     return UITK_OK;
 }
@@ -177,6 +194,7 @@ int uitk_destroy(uitk_model* m) {
     if (m->mel_frames) (void)hipFree(m->mel_frames);
     if (m->amax) (void)hipFree(m->amax);
     if (m->rowprobs) (void)hipFree(m->rowprobs);
+    f32_destroy(m);
     delete m;
     return UITK_OK;
 }
@@ -224,6 +242,17 @@ int uitk_reserve(uitk_model* m, int64_t B, int64_t T) {
         m->rowprobs = nullptr; m->rowprobs_cap = 0;
         HIP_TRY(hipMalloc((void**)&m->rowprobs, rp_bytes));
         m->rowprobs_cap = rp_bytes;
+    }
+    if (m->cfg.precision == UITK_PREC_F32) {                     // its front-end writes fp32 dB frames (the layout of uitk_mel_db), not 16-bit operands
+        const size_t need = (size_t)B * uitk_num_frames(m, T) * NMEL * 4;
+        if (need > m->mel_frames_cap) {
+            HIP_TRY(hipDeviceSynchronize());
+            if (m->mel_frames) (void)hipFree(m->mel_frames);
+            m->mel_frames = nullptr; m->mel_frames_cap = 0;
+            HIP_TRY(hipMalloc((void**)&m->mel_frames, need));
+            m->mel_frames_cap = need;
+        }
+        return f32_reserve(m, B * nc);
     }
     return UITK_OK;
 }
@@ -434,6 +463,11 @@ int uitk_frontend(uitk_model* m, const void* pcm, int in_dtype, int64_t B, int64
     if (in_dtype != UITK_IN_F32 && in_dtype != UITK_IN_I16) return fail(UITK_ERR_INVALID_ARG, "unknown in_dtype");
     if (int rc = uitk_reserve(m, B, T)) return rc;
     m->fe_B = 0; m->fe_T = 0;
+    if (m->cfg.precision == UITK_PREC_F32) {                     // fp32 dB frames for the fp32 forward (no pass-split tuning: not a timed path)
+        if (int rc = run_frontend(m, pcm, in_dtype, B, T, m->mel_frames, 0, (hipStream_t)stream)) return rc;
+        m->fe_B = B; m->fe_T = T;
+        return UITK_OK;
+    }
     pick_frontend_split(m, pcm, in_dtype, B, T, (hipStream_t)stream, m->cfg.fe_autotune != 0);
     if (int rc = run_frontend(m, pcm, in_dtype, B, T, m->mel, 1, (hipStream_t)stream)) return rc;
     m->fe_B = B; m->fe_T = T;
@@ -471,6 +505,12 @@ int uitk_encode(uitk_model* m, int64_t B, int64_t T, float* probs, float* logits
     a.split_pe = m->split_pe_env >= 0 ? m->split_pe_env : (m->cfg.precision == UITK_PREC_F16X2 || m->cfg.precision == UITK_PREC_F16AX);     // f16x2 / f16ax: the patch embed runs on its split weights too
     // (f16l6 keeps the structurally rounded single weights: same-box, worst sweep seeds 6.0e-4 / 5.1e-4 without vs 6.6e-4 / 4.8e-4 with, +1.2 % time)
     a.attention_full = m->cfg.attention_full; a.act_gelu = m->cfg.act_gelu; a.pooling = m->cfg.pooling;
+    if (m->cfg.precision == UITK_PREC_F32) {                     // the last rung of the parity ladder: the plain fp32 forward (calibrate.hip)
+        if (a.dbg || a.timing) return fail(UITK_ERR_UNSUPPORTED, "precision f32 has no token dump / stamps");
+        if (int rc = f32_encode(m, a.rows, a.nt, nF, nc, a.probs, a.logits, s)) return rc;
+        if (nc > 1) HIP_TRY(launch_crop_reduce(m->rowprobs, probs, B, nc, a.C, m->cfg.eval_avg, s));
+        return UITK_OK;
+    }
     // Workgroup shape.  Large batches: 8 waves (two per SIMD, every weight fragment read once per 16 clips).  A batch that fits ONE
     // 4-wave workgroup per CU (rows <= 8 per CU) runs on those instead: a lone wave per SIMD finishes its two clips 1.3-1.4x sooner
     // than a pair sharing the SIMD finishes four (XS: 0.14-0.15 ms against 0.20 ms up to 2048 clips; profiles/round4/occ_test.log),
@@ -725,6 +765,72 @@ int naive_net_bind(const uitk_model* m, NaiveNet* nn, int rows, size_t n_stats) 
     return UITK_OK;
 }
 
+}  // namespace
+
+// ---- precision 'f32' (UITK_PREC_F32; round 5): the LAST rung of the parity ladder.  The folded network in fp32 on the device
+// (naive_net_upload: the weights the calibration forward multiplies with), the head's parameters, and work buffers for F32_CHUNK
+// clip-crops at a time; uitk_encode walks the batch in chunks through launch_naive_forward (calibrate.hip).  Front-end, crop
+// reduction, options and the C ABI are the product's.  ~2 orders of magnitude slower than the MFMA encoder: for checkpoints no fp16
+// mode holds inside the budget (tools/auto_sweep.py ... sink4), where slow and right beats fast and warned about.
+constexpr int64_t F32_CHUNK = 2048;
+struct F32Path {
+    NaiveNet nn;
+    DevBuf head;                                                 // norm w/b, outputlayer LayerNorm w/b, Linear w/b (fp32)
+    NaiveHeadArgs hargs{};
+    int64_t work_rows = 0;
+};
+
+static int f32_create(uitk_model* m, const uitk_weights* w) {
+    F32Path* fp = new F32Path();
+    m->f32 = fp;
+    if (int rc = naive_net_upload(m, w, &fp->nn, nullptr)) return rc;
+    const int C = m->cfg.outputdim;
+    std::vector<float> host((size_t)4 * DIM + (size_t)C * DIM + C);
+    float* p = host.data();
+    std::memcpy(p, w->norm_w, DIM * 4); p += DIM; std::memcpy(p, w->norm_b, DIM * 4); p += DIM;
+    std::memcpy(p, w->head_ln_w, DIM * 4); p += DIM; std::memcpy(p, w->head_ln_b, DIM * 4); p += DIM;
+    std::memcpy(p, w->head_w, (size_t)C * DIM * 4); p += (size_t)C * DIM; std::memcpy(p, w->head_b, (size_t)C * 4);
+    HIP_TRY(hipMalloc(&fp->head.p, host.size() * 4));
+    HIP_TRY(hipMemcpy(fp->head.p, host.data(), host.size() * 4, hipMemcpyHostToDevice));
+    const float* d = (const float*)fp->head.p;
+    NaiveHeadArgs& h = fp->hargs;
+    h.norm_w = d; h.norm_b = d + DIM; h.hln_w = d + 2 * DIM; h.hln_b = d + 3 * DIM; h.head_w = d + 4 * DIM; h.head_b = h.head_w + (size_t)C * DIM;
+    h.C = C; h.pooling = m->cfg.pooling;
+    return UITK_OK;
+}
+
+static void f32_destroy(uitk_model* m) { delete m->f32; m->f32 = nullptr; }
+
+static int f32_reserve(uitk_model* m, int64_t rows) {
+    F32Path* fp = m->f32;
+    const int64_t want = std::min<int64_t>(rows, F32_CHUNK);
+    if (want <= fp->work_rows) return UITK_OK;
+    HIP_TRY(hipDeviceSynchronize());                             // (growing frees a buffer the device may still be reading)
+    if (int rc = naive_net_bind(m, &fp->nn, (int)want, 0)) return rc;
+    fp->work_rows = want;
+    return UITK_OK;
+}
+
+static int f32_encode(uitk_model* m, int rows, int nt, int nF, int ncrops, float* rowprobs, float* rowlogits, hipStream_t s) {
+    F32Path* fp = m->f32;
+    if (!fp || fp->work_rows < std::min<int64_t>(rows, F32_CHUNK)) return fail(UITK_ERR_WORKSPACE, "precision f32: no workspace (uitk_frontend / uitk_reserve first)");
+    for (int64_t r0 = 0; r0 < rows; r0 += F32_CHUNK) {
+        const int n = (int)std::min<int64_t>(F32_CHUNK, rows - r0);
+        CalibArgs a = fp->nn.a;                                  // (the buffers are laid out for work_rows: a shorter chunk uses their heads)
+        a.rows = n;
+        a.amax = m->amax + m->amax_cur * AMAX_SLOTS;
+        a.stats = nullptr;
+        NaiveFramesArgs fa{};
+        fa.frames = m->mel_frames; fa.nF = nF; fa.ncrops = ncrops; fa.tl = m->cfg.target_length; fa.row0 = r0;
+        NaiveHeadArgs h = fp->hargs;
+        h.rowprobs = rowprobs + (size_t)r0 * h.C;
+        h.rowlogits = rowlogits ? rowlogits + (size_t)r0 * h.C : nullptr;
+        HIP_TRY(launch_naive_forward(a, nt, &h, s, &fa));
+    }
+    return UITK_OK;
+}
+
+namespace {
 // What the reference computes from the last block's residual stream (models/uit.py:395, 398-412), in double on the host:
 // final LayerNorm (eps 1e-6) -> pooling -> outputlayer = LayerNorm (eps 1e-5) + Linear.  R: [rows][ntok][128] (the folded stream is
 // centred per token, which LayerNorm does not see).  out: [rows][C] pre-sigmoid logits; pooling 'dm': probabilities (it has no logits).
@@ -798,7 +904,13 @@ int heldout_prepare(uitk_model* m, const uitk_weights* w, NaiveNet* nn, hipStrea
     HIP_TRY(hipMalloc(&ho->outb.p, (size_t)2 * ho->Be * C * 4));
     if (int rc = uitk_frontend(m, ho->pcm.p, UITK_IN_I16, ho->Be, ho->Te, (void*)s)) return rc;
     if (int rc = naive_net_bind(m, nn, ho->Be, 0)) return rc;
-    HIP_TRY(launch_calibration(nn->a, s));
+    if (m->cfg.precision == UITK_PREC_F32) {                     // (its front-end left fp32 frames, not patch operands)
+        NaiveFramesArgs fa{};
+        fa.frames = m->mel_frames; fa.nF = uitk_num_frames(m, ho->Te); fa.ncrops = 1; fa.tl = m->cfg.target_length; fa.row0 = 0;
+        HIP_TRY(launch_naive_forward(nn->a, GT, nullptr, s, &fa));
+    } else {
+        HIP_TRY(launch_calibration(nn->a, s));
+    }
     const int ntok = nn->a.ntok;
     std::vector<float> R((size_t)ho->Be * ntok * DIM);
     HIP_TRY(hipMemcpyAsync(R.data(), nn->a.R, R.size() * 4, hipMemcpyDeviceToHost, s));
@@ -832,10 +944,15 @@ double parity_budget(const uitk_model* m) { return m->calib_budget_e6 * 1e-6 * (
 // over budget: pooling 'token' reads ONE row, what is left there is activation rounding -> split activation operands (f16a), and from
 // there split weights as well (f16ax: the top of that ladder); the other poolings: split weights (f16l6 for BNeckAttention + ReLU,
 // f16x2 otherwise)
+// from a split-weight handle (f16l6 / f16x2 / f16ax) the next and last rung is the plain fp32 forward (f32): slow, and right
 int parity_fallback_precision(const uitk_model* m) {
-    if (m->cfg.pooling == 2) return m->cfg.precision == UITK_PREC_F16A ? UITK_PREC_F16AX : UITK_PREC_F16A;
+    const int p = m->cfg.precision;
+    if (p == UITK_PREC_F16L6 || p == UITK_PREC_F16X2 || p == UITK_PREC_F16AX) return UITK_PREC_F32;
+    if (m->cfg.pooling == 2) return p == UITK_PREC_F16A ? UITK_PREC_F16AX : UITK_PREC_F16A;
     return (m->cfg.attention_full || m->cfg.act_gelu) ? UITK_PREC_F16X2 : UITK_PREC_F16L6;
 }
+// the precisions of the parity ladder (held to the budget); bf16 / fp8 / fp8w are measured modes
+bool parity_precision(int p) { return p == UITK_PREC_F16 || p == UITK_PREC_F16A || p == UITK_PREC_F16L6 || p == UITK_PREC_F16X2 || p == UITK_PREC_F16AX; }
 }  // namespace
 
 // The acceptance check of uitk_calibrate_weights: both candidate images -- rounded to nearest (uitk_create's) and calibrated -- run the
@@ -948,7 +1065,7 @@ int uitk_calibrate_weights(uitk_model* m, const uitk_weights* w, const void* pcm
             (void)hipDeviceSynchronize();
             (void)hipMemcpy(m->image, m->img_nearest.data(), m->img_nearest.size(), hipMemcpyHostToDevice);
             m->weights_calibrated = 0;
-            if (m->cfg.precision == UITK_PREC_F16 || m->cfg.precision == UITK_PREC_F16A) m->parity_escalate_to = parity_fallback_precision(m);
+            if (parity_precision(m->cfg.precision)) m->parity_escalate_to = parity_fallback_precision(m);
             return rc;
         }
         if (m->calib_report[4] >= 0.f) {                         // the check applied and left its choice on the device
@@ -957,7 +1074,7 @@ int uitk_calibrate_weights(uitk_model* m, const uitk_weights* w, const void* pcm
             // A refused calibration leaves the nearest-rounded image (measured at up to 1.2e-3 on trained-like checkpoints; harmless at init
             // scale): whichever image stays, over budget it is reported as "rebuild with the family's split-weight precision".
             const double dev = m->weights_calibrated ? m->calib_report[1] : m->calib_report[0];
-            if ((m->cfg.precision == UITK_PREC_F16 || m->cfg.precision == UITK_PREC_F16A) && m->calib_budget_e6 > 0 && !(dev <= parity_budget(m)))       // (bf16 / fp8 / fp8w are
+            if (parity_precision(m->cfg.precision) && m->calib_budget_e6 > 0 && !(dev <= parity_budget(m)))       // (bf16 / fp8 / fp8w are
                 m->parity_escalate_to = parity_fallback_precision(m);                                                  // measured modes, not parity modes)
             return UITK_OK;
         }

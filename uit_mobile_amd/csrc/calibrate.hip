@@ -1,4 +1,7 @@
-// calibrate.hip -- PACK-TIME ONLY: operand statistics for the calibrated rounding of pack.cpp (round_gptq).
+// calibrate.hip -- the plain fp32 forward of the folded network.  PACK TIME: operand statistics for the calibrated rounding of pack.cpp
+// (round_gptq) and the reference of the held-out check.  Round 5, late: the same kernels + a head kernel are also
+// precision 'f32' (UITK_PREC_F32, launch_naive_forward below): the LAST rung of the parity ladder -- fp32 arithmetic on the vector
+// ALUs, one simple kernel per operation, two orders of magnitude slower than the MFMA encoder and right for every checkpoint.
 //
 // uitk_calibrate (api.cpp) runs a calibration batch through the product front-end kernel and then through the plain fp32 forward
 // below -- the folded network of pack.h (`Folded`: exactly the numbers pack.cpp rounds), one simple kernel per operation -- and
@@ -15,6 +18,7 @@
 #include <stdint.h>
 
 #include "uitk_dev.h"
+#include "naive_forward.h"
 
 namespace uitk {
 
@@ -50,6 +54,32 @@ __global__ void cal_patch_kernel(const unsigned short* __restrict__ mel, const f
             const float sc = bn_sc[melbin], th = round_op16(floor_db * sc + bn_sh[melbin], bf16);
             const float y = op16_to_f32(mel[((int64_t)row * NTOK + ptok) * 256 + k], bf16);
             v = sc >= 0.f ? fmaxf(y, th) : fminf(y, th);
+        }
+        X0[i] = v;
+    }
+}
+
+// The same operand from the front-end's fp32 dB frames (precision 'f32'): crop logic of models/uit.py:468-481 (crops start every
+// target_length frames; the last one is the last target_length frames), top_db clamp, init_bn -- nothing rounded to 16 bits.
+__global__ void naive_patch_from_frames_kernel(NaiveFramesArgs fa, const float* __restrict__ amax, float top_db, const float* __restrict__ bn_sc,
+                                               const float* __restrict__ bn_sh, int rows, int ntok, int nt, float* __restrict__ X0) {
+    float amx = amax[0];
+    for (int i = 1; i < AMAX_SLOTS; ++i) amx = fmaxf(amx, amax[i]);
+    const float floor_db = amx - top_db;
+    const int64_t n = (int64_t)rows * ntok * 256;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const int k = (int)(i & 255);
+        const int64_t rt = i >> 8;
+        const int tok = (int)(rt % ntok);
+        const int64_t rowg = fa.row0 + rt / ntok;
+        const int ptok = ntok == NTOK ? tok : tok - 1;
+        float v = 0.f;
+        if (ptok >= 0 && ptok % GT < nt) {
+            const int64_t b = rowg / fa.ncrops;
+            const int crop = (int)(rowg % fa.ncrops);
+            const int melbin = 16 * (ptok / GT) + (k >> 4), t = 16 * (ptok % GT) + (k & 15);
+            const int f = fa.ncrops == 1 ? t : (crop < fa.ncrops - 1 ? crop * fa.tl + t : fa.nF - fa.tl + t);
+            if (f >= 0 && f < fa.nF) v = fmaxf(fa.frames[(b * fa.nF + f) * NMEL + melbin], floor_db) * bn_sc[melbin] + bn_sh[melbin];
         }
         X0[i] = v;
     }
@@ -108,25 +138,32 @@ __global__ void cal_layernorm_kernel(const float* __restrict__ R, float* __restr
 
 // softmax attention of one (clip-crop, head): QKV[m][which * inner + h * hd + d] (models/uit.py:110-111 / 147-148), the q rows
 // already carry 0.125 log2(e) (pack-time fold), so probabilities are exp2(s - max).  O[m][h * hd + d] (:119 / :175).
-__global__ void cal_attention_kernel(const float* __restrict__ QKV, float* __restrict__ O, int ntok, int inner) {
+// nt: valid time patches of the crop (short clips: tokens of time patch >= nt do not exist -- never a key; their own rows are garbage nobody reads)
+__device__ __forceinline__ bool naive_token_valid(int tok, int ntok, int nt) {
+    if (ntok != NTOK) { if (tok == 0) return true; tok -= 1; }          // the cls token of pooling 'token'
+    return tok % GT < nt;
+}
+__global__ void cal_attention_kernel(const float* __restrict__ QKV, float* __restrict__ O, int ntok, int inner, int nt) {
     const int row = blockIdx.x, h = blockIdx.y, t = threadIdx.x, hd = inner / 2;
     if (t >= ntok) return;
     const float* base = QKV + (int64_t)row * ntok * 3 * inner;
     const float* q = base + (int64_t)t * 3 * inner + h * hd;
     float s[NTOK + 1], mx = -INFINITY;
     for (int j = 0; j < ntok; ++j) {
+        s[j] = -INFINITY;
+        if (!naive_token_valid(j, ntok, nt)) continue;
         const float* k = base + (int64_t)j * 3 * inner + inner + h * hd;
         float acc = 0.f;
         for (int d = 0; d < hd; ++d) acc += q[d] * k[d];
         s[j] = acc; mx = fmaxf(mx, acc);
     }
     float sum = 0.f;
-    for (int j = 0; j < ntok; ++j) { s[j] = exp2f(s[j] - mx); sum += s[j]; }
+    for (int j = 0; j < ntok; ++j) { s[j] = s[j] == -INFINITY ? 0.f : exp2f(s[j] - mx); sum += s[j]; }
     const float inv = 1.0f / sum;
     float* o = O + ((int64_t)row * ntok + t) * inner + h * hd;
     for (int d = 0; d < hd; ++d) {
         float acc = 0.f;
-        for (int j = 0; j < ntok; ++j) acc += s[j] * base[(int64_t)j * 3 * inner + 2 * inner + h * hd + d];
+        for (int j = 0; j < ntok; ++j) if (s[j] != 0.f) acc += s[j] * base[(int64_t)j * 3 * inner + 2 * inner + h * hd + d];
         o[d] = acc * inv;
     }
 }
@@ -170,11 +207,61 @@ static hipError_t gram(const float* X, float* G, int M, int K, float scale, int 
     return hipGetLastError();
 }
 
-hipError_t launch_calibration(const CalibArgs& a, hipStream_t s) {
+// The head of the reference on the last block's residual stream (models/uit.py:395, 398-412): final LayerNorm (eps 1e-6) per token ->
+// pooling over the VALID tokens ('mean' :402-404, 'token' = the cls row :399-401, 'dm' :405-412) -> outputlayer = LayerNorm (eps 1e-5)
+// + Linear -> sigmoid.  One 128-thread workgroup per clip-crop; sums in double (cheap here, and the rung exists to be right).
+__global__ void __launch_bounds__(128) naive_head_kernel(const float* __restrict__ R, NaiveHeadArgs h, int ntok, int nt) {
+    __shared__ double red[128];
+    __shared__ float zn[DIM];
+    const int row = blockIdx.x, c = threadIdx.x;
+    auto block_sum = [&](double v) {
+        red[c] = v; __syncthreads();
+        for (int o = 64; o > 0; o >>= 1) { if (c < o) red[c] += red[c + o]; __syncthreads(); }
+        const double r = red[0]; __syncthreads();
+        return r;
+    };
+    const int ngroups = h.pooling == 1 ? nt : 1;                          // 'dm': one pooled vector per time patch
+    double acc[GT] = {};
+    int cnt[GT] = {};
+    for (int t = 0; t < ntok; ++t) {
+        if (!naive_token_valid(t, ntok, nt)) continue;
+        if (h.pooling == 2 && t != 0) continue;
+        const double x = R[((int64_t)row * ntok + t) * DIM + c];
+        const double mean = block_sum(x) / DIM, d = x - mean;
+        const double rstd = 1.0 / sqrt(block_sum(d * d) / DIM + 1e-6);
+        const double y = d * rstd * h.norm_w[c] + h.norm_b[c];
+        const int tp = ntok == NTOK ? t % GT : (t == 0 ? 0 : (t - 1) % GT);
+        const int gsel = h.pooling == 1 ? tp : 0;
+        acc[gsel] += y; cnt[gsel] += 1;
+    }
+    float* probs = h.rowprobs + (int64_t)row * h.C;
+    for (int o = c; o < h.C; o += 128) probs[o] = 0.f;
+    for (int gq = 0; gq < ngroups; ++gq) {
+        const double z = acc[gq] / (double)(cnt[gq] > 0 ? cnt[gq] : 1);
+        const double mean = block_sum(z) / DIM, d = z - mean;
+        const double rstd = 1.0 / sqrt(block_sum(d * d) / DIM + 1e-5);
+        zn[c] = (float)(d * rstd * h.hln_w[c] + h.hln_b[c]);
+        __syncthreads();
+        for (int o = c; o < h.C; o += 128) {
+            double lg = h.head_b[o];
+            const float* wrow = h.head_w + (int64_t)o * DIM;
+            for (int i = 0; i < DIM; ++i) lg += (double)zn[i] * (double)wrow[i];
+            if (h.rowlogits != nullptr && h.pooling != 1) h.rowlogits[(int64_t)row * h.C + o] = (float)lg;
+            probs[o] += (float)(1.0 / (1.0 + exp(-lg)) / ngroups);
+        }
+        __syncthreads();
+    }
+}
+
+hipError_t launch_calibration(const CalibArgs& a, hipStream_t s) { return launch_naive_forward(a, GT, nullptr, s, nullptr); }
+
+// the forward (statistics when a.stats is set), with the attention masked for nt < GT valid time patches, + the head when asked for
+hipError_t launch_naive_forward(const CalibArgs& a, int nt, const NaiveHeadArgs* head, hipStream_t s, const NaiveFramesArgs* frames) {
 #define CAL_TRY(e) do { hipError_t _e = (e); if (_e != hipSuccess) return _e; } while (0)
     const int M = a.rows * a.ntok, inner = a.inner;
     const int npatch = a.rows * NTOK;                                      // tokens that carry a patch
-    hipLaunchKernelGGL(cal_patch_kernel, dim3(1024), dim3(256), 0, s, a.mel, a.amax, a.top_db, a.bn_sc, a.bn_sh, a.op_bf16, a.rows, a.ntok, a.X0);
+    if (frames != nullptr) hipLaunchKernelGGL(naive_patch_from_frames_kernel, dim3(1024), dim3(256), 0, s, *frames, a.amax, a.top_db, a.bn_sc, a.bn_sh, a.rows, a.ntok, nt, a.X0);
+    else hipLaunchKernelGGL(cal_patch_kernel, dim3(1024), dim3(256), 0, s, a.mel, a.amax, a.top_db, a.bn_sc, a.bn_sh, a.op_bf16, a.rows, a.ntok, a.X0);
     CAL_TRY(hipGetLastError());
     if (a.stats) CAL_TRY(gram(a.X0, a.stats + a.off_pe, M, 256, 1.0f / (float)npatch, a.op_bf16, s));
     hipLaunchKernelGGL(cal_init_stream_kernel, dim3(512), dim3(256), 0, s, a.pe_bias, M, a.ntok, a.R);
@@ -193,7 +280,7 @@ hipError_t launch_calibration(const CalibArgs& a, hipStream_t s) {
             CAL_TRY(gram(a.Xn, st + a.off_ln1, M, DIM, inv_m, a.op_bf16, s, a.centre_ln1 ? mu : nullptr));
         }
         CAL_TRY(linear(a.Xn, wb + a.o_qkv_w, wb + a.o_qkv_b, a.QKV, M, DIM, 3 * inner, 0, 0, s));
-        hipLaunchKernelGGL(cal_attention_kernel, dim3(a.rows, 2), dim3(32), 0, s, a.QKV, a.O, a.ntok, inner);
+        hipLaunchKernelGGL(cal_attention_kernel, dim3(a.rows, 2), dim3(32), 0, s, a.QKV, a.O, a.ntok, inner, nt);
         CAL_TRY(hipGetLastError());
         if (st) CAL_TRY(gram(a.O, st + a.off_att, M, inner, inv_m, a.op_bf16, s));
         CAL_TRY(linear(a.O, wb + a.o_proj_w, wb + a.o_proj_b, a.R, M, inner, DIM, 0, 1, s));
@@ -203,6 +290,10 @@ hipError_t launch_calibration(const CalibArgs& a, hipStream_t s) {
         CAL_TRY(linear(a.Xn, wb + a.o_fc1_w, wb + a.o_fc1_b, a.Hd, M, DIM, HID, a.act_gelu ? 2 : 1, 0, s));
         if (st) CAL_TRY(gram(a.Hd, st + a.off_hid, M, HID, inv_m, a.op_bf16, s));
         CAL_TRY(linear(a.Hd, wb + a.o_fc2_w, wb + a.o_fc2_b, a.R, M, HID, DIM, 0, 1, s));
+    }
+    if (head != nullptr) {
+        hipLaunchKernelGGL(naive_head_kernel, dim3(a.rows), dim3(128), 0, s, a.R, *head, a.ntok, nt);
+        CAL_TRY(hipGetLastError());
     }
 #undef CAL_TRY
     return hipSuccess;

@@ -32,12 +32,14 @@ _CALIB_OPTIONS = ('calib_accept_pct', 'calib_budget_e6')            # (meaningfu
 # 'fp8c' / 'fp8w' (round 5, BASELINE config #5): the fp8 kernel on weights GPTQ-rounded to the MX e4m3 grid / the f16 kernel on fp8-grid weights
 # ("fp8 weights" read literally), both calibrated like 'f16c'; 'fp8' keeps its weights rounded to nearest (the reference point)
 _PRECISIONS = {'auto': _lib.PREC_F16, 'f16': _lib.PREC_F16, 'f16c': _lib.PREC_F16, 'bf16': _lib.PREC_BF16, 'fp8': _lib.PREC_FP8, 'fp8c': _lib.PREC_FP8,
-               'fp8w': _lib.PREC_FP8W, 'f16x2': _lib.PREC_F16X2, 'f16l6': _lib.PREC_F16L6, 'f16a': _lib.PREC_F16A, 'f16ax': _lib.PREC_F16AX}
-_PRECISION_NAMES = {_lib.PREC_F16: 'f16', _lib.PREC_BF16: 'bf16', _lib.PREC_FP8: 'fp8', _lib.PREC_F16X2: 'f16x2', _lib.PREC_F16L6: 'f16l6', _lib.PREC_F16A: 'f16a', _lib.PREC_F16AX: 'f16ax'}
+               'fp8w': _lib.PREC_FP8W, 'f16x2': _lib.PREC_F16X2, 'f16l6': _lib.PREC_F16L6, 'f16a': _lib.PREC_F16A, 'f16ax': _lib.PREC_F16AX, 'f32': _lib.PREC_F32}
+_PRECISION_NAMES = {_lib.PREC_F16: 'f16', _lib.PREC_BF16: 'bf16', _lib.PREC_FP8: 'fp8', _lib.PREC_F16X2: 'f16x2', _lib.PREC_F16L6: 'f16l6', _lib.PREC_F16A: 'f16a', _lib.PREC_F16AX: 'f16ax', _lib.PREC_F32: 'f32'}
 # 'f16a' (round 5, pooling 'token' only): 'f16c' + the MLP's activation operands of the cls column tile as hi + lo terms -- what 'auto' escalates
 # to there (the cls row is read without a mean over tokens: activation rounding, not weight rounding, is what is over budget)
 _CALIBRATING = ('auto', 'f16c', 'fp8c', 'fp8w', 'f16a', 'f16ax')    # precisions whose handle is built with uitk_calibrate_weights
 # 'f16ax' (round 5): 'f16a' on the split weights of 'f16x2' -- where 'auto' goes when an 'f16a' handle is over the budget
+# 'f32' (round 5): the plain fp32 forward of the library (vector ALUs; ~100x slower) -- the last rung of every ladder: where 'auto' ends when no
+# fp16 mode is inside the budget (checkpoints with strong attention sinks); any family, any pooling
 
 __all__ = ["UITBase", "UitkSetupWarning", "UitkParityWarning", "uit_xs", "uit_xxs", "uit_xxxs", "PRETRAINED_CHECKPOINTS",
            "audio_transformer_h128_d4_m3", "audio_transformer_h128_d4_m3_relu",
@@ -159,7 +161,7 @@ class UITBase(nn.Module):
                  norm_layer=None, act_layer=None, init_values=None, target_length=1012, pooling='token',
                  wavtransforms=None, spectransforms=None, time_patch_out=None, freq_patch_out=None,
                  block_type='Block', attention_type='Attention', eval_avg='mean', precision=None, fe_autotune=True,
-                 check_weights=True, **kwargs):
+                 check_weights=True, fp32_fallback=True, **kwargs):
         super().__init__()
         assert pooling in ('mean', 'token', 'dm')
         self.outputdim = outputdim
@@ -183,6 +185,9 @@ class UITBase(nn.Module):
         # every call compares a cheap version stamp of the weights (~15 us) and re-packs after an in-place edit; False: a caller that never
         # touches the weights after the first call (benchmark loops) skips the comparison (round 5: a constructor kwarg, no environment)
         self.check_weights = bool(check_weights)
+        # precision 'auto': may the ladder end in 'f32' (the library's plain fp32 forward, ~100x slower than the MFMA encoder) when no fp16 mode
+        # is inside the budget?  False: stay on the best fp16 build, warn, report within_budget = False (throughput over parity)
+        self.fp32_fallback = bool(fp32_fallback)
         self.depth = depth
         self.num_heads = num_heads
         self.mlp_hidden = int(embed_dim * mlp_ratio)
@@ -221,7 +226,7 @@ class UITBase(nn.Module):
             raise NotImplementedError("precision='f16l6' is built for BNeckAttention + ReLU (any pooling)")
         if precision in ('f16a', 'f16ax') and pooling != 'token':
             raise NotImplementedError("precision='f16a' / 'f16ax' (split activation operands of the cls tile) are built for pooling='token'")
-        if pooling != 'mean' and precision not in ('auto', 'f16', 'f16c', 'f16l6', 'f16x2', 'fp8w', 'f16a', 'f16ax'):
+        if pooling != 'mean' and precision not in ('auto', 'f16', 'f16c', 'f16l6', 'f16x2', 'fp8w', 'f16a', 'f16ax', 'f32'):
             raise NotImplementedError("pooling='dm' / 'token' are built for precision='auto' / 'f16' / 'f16c' / 'f16l6' / 'f16x2' / 'fp8w'")
 
         self.front_end = nn.Sequential(
@@ -523,9 +528,10 @@ class UITBase(nn.Module):
 
     def _hold_to_budget(self, L, w, handle, start_as, x, stream, idx):
         """The guarantee of the parity mode (round 5), after uitk_calibrate_weights on `handle`: read what the library measured on its
-        held-out clips and what it asks for (option parity_escalate_to); 'auto' builds the precision named there -- 'f16l6' / 'f16x2';
-        pooling 'token': 'f16a', then 'f16ax' -- calibrates it too (operand centring), measures it on the same clips (uitk_self_check) and
-        keeps the better of the two; an explicit 'f16c' / 'f16a' warns and stays.  Returns the _Handle to install; its .mode is the report."""
+        held-out clips and what it asks for (option parity_escalate_to); 'auto' climbs the ladder the library names -- 'f16l6' / 'f16x2';
+        pooling 'token': 'f16a', then 'f16ax'; last, for every family: 'f32', the plain fp32 forward -- calibrating each fp16 build (operand
+        centring), measuring it on the same clips (uitk_self_check), taking it when it is better, until one is inside the budget; an
+        explicit 'f16c' / 'f16a' warns and stays.  Returns the _Handle to install; its .mode is the report."""
         rep = (ctypes.c_float * 5)()
         _lib.check(L.uitk_get_calib_check(handle.ptr, rep), "uitk_get_calib_check")
         esc, budget = ctypes.c_int(-1), ctypes.c_int(0)
@@ -552,27 +558,49 @@ class UITBase(nn.Module):
             return handle
         if esc.value < 0:                                 # refused, yet inside the budget (harmless at init scale): reported, not escalated
             return handle
-        to = _PRECISION_NAMES[esc.value]
-        # the build the library names, of the same weights; the SAME calibration call gives it the operand centring of the attention (split
-        # weights are not re-rounded), and its own deviation on the held-out clips decides whether it stays
-        split = self._create(L, w, to)
-        self._calibrate_handle(L, split, w, x, stream)
-        out2 = (ctypes.c_float * 2)()
-        _lib.check(L.uitk_self_check(split.ptr, ctypes.byref(w), stream, out2), "uitk_self_check")
-        sc = None if out2[0] < 0 else (float(out2[0]), float(out2[1]))
-        if sc is not None and dev_now is not None and sc[0] >= dev_now:
-            # no better: what is over budget is not what that build splits -- the faster image stays, and the report says so
-            why += "; the build '%s' measures %.2e there (no better): kept" % (to, sc[0])
-            handle.mode.update(reason=why, within_budget=False, self_check_split=sc)
-            warnings.warn(f"uit_mobile_amd: precision='auto' on cuda:{idx}: {why}", UitkParityWarning, stacklevel=6)
-            return handle
-        inside = sc is None or sc[0] <= handle.mode["budget"]
-        warnings.warn(f"uit_mobile_amd: precision='auto' on cuda:{idx}: {why} -> rebuilding the handle in precision '{to}' "
-                      + ("(split activation operands + split weights: the top of pooling 'token''s ladder, slower)" if to == 'f16ax'
-                         else "(split activation operands of the cls tile, slower)" if to == 'f16a' else "(split weights: parity-grade, slower)")
-                      + ("" if inside else "; that build measures %.2e there: STILL OVER the budget" % sc[0]), UitkParityWarning, stacklevel=6)
-        split.mode.update(check=handle.mode["check"], budget=handle.mode["budget"], reason=why, escalated=True, self_check=sc, within_budget=inside)
-        return split                                      # (the first handle is destroyed when its last reference goes)
+        # the ladder: build what the library names, of the same weights -- the SAME calibration call gives a split build the operand centring
+        # of the attention (its weights are not re-rounded) and the library's verdict on it (the next rung, if it is over budget too) --
+        # measure it on the same clips, keep it if it is better, go on while it is over the budget and the library names another rung
+        cur, cur_dev, to_code, path = handle, dev_now, esc.value, [handle.mode["precision"]]
+        while to_code >= 0:
+            to = _PRECISION_NAMES[to_code]
+            nxt = self._create(L, w, to)
+            nxt_code = -1
+            if to != 'f32':                               # (the fp32 rung has nothing to calibrate)
+                self._calibrate_handle(L, nxt, w, x, stream)
+                e2 = ctypes.c_int(-1)
+                _lib.check(L.uitk_get_option(nxt.ptr, b"parity_escalate_to", ctypes.byref(e2)), "uitk_get_option")
+                nxt_code = e2.value
+            out2 = (ctypes.c_float * 2)()
+            _lib.check(L.uitk_self_check(nxt.ptr, ctypes.byref(w), stream, out2), "uitk_self_check")
+            sc = None if out2[0] < 0 else (float(out2[0]), float(out2[1]))
+            if sc is not None and cur_dev is not None and sc[0] >= cur_dev and to != 'f32':
+                # no better: what is over budget is not what that build splits -- it is not taken (the next rung still is tried)
+                why += "; the build '%s' measures %.2e there (no better)" % (to, sc[0])
+                cur.mode.setdefault("self_check_split", sc)
+            else:
+                nxt.mode.update(check=handle.mode["check"], budget=handle.mode["budget"], escalated=True, self_check=sc)
+                cur, cur_dev = nxt, (sc[0] if sc is not None else None)
+                path.append(to)
+            if cur_dev is not None and cur_dev <= handle.mode["budget"]:
+                break
+            to_code = nxt_code if nxt_code >= 0 else (_lib.PREC_F32 if to != 'f32' else -1)
+            if to_code == _lib.PREC_F32 and not self.fp32_fallback:
+                why += "; the fp32 rung is switched off (fp32_fallback=False)"
+                break
+        inside = cur_dev is None or cur_dev <= handle.mode["budget"]
+        cur.mode.update(reason=why, within_budget=inside, ladder=path)
+        if cur is handle:
+            warnings.warn(f"uit_mobile_amd: precision='auto' on cuda:{idx}: {why}: kept", UitkParityWarning, stacklevel=6)
+        else:
+            to = path[-1]
+            warnings.warn(f"uit_mobile_amd: precision='auto' on cuda:{idx}: {why} -> rebuilding the handle in precision '{to}' "
+                          + ("(the plain fp32 forward: the last rung, ~100x slower than the MFMA encoder -- and right)" if to == 'f32'
+                             else "(split activation operands + split weights: the top of pooling 'token''s fp16 ladder, slower)" if to == 'f16ax'
+                             else "(split activation operands of the cls tile, slower)" if to == 'f16a' else "(split weights: parity-grade, slower)")
+                          + ("" if inside else "; that build measures %.2e there: STILL OVER the budget" % cur_dev)
+                          + " [ladder: " + " -> ".join(path) + "]", UitkParityWarning, stacklevel=6)
+        return cur                                        # (the handles not taken are destroyed when their last reference goes)
 
     @staticmethod
     def _prep_input(x):

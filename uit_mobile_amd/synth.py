@@ -221,6 +221,30 @@ def make_structured_trained_like_state_dict(name="uit_xs", seed=0, outputdim=537
     return sd
 
 
+def make_sink_trained_like_state_dict(name="uit_xs", seed=0, outputdim=537, target_length=102, dim=128, n_mels=64, attention="bneck", gain=2.0):
+    """A THIRD family (round 5): make_trained_like_state_dict with an ATTENTION SINK in every block and head, as trained transformers
+    have them: the six tokens of frequency row 0 carry a key component along a direction u (written into W_k through the direction of
+    that row's positional embedding), and every query looks for u (q bias): scores of a few units x `gain` on those keys for all
+    queries.  A sink key is an outlier -- centring on the all-token mean does not shrink it -- so its fp16 rounding error, q . dk, is
+    large; what this does to the activation floor: tools/err_attrib_sink.py."""
+    sd = {k: np.array(v) for k, v in make_trained_like_state_dict(name, seed, outputdim, target_length, dim, n_mels, attention).items()}
+    rng = np.random.default_rng(13000 + seed)
+    inner = dim if attention == "full" else dim // 4
+    hd = inner // 2
+    fp = sd["freq_pos_embed"][0, :, :, 0].astype(np.float64)
+    p0 = fp[:, 0] - fp.mean(1)
+    p0 /= np.linalg.norm(p0)
+    for b in range(DEPTH[name]):
+        W, bias = sd[f"blocks.{b}.attn.qkv.weight"], sd[f"blocks.{b}.attn.qkv.bias"]
+        g1 = float(np.abs(sd[f"blocks.{b}.norm1.weight"]).mean())
+        for h in range(2):
+            u = rng.standard_normal(hd)
+            u /= np.linalg.norm(u)
+            bias[h * hd:(h + 1) * hd] += (gain * 6.0 * u).astype(np.float32)
+            W[inner + h * hd:inner + (h + 1) * hd] += (gain * 8.0 * np.outer(u, p0) / g1).astype(np.float32)
+    return sd
+
+
 # ---------------------------------------------------------------------------------------------- adversarial held-out signals
 # Round 5 (VERDICT r4 item 1b/1c): the signal families a calibration fit on noise / tones / chirps / harmonic stacks leaves
 # unconstrained.  Every family is a function (rng, T) -> float64 [T] in full-scale units; adversarial_pcm_i16 draws `per_family`
