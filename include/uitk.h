@@ -61,7 +61,7 @@ typedef enum uitk_precision {
                            what get_option("parity_escalate_to") names for it; 1.2-1.4x the encoder time of UITK_PREC_F16.  q, k and v of EVERY
                            column tile are hi + lo as well (the cls row's scores against all keys: with full-width attention the fp16 rounding
                            of the keys carried the error on heavy-tailed checkpoints, tools/err_attrib_token.py) */
-    UITK_PREC_F16AX = 7,/* round 5, pooling 'token' only, the top of its ladder: UITK_PREC_F16A's split activation operands on UITK_PREC_F16X2's
+    UITK_PREC_F16AX = 7,/* round 5, pooling 'token' only, the top of its fp16 ladder: UITK_PREC_F16A's split activation operands on UITK_PREC_F16X2's
                            split WEIGHTS (its parameter image and ring schedule) -- what is left is the fp16 rounding of the other tiles'
                            LayerNorm operands; ~2x the encoder time of UITK_PREC_F16.  get_option("parity_escalate_to") of a
                            UITK_PREC_F16A handle over its budget names it */

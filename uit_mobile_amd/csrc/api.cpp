@@ -942,7 +942,7 @@ int heldout_score(uitk_model* m, HeldOut* ho, hipStream_t s, double* mx, double*
 // whose slope against the logit is at most 1/4)
 double parity_budget(const uitk_model* m) { return m->calib_budget_e6 * 1e-6 * (m->cfg.pooling == 1 ? 0.25 : 1.0); }
 // over budget: pooling 'token' reads ONE row, what is left there is activation rounding -> split activation operands (f16a), and from
-// there split weights as well (f16ax: the top of that ladder); the other poolings: split weights (f16l6 for BNeckAttention + ReLU,
+// there split weights as well (f16ax: the top of that fp16 ladder); the other poolings: split weights (f16l6 for BNeckAttention + ReLU,
 // f16x2 otherwise)
 // from a split-weight handle (f16l6 / f16x2 / f16ax) the next and last rung is the plain fp32 forward (f32): slow, and right
 int parity_fallback_precision(const uitk_model* m) {
