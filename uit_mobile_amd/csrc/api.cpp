@@ -1006,7 +1006,7 @@ int uitk_self_check(uitk_model* m, const uitk_weights* w, void* stream, float* o
 int uitk_calibrate_weights(uitk_model* m, const uitk_weights* w, const void* pcm, int in_dtype, int64_t B, int64_t T, void* stream) {
     if (!m || !w) return fail(UITK_ERR_INVALID_ARG, "null argument");
     if (!calibratable_precision(m->cfg.precision))
-        return fail(UITK_ERR_UNSUPPORTED, "unknown precision");
+        return fail(UITK_ERR_UNSUPPORTED, m->cfg.precision == UITK_PREC_F32 ? "precision f32 has nothing to calibrate (nothing in it is rounded to 16 bits)" : "unknown precision");
     hipStream_t s = (hipStream_t)stream;
     {                                                            // a pack-time operation (allocates, synchronises): never inside a capture
         hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;

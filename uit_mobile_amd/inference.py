@@ -75,7 +75,7 @@ def main(argv=None):
     ap.add_argument("-m", "--model", type=str, nargs="?", default="uit_xs",
                     metavar=f"Public Checkpoint [{','.join(PRETRAINED_CHECKPOINTS)}] or Experiment Path")
     ap.add_argument("-k", "--topk", type=int, default=3, help="Print top-k results")
-    ap.add_argument("--precision", default=None, choices=["auto", "f16c", "f16l6", "f16", "f16x2", "bf16", "fp8", "fp8c", "fp8w"],
+    ap.add_argument("--precision", default=None, choices=["auto", "f16c", "f16l6", "f16", "f16x2", "f32", "bf16", "fp8", "fp8c", "fp8w"],
                     help="default: auto, the parity mode of every factory (the fp16 kernels on weights with calibrated rounding, held to the "
                          "library's deviation budget, else split weights)")
     args = ap.parse_args(argv)
