@@ -24,7 +24,7 @@ int main() {
     for (int full = 0; full < 2; ++full)
         for (int gelu = 0; gelu < 2; ++gelu)
             for (int pooling = 0; pooling < 3; ++pooling)
-                for (int prec = 0; prec <= UITK_PREC_F16A; ++prec)
+                for (int prec = 0; prec <= UITK_PREC_F16AX; ++prec)
                     for (int depth : {1, 2}) {
                         uitk_config c{};
                         c.depth = depth; c.embed_dim = 128; c.num_heads = 2; c.mlp_hidden = 384; c.outputdim = 537; c.target_length = 102;
