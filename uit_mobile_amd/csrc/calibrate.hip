@@ -1,7 +1,7 @@
 // calibrate.hip -- the plain fp32 forward of the folded network.  PACK TIME: operand statistics for the calibrated rounding of pack.cpp
 // (round_gptq) and the reference of the held-out check.  Round 5, late: the same kernels + a head kernel are also
 // precision 'f32' (UITK_PREC_F32, launch_naive_forward below): the LAST rung of the parity ladder -- fp32 arithmetic on the vector
-// ALUs, one simple kernel per operation, two orders of magnitude slower than the MFMA encoder and right for every checkpoint.
+// ALUs, one simple kernel per operation, ~20x slower than the MFMA encoder (507 k clips/s for UiT-XS) and right for every checkpoint.
 //
 // uitk_calibrate (api.cpp) runs a calibration batch through the product front-end kernel and then through the plain fp32 forward
 // below -- the folded network of pack.h (`Folded`: exactly the numbers pack.cpp rounds), one simple kernel per operation -- and
@@ -120,6 +120,52 @@ __global__ void cal_linear_kernel(const float* __restrict__ X, const float* __re
     }
 }
 
+// The same linear for the large token counts of precision 'f32' (a batch, not a calibration set): 64 x 64 outputs per workgroup, 4 x 4 per
+// thread, k ascending as above.  Plain register tiling on the vector ALUs: precision 'f32' 185 k -> 387 k clips/s (UiT-XS; 507 k with the attention kernel below); still the clear one.
+constexpr int LT = 64;
+__global__ void __launch_bounds__(256) naive_linear_tiled_kernel(const float* __restrict__ X, const float* __restrict__ W, const float* __restrict__ bias,
+                                                                 float* __restrict__ Y, int M, int K, int O, int act, int accumulate) {
+    __shared__ float xs[TS][LT + 4], ws[TS][LT + 4];                       // k-major: the inner loop reads four neighbours of a row
+    const int tid = threadIdx.x, tx = tid & 15, ty = tid >> 4;
+    const int m0 = blockIdx.y * LT, o0 = blockIdx.x * LT;
+    float acc[4][4] = {};
+    for (int k0 = 0; k0 < K; k0 += TS) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int idx = tid + 256 * i, r = idx >> 4, kk = idx & 15;
+            xs[kk][r] = m0 + r < M ? X[(int64_t)(m0 + r) * K + k0 + kk] : 0.f;
+            ws[kk][r] = o0 + r < O ? W[(int64_t)(o0 + r) * K + k0 + kk] : 0.f;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int kk = 0; kk < TS; ++kk) {
+            float a[4], b[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { a[i] = xs[kk][4 * ty + i]; b[i] = ws[kk][4 * tx + i]; }
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[i][j] += a[i] * b[j];
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int m = m0 + 4 * ty + i;
+        if (m >= M) continue;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int o = o0 + 4 * tx + j;
+            if (o >= O) continue;
+            float v = acc[i][j] + (bias ? bias[o] : 0.f);
+            if (act == 1) v = fmaxf(v, 0.f);
+            else if (act == 2) v = 0.5f * v * (1.0f + erff(v * 0.70710678118654752f));
+            float* y = Y + (int64_t)m * O + o;
+            *y = accumulate ? *y + v : v;
+        }
+    }
+}
+
 // Xn[m][:] = (R[m][:] - mean) / sqrt(var + eps): one wave per token, two elements per lane (the affine lives in the next linear)
 __global__ void cal_layernorm_kernel(const float* __restrict__ R, float* __restrict__ Xn, int M, float eps) {
     const int m = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6), lane = threadIdx.x & 63;
@@ -143,16 +189,21 @@ __device__ __forceinline__ bool naive_token_valid(int tok, int ntok, int nt) {
     if (ntok != NTOK) { if (tok == 0) return true; tok -= 1; }          // the cls token of pooling 'token'
     return tok % GT < nt;
 }
-__global__ void cal_attention_kernel(const float* __restrict__ QKV, float* __restrict__ O, int ntok, int inner, int nt) {
-    const int row = blockIdx.x, h = blockIdx.y, t = threadIdx.x, hd = inner / 2;
+// One workgroup per clip-crop, both heads: the crop's QKV rows are staged in LDS (coalesced), thread t = (head, query token).
+__global__ void __launch_bounds__(64) cal_attention_kernel(const float* __restrict__ QKV, float* __restrict__ O, int ntok, int inner, int nt) {
+    extern __shared__ float qkv[];                                         // [ntok][3 * inner + 1] (odd row pitch: the queries' reads spread over the banks)
+    const int row = blockIdx.x, hd = inner / 2, lg = 3 * inner, ld = lg + 1;
+    const float* base = QKV + (int64_t)row * ntok * lg;
+    for (int i = threadIdx.x; i < ntok * lg; i += 64) qkv[(i / lg) * ld + i % lg] = base[i];
+    __syncthreads();
+    const int h = threadIdx.x / 32, t = threadIdx.x % 32;
     if (t >= ntok) return;
-    const float* base = QKV + (int64_t)row * ntok * 3 * inner;
-    const float* q = base + (int64_t)t * 3 * inner + h * hd;
+    const float* q = qkv + t * ld + h * hd;
     float s[NTOK + 1], mx = -INFINITY;
     for (int j = 0; j < ntok; ++j) {
         s[j] = -INFINITY;
         if (!naive_token_valid(j, ntok, nt)) continue;
-        const float* k = base + (int64_t)j * 3 * inner + inner + h * hd;
+        const float* k = qkv + j * ld + inner + h * hd;
         float acc = 0.f;
         for (int d = 0; d < hd; ++d) acc += q[d] * k[d];
         s[j] = acc; mx = fmaxf(mx, acc);
@@ -163,7 +214,7 @@ __global__ void cal_attention_kernel(const float* __restrict__ QKV, float* __res
     float* o = O + ((int64_t)row * ntok + t) * inner + h * hd;
     for (int d = 0; d < hd; ++d) {
         float acc = 0.f;
-        for (int j = 0; j < ntok; ++j) if (s[j] != 0.f) acc += s[j] * base[(int64_t)j * 3 * inner + 2 * inner + h * hd + d];
+        for (int j = 0; j < ntok; ++j) if (s[j] != 0.f) acc += s[j] * qkv[j * ld + 2 * inner + h * hd + d];
         o[d] = acc * inv;
     }
 }
@@ -199,6 +250,10 @@ __global__ void cal_colmean_kernel(const float* __restrict__ X, float* __restric
 }
 
 static hipError_t linear(const float* X, const float* W, const float* b, float* Y, int M, int K, int O, int act, int accumulate, hipStream_t s) {
+    if (M >= 2048) {                                                       // (small sets -- the library's calibration clips, a B = 64 batch -- fill the chip better with the small tiles)
+        hipLaunchKernelGGL(naive_linear_tiled_kernel, dim3((O + LT - 1) / LT, (M + LT - 1) / LT), dim3(256), 0, s, X, W, b, Y, M, K, O, act, accumulate);
+        return hipGetLastError();
+    }
     hipLaunchKernelGGL(cal_linear_kernel, dim3((O + TS - 1) / TS, (M + TS - 1) / TS), dim3(TS, TS), 0, s, X, W, b, Y, M, K, O, act, accumulate);
     return hipGetLastError();
 }
@@ -280,7 +335,7 @@ hipError_t launch_naive_forward(const CalibArgs& a, int nt, const NaiveHeadArgs*
             CAL_TRY(gram(a.Xn, st + a.off_ln1, M, DIM, inv_m, a.op_bf16, s, a.centre_ln1 ? mu : nullptr));
         }
         CAL_TRY(linear(a.Xn, wb + a.o_qkv_w, wb + a.o_qkv_b, a.QKV, M, DIM, 3 * inner, 0, 0, s));
-        hipLaunchKernelGGL(cal_attention_kernel, dim3(a.rows, 2), dim3(32), 0, s, a.QKV, a.O, a.ntok, inner, nt);
+        hipLaunchKernelGGL(cal_attention_kernel, dim3(a.rows), dim3(64), (size_t)a.ntok * (3 * inner + 1) * 4, s, a.QKV, a.O, a.ntok, inner, nt);
         CAL_TRY(hipGetLastError());
         if (st) CAL_TRY(gram(a.O, st + a.off_att, M, inner, inv_m, a.op_bf16, s));
         CAL_TRY(linear(a.O, wb + a.o_proj_w, wb + a.o_proj_b, a.R, M, inner, DIM, 0, 1, s));

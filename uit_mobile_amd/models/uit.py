@@ -38,7 +38,7 @@ _PRECISION_NAMES = {_lib.PREC_F16: 'f16', _lib.PREC_BF16: 'bf16', _lib.PREC_FP8:
 # to there (the cls row is read without a mean over tokens: activation rounding, not weight rounding, is what is over budget)
 _CALIBRATING = ('auto', 'f16c', 'fp8c', 'fp8w', 'f16a', 'f16ax')    # precisions whose handle is built with uitk_calibrate_weights
 # 'f16ax' (round 5): 'f16a' on the split weights of 'f16x2' -- where 'auto' goes when an 'f16a' handle is over the budget
-# 'f32' (round 5): the plain fp32 forward of the library (vector ALUs; ~100x slower) -- the last rung of every ladder: where 'auto' ends when no
+# 'f32' (round 5): the plain fp32 forward of the library (vector ALUs; ~20x slower) -- the last rung of every ladder: where 'auto' ends when no
 # fp16 mode is inside the budget (checkpoints with strong attention sinks); any family, any pooling
 
 __all__ = ["UITBase", "UitkSetupWarning", "UitkParityWarning", "uit_xs", "uit_xxs", "uit_xxxs", "PRETRAINED_CHECKPOINTS",
@@ -185,7 +185,7 @@ class UITBase(nn.Module):
         # every call compares a cheap version stamp of the weights (~15 us) and re-packs after an in-place edit; False: a caller that never
         # touches the weights after the first call (benchmark loops) skips the comparison (round 5: a constructor kwarg, no environment)
         self.check_weights = bool(check_weights)
-        # precision 'auto': may the ladder end in 'f32' (the library's plain fp32 forward, ~100x slower than the MFMA encoder) when no fp16 mode
+        # precision 'auto': may the ladder end in 'f32' (the library's plain fp32 forward, ~20x slower than the MFMA encoder) when no fp16 mode
         # is inside the budget?  False: stay on the best fp16 build, warn, report within_budget = False (throughput over parity)
         self.fp32_fallback = bool(fp32_fallback)
         self.depth = depth
@@ -595,7 +595,7 @@ class UITBase(nn.Module):
         else:
             to = path[-1]
             warnings.warn(f"uit_mobile_amd: precision='auto' on cuda:{idx}: {why} -> rebuilding the handle in precision '{to}' "
-                          + ("(the plain fp32 forward: the last rung, ~100x slower than the MFMA encoder -- and right)" if to == 'f32'
+                          + ("(the plain fp32 forward: the last rung, ~20x slower than the MFMA encoder -- and right)" if to == 'f32'
                              else "(split activation operands + split weights: the top of pooling 'token''s fp16 ladder, slower)" if to == 'f16ax'
                              else "(split activation operands of the cls tile, slower)" if to == 'f16a' else "(split weights: parity-grade, slower)")
                           + ("" if inside else "; that build measures %.2e there: STILL OVER the budget" % cur_dev)
