@@ -78,7 +78,10 @@ int main(int argc, char** argv) {
 
     /* THE PARITY MODE as a C consumer builds it (what the Python wrapper's precision 'auto' does): create in f16, calibrate on the library's
      * own signals, then ask the handle whether the image it kept is inside the absolute budget on the held-out clips -- if not, rebuild in
-     * the split-weight precision it names.  argv[3] (optional): a calib_budget_e6 value, e.g. 1 = a budget nobody meets (the escalation path). */
+     * the precision it names and ask again: split weights (f16l6 / f16x2; pooling 'token': f16a, f16ax), and last UITK_PREC_F32, the plain
+     * fp32 forward, which has nothing to calibrate and nothing above it.  (The wrapper also measures each rung with uitk_self_check and skips
+     * one that is no better; a consumer that simply follows the handle ends on the same last rung.)
+     * argv[3] (optional): a calib_budget_e6 value, e.g. 1 = a budget no fp16 mode meets (the whole ladder). */
     uitk_model* m = NULL;
     CHECK_UITK(uitk_create(&cfg, &w, &m));
     if (argc > 3) CHECK_UITK(uitk_set_option(m, "calib_budget_e6", atoi(argv[3])));
@@ -87,13 +90,20 @@ int main(int argc, char** argv) {
     CHECK_UITK(uitk_get_calib_check(m, check));
     int escalate_to = -1;
     CHECK_UITK(uitk_get_option(m, "parity_escalate_to", &escalate_to));
-    if (escalate_to >= 0) {
+    for (int step = 0; step < 3 && escalate_to >= 0; ++step) {
         float self[2];
+        const int to = escalate_to;
         CHECK_UITK(uitk_destroy(m));
-        cfg.precision = escalate_to;
+        cfg.precision = to;
         CHECK_UITK(uitk_create(&cfg, &w, &m));
+        escalate_to = -1;
+        if (to != UITK_PREC_F32) {
+            if (argc > 3) CHECK_UITK(uitk_set_option(m, "calib_budget_e6", atoi(argv[3])));
+            CHECK_UITK(uitk_calibrate_weights(m, &w, NULL, UITK_IN_I16, 0, 0, NULL));      /* split weights: the operand centring + the verdict on this build */
+            CHECK_UITK(uitk_get_option(m, "parity_escalate_to", &escalate_to));
+        }
         CHECK_UITK(uitk_self_check(m, &w, NULL, self));
-        printf("over budget (or refused): rebuilt in precision %d, self check max %.2e rms %.2e\n", escalate_to, self[0], self[1]);
+        printf("over budget (or refused): rebuilt in precision %d, self check max %.2e rms %.2e\n", to, self[0], self[1]);
     }
 
     void *d_pcm = NULL, *d_probs = NULL, *d_logits = NULL;

@@ -1311,16 +1311,22 @@ def test_c_abi_consumer_in_plain_c(tmp_path):
     assert np.array_equal(out[:n].reshape(-1, 537), p.cpu().numpy()) and np.array_equal(out[n:2 * n].reshape(-1, 537), l.cpu().numpy().reshape(-1, 537))
     rep = m.calibration_report()
     assert out[2 * n + 4] == 1.0 and np.isclose(out[2 * n + 1], rep["max_calibrated"], rtol=0, atol=0)
-    # the escalation path in C (round 5): a budget nobody meets -> the consumer rebuilds in the precision the handle names (f16l6) and
-    # then writes what the wrapper's precision 'f16l6' writes
+    # the ladder in C (round 5): a budget no fp16 mode meets -> the consumer follows the handle rung by rung (f16l6, then f32) and writes
+    # what the wrapper's 'auto' writes under the same budget (which ends on the same last rung)
     r = subprocess.run([str(exe), str(blob), str(tmp_path / "out2.bin"), "1"], capture_output=True, text=True, timeout=300)
     print(r.stdout.strip(), r.stderr.strip())
-    assert r.returncode == 0 and "rebuilt in precision 4" in r.stdout, r.stderr
+    assert r.returncode == 0 and "rebuilt in precision 4" in r.stdout and "rebuilt in precision 8" in r.stdout, r.stderr
     out2 = np.fromfile(tmp_path / "out2.bin", np.float32)
-    m6, _ = build_trained("uit_xxxs", 205, prec="f16l6")
-    with torch.no_grad():
-        p6 = m6(torch.from_numpy(pcm).cuda())
-    assert np.array_equal(out2[:n].reshape(-1, 537), p6.cpu().numpy())
+    import warnings
+    m8 = models.uit_xxxs(outputdim=537, target_length=102)
+    m8.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()}, strict=True)
+    m8 = m8.cuda().eval()
+    m8.set_option("calib_budget_e6", 1)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        with torch.no_grad():
+            p8 = m8(torch.from_numpy(pcm).cuda())
+    assert m8.effective_precision() == "f32" and np.array_equal(out2[:n].reshape(-1, 537), p8.cpu().numpy())
 
 
 def test_inference_cli_counterpart_config1(golden, tmp_path, capsys):

@@ -142,6 +142,16 @@ def test_unsupported_variants_raise():
         m.packed_image()
 
 
+def test_causal_kwarg_is_swallowed_as_in_the_reference():
+    """`Attention(causal=True)` exists in the reference (models/uit.py:131, 164-169) but nothing can set it: Block builds its attention
+    without it (:224-228) and UITBase drops unknown kwargs (:276).  A factory called with causal=True is therefore the ordinary model there,
+    and here ("what's missing" 6)."""
+    a, b = models.audio_transformer_h128_d4_m3(causal=True), models.audio_transformer_h128_d4_m3()
+    assert a.attention_full and sorted(a.state_dict()) == sorted(b.state_dict())
+    ca, cb = a._config(), b._config()
+    assert all(getattr(ca, f) == getattr(cb, f) for f, _ in ca._fields_)
+
+
 def test_crop_planning_matches_reference_rule():
     m = models.uit_xs(outputdim=537, target_length=102)
     assert [m.num_frames(t) for t in (16000, 16160, 16384, 160000)] == [101, 102, 103, 1001]
