@@ -1,7 +1,7 @@
 // calibrate.hip -- the plain fp32 forward of the folded network.  PACK TIME: operand statistics for the calibrated rounding of pack.cpp
 // (round_gptq) and the reference of the held-out check.  Round 5, late: the same kernels + a head kernel are also
 // precision 'f32' (UITK_PREC_F32, launch_naive_forward below): the LAST rung of the parity ladder -- fp32 arithmetic on the vector
-// ALUs, one simple kernel per operation, ~20x slower than the MFMA encoder (507 k clips/s for UiT-XS) and right for every checkpoint.
+// ALUs, one simple kernel per operation, ~20x slower than the MFMA encoder (542 k clips/s for UiT-XS) and right for every checkpoint.
 //
 // uitk_calibrate (api.cpp) runs a calibration batch through the product front-end kernel and then through the plain fp32 forward
 // below -- the folded network of pack.h (`Folded`: exactly the numbers pack.cpp rounds), one simple kernel per operation -- and
@@ -120,15 +120,20 @@ __global__ void cal_linear_kernel(const float* __restrict__ X, const float* __re
     }
 }
 
-// The same linear for the large token counts of precision 'f32' (a batch, not a calibration set): 64 x 64 outputs per workgroup, 4 x 4 per
-// thread, k ascending as above.  Plain register tiling on the vector ALUs: precision 'f32' 185 k -> 387 k clips/s (UiT-XS; 507 k with the attention kernel below); still the clear one.
 constexpr int LT = 64;
-__global__ void __launch_bounds__(256) naive_linear_tiled_kernel(const float* __restrict__ X, const float* __restrict__ W, const float* __restrict__ bias,
-                                                                 float* __restrict__ Y, int M, int K, int O, int act, int accumulate) {
-    __shared__ float xs[TS][LT + 4], ws[TS][LT + 4];                       // k-major: the inner loop reads four neighbours of a row
-    const int tid = threadIdx.x, tx = tid & 15, ty = tid >> 4;
+// The same linear for the large token counts of precision 'f32' (a batch, not a calibration set): 64 x 64 outputs per workgroup on the matrix
+// pipe's EXACT-fp32 mode (v_mfma_f32_16x16x4_f32: fp32 operands, fp32 accumulate -- what the front-end's mel stage uses in its 4x4x1 form;
+// precision 'f32' 185 k clips/s with the kernel above -> 387 k with plain register tiling -> 415 k here; 542 k with the attention
+// kernel below).  Wave w owns token rows 16w .. 16w+15 of the tile and all four 16-wide output column tiles; per
+// 16-deep LDS stage four k-steps of 4.  Operand maps: A lane l = X[m = l % 16][k = l / 16], B lane l = W[o = l % 16][k = l / 16],
+// D lane l, register r = Y[m = 4 (l / 16) + r][o = l % 16].  Same products, sums in the MFMA's order instead of ascending k.
+typedef float f4m __attribute__((ext_vector_type(4)));
+__global__ void __launch_bounds__(256) naive_linear_mfma_kernel(const float* __restrict__ X, const float* __restrict__ W, const float* __restrict__ bias,
+                                                                float* __restrict__ Y, int M, int K, int O, int act, int accumulate) {
+    __shared__ float xs[TS][LT + 4], ws[TS][LT + 4];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, lr = lane & 15, lq = lane >> 4;
     const int m0 = blockIdx.y * LT, o0 = blockIdx.x * LT;
-    float acc[4][4] = {};
+    f4m acc[4] = {};
     for (int k0 = 0; k0 < K; k0 += TS) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
@@ -138,26 +143,23 @@ __global__ void __launch_bounds__(256) naive_linear_tiled_kernel(const float* __
         }
         __syncthreads();
 #pragma unroll
-        for (int kk = 0; kk < TS; ++kk) {
-            float a[4], b[4];
+        for (int ks = 0; ks < 4; ++ks) {
+            const float a = xs[4 * ks + lq][16 * wave + lr];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) { a[i] = xs[kk][4 * ty + i]; b[i] = ws[kk][4 * tx + i]; }
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-#pragma unroll
-                for (int j = 0; j < 4; ++j) acc[i][j] += a[i] * b[j];
+            for (int ot = 0; ot < 4; ++ot) acc[ot] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, ws[4 * ks + lq][16 * ot + lr], acc[ot], 0, 0, 0);
         }
         __syncthreads();
     }
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int m = m0 + 4 * ty + i;
-        if (m >= M) continue;
+    for (int ot = 0; ot < 4; ++ot) {
+        const int o = o0 + 16 * ot + lr;
+        if (o >= O) continue;
+        const float bo = bias ? bias[o] : 0.f;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int o = o0 + 4 * tx + j;
-            if (o >= O) continue;
-            float v = acc[i][j] + (bias ? bias[o] : 0.f);
+        for (int r = 0; r < 4; ++r) {
+            const int m = m0 + 16 * wave + 4 * lq + r;
+            if (m >= M) continue;
+            float v = acc[ot][r] + bo;
             if (act == 1) v = fmaxf(v, 0.f);
             else if (act == 2) v = 0.5f * v * (1.0f + erff(v * 0.70710678118654752f));
             float* y = Y + (int64_t)m * O + o;
@@ -251,7 +253,7 @@ __global__ void cal_colmean_kernel(const float* __restrict__ X, float* __restric
 
 static hipError_t linear(const float* X, const float* W, const float* b, float* Y, int M, int K, int O, int act, int accumulate, hipStream_t s) {
     if (M >= 2048) {                                                       // (small sets -- the library's calibration clips, a B = 64 batch -- fill the chip better with the small tiles)
-        hipLaunchKernelGGL(naive_linear_tiled_kernel, dim3((O + LT - 1) / LT, (M + LT - 1) / LT), dim3(256), 0, s, X, W, b, Y, M, K, O, act, accumulate);
+        hipLaunchKernelGGL(naive_linear_mfma_kernel, dim3((O + LT - 1) / LT, (M + LT - 1) / LT), dim3(256), 0, s, X, W, b, Y, M, K, O, act, accumulate);
         return hipGetLastError();
     }
     hipLaunchKernelGGL(cal_linear_kernel, dim3((O + TS - 1) / TS, (M + TS - 1) / TS), dim3(TS, TS), 0, s, X, W, b, Y, M, K, O, act, accumulate);
