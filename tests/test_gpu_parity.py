@@ -2009,3 +2009,52 @@ def test_auto_ends_in_f32_on_an_attention_sink_checkpoint(golden):
         m2, l2, e2 = run_(fp32_fallback=False)
     print(f"   fp32_fallback=False: stays on {m2.effective_precision()}: {e2:.2e} against the C oracle")
     assert m2.effective_precision() != "f32" and m2.calibration_report()["within_budget"] is False and e2 > e
+
+
+@pytest.mark.parametrize("factory,att,precision", [("uit_xxs", "bneck", "f16ax"), ("uit_xxs", "bneck", "f16a"), ("audio_transformer_h128_d4_m3", "full", "f16ax"),
+                                                      ("uit_xxs", "bneck", "f32")])
+def test_token_ladder_rungs_are_bit_stable_under_load(factory, att, precision):
+    """The rungs added late in round 5 -- pooling 'token' in 'f16a' / 'f16ax', and 'f32' -- twenty times on 1024 different clips, with a
+    SECOND model running the default kernels on another stream at the same time (different clocks, different contention in every repeat):
+    every output bit identical to the first run, finite, and the whole batch at the oracle.  The first build of the BNeckAttention
+    'f16ax' kernel was wrong in a way that depended on timing between the waves of a workgroup (profiles/round5/f16ax_bisect.log): a
+    result that is merely right on a quiet GPU would not be enough."""
+    from uit_mobile_amd.synth import make_structured_trained_like_state_dict
+    import uit_mobile_amd.models.uit as U
+    sd = make_structured_trained_like_state_dict(factory, 234, attention=att)
+    pooling = "mean" if precision == "f32" else "token"
+    act = "relu" if att == "bneck" else "gelu"
+    keep = U._CALIBRATING
+    U._CALIBRATING = tuple(p for p in keep if p != "f16ax")              # (f16ax on uitk_create's image: the case that was wrong)
+    try:
+        m = getattr(models, factory)(outputdim=537, target_length=102, pooling=pooling, precision=precision)
+        m.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()}, strict=True)
+        m = m.cuda().eval()
+        pcm = synth_pcm_i16(1024, 16000, seed=97)
+        x = torch.from_numpy(pcm).cuda()
+        import warnings
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            m.prepare("cuda", sample=x)
+    finally:
+        U._CALIBRATING = keep
+    noise = models.uit_xs(outputdim=537, target_length=102, precision="f16")
+    noise.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in make_state_dict("uit_xs", 3).items()})
+    noise = noise.cuda().eval()
+    xn = torch.from_numpy(synth_pcm_i16(4096, 16000, seed=5)).cuda()
+    side = torch.cuda.Stream()
+    with torch.no_grad():
+        noise(xn)
+        first = m(x, return_logits=True)[1].clone()
+        torch.cuda.synchronize()
+        differing = 0
+        for rep in range(20):
+            with torch.cuda.stream(side):
+                for _ in range(1 + rep % 3):
+                    noise(xn)
+            differing += int(not torch.equal(first, m(x, return_logits=True)[1]))
+            torch.cuda.synchronize()
+    ref = Oracle(sd, act=act, pooling=pooling).forward(pcm)["logits"]           # (the whole batch: the top_db floor is batch-global)
+    d = float(np.abs(first.cpu().numpy().reshape(ref.shape) - ref).max())
+    print(f"{factory} {precision}: 20 repeats beside a second model on another stream: {differing} differ; 1024 clips vs oracle {d:.2e}")
+    assert differing == 0 and bool(torch.isfinite(first).all()) and d < 8e-4
