@@ -462,7 +462,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=50)
     ap.add_argument("--model", default="uit_xs", choices=list(GEMM_FLOP))
     ap.add_argument("--batch-per-gpu", type=int, default=8192)
-    ap.add_argument("--precision", default="auto", choices=["auto", "f16c", "f16l6", "f16", "bf16", "fp8", "fp8c", "fp8w", "f16x2"],
+    # every precision of models.uit._PRECISIONS that runs the bench workload (pooling 'mean'); 'f16a' / 'f16ax' are built for pooling 'token'
+    # only (tools/variant_bench.py times them)
+    ap.add_argument("--precision", default="auto", choices=list(PARITY_NOTE),
                     help="auto (default) = THE parity mode and the factories' default: the fp16 kernel on weights with calibrated rounding "
                          "(uitk_calibrate_weights on the library's own signals), held to the library's absolute budget on its held-out clips, "
                          "else rebuilt on split weights -- the line's `effective_precision` says what ran; f16c = the same without the "

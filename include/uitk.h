@@ -209,6 +209,10 @@ int uitk_get_calib_check(const uitk_model* m, float* out5);
  * when no single-crop clip length covers target_length.  A pack-time operation like uitk_calibrate_weights: allocates, synchronises,
  * overwrites the workspace of a pending uitk_frontend; not under stream capture. */
 int uitk_self_check(uitk_model* m, const uitk_weights* w, void* stream, float* out2);
+/* Host-only (no GPU): the comparison uitk_self_check and the acceptance check make -- out2[0] = max |got - ref|, out2[1] = root mean
+ * square over n elements.  A non-finite deviation anywhere makes BOTH results NaN (sticky), so a caller's `!(x <= budget)` and
+ * `isfinite(x)` see it; an image that answers NaN on some held-out clips is never reported inside a budget. */
+int uitk_deviation_stats(const float* got, const double* ref, size_t n, double* out2);
 /* Host-only (no GPU): uitk_pack_weights with calibrated rounding against caller-supplied statistics (layout tests, offline packing).
  * Statistics with a non-finite or negative diagonal entry are rejected (UITK_ERR_INVALID_ARG). */
 int uitk_pack_weights_calibrated(const uitk_config* cfg, const uitk_weights* w, const double* stats, void* out, size_t cap, size_t* needed);

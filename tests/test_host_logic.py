@@ -358,3 +358,120 @@ def test_shorter_window_is_zero_padded_to_n_fft_at_pack_time():
         models.uit_xxxs(outputdim=537, target_length=102, win_size=640, precision="f16").eval().packed_image()
     with pytest.raises(ValueError):
         models.uit_xxxs(outputdim=537, target_length=102, n_fft=1024, win_size=1024, precision="f16").eval().packed_image()
+
+
+def test_deviation_stats_keep_a_nan_in_the_middle():
+    """the running maximum of the held-out comparison (`if (!(d <= mx)) mx = d`) kept a NaN only until the next finite element
+    replaced it: d = [1, NaN, 0.5] came out as 0.5, and the acceptance check, the absolute budget and uitk_self_check trusted that number.
+    uitk_deviation_stats is that comparison (host only): one non-finite deviation makes BOTH results NaN, whatever follows."""
+    L = _lib.load()
+
+    def stats(got, ref):
+        got = np.ascontiguousarray(got, np.float32)
+        ref = np.ascontiguousarray(ref, np.float64)
+        out = (ctypes.c_double * 2)()
+        assert L.uitk_deviation_stats(got.ctypes.data, ref.ctypes.data, got.size, out) == _lib.UITK_OK
+        return out[0], out[1]
+
+    mx, rms = stats([1.0, 2.0, 2.5], [0.0, 2.0, 2.0])
+    assert mx == 1.0 and abs(rms - np.sqrt((1.0 + 0.25) / 3)) < 1e-12
+    for bad in (np.nan, np.inf, -np.inf):
+        for pos in (0, 1, 2):                                    # first, MIDDLE (the case that slipped through), last
+            got = [1.0, 1.0, 0.5]
+            got[pos] = bad
+            mx, rms = stats(got, [0.0, 0.0, 0.0])
+            assert np.isnan(mx) and np.isnan(rms), (bad, pos, mx, rms)
+            assert not (mx <= 6e-4)                              # what the budget comparison sees
+    mx, rms = stats([1.0], [np.nan])                             # a non-finite REFERENCE is no better
+    assert np.isnan(mx)
+    assert L.uitk_deviation_stats(None, None, 0, None) == _lib.ERR_INVALID_ARG
+
+
+class _FakeLadderLib:
+    """Stand-in for libuitk.so in the parity ladder of models.uit (no GPU): every handle is a dict of what the library would report."""
+
+    def uitk_get_calib_check(self, ptr, rep):
+        for i, v in enumerate(ptr.state["check"]):
+            rep[i] = v
+        return 0
+
+    def uitk_get_option(self, ptr, name, ref):
+        ref._obj.value = {b"parity_escalate_to": ptr.state["esc"], b"calib_budget_e6": 600}[name]
+        return 0
+
+    def uitk_self_check(self, ptr, w, stream, out2):
+        out2[0], out2[1] = ptr.state["self_check"]
+        return 0
+
+
+class _FakePtr:
+    def __init__(self, state):
+        self.state = state
+
+    def __bool__(self):                                          # _Handle.__del__ must not hand this to uitk_destroy
+        return False
+
+
+def _ladder(monkeypatch, precision, pooling, first, rungs, **kw):
+    """run UITBase._hold_to_budget on fake handles: `first` = state of the calibrated handle, `rungs` = {precision name: state}"""
+    import uit_mobile_amd.models.uit as U
+    m = models.uit_xxs(outputdim=537, target_length=102, pooling=pooling, precision=precision, **kw).eval()
+    built = []
+
+    def create(L, w, prec):
+        h = U._Handle(_FakePtr(dict(rungs[prec])))
+        h.mode = {"precision": prec, "requested": precision, "escalated": False, "reason": None, "check": None}
+        built.append(prec)
+        return h
+
+    monkeypatch.setattr(m, "_create", create)
+    monkeypatch.setattr(U.UITBase, "_calibrate_handle", staticmethod(lambda L, handle, w, x, stream: None))
+    h0 = U._Handle(_FakePtr(dict(first)))
+    start = {"auto": "f16a" if pooling == "token" else "f16c"}.get(precision, precision)
+    h0.mode = {"precision": start, "requested": precision, "escalated": False, "reason": None, "check": None}
+    out = m._hold_to_budget(_FakeLadderLib(), ctypes.c_int(0), h0, start, None, None, 0)
+    return out, built, h0
+
+
+def test_ladder_never_installs_a_rung_that_is_not_finite(monkeypatch):
+    """a rung whose self check is NaN failed `sc[0] >= cur_dev` and was TAKEN in place of a finite build.  Now a non-finite
+    rung is worse than anything finite: skipped, reported, the ladder goes on; with the fp32 rung switched off the finite build stays and
+    is reported outside its budget."""
+    from uit_mobile_amd.models.uit import UitkParityWarning
+    P = _lib
+    nan = float("nan")
+    over = {"check": (1.5e-3, 9e-4, 1e-4, 1e-4, 1.0), "esc": P.PREC_F16AX}               # calibrated f16a: 9e-4 > 6e-4
+    rungs = {"f16ax": {"esc": P.PREC_F32, "self_check": (nan, nan), "check": (0,) * 5},
+             "f32": {"esc": -1, "self_check": (2e-6, 1e-6), "check": (0,) * 5}}
+    with pytest.warns(UitkParityWarning, match="f32"):
+        out, built, h0 = _ladder(monkeypatch, "auto", "token", over, rungs)
+    assert built == ["f16ax", "f32"] and out.mode["precision"] == "f32" and out.mode["within_budget"] is True
+    assert "not finite" in out.mode["reason"] and out.mode["ladder"] == ["f16a", "f32"]
+    with pytest.warns(UitkParityWarning, match="kept"):
+        out, built, h0 = _ladder(monkeypatch, "auto", "token", over, rungs, fp32_fallback=False)
+    assert out is h0 and out.mode["within_budget"] is False and "not finite" in out.mode["reason"]
+    # the installed image itself not finite on the held-out clips (sticky NaN from the library): any finite rung is better
+    first = {"check": (nan, nan, nan, nan, 0.0), "esc": P.PREC_F16AX}
+    rungs = {"f16ax": {"esc": -1, "self_check": (3e-4, 1e-4), "check": (0,) * 5}}
+    with pytest.warns(UitkParityWarning, match="f16ax"):
+        out, built, _ = _ladder(monkeypatch, "auto", "token", first, rungs)
+    assert out.mode["precision"] == "f16ax" and out.mode["within_budget"] is True
+
+
+def test_explicit_precisions_over_budget_warn(monkeypatch):
+    """explicit 'f16ax' (and 'fp8c' / 'fp8w' after a refusal) used to return from the ladder without a word."""
+    from uit_mobile_amd.models.uit import UitkParityWarning
+    import warnings
+    over = {"check": (2e-3, 1.1e-3, 1e-4, 1e-4, 1.0), "esc": _lib.PREC_F32}
+    with pytest.warns(UitkParityWarning, match="does not escalate"):
+        out, built, h0 = _ladder(monkeypatch, "f16ax", "token", over, {})
+    assert out is h0 and built == [] and out.mode["within_budget"] is False and "over the budget" in out.mode["reason"]
+    refused = {"check": (4e-2, 5e-2, 1e-2, 1e-2, 0.0), "esc": -1}                         # fp8c: measured mode, calibration refused
+    with pytest.warns(UitkParityWarning, match="nearest-rounded"):
+        out, _, _ = _ladder(monkeypatch, "fp8c", "mean", refused, {})
+    assert out.mode["precision"] == "fp8"
+    inside = {"check": (2e-4, 1e-4, 1e-5, 1e-5, 1.0), "esc": -1}
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")
+        out, _, _ = _ladder(monkeypatch, "f16ax", "token", inside, {})
+    assert out.mode["within_budget"] is True

@@ -15,7 +15,13 @@ HERE = Path(__file__).resolve().parent
 CSRC = HERE / "csrc"
 LIB = HERE / "libuitk.so"
 SOURCES = ["api.cpp", "pack.cpp", "frontend.hip", "encoder.hip", "epilogue.hip", "calibrate.hip"]
-HEADERS = ["uitk_dev.h", "pack.h", "../../include/uitk.h"]
+def _headers():
+    """every header a translation unit can include: csrc/*.h (globbed: a new header cannot be forgotten -- naive_forward.h once was, and
+    its structs travel by value between api.cpp and calibrate.hip) + the public C ABI"""
+    return sorted(p.name for p in CSRC.glob("*.h")) + ["../../include/uitk.h"]
+
+
+HEADERS = _headers()
 # -fno-slp-vectorize: the kernels write their packed math explicitly (float2 / ext_vector types); the SLP vectoriser's
 # own packing costs more v_mov than it saves (same-box A/B: front-end -4 %)
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-fno-slp-vectorize", "-Wall", "-Wno-unused-result", "-Wno-inline-asm"]

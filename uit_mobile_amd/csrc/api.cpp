@@ -877,6 +877,25 @@ void head_reference(const uitk_config& c, const uitk_weights* w, const float* R,
 }
 }  // namespace
 
+// The comparison behind the acceptance check, the absolute budget and uitk_self_check (host only, exported so that a CPU test can pin
+// it): largest and root-mean-square deviation of `got` from `ref`.  A non-finite deviation is STICKY -- one NaN / Inf anywhere makes
+// both results NaN, so `!(x <= budget)` and `isfinite(x)` see it whatever follows (`if (!(d <= mx)) mx = d` kept a NaN only
+// until the next finite element replaced it -- an image that answers NaN on some held-out clips could pass as inside the budget).
+int uitk_deviation_stats(const float* got, const double* ref, size_t n, double* out2) {
+    if (!got || !ref || !out2) return fail(UITK_ERR_INVALID_ARG, "null argument");
+    double mxv = 0.0, sq = 0.0;
+    bool bad = false;
+    for (size_t i = 0; i < n; ++i) {
+        const double d = std::fabs((double)got[i] - ref[i]);
+        if (!std::isfinite(d)) { bad = true; continue; }
+        if (d > mxv) mxv = d;
+        sq += d * d;
+    }
+    out2[0] = bad ? std::nan("") : mxv;
+    out2[1] = bad ? std::nan("") : (n ? std::sqrt(sq / (double)n) : 0.0);
+    return UITK_OK;
+}
+
 // The held-out evaluation shared by the acceptance check of uitk_calibrate_weights and by uitk_self_check: the 48 held-out clips of
 // the library (builtin_heldout_set) go through the PRODUCT front-end; the plain fp32 forward of calibrate.hip + head_reference give
 // what the unrounded network answers on those 16-bit patch operands; heldout_score runs the product encoder on whatever parameter
@@ -928,13 +947,9 @@ int heldout_score(uitk_model* m, HeldOut* ho, hipStream_t s, double* mx, double*
     if (int rc = uitk_encode(m, ho->Be, ho->Te, d_probs, d_logits, (void*)s)) return rc;
     HIP_TRY(hipMemcpyAsync(got.data(), d_logits ? d_logits : d_probs, got.size() * 4, hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));
-    double mxv = 0.0, sq = 0.0;
-    for (size_t i = 0; i < got.size(); ++i) {
-        const double d = std::fabs((double)got[i] - ho->ref[i]);
-        if (!(d <= mxv)) mxv = d;                                // (NaN counts as the maximum)
-        sq += d * d;
-    }
-    *mx = mxv; *rms = std::sqrt(sq / got.size());
+    double st[2];
+    uitk_deviation_stats(got.data(), ho->ref.data(), got.size(), st);
+    *mx = st[0]; *rms = st[1];
     return UITK_OK;
 }
 
@@ -971,7 +986,9 @@ static int calibration_acceptance(uitk_model* m, const uitk_weights* w, NaiveNet
         HIP_TRY(hipMemcpy(m->image, img.data(), img.size(), hipMemcpyHostToDevice));
         if (int rc = heldout_score(m, &ho, s, &mx[which], &rms[which])) return rc;
     }
-    const bool accept = std::isfinite(mx[1]) && mx[1] * 100.0 <= (double)m->calib_accept_pct * mx[0];
+    // (a nearest image that answers NaN on a held-out clip loses to any finite calibrated one; two NaN images: the nearest one stays and
+    //  the budget check below sends the handle up the ladder)
+    const bool accept = std::isfinite(mx[1]) && (!std::isfinite(mx[0]) || mx[1] * 100.0 <= (double)m->calib_accept_pct * mx[0]);
     if (!accept) {
         HIP_TRY(hipDeviceSynchronize());
         HIP_TRY(hipMemcpy(m->image, m->img_nearest.data(), m->img_nearest.size(), hipMemcpyHostToDevice));

@@ -96,37 +96,15 @@ __global__ void cal_init_stream_kernel(const float* __restrict__ table, int M, i
     }
 }
 
-// Y[m][o] = (accumulate ? Y[m][o] : 0) + act(bias[o] + sum_k X[m][k] W[o][k]);  K multiple of 16.  act: 0 none, 1 ReLU, 2 exact GELU
-__global__ void cal_linear_kernel(const float* __restrict__ X, const float* __restrict__ W, const float* __restrict__ bias,
-                                  float* __restrict__ Y, int M, int K, int O, int act, int accumulate) {
-    __shared__ float xs[TS][TS + 1], ws[TS][TS + 1];
-    const int tx = threadIdx.x, ty = threadIdx.y;
-    const int m = blockIdx.y * TS + ty, o = blockIdx.x * TS + tx, ow = blockIdx.x * TS + ty;
-    float acc = 0.f;
-    for (int k0 = 0; k0 < K; k0 += TS) {
-        xs[ty][tx] = m < M ? X[(int64_t)m * K + k0 + tx] : 0.f;
-        ws[ty][tx] = ow < O ? W[(int64_t)ow * K + k0 + tx] : 0.f;
-        __syncthreads();
-#pragma unroll
-        for (int kk = 0; kk < TS; ++kk) acc += xs[ty][kk] * ws[tx][kk];
-        __syncthreads();
-    }
-    if (m < M && o < O) {
-        float v = acc + (bias ? bias[o] : 0.f);
-        if (act == 1) v = fmaxf(v, 0.f);
-        else if (act == 2) v = 0.5f * v * (1.0f + erff(v * 0.70710678118654752f));
-        float* y = Y + (int64_t)m * O + o;
-        *y = accumulate ? *y + v : v;
-    }
-}
-
 constexpr int LT = 64;
-// The same linear for the large token counts of precision 'f32' (a batch, not a calibration set): 64 x 64 outputs per workgroup on the matrix
-// pipe's EXACT-fp32 mode (v_mfma_f32_16x16x4_f32: fp32 operands, fp32 accumulate -- what the front-end's mel stage uses in its 4x4x1 form;
-// precision 'f32' 185 k clips/s with the kernel above -> 387 k with plain register tiling -> 415 k here; 542 k with the attention
-// kernel below).  Wave w owns token rows 16w .. 16w+15 of the tile and all four 16-wide output column tiles; per
-// 16-deep LDS stage four k-steps of 4.  Operand maps: A lane l = X[m = l % 16][k = l / 16], B lane l = W[o = l % 16][k = l / 16],
-// D lane l, register r = Y[m = 4 (l / 16) + r][o = l % 16].  Same products, sums in the MFMA's order instead of ascending k.
+// Y[m][o] = (accumulate ? Y[m][o] : 0) + act(bias[o] + sum_k X[m][k] W[o][k]);  K multiple of 16.  act: 0 none, 1 ReLU, 2 exact GELU.
+// The ONE linear of the plain fp32 forward, for every token count (round 6: a 16 x 16-tile scalar kernel used to take M < 2048, so the
+// 'f32' rung and the calibration statistics changed bits with the batch size -- ADVICE r5; a batch must not change its arithmetic
+// with its size): 64 x 64 outputs per workgroup on the matrix pipe's EXACT-fp32 mode (v_mfma_f32_16x16x4_f32: fp32 operands, fp32
+// accumulate -- what the front-end's mel stage uses in its 4x4x1 form; precision 'f32': 185 k clips/s with a scalar tile -> 387 k with
+// plain register tiling -> 415 k here; 542 k with the attention kernel below).  Wave w owns token rows 16w .. 16w+15 of the tile and
+// all four 16-wide output column tiles; per 16-deep LDS stage four k-steps of 4.  Operand maps: A lane l = X[m = l % 16][k = l / 16],
+// B lane l = W[o = l % 16][k = l / 16], D lane l, register r = Y[m = 4 (l / 16) + r][o = l % 16].  Sums in the MFMA's order.
 typedef float f4m __attribute__((ext_vector_type(4)));
 __global__ void __launch_bounds__(256) naive_linear_mfma_kernel(const float* __restrict__ X, const float* __restrict__ W, const float* __restrict__ bias,
                                                                 float* __restrict__ Y, int M, int K, int O, int act, int accumulate) {
@@ -252,11 +230,7 @@ __global__ void cal_colmean_kernel(const float* __restrict__ X, float* __restric
 }
 
 static hipError_t linear(const float* X, const float* W, const float* b, float* Y, int M, int K, int O, int act, int accumulate, hipStream_t s) {
-    if (M >= 2048) {                                                       // (small sets -- the library's calibration clips, a B = 64 batch -- fill the chip better with the small tiles)
-        hipLaunchKernelGGL(naive_linear_mfma_kernel, dim3((O + LT - 1) / LT, (M + LT - 1) / LT), dim3(256), 0, s, X, W, b, Y, M, K, O, act, accumulate);
-        return hipGetLastError();
-    }
-    hipLaunchKernelGGL(cal_linear_kernel, dim3((O + TS - 1) / TS, (M + TS - 1) / TS), dim3(TS, TS), 0, s, X, W, b, Y, M, K, O, act, accumulate);
+    hipLaunchKernelGGL(naive_linear_mfma_kernel, dim3((O + LT - 1) / LT, (M + LT - 1) / LT), dim3(256), 0, s, X, W, b, Y, M, K, O, act, accumulate);
     return hipGetLastError();
 }
 static hipError_t gram(const float* X, float* G, int M, int K, float scale, int bf16, hipStream_t s, const float* mu = nullptr) {

@@ -156,9 +156,21 @@ __device__ __forceinline__ void ring_issue(const char* wstream, char* ring, int 
 template <int WAVES, bool SB = false>
 __device__ __forceinline__ void ring_step(const char* wstream, char* ring, int t, int wave, int lane) {
     constexpr int PER_WAVE = STAGE_FRAGS / WAVES;
+#if defined(UITK_LAB) && defined(AX_FENCE)           // lab probes of the ring's two orderings (profiles/round6/f16ax_race.log)
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+#endif
+#if defined(UITK_LAB) && defined(AX_BAR2)
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+#endif
     ring_issue<WAVES, SB>(wstream, ring, t + PREFETCH, wave, lane);
     // all but the PREFETCH*PER_WAVE youngest LDS-DMAs (stages t+1 .. t+PREFETCH) have landed => this wave's share of stage t
+#if defined(UITK_LAB) && defined(AX_VM0)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#else
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PREFETCH * PER_WAVE) : "memory");
+#endif
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
 }
@@ -1306,10 +1318,15 @@ __global__ __launch_bounds__(WAVES * 64, 2) void uit_encoder_kernel(EncoderArgs 
                         // disassembly shows nothing the hazard rules forbid.  Measured, not explained (profiles/round5/f16ax_bisect.log):
                         // the separate chain costs one packed add and is right (6e-5)
                         if (ct == 0) {
+#if defined(UITK_LAB) && defined(AX_CHAINED)
+#pragma unroll
+                            for (int s = 0; s < 4; ++s) acc = OP::mfma32(A[s], Xlo1[s], acc);      // lab: the chained form (profiles/round5/f16ax_bisect.log)
+#else
                             f4 accl = splat(0.f);
 #pragma unroll
                             for (int s = 0; s < 4; ++s) accl = OP::mfma32(A[s], Xlo1[s], accl);
                             acc = acc + accl;
+#endif
                         }
                     }
                     if (half == 0) Qh[i][ct] = OP::pack4(acc); else Kh[i][ct] = OP::pack4(acc);

@@ -543,9 +543,21 @@ class UITBase(nn.Module):
         refused = check is not None and not check["accepted"]
         if refused:                                       # the nearest-rounded image stayed
             handle.mode["precision"] = {'f16c': 'f16', 'fp8c': 'fp8'}.get(start_as, start_as + ' (nearest on its grid)')
-        if self.precision not in ('auto', 'f16c', 'f16a') or not (esc.value >= 0 or refused):
+        if not (esc.value >= 0 or refused):
             return handle
         dev_now = None if check is None else (check["max_nearest"] if refused else check["max_calibrated"])
+        if self.precision not in ('auto', 'f16c', 'f16a'):
+            # any other explicit calibrating precision ('f16ax', 'fp8c', 'fp8w'): no ladder, but never silent -- a refusal leaves
+            # the nearest image on its grid, and a parity precision over its budget ('f16ax': the library names the next rung) says so
+            if esc.value >= 0 or refused:
+                what = ("the acceptance check refused the calibrated image (calibrated %.2e vs nearest %.2e on the held-out clips): the handle runs the "
+                        "nearest-rounded image" % (check["max_calibrated"], check["max_nearest"])) if refused else \
+                       ("held-out deviation %s over the budget of %.1e" % ("n/a" if dev_now is None else "%.2e" % dev_now, handle.mode["budget"]))
+                handle.mode["reason"] = what
+                warnings.warn(f"uit_mobile_amd: precision='{self.precision}' on cuda:{idx}: {what}; an explicit '{self.precision}' does not escalate"
+                              + (f" (the library names '{_PRECISION_NAMES[esc.value]}' as the next rung)" if esc.value >= 0 else "")
+                              + " -- use precision='auto' (the default) for the guaranteed parity mode", UitkParityWarning, stacklevel=6)
+            return handle
         why = ("calibration refused by the acceptance check (calibrated %.2e vs nearest %.2e on the held-out clips)" % (check["max_calibrated"], check["max_nearest"])
                if refused else "held-out deviation of the calibrated image over the budget") if check is not None else "the held-out check failed"
         if dev_now is not None:
@@ -573,8 +585,13 @@ class UITBase(nn.Module):
                 nxt_code = e2.value
             out2 = (ctypes.c_float * 2)()
             _lib.check(L.uitk_self_check(nxt.ptr, ctypes.byref(w), stream, out2), "uitk_self_check")
-            sc = None if out2[0] < 0 else (float(out2[0]), float(out2[1]))
-            if sc is not None and cur_dev is not None and sc[0] >= cur_dev and to != 'f32':
+            sc = None if out2[0] < 0 else (float(out2[0]), float(out2[1]))      # (a negative value = "the check does not apply"; NaN is a measurement)
+            if sc is not None and not math.isfinite(sc[0]):
+                # a rung that answers NaN / Inf on a held-out clip is WORSE than anything finite (`nan >= cur_dev` is False, so
+                # the rung used to be taken): never installed, reported, and the ladder goes on
+                why += "; the build '%s' is not finite on the held-out clips (not taken)" % to
+                cur.mode.setdefault("self_check_split", sc)
+            elif sc is not None and cur_dev is not None and math.isfinite(cur_dev) and sc[0] >= cur_dev and to != 'f32':
                 # no better: what is over budget is not what that build splits -- it is not taken (the next rung still is tried)
                 why += "; the build '%s' measures %.2e there (no better)" % (to, sc[0])
                 cur.mode.setdefault("self_check_split", sc)
@@ -588,7 +605,7 @@ class UITBase(nn.Module):
             if to_code == _lib.PREC_F32 and not self.fp32_fallback:
                 why += "; the fp32 rung is switched off (fp32_fallback=False)"
                 break
-        inside = cur_dev is None or cur_dev <= handle.mode["budget"]
+        inside = cur_dev is None or (math.isfinite(cur_dev) and cur_dev <= handle.mode["budget"])
         cur.mode.update(reason=why, within_budget=inside, ladder=path)
         if cur is handle:
             warnings.warn(f"uit_mobile_amd: precision='auto' on cuda:{idx}: {why}: kept", UitkParityWarning, stacklevel=6)
