@@ -67,6 +67,14 @@ def _block_loop(k):
     return lo, hi, mf(lo, hi)
 
 
+# Round 6: the two most register-starved instantiations -- full-width attention + GELU on SHORT clips, f16, pooling mean / dm -- were
+# scratch-free in round 5 only because their asm statements (v_mbcnt pair, packed GELU arithmetic) were handed registers that MFMAs in
+# flight still read or had yet to write (test_no_mfma_hazard_that_the_compiler_cannot_see).  With honest register lifetimes they reload a
+# few values inside the block loop: measured +1 % encoder time on 0.5 s clips (0.1857 -> 0.1877 ms per 4096 clips,
+# profiles/round6/hazard_fix_ab.log).  Every other instantiation stays at zero.
+ROUND6_LOOP_SCRATCH = {"<0, 8, true, false, 1, 1, 0>": 10, "<0, 8, true, false, 1, 1, 1>": 10}
+
+
 def test_every_encoder_instantiation_has_a_scratch_free_block_loop(kernels):
     """Round 5: EVERY uit_encoder_kernel instantiation the product can launch -- short clips, GELU, full-width
     attention, the poolings, bf16 / fp8 / f16x2 / f16l6, 4-wave workgroups: all of the library's encoder kernels -- keeps its block
@@ -81,17 +89,18 @@ def test_every_encoder_instantiation_has_a_scratch_free_block_loop(kernels):
         lo, hi, n_mfma = _block_loop(k)
         assert n_mfma >= 150, (name, n_mfma)
         in_loop = [(hex(a), t) for a, t in k["insts"] if t.startswith("scratch_") and lo <= a <= hi]
-        if in_loop:
+        inst = name.split("uit_encoder_kernel")[1].split("(")[0]
+        if len(in_loop) > ROUND6_LOOP_SCRATCH.get(inst, 0):
             bad.append((name, in_loop))
         s = kernel_isa.summary(k)
         assert s["vgpr"] <= 256, name
-        spills[name.split("uit_encoder_kernel")[1].split("(")[0]] = s["vgpr_spill"]
+        spills[inst] = s["vgpr_spill"]
     assert not bad, bad
     # vector spills outside the loop (prologue / epilogue): none in the 8-wave default family; bounded everywhere
     worst = max(spills.items(), key=lambda kv: kv[1])
     print("vector registers spilled outside the block loop:", {k: v for k, v in spills.items() if v})
     assert spills["<0, 8, false, false, 0, 0, 0>"] == 0 and spills["<0, 8, true, false, 0, 0, 0>"] == 0
-    assert worst[1] <= 16, worst
+    assert worst[1] <= 20, worst                      # (round 5: 13; the 4-wave fp8 short-clip shape 19 with round 6's honest asm lifetimes)
 
 
 def test_design_md_kernel_table_matches_the_binary():
@@ -103,3 +112,33 @@ def test_design_md_kernel_table_matches_the_binary():
     have = text[text.index(design_tables.BEGIN):text.index(design_tables.END) + len(design_tables.END)]
     want = design_tables.isa_half()
     assert have == want, "DESIGN.md's generated kernel table is stale: run `python tools/design_tables.py --write`"
+
+
+def test_no_mfma_hazard_that_the_compiler_cannot_see(kernels):
+    """Round 6, the root cause of round 5's f16ax BNeckAttention race: an inline-asm VALU instruction is invisible to hipcc's hazard
+    recogniser.  With a free "=v" output the register allocator placed `v_max3_f32 v104` one instruction behind `v_mfma v[102:105]`
+    (rows 1..3 of the ones-row MFMA are dead on arrival): the MFMA's late write-back replaced the softmax maximum of a query tile by a row
+    sum -- NaN or 2.4e-3 on logits, depending on timing between the waves.  The library that shipped in round 5 had 271 such sites
+    (asm v_max / v_max3, the asm v_mbcnt pair, the GELU's packed asm) in 43 kernels, all latent but that one.  kernel_isa.mfma_hazards
+    applies the recogniser's wait-state rules to the shipped ISA; every kernel must come out clean."""
+    bad = [(name, hex(a), t, why) for name, k in kernels.items() for a, t, why in kernel_isa.mfma_hazards(k["insts"])]
+    assert not bad, bad[:10]
+
+
+def test_hazard_checker_sees_the_pattern_of_the_f16ax_race():
+    """the checker itself, on the instruction pair of the failing build (and on its padded form)"""
+    mk = lambda lines: [(4 * i, t) for i, t in enumerate(lines)]
+    race = mk(["v_mfma_f32_16x16x16_f16 v[102:105], v[116:117], v[72:73], v[68:71]", "v_max3_f32 v104, v121, v124, v195"])
+    assert len(kernel_isa.mfma_hazards(race)) == 1 and "writes v[104]" in kernel_isa.mfma_hazards(race)[0][2]
+    padded = mk(["v_mfma_f32_16x16x16_f16 v[102:105], v[116:117], v[72:73], v[68:71]", "s_nop 7", "v_max3_f32 v104, v121, v124, v195"])
+    assert kernel_isa.mfma_hazards(padded) == []
+    srcc = mk(["v_mfma_f32_16x16x32_f16 v[246:249], v[190:193], v[126:129], v[232:235]", "v_pk_mul_f32 v[232:233], v[220:221], s[44:45]"])
+    assert "SrcC" in kernel_isa.mfma_hazards(srcc)[0][2]
+    early_read = mk(["v_mfma_f32_16x16x32_f16 v[0:3], v[8:11], v[12:15], v[0:3]", "s_nop 3", "v_cvt_pk_f16_f32 v20, v0, v1"])
+    assert len(kernel_isa.mfma_hazards(early_read)) == 1
+    chain = mk(["v_mfma_f32_16x16x32_f16 v[0:3], v[8:11], v[12:15], v[0:3]", "v_mfma_f32_16x16x32_f16 v[0:3], v[8:11], v[12:15], v[0:3]"])
+    assert kernel_isa.mfma_hazards(chain) == []                    # an accumulate chain is the hardware's business
+    swap = mk(["v_max_f32_e32 v1, v2, v3", "v_mov_b32_e32 v4, v1", "v_permlane16_swap_b32_e32 v1, v4"])
+    assert any("permlane" in w for _, _, w in kernel_isa.mfma_hazards(swap))
+    trans = mk(["v_rcp_f32_e32 v1, v2", "v_pk_mul_f32 v[4:5], v[0:1], s[2:3]"])
+    assert any("transcendental" in w for _, _, w in kernel_isa.mfma_hazards(trans))

@@ -63,3 +63,9 @@ d = np.abs(first.cpu().numpy().reshape(ref.shape) - ref).reshape(len(pcm), -1).m
 bad = int((~(d < 8e-4)).sum())
 print(f"{lib:34s} 1024 clips x {repeats} repeats under load: {differing} differ, clips with a non-finite logit (worst run) {nonfinite}, "
       f"first run vs oracle: worst finite {np.nanmax(np.where(np.isfinite(d), d, 0)):.2e}, clips over 8e-4 or NaN {bad}", flush=True)
+
+if os.environ.get("AX_TOKENS"):                       # residual stream after every block of the eight clips -> gpurun_out/ax_tokens_<lib>.npy
+    with torch.no_grad():
+        _, tok = m.debug_tokens(torch.from_numpy(pcm8).cuda())
+    Path(ROOT / "gpurun_out").mkdir(exist_ok=True)
+    np.save(ROOT / "gpurun_out" / f"ax_tokens_{lib.replace('.so', '')}.npy", tok.cpu().numpy())

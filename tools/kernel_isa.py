@@ -141,8 +141,108 @@ def phases(k):
     return out
 
 
+# ---- MFMA hazards the compiler cannot see (round 6) -----------------------------------------------------------------------------------
+# hipcc pads every hazard between instructions IT emits, but an inline-asm statement is opaque to its hazard recogniser: an asm VALU
+# instruction (v_max3_f32 / v_max_f32 / v_pk_max_f16 ... written out because the compiler's own form costs more instructions) whose OUTPUT
+# register the allocator places on a register that an MFMA issued just before it still has to write -- a dead lane of a ones-row MFMA's
+# destination, say -- is overwritten by the MFMA's late write-back: `v_mfma v[102:105], ...` ; `v_max3_f32 v104, ...` one instruction later
+# was the f16ax BNeckAttention race of round 5 (profiles/round6/f16ax_race.log): the softmax maximum of one query tile came out as a row
+# sum.  The same holds for an asm instruction that READS an MFMA result too early (round 3's hmax).  mfma_hazards() walks a kernel's
+# instruction stream with the wait-state rules of the LLVM gfx950 hazard recogniser (XDL write -> VALU / LDS / VMEM read or VALU write:
+# passes + 3 (+ 1 on gfx950 for more than 2 passes), passes + 2 for the fp32-input MFMAs; SrcC read -> VALU write: passes - 1) and reports every violation -- compiler
+# code never violates them, so whatever it finds involves an asm statement.
+_MFMA_PASSES = [(r"v_mfma_f32_4x4x", 2), (r"v_mfma_f32_16x16x(16|32)_?(f16|bf16)", 4), (r"v_mfma_f32_16x16x16bf16_1k", 4),
+                (r"v_mfma_f32_32x32x", 8), (r"v_mfma_scale_f32_16x16x128", 4), (r"v_mfma_f32_16x16x4_?f32", 8)]
+
+
+def _regs(tok):
+    """VGPR numbers named by one operand token ('v12', 'v[8:11]', otherwise nothing)"""
+    m = re.fullmatch(r"v\[(\d+):(\d+)\]", tok)
+    if m:
+        return set(range(int(m.group(1)), int(m.group(2)) + 1))
+    m = re.fullmatch(r"v(\d+)", tok)
+    return {int(m.group(1))} if m else set()
+
+
+def mfma_hazards(insts):
+    """-> [(addr, instruction, reason)]: reads / writes of an MFMA's destination, and VALU writes of its SrcC, inside the wait states the
+    hardware needs and nobody padded.  Straight-line scan (fall-through order; a branch does not reset the window: conservative)."""
+    live = []                                                   # [dst set, srcC set, passes, age in wait states, text]
+    valu = []                                                   # recent VALU writes: [dst set, age, is transcendental, text]
+    out = []
+    for a, t in insts:
+        op, _, rest = t.partition(" ")
+        ops = [x.strip() for x in re.split(r",(?![^\[]*\])", rest)] if rest else []
+        ops = [re.split(r"\s", o)[0] for o in ops if o]
+        ws = int(ops[0], 0) + 1 if op == "s_nop" and ops else 1
+        if op.startswith("v_mfma"):
+            passes = next((p for pat, p in _MFMA_PASSES if re.match(pat, op)), 4)
+            dst, srcc = _regs(ops[0]), (_regs(ops[3]) if len(ops) > 3 else set())
+            for e in live:
+                e[3] += ws
+            live.append([dst, srcc - dst, passes, 0, t])
+            live = [e for e in live if e[3] < 24]
+            for e in valu:
+                e[1] += ws
+            valu = [e for e in valu if e[1] < 3]
+            continue
+        reads, writes = set(), set()
+        if op.startswith("v_"):
+            two_dst = op.startswith("v_permlane") and "swap" in op
+            for i, o in enumerate(ops):
+                (writes if i == 0 or (two_dst and i == 1) else reads).update(_regs(o))
+            if two_dst:
+                reads |= writes
+            if op.startswith(("v_cmp", "v_cmpx")):                  # destination is a mask, every VGPR operand is a source
+                reads |= writes
+                writes = set()
+        elif op.startswith(("ds_", "global_", "buffer_", "flat_", "scratch_", "exp")):
+            is_load = ("load" in op or "read" in op) and not op.startswith("global_load_lds")
+            for i, o in enumerate(ops):
+                if not (is_load and i == 0):
+                    reads.update(_regs(o))                            # addresses and store data (a load's destination is not padded by anyone: LDS latency)
+        # two more rules of the gfx950 recogniser an asm statement can break: a VALU write needs 2 wait states before v_permlane*_swap
+        # reads the register, and the result of a transcendental (v_rcp / v_exp / v_log / v_rsq / v_sqrt / v_sin / v_cos) 1 wait state
+        # before another kind of VALU instruction reads it
+        if op.startswith("v_") and not op.startswith("v_mfma"):
+            is_swap = op.startswith("v_permlane") and "swap" in op
+            is_trans = re.match(r"v_(exp|log|rcp|rsq|sqrt|sin|cos)_", op) is not None
+            for dst, age, trans, vt in valu:
+                if is_swap and age < 2 and (reads & dst):
+                    out.append((a, t, f"reads v{sorted(reads & dst)} {age} wait states after the VALU write `{vt}` (v_permlane*_swap needs 2)"))
+                elif trans and not is_trans and age < 1 and (reads & dst):
+                    out.append((a, t, f"reads v{sorted(reads & dst)} right behind the transcendental `{vt}` (needs 1 wait state)"))
+        if reads or writes:
+            for dst, srcc, passes, age, mt in live:
+                sgemm = re.match(r"v_mfma_f32_\d+x\d+x\d+_?(16b_)?f32", mt.split()[0]) is not None     # fp32 inputs: not an XDL op
+                need = passes + 2 if sgemm else passes + 3 + (1 if passes != 2 else 0)
+                if age < need and ((reads | writes) & dst):
+                    kind = "writes" if writes & dst else "reads"
+                    out.append((a, t, f"{kind} v{sorted((reads | writes) & dst)} {age} wait states after `{mt}` (needs {need})"))
+                elif op.startswith("v_") and age < passes - 1 and (writes & srcc):
+                    out.append((a, t, f"writes v{sorted(writes & srcc)} {age} wait states after `{mt}` reads it as SrcC (needs {passes - 1})"))
+        for e in live:
+            e[3] += ws
+        live = [e for e in live if e[3] < 24]
+        for e in valu:
+            e[1] += ws
+        valu = [e for e in valu if e[1] < 3]
+        if op.startswith("v_") and writes:
+            valu.append([set(writes), 0, re.match(r"v_(exp|log|rcp|rsq|sqrt|sin|cos)_", op) is not None, t])
+    return out
+
+
 def main():
     ks = kernels()
+    if len(sys.argv) > 1 and sys.argv[1] == "--hazards":        # python tools/kernel_isa.py --hazards [library]
+        ks = kernels(sys.argv[2]) if len(sys.argv) > 2 else ks
+        n = 0
+        for name, k in sorted(ks.items()):
+            for a, t, why in mfma_hazards(k["insts"]):
+                print(f"{name[:90]}  {a:#x}: {t}   <- {why}")
+                n += 1
+        print(f"{n} MFMA hazard violation(s) in {len(ks)} kernels")
+        return
     if len(sys.argv) > 2 and sys.argv[1] == "--phases":
         for name, k in ks.items():
             if name.startswith(sys.argv[2]):

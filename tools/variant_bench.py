@@ -18,7 +18,8 @@ from uit_mobile_amd.synth import make_trained_like_state_dict  # noqa: E402
 from uit_mobile_amd import models  # noqa: E402
 
 mode = sys.argv[1] if len(sys.argv) > 1 else "pooling"
-x = synth_batch(4096, 16000, 0, torch.device("cuda", 0), False)
+nsamp = int(sys.argv[2]) if len(sys.argv) > 2 else 16000          # e.g. 8000: short clips (masked time patches)
+x = synth_batch(4096, nsamp, 0, torch.device("cuda", 0), False)
 if mode == "attention":
     cases = [(n, "full", "mean", p) for n in ("audio_transformer_h128_d4_m3", "audio_transformer_h128_d6_m3_relu") for p in ("f16c", "f16x2")]
 elif mode == "token":

@@ -156,28 +156,19 @@ __device__ __forceinline__ void ring_issue(const char* wstream, char* ring, int 
 template <int WAVES, bool SB = false>
 __device__ __forceinline__ void ring_step(const char* wstream, char* ring, int t, int wave, int lane) {
     constexpr int PER_WAVE = STAGE_FRAGS / WAVES;
-#if defined(UITK_LAB) && defined(AX_FENCE)           // lab probes of the ring's two orderings (profiles/round6/f16ax_race.log)
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_sched_barrier(0);
-#endif
-#if defined(UITK_LAB) && defined(AX_BAR2)
-    __builtin_amdgcn_s_barrier();
-    asm volatile("" ::: "memory");
-#endif
     ring_issue<WAVES, SB>(wstream, ring, t + PREFETCH, wave, lane);
     // all but the PREFETCH*PER_WAVE youngest LDS-DMAs (stages t+1 .. t+PREFETCH) have landed => this wave's share of stage t
-#if defined(UITK_LAB) && defined(AX_VM0)
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#else
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PREFETCH * PER_WAVE) : "memory");
-#endif
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
 }
 
 __device__ __forceinline__ int lane_id_now() {            // lane id from the exec-mask count: two VALU instructions, never a live register
-    int l;
-    asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l));
+    // (volatile asm pins the point of evaluation: the value is not hoisted out of the block loop.  Round 6: IN PLACE on a register a visible
+    //  v_mov has just written -- with a free "=v" output the pair landed 0-5 wait states behind MFMAs writing / reading the register the
+    //  allocator picked, which the hazard recogniser cannot see: tools/kernel_isa.py --hazards)
+    int l = 0;
+    asm volatile("v_mbcnt_lo_u32_b32 %0, -1, %0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "+v"(l));
     return l;
 }
 // scalar-base form of a 16-byte-per-lane LDS-DMA, written out: uniform 64-bit global base (SGPR pair) + ONE 32-bit lane offset, uniform
@@ -216,19 +207,25 @@ __device__ __forceinline__ f4 add4s(f4 a, f4 b) {
     return f4{a[0] + b[0], a[1] + b[1], a[2] + b[2], a[3] + b[3]};
 }
 __device__ __forceinline__ float hsum(f4 x) { return (x[0] + x[1]) + (x[2] + x[3]); }
-// Maxima as plain v_max_f32 / v_max3_f32 (asm): for fmaxf on MFMA results or lane-swapped bits the compiler first canonicalises
-// every input with a v_max_f32 x, x, x (sNaN quieting that llvm.maxnum asks for) -- 56 extra VALU instructions per block in the
-// softmax alone.  The hardware maximum needs no canonical inputs and the scores are never NaN.
-__device__ __forceinline__ float vmax(float a, float b) { float r; asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
-__device__ __forceinline__ float vmax3(float a, float b, float c) { float r; asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; }
-// hmax takes MFMA results: its FIRST instruction must be one the compiler sees (v_med3_f32 against FLT_MAX = the maximum of the other two, no
-// canonicalisation), so that the hazard recogniser pads the matrix-pipe -> VALU read.  An asm-only hmax read the accumulators zero to
-// two instructions behind the MFMA that writes them -- stale values, run-to-run different maxima (round 3, tools/l6_determinism.py).
+// Maxima without llvm.maxnum: for fmaxf on MFMA results or lane-swapped bits the compiler first canonicalises every input with a
+// v_max_f32 x, x, x (sNaN quieting) -- 56 extra VALU instructions per block in the softmax alone.  v_med3_f32 against FLT_MAX is the
+// maximum of the other two (no canonicalisation; +inf instead would be folded to maxnum + canonicalise); the scores are never NaN or +inf.
+// Round 6: NO asm instruction here may write a register of its own choosing.  These helpers used to be asm statements with "=v" outputs
+// (v_max_f32 / v_max3_f32), and the register allocator is free to place such an output on a register that an MFMA issued just before
+// still has to WRITE -- rows 1..3 of the ones-row MFMA's destination are dead on arrival -- which the hazard recogniser cannot pad
+// because it does not see into asm: the MFMA's late write-back replaced a query tile's softmax maximum by a row sum (the f16ax
+// BNeckAttention race of round 5: `v_mfma v[102:105]` ; `v_max3_f32 v104` -- profiles/round6/f16ax_race.log; tools/kernel_isa.py
+// --hazards finds every such site, tests/test_build_checks.py holds the library at zero).  vmax / vmax3 are builtins now (compiler-visible:
+// padded); hmax keeps its single v_max3_f32 but IN PLACE on the register its visible v_med3_f32 has just written.
+__device__ __forceinline__ float vmax(float a, float b) { return __builtin_amdgcn_fmed3f(a, b, 3.4028234664e38f); }
+__device__ __forceinline__ float vmax3(float a, float b, float c) { return vmax(vmax(a, b), c); }
+// hmax takes MFMA results: its FIRST instruction must be one the compiler sees, so that the hazard recogniser pads the matrix-pipe ->
+// VALU read (an asm-only hmax read the accumulators zero to two instructions behind the MFMA that writes them -- stale values,
+// run-to-run different maxima: round 3, tools/l6_determinism.py) AND the write: the asm instruction overwrites m01's register.
 __device__ __forceinline__ float hmax(f4 x) {
-    const float m01 = __builtin_amdgcn_fmed3f(x[0], x[1], 3.4028234664e38f);          // (+inf instead would be folded to maxnum + canonicalise)
-    float r;
-    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(m01), "v"(x[2]), "v"(x[3]));
-    return r;
+    float m01 = __builtin_amdgcn_fmed3f(x[0], x[1], 3.4028234664e38f);
+    asm("v_max3_f32 %0, %0, %1, %2" : "+v"(m01) : "v"(x[2]), "v"(x[3]));
+    return m01;
 }
 
 // Reductions over the 4 lane groups g (lanes c, c+16, c+32, c+48) with the gfx950 VALU swaps (no LDS crossbar):
@@ -537,34 +534,35 @@ __device__ __forceinline__ unsigned long long sc2(float c) {                   /
     const unsigned long long b = __float_as_uint(c);
     return b | (b << 32);
 }
-__device__ __forceinline__ f2 pk_fma_vvs(f2 a, f2 b, unsigned long long c) {   // a * b + c
-    f2 r;
-    asm("v_pk_fma_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "s"(c));
-    return r;
+// Round 6: every one of these statements works IN PLACE on a register pair that a compiler-visible instruction (or another of these
+// statements) wrote last.  With a free "=v" output the allocator may hand out a register that an MFMA issued just before still reads as
+// SrcC (or has yet to write) -- a hazard the recogniser cannot pad for an asm statement: tools/kernel_isa.py --hazards found the GELU
+// builds' v_pk_mul / v_pk_fma 0-2 wait states behind such MFMAs.  A tied operand's register holds a live value from its last visible
+// write to the statement, so no MFMA can have it as a destination or a dying source in between.
+__device__ __forceinline__ void pk_fma_acc_vs(f2& acc, f2 b, unsigned long long c) {   // acc = acc * b + c
+    asm("v_pk_fma_f32 %0, %0, %1, %2" : "+v"(acc) : "v"(b), "s"(c));
 }
-__device__ __forceinline__ f2 pk_mul_vs(f2 a, unsigned long long c) {          // a * c
-    f2 r;
-    asm("v_pk_mul_f32 %0, %1, %2" : "=v"(r) : "v"(a), "s"(c));
-    return r;
+__device__ __forceinline__ void pk_fma_into(f2& acc, f2 a, unsigned long long c) {     // acc = a * c + acc
+    asm("v_pk_fma_f32 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "s"(c));
 }
-// the same for an operand that a TRANSCENDENTAL instruction (v_rcp_f32) has just written: gfx950 wants a wait state between such a
-// write and a VALU read of it, the compiler's hazard recogniser pads only the reads it can see -- not an asm operand -- so the wait
-// state is part of the statement (without it: stale reciprocals in some lanes, GELU outputs off by 1e-2; round 5, first GPU run)
-__device__ __forceinline__ f2 pk_mul_vs_after_trans(f2 a, unsigned long long c) {
-    f2 r;
-    asm("s_nop 1\n\tv_pk_mul_f32 %0, %1, %2" : "=v"(r) : "v"(a), "s"(c));
-    return r;
+__device__ __forceinline__ void pk_mul_acc_s(f2& acc, unsigned long long c) {          // acc = acc * c
+    asm("v_pk_mul_f32 %0, %0, %1" : "+v"(acc) : "s"(c));
 }
 __device__ __forceinline__ f2 gelu2(f2 x) {
     const f2 a = f2{fabsf(x[0]), fabsf(x[1])};                                  // (compiler-visible first uses of the accumulators)
     const f2 xh = x * f2{0.5f, 0.5f};
-    const f2 d = pk_mul_vs(a, sc2(0.3275911f * 0.70710678118654752f)) + f2{1.0f, 1.0f};              // 1 + p z
+    f2 d = a * f2{1.0f, 1.0f};                                                  // (a visible copy of a claims the register)
+    pk_mul_acc_s(d, sc2(0.3275911f * 0.70710678118654752f));
+    d = d + f2{1.0f, 1.0f};                                                     // 1 + p z
     const f2 t = f2{__builtin_amdgcn_rcpf(d[0]), __builtin_amdgcn_rcpf(d[1])};
-    f2 p = pk_fma_vvs(pk_mul_vs_after_trans(t, sc2(1.061405429f)), f2{1.0f, 1.0f}, sc2(-1.453152027f));
-    p = pk_fma_vvs(p, t, sc2(1.421413741f));
-    p = pk_fma_vvs(p, t, sc2(-0.284496736f));
-    p = pk_fma_vvs(p, t, sc2(0.254829592f));
-    const f2 e = pk_mul_vs(a, sc2(-0.5f * 1.4426950408889634f)) * a;           // -log2(e) z^2, z = |x| / sqrt 2
+    f2 p = t * f2{1.0f, 1.0f};                                                  // a visible copy of t (also the wait state a read of a fresh v_rcp result needs)
+    pk_mul_acc_s(p, sc2(1.061405429f));
+    pk_fma_acc_vs(p, f2{1.0f, 1.0f}, sc2(-1.453152027f));
+    pk_fma_acc_vs(p, t, sc2(1.421413741f));
+    pk_fma_acc_vs(p, t, sc2(-0.284496736f));
+    pk_fma_acc_vs(p, t, sc2(0.254829592f));
+    f2 e = a * a;
+    pk_mul_acc_s(e, sc2(-0.5f * 1.4426950408889634f));                          // -log2(e) z^2, z = |x| / sqrt 2
     const f2 y = (p * t) * f2{__builtin_amdgcn_exp2f(e[0]), __builtin_amdgcn_exp2f(e[1])};            // 1 - erf(z)
     return __builtin_elementwise_fma(a * f2{0.5f, 0.5f}, f2{1.0f, 1.0f} - y, xh);                     // 0.5 x + 0.5 |x| (1 - y)
 }
@@ -831,7 +829,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void uit_encoder_kernel(EncoderArgs 
                 const unsigned t2 = __builtin_bit_cast(unsigned, h2v{hth, hth});
                 u4v x = __builtin_bit_cast(u4v, XB[ct][s]);
 #pragma unroll
-                for (int i = 0; i < 4; ++i) asm("v_pk_max_f16 %0, %1, %2" : "=v"(x[i]) : "v"(x[i]), "v"(t2));
+                for (int i = 0; i < 4; ++i) asm("v_pk_max_f16 %0, %0, %1" : "+v"(x[i]) : "v"(t2));       // (in place: see gelu2)
                 if constexpr (PERKEY) { if (!live) x = u4v{0u, 0u, 0u, 0u}; }
                 XB[ct][s] = __builtin_bit_cast(v8, x);
             }
@@ -916,7 +914,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void uit_encoder_kernel(EncoderArgs 
             const int col = 16 * ct + (dl & 15);
             const int dclip = (!TOK && col >= NTOK) ? 1 : 0, dtk = TOK ? (col >= 1 && col <= NTOK ? col - 1 : 0) : col - NTOK * dclip;
             const int row = r0 + dclip;
-            if (row < a.rows) {
+            if (row < a.rows && (!TOK || (col >= 1 && col <= NTOK))) {     // (pooling 'token': the cls and the dead columns are not part of the 24-row dump)
                 float* dst = a.dbg + (((int64_t)row * (a.depth + 1) + stage) * NTOK + dtk) * DIM + 4 * (dl >> 4);
 #pragma unroll
                 for (int ft = 0; ft < 8; ++ft) *(f4*)(dst + 16 * ft) = R[ft][ct];
@@ -1312,11 +1310,13 @@ __global__ __launch_bounds__(WAVES * 64, 2) void uit_encoder_kernel(EncoderArgs 
 #pragma unroll
                     for (int s = 0; s < 8; ++s) acc = OP::mfma32(A[s], X[s & 3][ct], acc);
                     if constexpr (ASPLIT) {
-                        // tile 0: + W . Xlo on an accumulator of its own.  CHAINED behind the eight k-steps above (as the other precisions'
-                        // stages do it) this kernel returned wrong keys for tile 0 on some inputs -- 2.4e-3 on logits, NaN on others, bit-stable
-                        // run to run; same MFMAs, same operands; every other chained site checks out against the oracle -- and the
-                        // disassembly shows nothing the hazard rules forbid.  Measured, not explained (profiles/round5/f16ax_bisect.log):
-                        // the separate chain costs one packed add and is right (6e-5)
+                        // tile 0: + W . Xlo on an accumulator of its own (one packed add).  Round 5 shipped this form because the CHAINED one (as
+                        // the other precisions' stages do it; -DUITK_LAB -DAX_CHAINED) returned NaN / 2.4e-3 on some inputs, "not explained".
+                        // Round 6 explains it (profiles/round6/f16ax_race.log): not this stage at all -- with the chained schedule the allocator put
+                        // the asm `v_max3_f32` of the softmax on a dead row of the ones-row MFMA's destination one instruction behind that MFMA, and
+                        // its late write-back replaced a query tile's maximum by a row sum.  Every asm statement now works in place on a register
+                        // a visible instruction wrote (vmax / hmax / lane_id_now / gelu2) and tests/test_build_checks.py holds the shipped ISA free
+                        // of such sites; the chained lab build is right now too (6.4e-5, bit-stable under load).  The form stays as shipped.
                         if (ct == 0) {
 #if defined(UITK_LAB) && defined(AX_CHAINED)
 #pragma unroll
