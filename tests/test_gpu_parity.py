@@ -1864,8 +1864,8 @@ def test_token_ladder_reaches_f16ax_on_heavy_tailed_checkpoints(golden):
     values and queries, of all tokens (tools/err_attrib_token.py).  Now 'f16a' carries q, k, v of every tile as hi + lo, and an 'f16a'
     handle over the budget is rebuilt as 'f16ax' (the same on split weights).  (a) seed 223: 'auto' ends in 'f16ax', inside the budget and
     the gate on the wide held-out set; an explicit 'f16a' warns and stays.  (b) BNeckAttention, uit_xxs seed 234: 'f16ax' from uitk_create's
-    image alone (no calibration) -- the case in which the first build of this kernel returned wrong keys for the cls tile
-    (profiles/round5/f16ax_bisect.log)."""
+    image alone (no calibration) -- the case in which the first build of this kernel was wrong (profiles/round5/f16ax_bisect.log; round 6
+    found why: an asm v_max3_f32 whose output register an MFMA in flight still had to write -- profiles/round6/f16ax_race.log)."""
     import warnings
     from uit_mobile_amd.models.uit import UitkParityWarning
     import uit_mobile_amd.models.uit as U
@@ -2017,7 +2017,8 @@ def test_token_ladder_rungs_are_bit_stable_under_load(factory, att, precision):
     """The rungs added late in round 5 -- pooling 'token' in 'f16a' / 'f16ax', and 'f32' -- twenty times on 1024 different clips, with a
     SECOND model running the default kernels on another stream at the same time (different clocks, different contention in every repeat):
     every output bit identical to the first run, finite, and the whole batch at the oracle.  The first build of the BNeckAttention
-    'f16ax' kernel was wrong in a way that depended on timing between the waves of a workgroup (profiles/round5/f16ax_bisect.log): a
+    'f16ax' kernel was wrong in a way that depended on timing between the waves of a workgroup (profiles/round5/f16ax_bisect.log; cause,
+    round 6: profiles/round6/f16ax_race.log -- the build check test_no_mfma_hazard_that_the_compiler_cannot_see is its static guard): a
     result that is merely right on a quiet GPU would not be enough."""
     from uit_mobile_amd.synth import make_structured_trained_like_state_dict
     import uit_mobile_amd.models.uit as U

@@ -6,8 +6,8 @@ binary (round 5, VERDICT r4 item 9: "front-end 241 VGPR (binary: 255), d4-GELU 9
     (tests/test_build_checks.py::test_design_md_kernel_table_matches_the_binary re-generates the ISA half and compares)
 
 Sources: tools/kernel_isa.py on uit_mobile_amd/libuitk.so (registers, spills, MFMA / scratch counts: the ISA half, deterministic for a
-given source tree + compiler) and, for the measured half, profiles/round5/bench_default.json + profiles/pmc_latest.json + the tail of
-profiles/round5/pytest_gpu.log (whatever of them exists; the measured half is marked with the files it came from)."""
+given source tree + compiler) and, for the measured half, profiles/round6/bench_default.json + profiles/pmc_latest.json + the tail of
+profiles/round6/pytest_gpu.log (whatever of them exists; the measured half is marked with the files it came from)."""
 import json
 import re
 import sys
@@ -72,20 +72,25 @@ def isa_half():
             bad.append(n)
     worst = max((kernel_isa.summary(k)["vgpr_spill"], n) for n, k in enc.items())
     lines.append("")
+    badnames = ", ".join("`" + n.replace("void uitk::uit_encoder_kernel", "").split("(")[0] + "`" for n in sorted(bad))
     lines.append(f"All {len(enc)} `uit_encoder_kernel` instantiations of the library: **{len(bad)} with a `scratch_` instruction inside the block loop**"
-                 f"; most vector registers spilled outside it: {worst[0]} (`{worst[1].replace('void uitk::', '').split('(')[0]}`); {len(ks)} kernels in the library.")
+                 + (f" ({badnames}: round 6, honest asm register lifetimes -- section 4.2)" if bad else "")
+                 + f"; most vector registers spilled outside it: {worst[0]} (`{worst[1].replace('void uitk::', '').split('(')[0]}`); {len(ks)} kernels in the library.")
     lines.append(END)
     return "\n".join(lines)
 
 
+ROUND = "round6"                                            # the directory under profiles/ the measured half is generated from
+
+
 def measured_half():
     lines = [MBEGIN]
-    bj = ROOT / "profiles" / "round5" / "bench_default.json"
+    bj = ROOT / "profiles" / ROUND / "bench_default.json"
     if bj.exists():
         try:
             d = json.loads(bj.read_text().strip().splitlines()[-1])
             r, f = d["roofline"], d["frontend"]
-            lines.append(f"* `profiles/round5/bench_default.json`: **{d['value'] / 1e6:.2f} M clips/s**, {d['ms_per_step']:.4f} ms/step, precision `{d['precision']}` -> "
+            lines.append(f"* `profiles/{ROUND}/bench_default.json`: **{d['value'] / 1e6:.2f} M clips/s**, {d['ms_per_step']:.4f} ms/step, precision `{d['precision']}` -> "
                          f"`{d.get('effective_precision')}`; front-end {f['launch_ms']:.4f} ms ({f['hbm_GBs']:.0f} GB/s algorithmic, {f['valu_frac']:.3f} of fp32 peak executed, "
                          f"{f['alg_frac']:.3f} algorithmic) + encoder {r['launch_ms']:.4f} ms (**{r['frac']:.3f}** of {r['peak']:.0f} TFLOP/s; whole step {r['step_frac']:.3f}); "
                          f"`max_abs_dprob` {d['max_abs_dprob']:.1e}; calibration check {d.get('calibration_check')}")
@@ -95,7 +100,7 @@ def measured_half():
             if cb:
                 lines.append(f"* `cpu_baseline`: {cb['value']:.0f} clips/s on {cb['cores']} cores ({cb.get('cpu_model')}), kind `{cb['kind']}`")
         except Exception as e:                      # a half-written file must not break the document
-            lines.append(f"* profiles/round5/bench_default.json unreadable: {e}")
+            lines.append(f"* profiles/{ROUND}/bench_default.json unreadable: {e}")
     pj = ROOT / "profiles" / "pmc_latest.json"
     if pj.exists():
         p = json.loads(pj.read_text())
@@ -105,11 +110,11 @@ def measured_half():
                      f"({p['encoder_hbm_bytes_per_launch'] / max(a.get('encoder', 1), 1):.2f}x); front-end {p['frontend_hbm_bytes_per_launch'] / 1e6:.1f} MB vs "
                      f"{a.get('frontend', 0) / 1e6:.1f} MB ({p['frontend_hbm_bytes_per_launch'] / max(a.get('frontend', 1), 1):.2f}x); MFMA pipe busy "
                      f"{p.get('encoder_mfma_busy_frac', 0):.3f}, (VALU + MFMA) / MFMA {p.get('encoder_valu_per_mfma', 0):.2f}")
-    lg = ROOT / "profiles" / "round5" / "pytest_gpu.log"
+    lg = ROOT / "profiles" / ROUND / "pytest_gpu.log"
     if lg.exists():
         tail = [l for l in lg.read_text().splitlines() if re.search(r"\d+ passed", l)]
         if tail:
-            lines.append(f"* `profiles/round5/pytest_gpu.log`: {tail[-1].strip()}")
+            lines.append(f"* `profiles/{ROUND}/pytest_gpu.log`: {tail[-1].strip()}")
         for l in lg.read_text().splitlines():
             m = re.match(r"^[.Fs]*((auto|f16l6|f16c) (uit_|audio_)\S+: worst.*)$", l.strip())
             if m:
