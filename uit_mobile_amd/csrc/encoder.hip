@@ -164,12 +164,13 @@ __device__ __forceinline__ void ring_step(const char* wstream, char* ring, int t
 }
 
 __device__ __forceinline__ int lane_id_now() {            // lane id from the exec-mask count: two VALU instructions, never a live register
-    // (volatile asm pins the point of evaluation: the value is not hoisted out of the block loop.  Round 6: IN PLACE on a register a visible
-    //  v_mov has just written -- with a free "=v" output the pair landed 0-5 wait states behind MFMAs writing / reading the register the
-    //  allocator picked, which the hazard recogniser cannot see: tools/kernel_isa.py --hazards)
-    int l = 0;
-    asm volatile("v_mbcnt_lo_u32_b32 %0, -1, %0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "+v"(l));
-    return l;
+    // (round 6: the two v_mbcnt as BUILTINS on an opaque scalar zero.  The volatile asm statement pins the point of evaluation -- the value
+    //  is not hoisted out of the block loop -- while the v_mbcnt pair stays compiler-visible: as an asm statement with a free "=v" output
+    //  it landed 0-5 wait states behind MFMAs writing / reading the register the allocator picked, which the hazard recogniser cannot
+    //  see: tools/kernel_isa.py --hazards)
+    unsigned z;
+    asm volatile("s_mov_b32 %0, 0" : "=s"(z));
+    return (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, z));
 }
 // scalar-base form of a 16-byte-per-lane LDS-DMA, written out: uniform 64-bit global base (SGPR pair) + ONE 32-bit lane offset, uniform
 // LDS address in M0.  The builtin selects the 64-bit per-lane address form, i.e. a register pair per distinct piece that stays live
