@@ -9,6 +9,7 @@ head runs on split hi+lo operands -- held to the library's absolute budget on it
 subject.  The bf16-operand and fp8 modes are measured, non-parity modes: their tests assert measured bounds and say so.
 """
 import os
+import sys
 from pathlib import Path
 
 import numpy as np
@@ -2059,3 +2060,16 @@ def test_token_ladder_rungs_are_bit_stable_under_load(factory, att, precision):
     d = float(np.abs(first.cpu().numpy().reshape(ref.shape) - ref).max())
     print(f"{factory} {precision}: 20 repeats beside a second model on another stream: {differing} differ; 1024 clips vs oracle {d:.2e}")
     assert differing == 0 and bool(torch.isfinite(first).all()) and d < 8e-4
+
+
+@pytest.mark.gpu
+def test_fuzz_over_instantiations_against_the_oracle():
+    """Round 6: random combinations of factory x pooling x precision x clip length (short / full / odd / multi-crop) x batch size x
+    input dtype x workgroup shape against the C oracle on trained-like weights (tools/fuzz_instantiations.py; 2 000 cases on record in
+    profiles/round6/fuzz_instantiations.log).  After the hazard clean-up of the encoder's inline asm every instantiation's ISA changed;
+    the tests above walk the families one at a time, this walks combinations nobody wrote down.  Fixed seed, time-boxed."""
+    sys.path.insert(0, str(Path(__file__).resolve().parents[1] / "tools"))
+    import fuzz_instantiations
+    rows, bad = fuzz_instantiations.run(cases=100, seed=6, budget_s=90, verbose=False)
+    print(f"{len(rows)} random cases; " + ("all inside their gates" if not bad else f"{len(bad)} outside"))
+    assert len(rows) >= 40 and not bad, bad[:5]
