@@ -106,26 +106,43 @@ constexpr int LT = 64;
 // all four 16-wide output column tiles; per 16-deep LDS stage four k-steps of 4.  Operand maps: A lane l = X[m = l % 16][k = l / 16],
 // B lane l = W[o = l % 16][k = l / 16], D lane l, register r = Y[m = 4 (l / 16) + r][o = l % 16].  Sums in the MFMA's order.
 typedef float f4m __attribute__((ext_vector_type(4)));
+// (Round 6: the global loads of a stage are one 16-byte load per thread and operand, issued a whole stage ahead into registers, and the
+// LDS tiles ping-pong -- one __syncthreads per 16-deep stage instead of two, the memory round trip under the previous stage's MFMAs.
+// The same products summed in the same order: bit-identical with the kernel as it was.)
 __global__ void __launch_bounds__(256) naive_linear_mfma_kernel(const float* __restrict__ X, const float* __restrict__ W, const float* __restrict__ bias,
                                                                 float* __restrict__ Y, int M, int K, int O, int act, int accumulate) {
-    __shared__ float xs[TS][LT + 4], ws[TS][LT + 4];
+    __shared__ float xs[2][TS][LT + 4], ws[2][TS][LT + 4];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, lr = lane & 15, lq = lane >> 4;
     const int m0 = blockIdx.y * LT, o0 = blockIdx.x * LT;
-    f4m acc[4] = {};
-    for (int k0 = 0; k0 < K; k0 += TS) {
+    const int lrow = tid >> 2, lk = 4 * (tid & 3);                        // this thread's row of the tile and its four k of a stage
+    const bool xok = m0 + lrow < M, wok = o0 + lrow < O;
+    const float* xp = X + (int64_t)(m0 + lrow) * K + lk;
+    const float* wp = W + (int64_t)(o0 + lrow) * K + lk;
+    const f4m zero4 = {0.f, 0.f, 0.f, 0.f};
+    auto fetch = [&](int k0, f4m& xv, f4m& wv) {
+        xv = xok ? *(const f4m*)(xp + k0) : zero4;
+        wv = wok ? *(const f4m*)(wp + k0) : zero4;
+    };
+    auto stash = [&](int buf, const f4m& xv, const f4m& wv) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int idx = tid + 256 * i, r = idx >> 4, kk = idx & 15;
-            xs[kk][r] = m0 + r < M ? X[(int64_t)(m0 + r) * K + k0 + kk] : 0.f;
-            ws[kk][r] = o0 + r < O ? W[(int64_t)(o0 + r) * K + k0 + kk] : 0.f;
-        }
-        __syncthreads();
+        for (int j = 0; j < 4; ++j) { xs[buf][lk + j][lrow] = xv[j]; ws[buf][lk + j][lrow] = wv[j]; }
+    };
+    f4m acc[4] = {};
+    f4m xv, wv;
+    fetch(0, xv, wv);
+    stash(0, xv, wv);
+    __syncthreads();
+    const int nst = K / TS;
+    for (int st = 0; st < nst; ++st) {
+        const int buf = st & 1;
+        if (st + 1 < nst) fetch((st + 1) * TS, xv, wv);
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
-            const float a = xs[4 * ks + lq][16 * wave + lr];
+            const float a = xs[buf][4 * ks + lq][16 * wave + lr];
 #pragma unroll
-            for (int ot = 0; ot < 4; ++ot) acc[ot] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, ws[4 * ks + lq][16 * ot + lr], acc[ot], 0, 0, 0);
+            for (int ot = 0; ot < 4; ++ot) acc[ot] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, ws[buf][4 * ks + lq][16 * ot + lr], acc[ot], 0, 0, 0);
         }
+        if (st + 1 < nst) stash(buf ^ 1, xv, wv);
         __syncthreads();
     }
 #pragma unroll
