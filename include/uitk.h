@@ -67,7 +67,7 @@ typedef enum uitk_precision {
                            UITK_PREC_F16A handle over its budget names it */
     UITK_PREC_F32 = 8,  /* round 5: the LAST rung of the parity ladder, any family / pooling: the folded network in fp32 on the vector ALUs (the
                            plain forward of csrc/calibrate.hip: one simple kernel per operation, sums of the head in double) behind the
-                           product front-end -- ~15x slower than the MFMA encoder (711 k clips/s for UiT-XS: 60x the 64-core CPU port) and
+                           product front-end -- ~13x slower than the MFMA encoder (831 k clips/s for UiT-XS: 70x the 64-core CPU port) and
                            right for every checkpoint, e.g. those with strong attention sinks, whose fp16 activation floor no split
                            mode brings inside the budget (tools/err_attrib_sink.py).  get_option("parity_escalate_to") of a split-weight
                            handle (f16l6 / f16x2 / f16ax) that uitk_calibrate_weights measured over its budget names it */

@@ -774,7 +774,7 @@ int naive_net_bind(const uitk_model* m, NaiveNet* nn, int rows, size_t n_stats) 
 // clip-crops at a time; uitk_encode walks the batch in chunks through launch_naive_forward (calibrate.hip).  Front-end, crop
 // reduction, options and the C ABI are the product's.  ~20x slower than the MFMA encoder: for checkpoints no fp16
 // mode holds inside the budget (tools/auto_sweep.py ... sink4), where slow and right beats fast and warned about.
-constexpr int64_t F32_CHUNK = 2048;
+constexpr int64_t F32_CHUNK = 8192;                         // (round 6: 2048 -> 8192 rows per chunk: the small kernels fill the chip; ~135 KB of work buffers per row)
 struct F32Path {
     NaiveNet nn;
     DevBuf head;                                                 // norm w/b, outputlayer LayerNorm w/b, Linear w/b (fp32)
