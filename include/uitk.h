@@ -291,7 +291,11 @@ int uitk_set_timing_buffers(uitk_model* m, unsigned long long* enc_buf, unsigned
  *                       held-out clips is at most this many per cent of the nearest-rounded image's (see there); 0 = no check, install
  *                       unconditionally; 1 = refuse in practice (test of the fallback)
  *   "calib_budget_e6"   0..1000000 (default 600): absolute budget, in 1e-6 units, for the largest deviation of the image that stays
- *                       installed after uitk_calibrate_weights on the held-out clips (see there); 0 = no budget */
+ *                       installed after uitk_calibrate_weights on the held-out clips (see there); 0 = no budget
+ *   "calib_short_check" 0 (default) / 1 (round 6): the held-out clips of the acceptance check, the budget and uitk_self_check are ALSO
+ *                       scored at half length (three of six time patches: 12 of 24 tokens, masked attention) and every reported
+ *                       maximum is over both lengths -- for deployments on short clips, where fewer tokens average the rounding
+ *                       (the Python wrapper's prepare() switches it on when the prepared clip length has fewer than six time patches) */
 int uitk_set_option(uitk_model* m, const char* name, int value);
 /* Current value of an option ("fe_asym_pm": the explicit setting, else the share the latest front-end launch used, -1 = the
  * built-in 590 because nothing was measured for its shape); also "weights_calibrated" (read-only: 1 when the

@@ -1143,13 +1143,23 @@ def test_auto_escalates_instead_of_falling_back_to_nearest(golden):
     e_near, p_near = err_of(make("f16"))
     # (b)
     with pytest.warns(UitkParityWarning, match="f16l6"):
-        m = make("auto", calib_accept_pct=1)
+        m = make("auto", calib_accept_pct=1)                               # the default check (full clips only): the split build is inside the budget
         e_esc, _ = err_of(m)
     rep = m.calibration_report()
     print(f"sabotaged calibration, XS seed 207: nearest {e_near:.2e}, auto (healthy) {e_auto:.2e}, auto (sabotaged -> {m.effective_precision()}) {e_esc:.2e}; report {rep}")
     assert m.effective_precision() == "f16l6" and rep["escalated"] and not rep["accepted"] and rep["max_nearest"] > rep["budget"]
     assert rep["self_check"] is not None and rep["self_check"][0] < rep["budget"]
     assert e_near > 9e-4 and e_esc < 8e-4 and e_auto < 7e-4
+    # round 6, option calib_short_check (what prepare() switches on for a short-clip deployment): the held-out clips are also scored at
+    # half length (12 of 24 tokens: less averaging).  There the split-weight build of this checkpoint is over the budget too, so the
+    # ladder goes on -- measured: to 'f32', 3.0e-4 against the oracle
+    with pytest.warns(UitkParityWarning, match="f16l6"):
+        m = make("auto", calib_accept_pct=1, calib_short_check=1)
+        e_esc2, _ = err_of(m)
+    rep = m.calibration_report()
+    print(f"   with the half-length leg of the check: auto (sabotaged -> {m.effective_precision()}) {e_esc2:.2e}; ladder {rep.get('ladder')}")
+    assert m.effective_precision() in ("f16l6", "f32") and rep["escalated"] and "f16l6" in rep["ladder"] and e_esc2 < 8e-4
+    assert rep["within_budget"] and rep["self_check"][0] <= rep["budget"]
     with pytest.warns(UitkParityWarning, match="does not escalate"):
         m = make("f16c", calib_accept_pct=1)
         e_c, p_c = err_of(m)
@@ -2073,3 +2083,37 @@ def test_fuzz_over_instantiations_against_the_oracle():
     rows, bad = fuzz_instantiations.run(cases=100, seed=6, budget_s=90, verbose=False)
     print(f"{len(rows)} random cases; " + ("all inside their gates" if not bad else f"{len(bad)} outside"))
     assert len(rows) >= 40 and not bad, bad[:5]
+
+
+@pytest.mark.gpu
+def test_a_short_clip_deployment_is_judged_on_short_clips(golden):
+    """Round 6 (option calib_short_check): prepare() for clips of fewer than six time patches switches the half-length leg of the held-out
+    check on -- the library then scores its 48 held-out clips at 0.5 s too (12 of 24 tokens, masked attention) and every maximum it
+    reports, the budget decision included, is over both lengths; a model prepared for 1 s clips keeps round 5's check (it must not be sent
+    up the ladder for what it would do on clips it never sees).  Estimate with the leg >= estimate without (a maximum over a superset),
+    and the short clips themselves inside the gate against the C oracle."""
+    sd = make_trained_like_state_dict("uit_xs", 207)
+    tsd = {k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()}
+
+    def make():
+        m = models.uit_xs(outputdim=537, target_length=102)
+        m.load_state_dict(tsd, strict=True)
+        return m.cuda().eval()
+
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        full = make().prepare("cuda", (8, 16000))
+        short = make().prepare("cuda", (8, 8000))
+    assert "calib_short_check" not in full._options and short._options.get("calib_short_check") == 1
+    sc_full, sc_short = full.self_check(), short.self_check()
+    rep = short.calibration_report()
+    print(f"uit_xs seed 207: held-out estimate, full clips only {sc_full[0]:.2e}; with the half-length leg {sc_short[0]:.2e} -> {short.effective_precision()}; report {rep}")
+    assert sc_short[0] >= sc_full[0] * 0.999 or short.effective_precision() != full.effective_precision()
+    x = held_out_inputs(golden)[:24, 4000:12000]
+    ref = Oracle(sd).forward(np.ascontiguousarray(x))["logits"]
+    with torch.no_grad():
+        lg = short(torch.from_numpy(np.ascontiguousarray(x)).cuda(), return_logits=True)[1].cpu().numpy()
+    d = float(np.abs(lg.reshape(ref.shape) - ref).max())
+    print(f"   24 clips of 0.5 s against the oracle: {d:.2e}")
+    assert d < 8e-4

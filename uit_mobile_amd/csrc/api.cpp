@@ -72,6 +72,11 @@ struct uitk_model {
     int calib_accept_pct = 105;        // option calib_accept_pct: uitk_calibrate_weights keeps its image only if, on the held-out clips, its
                                        // largest deviation is at most this many per cent of the nearest-rounded image's; 0 = no check
     float calib_report[5] = {-1.f, -1.f, -1.f, -1.f, -1.f};   // uitk_get_calib_check
+    int calib_short_check = 0;         // option calib_short_check (round 6; default off = round 5's check): the held-out clips are ALSO scored at half length (three time patches: 12 of 24
+                                       // tokens, masked attention) -- with fewer tokens to average over, a checkpoint can be inside the budget on full clips and at
+                                       // the gate on short ones; the report's maximum is then over both lengths.  For deployments on short clips: the wrapper's
+                                       // prepare() switches it on when the prepared clip length has fewer than six time patches.  Off by default: a model that
+                                       // only ever sees 1 s clips must not be sent up the ladder (to a 12x slower rung) for what it would do on 0.5 s clips
     int calib_budget_e6 = 600;         // option calib_budget_e6: ABSOLUTE budget (1e-6 units) for the largest deviation of the installed image on the
                                        // held-out clips (logits; a quarter of it for the probabilities of pooling 'dm'); over it -- or calibration
                                        // refused -- the handle reports the precision to rebuild with ("parity_escalate_to"); 0 = no budget
@@ -403,6 +408,9 @@ int uitk_set_option(uitk_model* m, const char* name, int value) {
     } else if (n == "calib_accept_pct") {     // 0 = uitk_calibrate_weights installs its image without the held-out comparison
         if (value < 0 || value > 1000) return fail(UITK_ERR_INVALID_ARG, "calib_accept_pct: 0..1000");
         m->calib_accept_pct = value;
+    } else if (n == "calib_short_check") {    // 1: the held-out check also scores its clips at half length; 0 (default): full clips only
+        if (value < 0 || value > 1) return fail(UITK_ERR_INVALID_ARG, "calib_short_check: 0 or 1");
+        m->calib_short_check = value;
     } else if (n == "calib_budget_e6") {      // absolute deviation budget of the held-out check, 1e-6 units (0 = none)
         if (value < 0 || value > 1000000) return fail(UITK_ERR_INVALID_ARG, "calib_budget_e6: 0..1000000");
         m->calib_budget_e6 = value;
@@ -424,6 +432,7 @@ int uitk_get_option(const uitk_model* m, const char* name, int* value) {
     else if (n == "fe_tail_skip") *value = m->fe_tail_skip;
     else if (n == "calib_accept_pct") *value = m->calib_accept_pct;
     else if (n == "calib_budget_e6") *value = m->calib_budget_e6;
+    else if (n == "calib_short_check") *value = m->calib_short_check;
     else if (n == "parity_escalate_to") *value = m->parity_escalate_to;
     else return fail(UITK_ERR_UNSUPPORTED, "unknown option: " + n);
     return UITK_OK;
@@ -836,7 +845,8 @@ namespace {
 // What the reference computes from the last block's residual stream (models/uit.py:395, 398-412), in double on the host:
 // final LayerNorm (eps 1e-6) -> pooling -> outputlayer = LayerNorm (eps 1e-5) + Linear.  R: [rows][ntok][128] (the folded stream is
 // centred per token, which LayerNorm does not see).  out: [rows][C] pre-sigmoid logits; pooling 'dm': probabilities (it has no logits).
-void head_reference(const uitk_config& c, const uitk_weights* w, const float* R, int rows, int ntok, std::vector<double>* out) {
+void head_reference(const uitk_config& c, const uitk_weights* w, const float* R, int rows, int ntok, std::vector<double>* out, int nt = GT) {
+    // nt < GT (short clips): only the tokens of time patches 0 .. nt-1 exist (naive_token_valid / naive_head_kernel in calibrate.hip)
     const int C = c.outputdim;
     out->assign((size_t)rows * C, 0.0);
     auto layernorm = [](const double* x, const float* g, const float* b, double eps, double* y) {
@@ -865,14 +875,18 @@ void head_reference(const uitk_config& c, const uitk_weights* w, const float* R,
         double* dst = out->data() + (size_t)r * C;
         if (c.pooling == 2) {                                    // 'token': the cls row
             head(tokn.data(), dst);
-        } else if (c.pooling == 0) {                             // 'mean' over the 24 tokens
-            for (int i = 0; i < DIM; ++i) { double acc = 0.0; for (int t = 0; t < NTOK; ++t) acc += tokn[(size_t)t * DIM + i]; z[i] = acc / NTOK; }
+        } else if (c.pooling == 0) {                             // 'mean' over the valid tokens (all 24 of a full clip)
+            for (int i = 0; i < DIM; ++i) {
+                double acc = 0.0;
+                for (int t = 0; t < NTOK; ++t) if (t % GT < nt) acc += tokn[(size_t)t * DIM + i];
+                z[i] = acc / (double)((NTOK / GT) * nt);
+            }
             head(z.data(), dst);
         } else {                                                 // 'dm': mean over frequency patches, head + sigmoid per time patch, mean over time
-            for (int tp = 0; tp < GT; ++tp) {
+            for (int tp = 0; tp < nt; ++tp) {
                 for (int i = 0; i < DIM; ++i) { double acc = 0.0; for (int f = 0; f < NTOK / GT; ++f) acc += tokn[(size_t)(f * GT + tp) * DIM + i]; z[i] = acc / (NTOK / GT); }
                 head(z.data(), lg.data());
-                for (int o = 0; o < C; ++o) dst[o] += 1.0 / (1.0 + std::exp(-lg[o])) / GT;
+                for (int o = 0; o < C; ++o) dst[o] += 1.0 / (1.0 + std::exp(-lg[o])) / nt;
             }
         }
     }
@@ -906,16 +920,21 @@ namespace {
 struct HeldOut {
     int Be = 48;                                                 // (round 5: 16 -> 48 clips, see builtin_heldout_set)
     int64_t Te = 0;                                              // 0: no single-crop clip length covers target_length (check does not apply)
+    int nt = GT;                                                 // valid time patches of the clips (GT: full clips; 3: the half-length leg)
     DevBuf pcm, outb;
     std::vector<double> ref;
 };
 
-int heldout_prepare(uitk_model* m, const uitk_weights* w, NaiveNet* nn, hipStream_t s, HeldOut* ho) {
+int heldout_prepare(uitk_model* m, const uitk_weights* w, NaiveNet* nn, hipStream_t s, HeldOut* ho, int want_nt = GT) {
     const int C = m->cfg.outputdim;
     ho->Te = 0;
-    for (int64_t k = GT * 16 - 1; k < 4096 && !ho->Te; ++k) {
+    ho->nt = want_nt;
+    for (int64_t k = want_nt * 16 - 1; k < 4096 && !ho->Te; ++k) {
         const int64_t T = k * (int64_t)m->cfg.hop_size + (m->cfg.center ? 0 : m->cfg.n_fft);
-        if (uitk_num_crops(m, T) == 1 && uitk_num_frames(m, T) >= GT * 16 && uitk_num_frames(m, T) <= m->cfg.target_length) ho->Te = T;
+        const int nf = uitk_num_frames(m, T);
+        const bool fits = want_nt == GT ? (nf >= GT * 16 && nf <= m->cfg.target_length) : (nf >= want_nt * 16 && nf < (want_nt + 1) * 16);
+        if (uitk_num_crops(m, T) == 1 && fits) ho->Te = T;
+        if (nf >= (want_nt + 1) * 16 && want_nt != GT) break;
     }
     if (!ho->Te) return UITK_OK;
     std::vector<int16_t> host;
@@ -928,16 +947,28 @@ int heldout_prepare(uitk_model* m, const uitk_weights* w, NaiveNet* nn, hipStrea
     if (m->cfg.precision == UITK_PREC_F32) {                     // (its front-end left fp32 frames, not patch operands)
         NaiveFramesArgs fa{};
         fa.frames = m->mel_frames; fa.nF = uitk_num_frames(m, ho->Te); fa.ncrops = 1; fa.tl = m->cfg.target_length; fa.row0 = 0;
-        HIP_TRY(launch_naive_forward(nn->a, GT, nullptr, s, &fa));
+        HIP_TRY(launch_naive_forward(nn->a, want_nt, nullptr, s, &fa));
     } else {
-        HIP_TRY(launch_calibration(nn->a, s));
+        HIP_TRY(launch_naive_forward(nn->a, want_nt, nullptr, s, nullptr));
     }
     const int ntok = nn->a.ntok;
     std::vector<float> R((size_t)ho->Be * ntok * DIM);
     HIP_TRY(hipMemcpyAsync(R.data(), nn->a.R, R.size() * 4, hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));
-    head_reference(m->cfg, w, R.data(), ho->Be, ntok, &ho->ref);
+    head_reference(m->cfg, w, R.data(), ho->Be, ntok, &ho->ref, want_nt);
     return UITK_OK;
+}
+// the legs of the held-out evaluation: full clips, and (option calib_short_check) clips of three time patches
+int heldout_legs(const uitk_model* m, int* nts) {
+    nts[0] = GT;
+    if (m->calib_short_check && GT > 3) { nts[1] = 3; return 2; }
+    return 1;
+}
+// maximum over the legs (a non-finite leg stays non-finite), root mean square over all their elements (legs of equal size)
+void heldout_merge(double* mx, double* msq, int leg, double leg_mx, double leg_rms) {
+    if (leg == 0) { *mx = leg_mx; *msq = leg_rms * leg_rms; return; }
+    *mx = (std::isfinite(*mx) && std::isfinite(leg_mx)) ? std::max(*mx, leg_mx) : std::nan("");
+    *msq += leg_rms * leg_rms;
 }
 
 // the product encoder on the operands heldout_prepare left in the workspace, with the image the handle holds right now
@@ -978,22 +1009,32 @@ bool parity_precision(int p) { return p == UITK_PREC_F16 || p == UITK_PREC_F16A 
 // calibrated, accepted.  Leaves the chosen image on the device.  Returns UITK_OK with report[4] = -1 when the check does not apply.
 static int calibration_acceptance(uitk_model* m, const uitk_weights* w, NaiveNet* nn, const std::vector<char>& img_cal, hipStream_t s, float* report) {
     for (int i = 0; i < 5; ++i) report[i] = -1.f;
-    HeldOut ho;
-    if (int rc = heldout_prepare(m, w, nn, s, &ho)) return rc;
-    if (!ho.Te) return UITK_OK;
-    double mx[2] = {0.0, 0.0}, rms[2] = {0.0, 0.0};
-    for (int which = 0; which < 2; ++which) {                    // 0: nearest, 1: calibrated (stays on the device if accepted)
-        const std::vector<char>& img = which ? img_cal : m->img_nearest;
-        HIP_TRY(hipDeviceSynchronize());
-        HIP_TRY(hipMemcpy(m->image, img.data(), img.size(), hipMemcpyHostToDevice));
-        if (int rc = heldout_score(m, &ho, s, &mx[which], &rms[which])) return rc;
+    int nts[2];
+    const int nlegs = heldout_legs(m, nts);
+    double mx[2] = {0.0, 0.0}, msq[2] = {0.0, 0.0}, rms[2] = {0.0, 0.0};
+    int legs_done = 0;
+    for (int leg = 0; leg < nlegs; ++leg) {
+        HeldOut ho;
+        if (int rc = heldout_prepare(m, w, nn, s, &ho, nts[leg])) return rc;
+        if (!ho.Te) { if (leg == 0) return UITK_OK; else continue; }   // (no full clip: the check does not apply; no short one: full clips only)
+        for (int which = 0; which < 2; ++which) {                // 0: nearest, 1: calibrated
+            const std::vector<char>& img = which ? img_cal : m->img_nearest;
+            HIP_TRY(hipDeviceSynchronize());
+            HIP_TRY(hipMemcpy(m->image, img.data(), img.size(), hipMemcpyHostToDevice));
+            double lmx = 0.0, lrms = 0.0;
+            if (int rc = heldout_score(m, &ho, s, &lmx, &lrms)) return rc;
+            heldout_merge(&mx[which], &msq[which], legs_done, lmx, lrms);
+        }
+        ++legs_done;
     }
+    for (int which = 0; which < 2; ++which) rms[which] = std::sqrt(msq[which] / std::max(legs_done, 1));
     // (a nearest image that answers NaN on a held-out clip loses to any finite calibrated one; two NaN images: the nearest one stays and
     //  the budget check below sends the handle up the ladder)
     const bool accept = std::isfinite(mx[1]) && (!std::isfinite(mx[0]) || mx[1] * 100.0 <= (double)m->calib_accept_pct * mx[0]);
-    if (!accept) {
+    {                                                            // leave the chosen image on the device
+        const std::vector<char>& keep = accept ? img_cal : m->img_nearest;
         HIP_TRY(hipDeviceSynchronize());
-        HIP_TRY(hipMemcpy(m->image, m->img_nearest.data(), m->img_nearest.size(), hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(m->image, keep.data(), keep.size(), hipMemcpyHostToDevice));
     }
     report[0] = (float)mx[0]; report[1] = (float)mx[1];
     report[2] = (float)rms[0]; report[3] = (float)rms[1];
@@ -1012,13 +1053,21 @@ int uitk_self_check(uitk_model* m, const uitk_weights* w, void* stream, float* o
     out2[0] = out2[1] = -1.f;
     NaiveNet nn;
     if (int rc = naive_net_upload(m, w, &nn, s)) return rc;
-    HeldOut ho;
-    int rc = heldout_prepare(m, w, &nn, s, &ho);
-    double mx = 0.0, rms = 0.0;
-    if (rc == UITK_OK && ho.Te) rc = heldout_score(m, &ho, s, &mx, &rms);
+    int nts[2];
+    const int nlegs = heldout_legs(m, nts);
+    double mx = 0.0, msq = 0.0;
+    int rc = UITK_OK, legs_done = 0;
+    for (int leg = 0; leg < nlegs && rc == UITK_OK; ++leg) {
+        HeldOut ho;
+        rc = heldout_prepare(m, w, &nn, s, &ho, nts[leg]);
+        if (rc != UITK_OK || !ho.Te) { if (leg == 0) break; else continue; }
+        double lmx = 0.0, lrms = 0.0;
+        rc = heldout_score(m, &ho, s, &lmx, &lrms);
+        if (rc == UITK_OK) { heldout_merge(&mx, &msq, legs_done, lmx, lrms); ++legs_done; }
+    }
     m->fe_B = 0; m->fe_T = 0;                                    // the workspace held the check's operands, not the caller's
     if (rc != UITK_OK) return rc;
-    if (ho.Te) { out2[0] = (float)mx; out2[1] = (float)rms; }
+    if (legs_done) { out2[0] = (float)mx; out2[1] = (float)std::sqrt(msq / legs_done); }
     return UITK_OK;
 }
 
