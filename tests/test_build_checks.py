@@ -142,3 +142,8 @@ def test_hazard_checker_sees_the_pattern_of_the_f16ax_race():
     assert any("permlane" in w for _, _, w in kernel_isa.mfma_hazards(swap))
     trans = mk(["v_rcp_f32_e32 v1, v2", "v_pk_mul_f32 v[4:5], v[0:1], s[2:3]"])
     assert any("transcendental" in w for _, _, w in kernel_isa.mfma_hazards(trans))
+    # across a loop's back edge: the MFMA at the end of the body against the asm statement at its head
+    loop = mk(["v_max3_f32 v104, v121, v124, v195", "v_mfma_f32_16x16x16_f16 v[102:105], v[116:117], v[72:73], v[68:71]", "s_cbranch_scc1 65533"])
+    assert any("back edge" in w for _, _, w in kernel_isa.mfma_hazards(loop))
+    padded_loop = mk(["v_max3_f32 v104, v121, v124, v195", "v_mfma_f32_16x16x16_f16 v[102:105], v[116:117], v[72:73], v[68:71]", "s_nop 7", "s_cbranch_scc1 65532"])
+    assert kernel_isa.mfma_hazards(padded_loop) == []

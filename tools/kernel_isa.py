@@ -166,7 +166,33 @@ def _regs(tok):
 
 def mfma_hazards(insts):
     """-> [(addr, instruction, reason)]: reads / writes of an MFMA's destination, and VALU writes of its SrcC, inside the wait states the
-    hardware needs and nobody padded.  Straight-line scan (fall-through order; a branch does not reset the window: conservative)."""
+    hardware needs and nobody padded.  The fall-through order of the whole kernel, then every loop's back edge: the instructions in front
+    of a backward branch followed by the ones at its target (an MFMA at the end of a loop body against an asm statement at its head)."""
+    out = _mfma_hazards_linear(insts)
+    addr_index = {a: i for i, (a, _) in enumerate(insts)}
+    seen = {(a, why) for a, _, why in out}
+    for i, (a, t) in enumerate(insts):
+        m = re.match(r"s_cbranch_\w+ (\d+)|s_branch (\d+)", t)
+        if not m:
+            continue
+        off = int(m.group(1) or m.group(2))
+        if off >= 0x8000:
+            off -= 0x10000
+        tgt = a + 4 + 4 * off
+        if tgt > a or tgt not in addr_index:
+            continue
+        j = addr_index[tgt]
+        tail, head = insts[max(0, i - 16):i], insts[j:j + 16]
+        for b, u, why in _mfma_hazards_linear(tail + head):
+            if any(b == hb for hb, _ in head) and "wait states after" in why and (b, why) not in seen:
+                # only pairs that straddle the edge: the producer must sit in the tail
+                if any(prod in why for _, prod in tail):
+                    out.append((b, u, why + "  [across the back edge at %#x]" % a))
+                    seen.add((b, why))
+    return out
+
+
+def _mfma_hazards_linear(insts):
     live = []                                                   # [dst set, srcC set, passes, age in wait states, text]
     valu = []                                                   # recent VALU writes: [dst set, age, is transcendental, text]
     out = []
