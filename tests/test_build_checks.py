@@ -67,12 +67,10 @@ def _block_loop(k):
     return lo, hi, mf(lo, hi)
 
 
-# Round 6: the two most register-starved instantiations -- full-width attention + GELU on SHORT clips, f16, pooling mean / dm -- were
-# scratch-free in round 5 only because their asm statements (v_mbcnt pair, packed GELU arithmetic) were handed registers that MFMAs in
-# flight still read or had yet to write (test_no_mfma_hazard_that_the_compiler_cannot_see).  With honest register lifetimes they reload a
-# few values inside the block loop: measured +1 % encoder time on 0.5 s clips (0.1857 -> 0.1877 ms per 4096 clips,
-# profiles/round6/hazard_fix_ab.log).  Every other instantiation stays at zero.
-ROUND6_LOOP_SCRATCH = {"<0, 8, true, false, 1, 1, 0>": 10, "<0, 8, true, false, 1, 1, 1>": 10}
+# Round 6: with honest register lifetimes for the asm statements (test_no_mfma_hazard_that_the_compiler_cannot_see) the two most
+# register-starved instantiations -- full-width attention + GELU on SHORT clips -- reloaded six values inside the block loop until gelu4
+# ran its two halves one after the other (a scheduling barrier; same encoder time: profiles/round6/gelu_seq_ab.log).  No allowance left.
+ROUND6_LOOP_SCRATCH = {}
 
 
 def test_every_encoder_instantiation_has_a_scratch_free_block_loop(kernels):

@@ -568,7 +568,12 @@ __device__ __forceinline__ f2 gelu2(f2 x) {
     return __builtin_elementwise_fma(a * f2{0.5f, 0.5f}, f2{1.0f, 1.0f} - y, xh);                     // 0.5 x + 0.5 |x| (1 - y)
 }
 __device__ __forceinline__ f4 gelu4(f4 x) {
-    const f2 lo = gelu2(f2{x[0], x[1]}), hi = gelu2(f2{x[2], x[3]});
+    // the two halves ONE AFTER THE OTHER (round 6): left to the scheduler, the four chains of a tile pair ran interleaved and the short-clip
+    // full-attention builds spilled 11-14 registers, 6 reloads inside the block loop -- once their asm statements had honest register
+    // lifetimes (see hmax).  Sequenced: 2 spilled, none in any loop, the same encoder time (profiles/round6/gelu_seq_ab.log)
+    const f2 lo = gelu2(f2{x[0], x[1]});
+    __builtin_amdgcn_sched_barrier(0);
+    const f2 hi = gelu2(f2{x[2], x[3]});
     return f4{lo[0], lo[1], hi[0], hi[1]};
 }
 
