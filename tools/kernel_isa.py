@@ -203,6 +203,9 @@ def _mfma_hazards_linear(insts):
         ws = int(ops[0], 0) + 1 if op == "s_nop" and ops else 1
         if op.startswith("v_mfma"):
             passes = next((p for pat, p in _MFMA_PASSES if re.match(pat, op)), 4)
+            if op.startswith("v_mfma_scale_f32_16x16x128"):         # MX operands: fp8 on either side (format 0 / 1, the default) = 8 passes, fp6 x fp4 = 4
+                fmt = lambda key: int(re.search(key + r":(\d+)", t).group(1)) if re.search(key + r":(\d+)", t) else 0
+                passes = 8 if (fmt("cbsz") <= 1 or fmt("blgp") <= 1) else 4
             dst, srcc = _regs(ops[0]), (_regs(ops[3]) if len(ops) > 3 else set())
             for e in live:
                 e[3] += ws
