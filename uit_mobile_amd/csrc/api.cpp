@@ -781,7 +781,7 @@ int naive_net_bind(const uitk_model* m, NaiveNet* nn, int rows, size_t n_stats) 
 // ---- precision 'f32' (UITK_PREC_F32; round 5): the LAST rung of the parity ladder.  The folded network in fp32 on the device
 // (naive_net_upload: the weights the calibration forward multiplies with), the head's parameters, and work buffers for F32_CHUNK
 // clip-crops at a time; uitk_encode walks the batch in chunks through launch_naive_forward (calibrate.hip).  Front-end, crop
-// reduction, options and the C ABI are the product's.  ~20x slower than the MFMA encoder: for checkpoints no fp16
+// reduction, options and the C ABI are the product's.  ~13x slower than the MFMA encoder (round 5: 20x): for checkpoints no fp16
 // mode holds inside the budget (tools/auto_sweep.py ... sink4), where slow and right beats fast and warned about.
 constexpr int64_t F32_CHUNK = 8192;                         // (round 6: 2048 -> 8192 rows per chunk: the small kernels fill the chip; ~135 KB of work buffers per row)
 struct F32Path {
