@@ -318,6 +318,34 @@ int uitk_topk(const float* probs, int64_t B, int32_t C, int32_t k, float* values
 int uitk_kws_transform(float* y_pred, const float* y, int64_t B, int32_t C, int32_t num_fillers, float threshold,
                        int64_t* y_index, void* stream);
 
+/* ---- The GENERAL engine (round 6; csrc/general.hip): UITBase.forward (eval) for every geometry the reference's constructor admits
+ * (models/uit.py:253-363: n_mels / n_fft / win_size / hop_size / center, patch_size (== stride), target_length, embed_dim, depth,
+ * num_heads, mlp_ratio, both attention classes, ReLU / GELU, the three poolings) that the MFMA kernels above are NOT specialised to --
+ * uitk_create refuses those (UITK_ERR_UNSUPPORTED).  Plain fp32 arithmetic on the device in the reference's order of operations (the
+ * dense layers on the matrix pipe's exact-fp32 mode); cfg->precision must be UITK_PREC_F32; nothing to calibrate or tune.  The weights
+ * use uitk_weights with the shapes the config implies: pe_w [embed, 1, P, P], time_pos [1, embed, 1, target_length / P],
+ * freq_pos [1, embed, n_mels / P, 1], qkv_w [3 inner, embed] (inner = embed, or embed / 4 for BNeckAttention), proj_w [embed, inner],
+ * fc1_w [mlp_hidden, embed], fc2_w [embed, mlp_hidden], head_w [outputdim, embed], mel_fb [n_fft / 2 + 1, n_mels], window [win_size].
+ * Limits: n_fft even, 16..4096 (a power of two runs an FFT, any other value the DFT sum in double); patch_size a multiple of 4;
+ * embed_dim, mlp_hidden and the attention's inner width multiples of 16.
+ * Same calling rules as the uitk_model functions: one handle per device, enqueue-only on `stream` once the workspace is reserved,
+ * uitk_general_frontend / uitk_general_encode are the two stages of uitk_general_forward (the batch amax -- uitk_general_amax_ptr,
+ * UITK_AMAX_SLOTS floats -- may be MAX-reduced across ranks between them), errors through uitk_last_error.
+ * Stand in for: UITBase(**kwargs) + load_state_dict + .to(DEVICE).eval() and model(x) (models/uit.py:253-363, 452-493). */
+typedef struct uitk_general uitk_general;
+int uitk_general_create(const uitk_config* cfg, const uitk_weights* w, uitk_general** out);
+int uitk_general_destroy(uitk_general* m);
+int uitk_general_num_frames(const uitk_general* m, int64_t T);
+int uitk_general_num_crops(const uitk_general* m, int64_t T);
+int uitk_general_reserve(uitk_general* m, int64_t B, int64_t T);
+int uitk_general_frontend(uitk_general* m, const void* pcm, int in_dtype, int64_t B, int64_t T, void* stream);
+float* uitk_general_amax_ptr(uitk_general* m);
+/* probs [B, outputdim]; logits [B, ncrops, outputdim] or NULL (must be NULL for pooling 'dm') */
+int uitk_general_encode(uitk_general* m, int64_t B, int64_t T, float* probs, float* logits, void* stream);
+int uitk_general_forward(uitk_general* m, const void* pcm, int in_dtype, int64_t B, int64_t T, float* probs, float* logits, void* stream);
+/* out [B, n_mels, frames]: what self.front_end(x) returns (models/uit.py:455), the batch-global top_db floor applied */
+int uitk_general_mel_db(uitk_general* m, const void* pcm, int in_dtype, int64_t B, int64_t T, float* out, void* stream);
+
 /* Last error message of the calling thread ("" if none). */
 const char* uitk_last_error(void);
 const char* uitk_version(void);

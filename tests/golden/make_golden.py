@@ -277,7 +277,39 @@ def main_heldout():
     print("wavs:", wavs, "adversarial:", names)
 
 
+def main_general():
+    """Round-6 fixtures: UITBase geometries OUTSIDE the published factories' (general_cases.py) through the reference's own UITBase --
+    what pins the oracle, and through it the library's general engine (csrc/general.hip), for n_mels / n_fft / win / hop / center /
+    patch_size / target_length / embed_dim / num_heads / mlp_ratio / f_min / f_max away from their defaults."""
+    from general_cases import GENERAL_CASES, state_dict_args
+    from uit_mobile_amd.synth import make_general_state_dict
+    for tag, case in GENERAL_CASES.items():
+        kw = dict(case["kwargs"])
+        kw["attention_type"] = {"bneck": "BNeckAttention", "full": "Attention"}[case["attention"]]
+        kw["act_layer"] = {"relu": torch.nn.ReLU, "gelu": torch.nn.GELU}[case["act"]]
+        m = uit.UITBase(**kw)
+        sd = {k: torch.from_numpy(np.asarray(v)) for k, v in make_general_state_dict(**state_dict_args(case)).items()}
+        diff = set(m.state_dict().keys()) ^ set(sd.keys())
+        assert not diff, (tag, diff)
+        m.load_state_dict(sd, strict=True)
+        m.eval()
+        out = {}
+        for i, (B, T) in enumerate(case["clips"]):
+            pcm = synth_pcm_i16(B, T, seed=300 + 10 * case["seed"] + i)
+            if B > 2:
+                pcm[B - 1] = 0                                   # a silent clip: the batch-global floor
+            r = run_ref(m, pcm)
+            out[f"c{i}_pcm"], out[f"c{i}_probs"], out[f"c{i}_mel_db"] = pcm, r["probs"], r["mel_db"]
+            if kw["pooling"] != "dm":
+                out[f"c{i}_logits"] = r["logits"]
+            print("general", tag, "clips", (B, T), "frames", r["mel_db"].shape[-1], "crops", r["logits"].shape[1],
+                  "logit range", float(r["logits"].min()), float(r["logits"].max()), "prob range", float(r["probs"].min()), float(r["probs"].max()))
+        np.savez_compressed(HERE / f"general_{tag}.npz", **out)
+
+
 def main():
+    if "--general" in sys.argv:
+        return main_general()
     if "--heldout" in sys.argv:
         return main_heldout()
     if "--kwargs" in sys.argv:

@@ -1,0 +1,139 @@
+"""GPU: the GENERAL engine (csrc/general.hip) -- UITBase geometries outside the published factories', plain fp32 on the device --
+against the fixtures the imported reference produced (tests/golden/general_*.npz, make_golden.py --general) and against the C oracle.
+
+Tolerance: the task's 1e-3 on logits / probabilities; measured ~1e-5 (fp32 against fp32: summation order), 4e-4 on the full-scale
+pure-tone clip of every batch (the fp32 FFT round-off floor: conftest.assert_mel_close)."""
+import warnings
+
+import numpy as np
+import pytest
+import torch
+import torch.nn as nn
+
+from conftest import assert_mel_close
+from general_cases import GENERAL_CASES, state_dict_args
+from uit_mobile_amd import models
+from uit_mobile_amd.models.uit import UITBase, UitkSetupWarning
+from uit_mobile_amd.synth import make_general_state_dict, synth_pcm_i16
+
+pytestmark = pytest.mark.gpu
+
+
+def build(case, **over):
+    kw = dict(case["kwargs"])
+    kw["attention_type"] = {"bneck": "BNeckAttention", "full": "Attention"}[case["attention"]]
+    kw["act_layer"] = {"relu": nn.ReLU, "gelu": nn.GELU}[case["act"]]
+    kw.update(over)
+    m = UITBase(**kw)
+    sd = make_general_state_dict(**state_dict_args(case))
+    m.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()}, strict=True)
+    return m.cuda().eval(), sd
+
+
+@pytest.mark.parametrize("tag", list(GENERAL_CASES))
+def test_general_engine_against_the_reference(golden, tag):
+    case, g = GENERAL_CASES[tag], golden(f"general_{tag}")
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore", UitkSetupWarning)
+        m, _ = build(case)
+        assert m.general and m.precision == "f32"
+        for i, (B, T) in enumerate(case["clips"]):
+            pcm = g[f"c{i}_pcm"]
+            for x in (torch.from_numpy(pcm).cuda(), torch.from_numpy(pcm.astype(np.float32) / 32768.0).cuda()):
+                with torch.no_grad():
+                    if case["kwargs"]["pooling"] == "dm":
+                        probs, logits = m(x), None
+                    else:
+                        probs, logits = m(x, return_logits=True)
+                    mel = m.melspec_db(x)
+                torch.cuda.synchronize()
+                assert_mel_close(mel.cpu().numpy(), g[f"c{i}_mel_db"])
+                dp = np.abs(probs.cpu().numpy() - g[f"c{i}_probs"]).reshape(B, -1).max(1)
+                tone = np.arange(B) == 1
+                assert dp.max() < 1e-3 and dp[~tone].max() < 2e-5, (tag, i, dp)
+                if logits is not None:
+                    dl = np.abs(logits.cpu().numpy() - g[f"c{i}_logits"]).reshape(B, -1).max(1)
+                    assert dl.max() < 1e-3 and dl[~tone].max() < 1e-4, (tag, i, dl)
+        assert m.effective_precision() == "f32"
+
+
+def test_general_engine_against_the_oracle_on_a_larger_batch():
+    """70 random clips of 1.3 s through the 128-mel / 1024-point configuration (two crops each) and the oracle; the two-stage API
+    (frontend -> amax -> encode: what the data-parallel wrapper uses) gives the same bits as forward()."""
+    from test_oracle_golden import general_oracle
+    case = GENERAL_CASES["mels128_fft1024"]
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore", UitkSetupWarning)
+        m, _ = build(case)
+        pcm = synth_pcm_i16(70, 20800, seed=77)
+        x = torch.from_numpy(pcm).cuda()
+        with torch.no_grad():
+            probs, logits = m(x, return_logits=True)
+            st = m.frontend(x)
+            amax = m.amax_tensor(st[2]).clone()
+            probs2 = m.encode(st)
+        torch.cuda.synchronize()
+    ref = general_oracle(case).forward(pcm)
+    assert logits.shape == ref["logits"].shape == (70, 2, 50)
+    assert torch.equal(probs, probs2)
+    assert abs(float(amax.max()) - float(ref["mel_db"].max())) < 1e-3
+    tone = np.arange(70) % 8 == 1
+    dl = np.abs(logits.cpu().numpy() - ref["logits"]).reshape(70, -1).max(1)
+    dp = np.abs(probs.cpu().numpy() - ref["probs"]).reshape(70, -1).max(1)
+    print(f"general engine, 70 x 1.3 s clips, 128 mels / n_fft 1024: max|dlogit| {dl.max():.2e} (pure tones) / {dl[~tone].max():.2e} (others), max|dprob| {dp.max():.2e}")
+    assert dl.max() < 1e-3 and dp.max() < 1e-3 and dl[~tone].max() < 1e-4
+
+
+def test_published_geometry_never_takes_the_general_engine_and_the_general_engine_says_what_it_is():
+    m = models.uit_xxxs(outputdim=537, target_length=102)
+    assert not m.general and m.precision == "auto"
+    case = GENERAL_CASES["patch8_token"]
+    m, _ = build(case)
+    x = torch.from_numpy(synth_pcm_i16(2, 16000, seed=5)).cuda()
+    with pytest.warns(UitkSetupWarning, match="GENERAL fp32 engine"):
+        with torch.no_grad():
+            m(x)
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")                     # said once per model
+        with torch.no_grad():
+            m(x)
+    assert m.calibration_report() is None
+    for call in (lambda: m.set_option("enc_waves", 4), lambda: m.calibrate(), lambda: m.self_check(), lambda: m.debug_tokens(x), lambda: m.packed_image()):
+        with pytest.raises(NotImplementedError, match="general"):
+            call()
+    with pytest.raises(ValueError, match="shorter than one patch|longer than n_fft"):
+        with torch.no_grad():
+            m(x[:, :100])
+
+
+def test_general_engine_is_stream_ordered_after_prepare():
+    """prepare() reserves the workspace; later forwards of that shape are enqueue-only: a HIP graph captures and replays one."""
+    case = GENERAL_CASES["tl256_h4"]
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore", UitkSetupWarning)
+        m, _ = build(case)
+        m.prepare("cuda", (3, 30000))
+        x = torch.from_numpy(synth_pcm_i16(3, 30000, seed=9).astype(np.float32) / 32768.0).cuda()
+        with torch.no_grad():
+            want = m(x).clone()
+        s = torch.cuda.Stream()
+        s.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s):
+            gr = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(gr, stream=s), torch.no_grad():
+                out = m(x)
+        gr.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(out, want)
+
+
+def test_fuzz_over_general_geometries_against_the_oracle():
+    """tools/fuzz_general.py, time-boxed: random embed_dim / heads / mlp_ratio / depth / attention / activation / pooling / patch size / n_mels /
+    n_fft (powers of two and not) / win / hop / center / target_length / eval_avg / f_min / f_max, batch and clip length (short, full,
+    several crops) -- every case inside 1e-3 of the C oracle (profiles/round6/fuzz_general.log: 120 cases, worst 5.7e-4 on a pure tone)."""
+    import sys
+    from pathlib import Path
+    sys.path.insert(0, str(Path(__file__).resolve().parents[1] / "tools"))
+    import fuzz_general
+    rows, bad = fuzz_general.run(cases=40, seed=7, budget_s=45, verbose=False)
+    assert len(rows) >= 15 and not bad, "\n".join(bad)

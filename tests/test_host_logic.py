@@ -120,26 +120,35 @@ def test_strict_load_and_pos_embed_resize():
 
 
 def test_unsupported_variants_raise():
+    tl = dict(target_length=102)                                # (the published geometry: the MFMA kernels; UITBase's own default, 1012 frames, is a general one)
     with pytest.raises(NotImplementedError):
-        models.uit_xs(patch_size=8, patch_stride=8)
-    assert models.uit_xs(pooling="dm").pooling == "dm"          # POOL = 1 instantiation
-    assert models.UITBase(embed_dim=128, depth=4, num_heads=2, mlp_ratio=3.0).pooling == "token"   # the reference's defaults: POOL = 2
+        models.uit_xs(patch_size=16, patch_stride=8, **tl)      # overlapping patches: no engine
+    assert models.uit_xs(patch_size=8, patch_stride=8, **tl).general        # (round 6: other geometries run on the general fp32 engine)
+    assert models.uit_xs(pooling="dm", **tl).pooling == "dm"    # POOL = 1 instantiation
+    assert models.UITBase(embed_dim=128, depth=4, num_heads=2, mlp_ratio=3.0, **tl).pooling == "token"   # the reference's defaults: POOL = 2
     with pytest.raises(NotImplementedError):
-        models.uit_xs(pooling="token", precision="bf16")
+        models.uit_xs(pooling="token", precision="bf16", **tl)
     with pytest.raises(NotImplementedError):
-        models.uit_xs(pooling="dm", precision="bf16")
+        models.uit_xs(pooling="dm", precision="bf16", **tl)
     with pytest.raises(NotImplementedError):
-        models.uit_xs(act_layer=torch.nn.SiLU)
+        models.uit_xs(act_layer=torch.nn.SiLU, **tl)
     for pooling in ("mean", "dm", "token"):                     # the fp32 rung: any family, any pooling; its image is the f16 one (front-end tables)
         mf = models.uit_xxxs(outputdim=537, target_length=102, pooling=pooling, precision="f32")
         assert len(mf.packed_image()) == len(models.uit_xxxs(outputdim=537, target_length=102, pooling=pooling, precision="f16").packed_image())
     for prec in ("f16a", "f16ax"):                              # the split-activation precisions are pooling 'token''s ladder only
         with pytest.raises(NotImplementedError):
-            models.uit_xs(precision=prec)
-        assert models.uit_xs(pooling="token", precision=prec).precision == prec
-    m = models.uit_xs(embed_dim=256)                # geometry outside the kernels' family -> C ABI rejects it
-    with pytest.raises(ValueError):
+            models.uit_xs(precision=prec, **tl)
+        assert models.uit_xs(pooling="token", precision=prec, **tl).precision == prec
+    m = models.uit_xs(embed_dim=256, **tl)          # geometry outside the MFMA kernels' family: the general engine, which has no packed image ...
+    assert m.general
+    with pytest.raises(NotImplementedError):
         m.packed_image()
+    cfg = m._config()                               # ... and the MFMA side of the C ABI still rejects it by name
+    w, keep = m._host_weights()
+    need = ctypes.c_size_t()
+    cfg.precision = _lib.PREC_F16
+    assert _lib.load().uitk_pack_weights(ctypes.byref(cfg), ctypes.byref(w), None, 0, ctypes.byref(need)) == _lib.ERR_UNSUPPORTED
+    assert "embed_dim must be 128" in _lib.last_error()
 
 
 def test_causal_kwarg_is_swallowed_as_in_the_reference():
@@ -343,7 +352,7 @@ def test_clip_store_feeds_collated_int16_batches(tmp_path):
 
 def test_shorter_window_is_zero_padded_to_n_fft_at_pack_time():
     """win_size < n_fft (models/uit.py:290): the packed front-end window table holds the state_dict's window centred in 512 zeros
-    (what torch.stft does with win_length < n_fft); win_size > n_fft and other n_fft are refused by the packer."""
+    (what torch.stft does with win_length < n_fft); win_size > 512 and other n_fft are not the MFMA front-end's."""
     import struct
     m = models.uit_xxxs(outputdim=537, target_length=102, win_size=400, precision="f16").eval()
     assert tuple(m.state_dict()["front_end.0.spectrogram.window"].shape) == (400,)
@@ -354,10 +363,13 @@ def test_shorter_window_is_zero_padded_to_n_fft_at_pack_time():
     want = np.zeros(512, np.float32)
     want[56:456] = m.state_dict()["front_end.0.spectrogram.window"].numpy()
     assert np.array_equal(tab, want)
-    with pytest.raises(ValueError):
-        models.uit_xxxs(outputdim=537, target_length=102, win_size=640, precision="f16").eval().packed_image()
-    with pytest.raises(ValueError):
-        models.uit_xxxs(outputdim=537, target_length=102, n_fft=1024, win_size=1024, precision="f16").eval().packed_image()
+    # (round 6) a window longer than 512 or another n_fft is outside the MFMA front-end's geometry: an explicit MFMA precision is refused by
+    # name, the default runs on the general engine (which validates win_size <= n_fft when its handle is created, as torch.stft does)
+    with pytest.raises(NotImplementedError, match="MFMA-kernel mode"):
+        models.uit_xxxs(outputdim=537, target_length=102, win_size=640, precision="f16")
+    with pytest.raises(NotImplementedError, match="MFMA-kernel mode"):
+        models.uit_xxxs(outputdim=537, target_length=102, n_fft=1024, win_size=1024, precision="f16")
+    assert models.uit_xxxs(outputdim=537, target_length=102, n_fft=1024, win_size=1024).general
 
 
 def test_deviation_stats_keep_a_nan_in_the_middle():
@@ -475,3 +487,32 @@ def test_explicit_precisions_over_budget_warn(monkeypatch):
         warnings.simplefilter("error")
         out, _, _ = _ladder(monkeypatch, "f16ax", "token", inside, {})
     assert out.mode["within_budget"] is True
+
+
+# ---- round 6: the general engine's host side (no GPU)
+def test_general_geometry_builds_the_reference_key_set_and_names_its_engine():
+    """UITBase with a geometry outside the published factories' constructs (it used to be refused), holds the state_dict the reference's
+    constructor gives those kwargs (the fixtures' checkpoints load strictly: they were loaded strictly into the reference's own UITBase by
+    make_golden.py --general), runs in 'f32' on the general engine, and refuses the MFMA-kernel precisions by name."""
+    import numpy as np
+    import torch
+    import torch.nn as nn
+    from general_cases import GENERAL_CASES, state_dict_args
+    from uit_mobile_amd.models.uit import UITBase
+    from uit_mobile_amd.synth import make_general_state_dict
+    for tag, case in GENERAL_CASES.items():
+        kw = dict(case["kwargs"], attention_type={"bneck": "BNeckAttention", "full": "Attention"}[case["attention"]],
+                  act_layer={"relu": nn.ReLU, "gelu": nn.GELU}[case["act"]])
+        m = UITBase(**kw)
+        assert m.general and m.precision == "f32", tag
+        sd = make_general_state_dict(**state_dict_args(case))
+        m.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()}, strict=True)
+        assert m.patch_embed.grid_size == (kw.get("n_mels", 64) // kw["patch_size"], kw["target_length"] // kw["patch_size"])
+        with pytest.raises(NotImplementedError, match="MFMA-kernel mode"):
+            UITBase(**kw, precision="f16c")
+        with pytest.raises(RuntimeError, match="HIP device only"):
+            m.eval()(torch.zeros(1, 16000))
+    assert not models.uit_xs(target_length=102).general
+    assert models.uit_xs().general                       # the constructor's own default target_length (1012 frames: 63 time patches) is a general geometry
+    with pytest.raises(NotImplementedError, match="patch_stride"):
+        UITBase(patch_size=16, patch_stride=8, embed_dim=128, depth=1, num_heads=2, target_length=102)

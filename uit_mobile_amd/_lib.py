@@ -20,7 +20,9 @@ EXPORTS = ["uitk_create", "uitk_destroy", "uitk_pack_weights", "uitk_num_frames"
            "uitk_reserve", "uitk_forward", "uitk_frontend", "uitk_amax_ptr", "uitk_encode", "uitk_mel_db",
            "uitk_set_debug_tokens", "uitk_set_timing_buffers", "uitk_set_option", "uitk_get_option", "uitk_topk", "uitk_kws_transform", "uitk_last_error",
            "uitk_version", "uitk_calibrate_weights", "uitk_calib_stats_doubles", "uitk_get_calib_stats", "uitk_pack_weights_calibrated",
-           "uitk_tune_frontend", "uitk_get_calib_check", "uitk_self_check", "uitk_deviation_stats"]
+           "uitk_tune_frontend", "uitk_get_calib_check", "uitk_self_check", "uitk_deviation_stats",
+           "uitk_general_create", "uitk_general_destroy", "uitk_general_num_frames", "uitk_general_num_crops", "uitk_general_reserve",
+           "uitk_general_frontend", "uitk_general_amax_ptr", "uitk_general_encode", "uitk_general_forward", "uitk_general_mel_db"]
 
 
 class Config(Structure):
@@ -86,6 +88,17 @@ def load():
     L.uitk_self_check.argtypes = [c_void_p, POINTER(Weights), c_void_p, c_void_p]
     L.uitk_tune_frontend.argtypes = [c_void_p, c_void_p, c_int, c_int64, c_int64, c_void_p]
     L.uitk_deviation_stats.argtypes = [c_void_p, c_void_p, c_size_t, c_void_p]
+    L.uitk_general_create.argtypes = [POINTER(Config), POINTER(Weights), POINTER(c_void_p)]
+    L.uitk_general_destroy.argtypes = [c_void_p]
+    L.uitk_general_num_frames.argtypes = [c_void_p, c_int64]
+    L.uitk_general_num_crops.argtypes = [c_void_p, c_int64]
+    L.uitk_general_reserve.argtypes = [c_void_p, c_int64, c_int64]
+    L.uitk_general_frontend.argtypes = [c_void_p, c_void_p, c_int, c_int64, c_int64, c_void_p]
+    L.uitk_general_amax_ptr.argtypes = [c_void_p]
+    L.uitk_general_amax_ptr.restype = c_void_p
+    L.uitk_general_encode.argtypes = [c_void_p, c_int64, c_int64, c_void_p, c_void_p, c_void_p]
+    L.uitk_general_forward.argtypes = [c_void_p, c_void_p, c_int, c_int64, c_int64, c_void_p, c_void_p, c_void_p]
+    L.uitk_general_mel_db.argtypes = [c_void_p, c_void_p, c_int, c_int64, c_int64, c_void_p, c_void_p]
     for name in EXPORTS:                      # every entry point include/uitk.h declares must be exported
         getattr(L, name)
     _lib = L

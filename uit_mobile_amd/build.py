@@ -14,7 +14,7 @@ from pathlib import Path
 HERE = Path(__file__).resolve().parent
 CSRC = HERE / "csrc"
 LIB = HERE / "libuitk.so"
-SOURCES = ["api.cpp", "pack.cpp", "frontend.hip", "encoder.hip", "epilogue.hip", "calibrate.hip"]
+SOURCES = ["api.cpp", "pack.cpp", "frontend.hip", "encoder.hip", "epilogue.hip", "calibrate.hip", "general.hip"]
 def _headers():
     """every header a translation unit can include: csrc/*.h (globbed: a new header cannot be forgotten -- naive_forward.h once was, and
     its structs travel by value between api.cpp and calibrate.hip) + the public C ABI"""

@@ -33,6 +33,7 @@ static bool calibratable_precision(int p) { return single_weight_precision(p) ||
 static uitk_config pack_config(const uitk_config* cfg) { uitk_config c = *cfg; if (c.precision == UITK_PREC_F32) c.precision = UITK_PREC_F16; return c; }
 static int kernel_precision(int p) { return p == UITK_PREC_FP8W ? UITK_PREC_F16 : p == UITK_PREC_F16A ? 5 : p == UITK_PREC_F16AX ? 6 : p; }
 static int fail(int code, const std::string& msg) { g_err = msg; return code; }
+namespace uitk { int set_error(int code, const std::string& msg) { g_err = msg; return code; } }   // general.hip reports through the same uitk_last_error
 #define HIP_TRY(expr)                                                                                   \
     do {                                                                                                \
         hipError_t _e = (expr);                                                                         \

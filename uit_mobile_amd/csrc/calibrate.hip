@@ -250,6 +250,10 @@ static hipError_t linear(const float* X, const float* W, const float* b, float* 
     hipLaunchKernelGGL(naive_linear_mfma_kernel, dim3((O + LT - 1) / LT, (M + LT - 1) / LT), dim3(256), 0, s, X, W, b, Y, M, K, O, act, accumulate);
     return hipGetLastError();
 }
+// the same dense layer for the general engine (general.hip)
+hipError_t launch_naive_linear(const float* X, const float* W, const float* b, float* Y, int M, int K, int O, int act, int accumulate, hipStream_t s) {
+    return linear(X, W, b, Y, M, K, O, act, accumulate, s);
+}
 static hipError_t gram(const float* X, float* G, int M, int K, float scale, int bf16, hipStream_t s, const float* mu = nullptr) {
     hipLaunchKernelGGL(cal_gram_kernel, dim3(K / TS, K / TS), dim3(TS, TS), 0, s, X, G, M, K, scale, bf16, mu);
     return hipGetLastError();

@@ -28,4 +28,8 @@ struct NaiveFramesArgs {
 // head = nullptr: stop at the last block's residual stream (the calibration / held-out uses); frames = nullptr: the patch operands a.mel
 hipError_t launch_naive_forward(const CalibArgs& a, int nt, const NaiveHeadArgs* head, hipStream_t stream, const NaiveFramesArgs* frames = nullptr);
 
+// Y[m][o] = (accumulate ? Y[m][o] : 0) + act(b[o] + sum_k X[m][k] W[o][k]) on the matrix pipe's exact-fp32 mode (calibrate.hip:
+// naive_linear_mfma_kernel); K a multiple of 16; act: 0 none, 1 ReLU, 2 exact GELU; b may be null.  Used by the general engine (general.hip).
+hipError_t launch_naive_linear(const float* X, const float* W, const float* b, float* Y, int M, int K, int O, int act, int accumulate, hipStream_t s);
+
 }  // namespace uitk

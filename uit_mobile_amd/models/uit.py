@@ -128,14 +128,16 @@ class _Handle:
     """Owns one uitk_model* (per device).  `mode`: what the handle actually runs -- {'precision', 'requested', 'escalated', 'reason',
     'check'} (UITBase.calibration_report)."""
 
-    def __init__(self, ptr):
+    def __init__(self, ptr, general=False):
         self.ptr = ptr
         self.mode = None
+        self.general = general      # a uitk_general* (the general fp32 engine, csrc/general.hip) instead of a uitk_model*
 
     def __del__(self):
         try:
             if self.ptr:
-                _lib.load().uitk_destroy(self.ptr)
+                L = _lib.load()
+                (L.uitk_general_destroy if self.general else L.uitk_destroy)(self.ptr)
         except Exception:
             pass
 
@@ -204,10 +206,25 @@ class UITBase(nn.Module):
         # qkv_bias=False are exact pack-time folds (see _host_weights); center=False is a front-end option (uitk_config.center)
         self.use_init_bn, self.init_values, self.qkv_bias = bool(init_bn), init_values, bool(qkv_bias)
         if not init_bn and self.n_mels != 64: unsupported.append("init_bn=False is defined for n_mels=64 only (as in the reference)")
-        if patch_size != 16 or patch_stride != 16: unsupported.append("patch 16x16 stride 16 only")
+        if patch_stride != patch_size: unsupported.append("patch_stride must equal patch_size (non-overlapping patches)")
+        # The MFMA kernels are specialised to the geometry of the published factories.  Every OTHER geometry UITBase admits (n_mels, n_fft,
+        # win_size, hop_size, patch_size, target_length, embed_dim, num_heads, mlp_ratio: uit.py:253-293) runs on the library's GENERAL
+        # engine (round 6; csrc/general.hip): plain fp32 on the device in the reference's order of operations -- the general-geometry
+        # sibling of precision 'f32': slower than the MFMA path by an order of magnitude, and right.  No calibration, tuning or options.
+        self.general = not (embed_dim == 128 and num_heads == 2 and self.mlp_hidden == 384 and self.n_mels == 64 and n_fft == 512
+                            and patch_size == 16 and target_length // 16 == 6 and 1 <= self.hop_size <= 512 and 1 <= self.win_size <= 512)
         if block_type != 'Block': unsupported.append("block_type must be 'Block'")
         if unsupported:
-            raise NotImplementedError("uit_mobile_amd implements the uit_xs/xxs/xxxs family only: " + "; ".join(unsupported))
+            raise NotImplementedError("uit_mobile_amd does not implement this UITBase configuration: " + "; ".join(unsupported))
+        if precision is not None and precision not in _PRECISIONS:
+            raise ValueError(f"Unknown precision ({precision})")
+        if self.general:
+            if precision not in (None, 'auto', 'f32'):
+                raise NotImplementedError(f"precision='{precision}' is an MFMA-kernel mode, built for the geometry of the published factories (embed 128, 2 heads, "
+                                          "MLP x 3, 64 mels, n_fft 512, 16 x 16 patches, 6 time patches); this configuration runs on the general fp32 "
+                                          "engine: precision None / 'auto' / 'f32'")
+            precision = 'f32'
+            self.precision = precision
         if precision is None:
             # default = THE PARITY MODE, for every family and pooling (round 5: 'auto').  It starts as 'f16c' -- single fp16 weights with
             # CALIBRATED rounding: the kernels of 'f16', the weights rounded against operand statistics (uitk_calibrate_weights) of the
@@ -248,6 +265,7 @@ class UITBase(nn.Module):
         self._calib_input = None    # calibrate(x): the caller's calibration clips (None = the library's own signals)
         self._tensors = None        # cached list of parameter / buffer tensors for the per-call stamp
         self._warned_setup = False  # UitkSetupWarning is given once per model
+        self._warned_general = False
 
     def init_weights(self, module):
         if isinstance(module, nn.Linear):
@@ -303,6 +321,7 @@ class UITBase(nn.Module):
         library's own synthetic signals (the default).  Takes effect when the parameter image is (re)built -- now, for live handles.
         Results stay within the parity tolerance either way (tests/test_gpu_parity.py::test_calibrated_rounding_*): calibration only
         decides in which direction each fp16 weight is rounded."""
+        self._not_general("calibrate()")
         if self.precision not in _CALIBRATING:
             raise ValueError("calibrate() applies to the calibrated precisions 'auto' / 'f16c' / 'f16a' / 'f16ax' and 'fp8c' / 'fp8w'")
         if x is not None:
@@ -314,6 +333,7 @@ class UITBase(nn.Module):
     def set_option(self, name, value):
         """Explicit tuning / test option of the C library (uitk_set_option: 'fe_asym_pm', 'fe_wg_per_cu', 'enc_waves', 'split_pe',
         'enc_generic_clamp', 'fe_tail_skip').  None changes a result bit.  Applied to the live handles and to every handle created later."""
+        self._not_general("set_option()")
         if str(name) not in _OPTIONS:                    # (validated here too: without a live handle nothing else would reject it)
             raise ValueError(f"uitk_set_option: unknown option: {name}")
         for h, _ in self._handles.values():
@@ -326,6 +346,7 @@ class UITBase(nn.Module):
         """Current value of a library option on the live handle(s) (uitk_get_option) -- e.g. 'fe_asym_pm' after the first full-size call:
         the front-end pass split measured on this device.  {device: value}."""
         import ctypes
+        self._not_general("get_option()")
         out = {}
         for dev, (h, _) in self._handles.items():
             v = ctypes.c_int(0)
@@ -339,6 +360,15 @@ class UITBase(nn.Module):
             self._handles.clear()
             self._tensors = None                          # .to() / .cuda() replace the tensors
         return out
+
+    def _fn(self, name):
+        """The C entry point `name` of the engine this model runs on: uitk_<name> (MFMA kernels) or uitk_general_<name>."""
+        return getattr(_lib.load(), ("uitk_general_" if self.general else "uitk_") + name)
+
+    def _not_general(self, what):
+        if self.general:
+            raise NotImplementedError(f"{what} belongs to the MFMA kernels (the published factories' geometry); this model runs on the general "
+                                      "fp32 engine, which rounds nothing, calibrates nothing and has no options")
 
     def _config(self, precision=None):
         return _lib.Config(depth=self.depth, embed_dim=self.embed_dim, num_heads=self.num_heads,
@@ -406,6 +436,7 @@ class UITBase(nn.Module):
     def packed_image(self, calib_stats=None):
         """Host-only: the packed parameter image uitk_create would upload (bytes).  No GPU needed.  calib_stats: float64 array of
         uitk_calib_stats_doubles values -> the image uitk_calibrate_weights would build from those statistics (uitk_pack_weights_calibrated)."""
+        self._not_general("packed_image()")
         L = _lib.load()
         cfg = self._config()
         w, keep = self._host_weights()
@@ -424,6 +455,7 @@ class UITBase(nn.Module):
 
     def calib_stats(self, device=None):
         """The operand statistics the live handle's calibration measured (float64, layout of include/uitk.h: uitk_calib_stats_doubles)."""
+        self._not_general("calib_stats()")
         L = _lib.load()
         device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
         h = self._handle(device)
@@ -456,6 +488,7 @@ class UITBase(nn.Module):
         """(max, rms) deviation of the live handle -- ANY precision -- on the library's held-out clips against the fp32 forward of the
         unrounded network (uitk_self_check): the oracle-free estimate of this handle's parity margin.  A set-up operation (allocates,
         synchronises); None when no single-crop clip length covers target_length."""
+        self._not_general("self_check()")
         device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
         h = self._handle_obj(device)
         idx = device.index if device.index is not None else torch.cuda.current_device()
@@ -470,6 +503,11 @@ class UITBase(nn.Module):
         """uitk_create on the current device in `precision` + this model's options -> _Handle (owned: a failure destroys it)."""
         cfg = self._config(precision)
         out = ctypes.c_void_p()
+        if self.general:
+            _lib.check(L.uitk_general_create(ctypes.byref(cfg), ctypes.byref(w), ctypes.byref(out)), "uitk_general_create")
+            handle = _Handle(out.value, general=True)
+            handle.mode = {"precision": "f32", "requested": self.precision, "escalated": False, "reason": None, "check": None, "engine": "general"}
+            return handle
         _lib.check(L.uitk_create(ctypes.byref(cfg), ctypes.byref(w), ctypes.byref(out)), "uitk_create")
         handle = _Handle(out.value)
         for name, value in self._options.items():
@@ -499,6 +537,11 @@ class UITBase(nn.Module):
         stamp = self._stamp() if (self.check_weights or h is None) else None
         if h is not None and (stamp is None or h[1] == stamp):
             return h[0]
+        if self.general and not self._warned_general:
+            self._warned_general = True
+            warnings.warn("uit_mobile_amd: this configuration is outside the geometry of the published factories (embed 128, 2 heads, MLP x 3, 64 mels, "
+                          "n_fft 512, 16 x 16 patches, 6 time patches): it runs on the library's GENERAL fp32 engine -- on the device, in the reference's "
+                          "order of operations, an order of magnitude slower than the MFMA kernels", UitkSetupWarning, stacklevel=4)
         if self.precision in _CALIBRATING and _from_forward and not self._warned_setup:
             self._warned_setup = True
             warnings.warn("uit_mobile_amd: this forward call builds the parameter image first (weight calibration + acceptance check, "
@@ -665,8 +708,8 @@ class UITBase(nn.Module):
             probs = torch.empty((B, self.outputdim), device=x.device, dtype=torch.float32)
             logits = torch.empty((B, self.num_crops(T), self.outputdim), device=x.device, dtype=torch.float32) if return_logits else None
             lp = ctypes.c_void_p(logits.data_ptr()) if return_logits else None
-            _lib.check(L.uitk_forward(h, ctypes.c_void_p(x.data_ptr()), in_dtype, B, T,
-                                      ctypes.c_void_p(probs.data_ptr()), lp, stream), "uitk_forward")
+            _lib.check(self._fn("forward")(h, ctypes.c_void_p(x.data_ptr()), in_dtype, B, T,
+                                           ctypes.c_void_p(probs.data_ptr()), lp, stream), "uitk_forward")
         return (probs, logits) if return_logits else probs
 
     def prepare(self, device="cuda", batch_shape=None, dtype=torch.float32, sample=None):
@@ -724,12 +767,14 @@ class UITBase(nn.Module):
         if device.index is None:
             device = torch.device("cuda", torch.cuda.current_device())
         with torch.cuda.device(device):
-            _lib.check(_lib.load().uitk_reserve(self._handle(device), int(B), int(T)), "uitk_reserve")
+            _lib.check(self._fn("reserve")(self._handle(device), int(B), int(T)), "uitk_reserve")
 
     def tune_frontend(self, x):
         """Measure the front-end's pass split for batches shaped like `x` on x's device now (uitk_tune_frontend: ~140 short launches
         on x's buffer and the current stream, event waits only).  The result is shared by every model of the process on that device;
         with fe_autotune=True (default) the first forward of an unmeasured shape does this by itself."""
+        if self.general:
+            return                                        # (nothing to tune)
         x, in_dtype = self._prep_input(x)
         B, T = x.shape
         h = self._handle(x.device)
@@ -749,7 +794,7 @@ class UITBase(nn.Module):
         h = self._handle_obj(x.device, _from_forward=True)
         with torch.cuda.device(x.device):
             stream = ctypes.c_void_p(torch.cuda.current_stream(x.device).cuda_stream)
-            _lib.check(_lib.load().uitk_frontend(h.ptr, ctypes.c_void_p(x.data_ptr()), in_dtype, B, T, stream), "uitk_frontend")
+            _lib.check(self._fn("frontend")(h.ptr, ctypes.c_void_p(x.data_ptr()), in_dtype, B, T, stream), "uitk_frontend")
         # the _Handle OBJECT rides along: it keeps the uitk_model alive until `encode` has used it, and `encode` need not look
         # the weights over a second time -- it only checks that this is still the model's live handle
         return (B, T, x.device, h)
@@ -769,12 +814,12 @@ class UITBase(nn.Module):
             probs = torch.empty((B, self.outputdim), device=device, dtype=torch.float32)
             logits = torch.empty((B, self.num_crops(T), self.outputdim), device=device, dtype=torch.float32) if return_logits else None
             lp = ctypes.c_void_p(logits.data_ptr()) if return_logits else None
-            _lib.check(_lib.load().uitk_encode(h, B, T, ctypes.c_void_p(probs.data_ptr()), lp, stream), "uitk_encode")
+            _lib.check(self._fn("encode")(h, B, T, ctypes.c_void_p(probs.data_ptr()), lp, stream), "uitk_encode")
         return (probs, logits) if return_logits else probs
 
     def amax_tensor(self, device):
         h = self._handle(device)
-        ptr = _lib.load().uitk_amax_ptr(h)
+        ptr = self._fn("amax_ptr")(h)
         return torch.as_tensor(_DevPtr(ptr, _lib.AMAX_SLOTS), device=device)
 
     # ------------------------------------------------------------------ stage outputs for parity tests
@@ -787,8 +832,8 @@ class UITBase(nn.Module):
         with torch.cuda.device(x.device):
             stream = ctypes.c_void_p(torch.cuda.current_stream(x.device).cuda_stream)
             out = torch.empty((B, self.n_mels, self.num_frames(T)), device=x.device, dtype=torch.float32)
-            _lib.check(L.uitk_mel_db(h, ctypes.c_void_p(x.data_ptr()), in_dtype, B, T,
-                                     ctypes.c_void_p(out.data_ptr()), stream), "uitk_mel_db")
+            _lib.check(self._fn("mel_db")(h, ctypes.c_void_p(x.data_ptr()), in_dtype, B, T,
+                                          ctypes.c_void_p(out.data_ptr()), stream), "uitk_mel_db")
         return out
 
     def precision_margin(self, x, gate=1e-3):
@@ -797,6 +842,7 @@ class UITBase(nn.Module):
         logit difference: that difference IS the weight-rounding term plain fp16 would carry -- most of its error at trained-checkpoint
         magnitudes.  'f16' is recommended (it is 1.25x faster) only while the term stays under 0.3 * gate.  No
         reference, no CPU: two forward passes on the device."""
+        self._not_general("precision_margin()")
         if self.precision not in ('auto', 'f16', 'f16c', 'f16x2', 'f16l6'):
             raise ValueError("precision_margin compares the fp16 precisions 'f16' and the family's parity mode")
         # the parity mode of this family: f16l6 (BNeckAttention + ReLU), f16x2 (full-width attention / GELU, mean pooling)
@@ -817,6 +863,7 @@ class UITBase(nn.Module):
 
     def debug_tokens(self, x):
         """(probs, tokens[B, ncrops, depth+1, 24, 128]): residual stream after patch-embed and after each block."""
+        self._not_general("debug_tokens()")
         x, _ = self._prep_input(x)
         B, T = x.shape
         L = _lib.load()

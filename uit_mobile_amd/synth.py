@@ -175,6 +175,62 @@ def make_trained_like_state_dict(name="uit_xs", seed=0, outputdim=537, target_le
     return sd
 
 
+def make_general_state_dict(embed_dim=128, depth=2, mlp_ratio=3.0, attention="bneck", n_mels=64, n_fft=512, win_size=512, f_min=0.0, f_max=8000.0,
+                            patch_size=16, target_length=102, outputdim=537, seed=0):
+    """Checkpoint of a UITBase built with ANY geometry (models/uit.py:253-363) -- the state_dict key set and shapes the reference's
+    constructor gives those kwargs (loaded with strict=True into the reference's own UITBase by make_golden.py --general), magnitudes
+    after make_trained_like_state_dict (matmul weights scaled with 1 / sqrt(fan-in) so that activations stay O(1..10) at any width).
+    Feeds the general engine (csrc/general.hip), the oracle and the reference alike."""
+    rng = np.random.default_rng(13000 + seed)
+    dim, P = embed_dim, patch_size
+    gt, gf, inner, hidden = target_length // P, n_mels // P, (dim if attention == "full" else dim // 4), int(dim * mlp_ratio)
+
+    def nrm(*shape, std=1.0, mean=0.0):
+        return (mean + std * rng.standard_normal(shape)).astype(np.float32)
+
+    def gain(n):
+        g = np.exp(rng.normal(0.0, 0.4, n)).astype(np.float32)
+        g[rng.integers(0, n, 2)] *= -1.0
+        return g
+
+    sd = {}
+    sd["cls_token"] = nrm(1, 1, dim, std=0.3)
+    sd["token_pos_embed"] = nrm(1, dim, std=0.3)
+    sd["time_pos_embed"] = nrm(1, dim, 1, gt, std=0.25, mean=1.0)
+    sd["freq_pos_embed"] = nrm(1, dim, gf, 1, std=0.25, mean=1.0)
+    sd["front_end.0.spectrogram.window"] = hann_periodic(win_size)
+    sd["front_end.0.mel_scale.fb"] = melscale_fbanks(n_fft // 2 + 1, f_min, f_max, n_mels, 16000)
+    tilt = np.linspace(-18.0, -48.0, n_mels)
+    sd["init_bn.1.weight"] = nrm(n_mels, std=0.25, mean=1.1)
+    sd["init_bn.1.bias"] = nrm(n_mels, std=0.3)
+    sd["init_bn.1.running_mean"] = (tilt + 3.0 * rng.standard_normal(n_mels)).astype(np.float32)
+    sd["init_bn.1.running_var"] = (120.0 + 400.0 * rng.random(n_mels)).astype(np.float32)
+    sd["init_bn.1.num_batches_tracked"] = np.array(250000, dtype=np.int64)
+    sd["patch_embed.proj.weight"] = nrm(dim, 1, P, P, std=0.8 / P)
+    sd["patch_embed.proj.bias"] = nrm(dim, std=0.3, mean=0.5)
+    for b in range(depth):
+        p = f"blocks.{b}."
+        sd[p + "norm1.weight"] = gain(dim)
+        sd[p + "norm1.bias"] = nrm(dim, std=0.3)
+        sd[p + "attn.qkv.weight"] = nrm(3 * inner, dim, std=0.9 / math.sqrt(dim))
+        sd[p + "attn.qkv.bias"] = nrm(3 * inner, std=0.3)
+        sd[p + "attn.proj.weight"] = nrm(dim, inner, std=0.5 / math.sqrt(inner))
+        sd[p + "attn.proj.bias"] = nrm(dim, std=0.2, mean=0.1)
+        sd[p + "norm2.weight"] = gain(dim)
+        sd[p + "norm2.bias"] = nrm(dim, std=0.3)
+        sd[p + "mlp.fc1.weight"] = nrm(hidden, dim, std=0.8 / math.sqrt(dim))
+        sd[p + "mlp.fc1.bias"] = nrm(hidden, std=0.3, mean=-0.2)
+        sd[p + "mlp.fc2.weight"] = nrm(dim, hidden, std=1.2 / math.sqrt(hidden))
+        sd[p + "mlp.fc2.bias"] = nrm(dim, std=0.2, mean=0.1)
+    sd["norm.weight"] = gain(dim)
+    sd["norm.bias"] = nrm(dim, std=0.3)
+    sd["outputlayer.0.weight"] = gain(dim)
+    sd["outputlayer.0.bias"] = nrm(dim, std=0.3)
+    sd["outputlayer.1.weight"] = nrm(outputdim, dim, std=1.1 / math.sqrt(dim))
+    sd["outputlayer.1.bias"] = nrm(outputdim, std=2.0, mean=-3.0)
+    return sd
+
+
 def make_kwargs_variant_state_dict(name="uit_xxxs", seed=0, scale=2.0, outputdim=537):
     """Checkpoint of a model built with the OTHER kwargs of UITBase (models/uit.py:253-293, Block :206-243): qkv_bias=False (no
     attn.qkv.bias keys), init_values=<x> (LayerScale: blocks.N.ls1.gamma / ls2.gamma, gains 0.2..1.2) and init_bn=False (no init_bn
