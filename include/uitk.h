@@ -326,7 +326,7 @@ int uitk_kws_transform(float* y_pred, const float* y, int64_t B, int32_t C, int3
  * use uitk_weights with the shapes the config implies: pe_w [embed, 1, P, P], time_pos [1, embed, 1, target_length / P],
  * freq_pos [1, embed, n_mels / P, 1], qkv_w [3 inner, embed] (inner = embed, or embed / 4 for BNeckAttention), proj_w [embed, inner],
  * fc1_w [mlp_hidden, embed], fc2_w [embed, mlp_hidden], head_w [outputdim, embed], mel_fb [n_fft / 2 + 1, n_mels], window [win_size].
- * Limits: n_fft even, 16..4096 (a power of two runs an FFT, any other value the DFT sum in double); patch_size a multiple of 4;
+ * Limits: n_fft even, 16..4096 (a power of two runs an FFT; any other value, up to 2048, the DFT sum in double); patch_size a multiple of 4;
  * embed_dim, mlp_hidden and the attention's inner width multiples of 16.
  * Same calling rules as the uitk_model functions: one handle per device, enqueue-only on `stream` once the workspace is reserved,
  * uitk_general_frontend / uitk_general_encode are the two stages of uitk_general_forward (the batch amax -- uitk_general_amax_ptr,

@@ -25,7 +25,14 @@ GENERAL_CASES = {
         kwargs=dict(outputdim=40, patch_size=16, patch_stride=16, embed_dim=128, depth=1, num_heads=4, mlp_ratio=4.0, pooling="token",
                     target_length=256, n_mels=64, f_min=50, f_max=7600, hop_size=128, win_size=400),
         act="gelu", attention="full", seed=4, clips=[(2, 30000), (2, 40000)]),
+    # UITBase() as the reference's constructor builds it when NOTHING but the class count is given (models/uit.py:253-275): 768 wide, 12
+    # blocks, 12 heads, MLP x 4, full attention, GELU, cls token, target_length 1012 -- 85.7 M parameters, 4 x 62 + 1 tokens on a 10 s clip
+    "default_uitbase": dict(
+        kwargs=dict(outputdim=527, patch_size=16, patch_stride=16, embed_dim=768, depth=12, num_heads=12, mlp_ratio=4.0, pooling="token",
+                    target_length=1012),
+        act="gelu", attention="full", seed=5, clips=[(1, 160000)]),
 }
+SMALL_CASES = [t for t in GENERAL_CASES if t != "default_uitbase"]      # (what the sanitizer run and the quick loops walk)
 
 
 def state_dict_args(case):

@@ -37,6 +37,18 @@ for name, att, act in (("uit_xxxs", "bneck", "relu"), ("audio_transformer_h128_d
         r = o.forward(synth_pcm_i16(3, T, seed=T), want_stages=True)
         assert np.isfinite(r["probs"]).all()
     o.melspec_db(synth_pcm_i16(2, 16001, seed=1).astype(np.float32) / 32768.0)
+# round 6: the general geometries (other n_fft -- 400 is no power of two: the radix-2 FFT once walked off its arrays there --, n_mels, patch
+# size, widths, heads, poolings), short clips, one and several crops
+from general_cases import GENERAL_CASES, SMALL_CASES, state_dict_args
+from uit_mobile_amd.synth import make_general_state_dict
+for tag in SMALL_CASES:
+    case = GENERAL_CASES[tag]
+    k = case["kwargs"]
+    o = O.Oracle(make_general_state_dict(**state_dict_args(case)), target_length=k["target_length"], eval_avg=k.get("eval_avg", "mean"),
+                 hop=k.get("hop_size", 160), heads=k["num_heads"], act=case["act"], pooling=k["pooling"], center=k.get("center", True))
+    for T in (6000, 16000, 40000):
+        r = o.forward(synth_pcm_i16(2, T, seed=T), want_stages=True)
+        assert np.isfinite(r["probs"]).all(), (tag, T)
 print("sanitizer run ok")
 """
     env = dict(os.environ, LD_PRELOAD=_libasan(), ASAN_OPTIONS="detect_leaks=0", OMP_NUM_THREADS="2")

@@ -369,6 +369,7 @@ static int gen_validate(const uitk_config* c, std::string* why) {
     auto bad = [&](const char* s) { *why = s; return UITK_ERR_UNSUPPORTED; };
     if (c->precision != UITK_PREC_F32) return bad("the general engine computes in fp32: precision must be UITK_PREC_F32");
     if (c->n_fft < 16 || c->n_fft > 4096 || (c->n_fft & 1)) return bad("general engine: n_fft must be even, 16..4096");
+    if ((c->n_fft & (c->n_fft - 1)) && c->n_fft > 2048) return bad("general engine: an n_fft that is no power of two must be <= 2048 (the DFT path keeps its twiddles in LDS)");
     if (c->win_size < 1 || c->win_size > c->n_fft) return bad("win_size must be 1..n_fft");
     if (c->hop_size < 1) return bad("hop_size must be positive");
     if (c->n_mels < 1 || c->n_mels > 512) return bad("general engine: n_mels must be 1..512");
