@@ -138,3 +138,48 @@ def test_fuzz_over_general_geometries_against_the_oracle():
     import fuzz_general
     rows, bad = fuzz_general.run(cases=40, seed=7, budget_s=45, verbose=False)
     assert len(rows) >= 15 and not bad, "\n".join(bad)
+
+
+def test_general_engine_from_plain_c(tmp_path):
+    """The general engine is C ABI too (include/uitk.h: uitk_general_*): a plain-C99 consumer (tests/native/cabi_general_consumer.c: gcc, no
+    C++, no Python, no torch) builds the 8 x 8-patch / 96-wide / 3-head / cls-token model from raw float arrays -- after seeing uitk_create
+    refuse that geometry by name -- and writes, bit for bit, what the Python wrapper returns for the same checkpoint and clips."""
+    import shutil
+    import subprocess
+    from pathlib import Path
+    if shutil.which("gcc") is None:
+        pytest.skip("no gcc on this box")
+    ROOT = Path(__file__).resolve().parents[1]
+    case = GENERAL_CASES["patch8_token"]
+    k = case["kwargs"]
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore", UitkSetupWarning)
+        m, sd = build(case)
+        pcm = synth_pcm_i16(3, 17000, seed=12)
+        with torch.no_grad():
+            x = torch.from_numpy(pcm).cuda()
+            want_p, want_mel = m(x).cpu().numpy(), m.melspec_db(x).cpu().numpy()
+    order = ["front_end.0.spectrogram.window", "front_end.0.mel_scale.fb", "init_bn.1.weight", "init_bn.1.bias", "init_bn.1.running_mean",
+             "init_bn.1.running_var", "patch_embed.proj.weight", "patch_embed.proj.bias", "time_pos_embed", "freq_pos_embed", "norm.weight",
+             "norm.bias", "outputlayer.0.weight", "outputlayer.0.bias", "outputlayer.1.weight", "outputlayer.1.bias", "cls_token", "token_pos_embed"]
+    for b in range(k["depth"]):
+        order += [f"blocks.{b}.{n}" for n in ("norm1.weight", "norm1.bias", "attn.qkv.weight", "attn.qkv.bias", "attn.proj.weight", "attn.proj.bias",
+                                              "norm2.weight", "norm2.bias", "mlp.fc1.weight", "mlp.fc1.bias", "mlp.fc2.weight", "mlp.fc2.bias")]
+    hdr = [k["depth"], k["embed_dim"], k["num_heads"], int(k["embed_dim"] * k["mlp_ratio"]), k["outputdim"], k["target_length"], 64, 512, 160, 512,
+           k["patch_size"], 1, 1, 1, 2, pcm.shape[0], pcm.shape[1]]
+    blob = tmp_path / "general.bin"
+    with open(blob, "wb") as f:
+        f.write(np.array(hdr, np.int32).tobytes())
+        for name in order:
+            f.write(np.ascontiguousarray(np.asarray(sd[name]), dtype=np.float32).tobytes())
+        f.write(np.ascontiguousarray(pcm).tobytes())
+    exe, lib = tmp_path / "cabi_general_consumer", ROOT / "uit_mobile_amd"
+    subprocess.run(["gcc", "-std=c99", "-Wall", "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include", f"-I{ROOT / 'include'}",
+                    str(ROOT / "tests" / "native" / "cabi_general_consumer.c"), "-o", str(exe), f"-L{lib}", "-luitk", "-L/opt/rocm/lib", "-lamdhip64",
+                    f"-Wl,-rpath,{lib}", "-Wl,-rpath,/opt/rocm/lib"], check=True)
+    r = subprocess.run([str(exe), str(blob), str(tmp_path / "out.bin")], capture_output=True, text=True, timeout=300)
+    print(r.stdout.strip(), r.stderr.strip())
+    assert r.returncode == 0 and "patch_size must be 16" in r.stdout or "embed_dim must be 128" in r.stdout, r.stdout + r.stderr
+    out = np.fromfile(tmp_path / "out.bin", np.float32)
+    n = want_p.size
+    assert np.array_equal(out[:n].reshape(want_p.shape), want_p) and np.array_equal(out[n:].reshape(want_mel.shape), want_mel)
