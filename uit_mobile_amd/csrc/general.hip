@@ -202,19 +202,32 @@ __global__ void __launch_bounds__(256) gen_layernorm_kernel(const float* __restr
 
 // softmax attention, thread = one query of one (clip-crop, head): scores (q . k) * scale, max, exp, sum, (p . v) / sum -- two passes over
 // the keys (the reference's order: softmax first, then @ v).  QKV[m][which * inner + h * hd + d] (models/uit.py:110-111 / 147-148).
-// Every thread of a workgroup walks the same keys: the k / v rows are broadcast loads.
-template <int HDP>
-__global__ void __launch_bounds__(64) gen_attention_kernel(const float* __restrict__ QKV, float* __restrict__ O, int ntok, int heads, int inner, int hd, float scale) {
-    const int row = blockIdx.x / heads, h = blockIdx.x % heads, t = blockIdx.y * 64 + threadIdx.x;
-    if (t >= ntok) return;
+// Every thread of a workgroup walks the same keys: the head's k and v rows are staged in LDS once per workgroup (STAGE; every read is
+// a broadcast) when they fit, else read from memory (broadcast loads).  The same arithmetic either way.
+template <int HDP, bool STAGE>
+__global__ void __launch_bounds__(256) gen_attention_kernel(const float* __restrict__ QKV, float* __restrict__ O, int ntok, int heads, int inner, int hd, float scale) {
+    extern __shared__ float kv[];                                          // STAGE: K [ntok][hd], then V [ntok][hd]
+    const int row = blockIdx.x / heads, h = blockIdx.x % heads, t = blockIdx.y * blockDim.x + threadIdx.x;
     const int lg = 3 * inner;
     const float* base = QKV + (int64_t)row * ntok * lg;
+    if constexpr (STAGE) {
+        for (int i = threadIdx.x; i < ntok * hd; i += blockDim.x) {
+            const int j = i / hd, d = i - j * hd;
+            kv[i] = base[(int64_t)j * lg + inner + h * hd + d];
+            kv[ntok * hd + i] = base[(int64_t)j * lg + 2 * inner + h * hd + d];
+        }
+        __syncthreads();
+    }
+    if (t >= ntok) return;
+    const int64_t kstride = STAGE ? hd : lg;
+    const float* kbase = STAGE ? kv : base + inner + h * hd;
+    const float* vbase = STAGE ? kv + ntok * hd : base + 2 * inner + h * hd;
     float q[HDP], acc[HDP];
 #pragma unroll
     for (int d = 0; d < HDP; ++d) { q[d] = d < hd ? base[(int64_t)t * lg + h * hd + d] : 0.f; acc[d] = 0.f; }
     float mx = -INFINITY;
     for (int j = 0; j < ntok; ++j) {
-        const float* k = base + (int64_t)j * lg + inner + h * hd;
+        const float* k = kbase + j * kstride;
         float s = 0.f;
 #pragma unroll
         for (int d = 0; d < HDP; ++d) if (d < hd) s = fmaf(q[d], k[d], s);
@@ -222,8 +235,8 @@ __global__ void __launch_bounds__(64) gen_attention_kernel(const float* __restri
     }
     float sum = 0.f;
     for (int j = 0; j < ntok; ++j) {
-        const float* k = base + (int64_t)j * lg + inner + h * hd;
-        const float* v = base + (int64_t)j * lg + 2 * inner + h * hd;
+        const float* k = kbase + j * kstride;
+        const float* v = vbase + j * kstride;
         float s = 0.f;
 #pragma unroll
         for (int d = 0; d < HDP; ++d) if (d < hd) s = fmaf(q[d], k[d], s);
@@ -420,7 +433,12 @@ static int gen_grow(float** p, size_t* cap, size_t bytes) {
 
 template <int HDP>
 static void gen_launch_attention(const float* QKV, float* O, int rows, const GenGeom& g, int ntok, float scale, hipStream_t s) {
-    hipLaunchKernelGGL((gen_attention_kernel<HDP>), dim3(rows * g.heads, (ntok + 63) / 64), dim3(64), 0, s, QKV, O, ntok, g.heads, g.inner, g.hd, scale);
+    // a workgroup = up to 256 queries of one (clip-crop, head): one staging of the head's keys and values serves all of them
+    const size_t lds = (size_t)2 * ntok * g.hd * 4;
+    const int threads = std::min(256, (ntok + 63) / 64 * 64);
+    const dim3 grid(rows * g.heads, (ntok + threads - 1) / threads);
+    if (lds <= 60 * 1024) hipLaunchKernelGGL((gen_attention_kernel<HDP, true>), grid, dim3(threads), lds, s, QKV, O, ntok, g.heads, g.inner, g.hd, scale);
+    else hipLaunchKernelGGL((gen_attention_kernel<HDP, false>), grid, dim3(threads), 0, s, QKV, O, ntok, g.heads, g.inner, g.hd, scale);
 }
 
 extern "C" {
