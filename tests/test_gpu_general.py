@@ -131,7 +131,7 @@ def test_general_engine_is_stream_ordered_after_prepare():
 def test_fuzz_over_general_geometries_against_the_oracle():
     """tools/fuzz_general.py, time-boxed: random embed_dim / heads / mlp_ratio / depth / attention / activation / pooling / patch size / n_mels /
     n_fft (powers of two and not) / win / hop / center / target_length / eval_avg / f_min / f_max, batch and clip length (short, full,
-    several crops) -- every case inside 1e-3 of the C oracle (profiles/round6/fuzz_general.log: 120 cases, worst 5.7e-4 on a pure tone)."""
+    several crops) -- every case inside 1e-3 of the C oracle (profiles/round6/fuzz_general.log: 120 cases, worst 4.7e-4 on a pure tone)."""
     import sys
     from pathlib import Path
     sys.path.insert(0, str(Path(__file__).resolve().parents[1] / "tools"))
