@@ -183,3 +183,51 @@ def test_general_engine_from_plain_c(tmp_path):
     out = np.fromfile(tmp_path / "out.bin", np.float32)
     n = want_p.size
     assert np.array_equal(out[:n].reshape(want_p.shape), want_p) and np.array_equal(out[n:].reshape(want_mel.shape), want_mel)
+
+
+def test_general_engine_and_the_f32_rung_agree_on_the_published_geometry():
+    """Two independent fp32 implementations of the same model on the device: the `f32` rung of the MFMA library (the product front-end
+    + the folded network of calibrate.hip) and the general engine (its own front-end, the reference's order of operations, nothing
+    folded) -- made to take the PUBLISHED geometry here, which the wrapper never does by itself -- and the C oracle: all three within
+    2e-4 on logits on noise clips (the full-scale tone: the FFT floor)."""
+    from oracle.oracle import Oracle
+    from uit_mobile_amd.synth import make_trained_like_state_dict
+    sd = make_trained_like_state_dict("uit_xxs", 204)
+    pcm = synth_pcm_i16(24, 16000, seed=31)
+    outs = {}
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        for engine in ("f32", "general"):
+            m = models.uit_xxs(outputdim=537, target_length=102, precision="f32")
+            m.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()}, strict=True)
+            m.general = engine == "general"
+            m = m.cuda().eval()
+            with torch.no_grad():
+                outs[engine] = m(torch.from_numpy(pcm).cuda(), return_logits=True)[1].cpu().numpy()
+            assert m.effective_precision() == "f32" and (m._handle_obj(torch.device("cuda", 0)).general == (engine == "general"))
+    ref = Oracle(sd).forward(pcm)["logits"]
+    tone = np.arange(24) % 8 == 1
+    d = {k: np.abs(a - b).reshape(24, -1).max(1) for k, (a, b) in {"general-oracle": (outs["general"], ref), "f32-oracle": (outs["f32"], ref),
+                                                                    "general-f32": (outs["general"], outs["f32"])}.items()}
+    print("published geometry, uit_xxs trained-like 204, 24 clips: " + ", ".join(f"{k} {v[~tone].max():.1e} (tones {v[tone].max():.1e})" for k, v in d.items()))
+    for k, v in d.items():
+        assert v[~tone].max() < 2e-4 and v.max() < 1e-3, (k, v)
+
+
+def test_general_engine_refuses_to_grow_its_workspace_inside_a_capture():
+    case = GENERAL_CASES["patch8_token"]
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore", UitkSetupWarning)
+        m, _ = build(case)
+        x = torch.from_numpy(synth_pcm_i16(2, 16000, seed=3)).cuda()
+        m._handle_obj(x.device)                                # the handle exists, the workspace does not
+        s = torch.cuda.Stream()
+        s.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s):
+            gr = torch.cuda.CUDAGraph()
+            with pytest.raises(RuntimeError, match="workspace has to grow"):
+                with torch.cuda.graph(gr, stream=s), torch.no_grad():
+                    m(x)
+        torch.cuda.synchronize()
+        with torch.no_grad():
+            assert torch.isfinite(m(x)).all()                  # outside a capture the same call allocates and runs

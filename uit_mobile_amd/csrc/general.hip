@@ -421,8 +421,12 @@ static size_t gen_row_floats(const GenGeom& g, int ntok) {
 }
 constexpr size_t GEN_WORK_BYTES = (size_t)3 << 30;                        // rows are processed in chunks that fit this
 
-static int gen_grow(float** p, size_t* cap, size_t bytes) {
+static int gen_grow(float** p, size_t* cap, size_t bytes, hipStream_t s) {
     if (bytes <= *cap) return UITK_OK;
+    hipStreamCaptureStatus capturing = hipStreamCaptureStatusNone;          // growing synchronises: never inside a stream capture
+    if (hipStreamIsCapturing(s, &capturing) != hipSuccess) (void)hipGetLastError();
+    else if (capturing != hipStreamCaptureStatusNone)
+        return set_error(UITK_ERR_WORKSPACE, "general engine: the workspace has to grow for this shape and the stream is being captured (uitk_general_reserve first)");
     GEN_HIP(hipDeviceSynchronize());                                       // (the device may still be reading the old buffer)
     if (*p) (void)hipFree(*p);
     *p = nullptr; *cap = 0;
@@ -540,22 +544,24 @@ int uitk_general_num_frames(const uitk_general* m, int64_t T) { return m ? gen_n
 int uitk_general_num_crops(const uitk_general* m, int64_t T) { return m ? gen_num_crops(m, T) : -1; }
 float* uitk_general_amax_ptr(uitk_general* m) { return m ? m->amax : nullptr; }
 
-int uitk_general_reserve(uitk_general* m, int64_t B, int64_t T) {
+static int gen_reserve(uitk_general* m, int64_t B, int64_t T, hipStream_t s) {
     if (int rc = gen_check_shape(m, B, T)) return rc;
     const int nF = gen_num_frames(m, T), nc = gen_num_crops(m, T), nt = gen_time_patches(m, T);
     const int ntok = m->g.GF * nt + m->g.cls;
-    if (int rc = gen_grow(&m->frames, &m->frames_cap, (size_t)B * nF * m->g.M * 4)) return rc;
+    if (int rc = gen_grow(&m->frames, &m->frames_cap, (size_t)B * nF * m->g.M * 4, s)) return rc;
     const int64_t rows = B * nc;
     const size_t per_row = gen_row_floats(m->g, ntok) * 4;
     int64_t chunk = (int64_t)std::max<size_t>(1, GEN_WORK_BYTES / per_row);
     chunk = std::min<int64_t>(chunk, rows);
     chunk = std::min<int64_t>(chunk, (int64_t)65535 * 64 / ntok);          // the dense kernel's grid: 64 token rows per workgroup in gridDim.y
     if (chunk < 1) return set_error(UITK_ERR_UNSUPPORTED, "general engine: one clip-crop exceeds the work buffer");
-    if (int rc = gen_grow(&m->work, &m->work_cap, (size_t)chunk * per_row)) return rc;
+    if (int rc = gen_grow(&m->work, &m->work_cap, (size_t)chunk * per_row, s)) return rc;
     m->work_rows = (int64_t)(m->work_cap / per_row); m->work_ntok = ntok;
-    if (int rc = gen_grow(&m->rowprobs, &m->rowprobs_cap, nc > 1 ? (size_t)rows * m->g.C * 4 : 0)) return rc;
+    if (int rc = gen_grow(&m->rowprobs, &m->rowprobs_cap, nc > 1 ? (size_t)rows * m->g.C * 4 : 0, s)) return rc;
     return UITK_OK;
 }
+
+int uitk_general_reserve(uitk_general* m, int64_t B, int64_t T) { return gen_reserve(m, B, T, nullptr); }
 
 static int gen_run_frontend(uitk_general* m, const void* pcm, int in_dtype, int64_t B, int64_t T, hipStream_t s) {
     GenFrontArgs a{};
@@ -575,7 +581,7 @@ int uitk_general_frontend(uitk_general* m, const void* pcm, int in_dtype, int64_
     if (int rc = gen_check_shape(m, B, T)) return rc;
     if (!pcm) return set_error(UITK_ERR_INVALID_ARG, "null pcm");
     if (in_dtype != UITK_IN_F32 && in_dtype != UITK_IN_I16) return set_error(UITK_ERR_INVALID_ARG, "unknown in_dtype");
-    if (int rc = uitk_general_reserve(m, B, T)) return rc;
+    if (int rc = gen_reserve(m, B, T, (hipStream_t)stream)) return rc;
     if (int rc = gen_run_frontend(m, pcm, in_dtype, B, T, (hipStream_t)stream)) return rc;
     m->fe_B = B; m->fe_T = T;
     return UITK_OK;
