@@ -518,3 +518,32 @@ def test_general_geometry_builds_the_reference_key_set_and_names_its_engine():
     assert models.uit_xs().general                       # the constructor's own default target_length (1012 frames: 63 time patches) is a general geometry
     with pytest.raises(NotImplementedError, match="patch_stride"):
         UITBase(patch_size=16, patch_stride=8, embed_dim=128, depth=1, num_heads=2, target_length=102)
+
+
+def test_general_engine_validates_its_config_before_it_looks_for_a_device():
+    """uitk_general_create (no GPU here): a config it cannot run is refused with the limit it breaks; one it can run gets as far as the
+    device query (UITK_ERR_NO_DEVICE on this box, or a handle on a GPU box: destroyed again)."""
+    L = _lib.load()
+    m = models.UITBase(embed_dim=96, depth=1, num_heads=3, mlp_ratio=2.0, patch_size=8, patch_stride=8, target_length=102, outputdim=10)
+    w, keep = m._host_weights()
+
+    def create(**over):
+        cfg = m._config()
+        for k, v in over.items():
+            setattr(cfg, k, v)
+        out = ctypes.c_void_p()
+        rc = L.uitk_general_create(ctypes.byref(cfg), ctypes.byref(w), ctypes.byref(out))
+        if rc == _lib.UITK_OK:
+            L.uitk_general_destroy(out)
+        return rc, _lib.last_error()
+
+    for over, why in ((dict(precision=_lib.PREC_F16), "precision must be UITK_PREC_F32"), (dict(n_fft=511), "n_fft must be even"), (dict(n_fft=3000), "no power of two must be <= 2048"),
+                      (dict(win_size=600), "win_size must be 1..n_fft"), (dict(patch_size=6), "multiple of 4"), (dict(embed_dim=100), "multiple of 16"),
+                      (dict(mlp_hidden=100), "multiple of 16"), (dict(num_heads=5), "divisible by num_heads"), (dict(pooling=3), "pooling must be"),
+                      (dict(n_mels=4), "smaller than one patch"), (dict(target_length=7), "smaller than one patch"), (dict(eval_avg=7), "unknown eval_avg")):
+        rc, msg = create(**over)
+        assert rc == _lib.ERR_UNSUPPORTED and why in msg, (over, rc, msg)
+    rc, msg = create()
+    assert rc in (_lib.UITK_OK, _lib.ERR_NO_DEVICE), (rc, msg)
+    assert L.uitk_general_create(None, None, None) == _lib.ERR_INVALID_ARG
+    assert L.uitk_general_num_frames(None, 16000) == -1 and L.uitk_general_destroy(None) == _lib.UITK_OK
