@@ -683,8 +683,11 @@ def main():
             sub = last_x[rows].cpu().numpy()
             ref = Oracle(sd).forward(sub)
             got = out[rows].float().cpu().numpy()
-            parity = {"max_abs_dprob": float(np.abs(got - ref["probs"]).max()), "rows": rows,
+            dev_rows = np.abs(got - ref["probs"]).max(1)
+            parity = {"max_abs_dprob": float(dev_rows.max()), "rows": rows,
                       "what": f"{len(rows)} rows of the last timed step's gathered output vs oracle/uit_oracle.c on the same clips"}
+            if parity["max_abs_dprob"] > 1e-3:             # say WHICH rows (a diagnosis, not a pass): row -> deviation
+                parity["rows_over_1e-3"] = {int(r): float(d) for r, d in zip(rows, dev_rows) if d > 1e-3}
         except Exception as e:                              # the check is reported, never silently skipped
             parity = {"max_abs_dprob": None, "error": str(e)[:200]}
     t = torch.tensor([el], device=dev, dtype=torch.float64)
