@@ -8,10 +8,11 @@
  * uit_mobile_amd/models/uit.py keeps that API and calls these entry points through ctypes; nothing else
  * does.  Each entry point names the reference interface it stands in for.
  *
- * Two engines behind one header: uitk_model (uitk_create ...) = the MFMA kernels, specialised to the geometry of the published
+ * Two engines behind one header.  Handles of type uitk_model: the MFMA kernels, specialised to the geometry of the published
  * factories (embed 128, 2 heads, MLP x 3, 64 mels, n_fft 512, 16 x 16 patches, six time patches) -- the fast path every BASELINE
- * config runs on; uitk_general (uitk_general_create ..., at the end of this file) = plain fp32 for every OTHER geometry the
- * reference's UITBase constructor admits.  uitk_create refuses what it is not built for by name (UITK_ERR_UNSUPPORTED).
+ * config runs on.  Handles of type uitk_general -- the uitk_general_* entry points at the end of this file -- plain fp32 for every
+ * OTHER geometry the reference's UITBase constructor admits.  uitk_create refuses what it is not built for by name
+ * (UITK_ERR_UNSUPPORTED).
  *
  * Conventions: plain pointers and sizes, int return codes (0 = ok, no exceptions across the boundary),
  * caller owns input/output device buffers, the model owns packed weights + workspace, every call is
