@@ -482,6 +482,7 @@ def main():
     ap.add_argument("--gather", default="auto", choices=["auto", "rccl", "peer"],
                     help="N>1: 'peer' = copy-engine fan-out into IPC-mapped peer buffers (no CU, all xGMI links at once), 'rccl' = "
                          "all_gather_into_tensor; 'auto' (default) = peer when its IPC self-check passes on every rank, else rccl")
+    ap.add_argument("--gloo-device-tensors", action="store_true", help=argparse.SUPPRESS)   # lab: the pre-hardening gloo path (tools/wd_repeat.sh)
     ap.add_argument("--gather-dtype", default="f32", choices=["f32", "f16"],
                     help="N>1: payload of the gather: fp32 probabilities (2 148 B per clip; default -- what the single-GPU path and the "
                          "reference deliver) or, opt-in, float16 (1 074 B per clip, ~2.4e-4 rounding on probabilities near 1)")
@@ -514,6 +515,9 @@ def main():
         raise SystemExit("bench.py needs a HIP device (there is no CPU path to benchmark)")
     if args.all_ranks_on_device0:
         local_rank = 0
+    if args.gloo_device_tensors:
+        import uit_mobile_amd.sharded as _sh
+        _sh._HOST_STAGED = False
     if world > 1:
         start_worker_watchdog(rank)
         phase("process_group", args.setup_timeout)          # one budget for the whole set-up, a second one from "warmup" on
@@ -688,6 +692,17 @@ def main():
                       "what": f"{len(rows)} rows of the last timed step's gathered output vs oracle/uit_oracle.c on the same clips"}
             if parity["max_abs_dprob"] > 1e-3:             # say WHICH rows (a diagnosis, not a pass): row -> deviation
                 parity["rows_over_1e-3"] = {int(r): float(d) for r, d in zip(rows, dev_rows) if d > 1e-3}
+                # ... and WHAT they hold: the same rows computed again, locally, from every input buffer -- a gathered row that matches
+                # another buffer's recomputation is another step's output (transport / ordering), one that matches none is a compute error
+                try:
+                    with torch.no_grad():
+                        again = [reps[0](xb).float().cpu().numpy()[rows] for xb in xs]
+                    last = (args.warmup + args.steps - 1) % nbuf_in
+                    parity["recomputed_last_vs_oracle"] = float(np.abs(again[last] - ref["probs"]).max())
+                    parity["gathered_vs_recomputed_buffer"] = {str(k): float(np.abs(got - a).max()) for k, a in enumerate(again)}
+                    parity["last_buffer"] = last
+                except Exception as e2:
+                    parity["recompute_error"] = str(e2)[:200]
         except Exception as e:                              # the check is reported, never silently skipped
             parity = {"max_abs_dprob": None, "error": str(e)[:200]}
     t = torch.tensor([el], device=dev, dtype=torch.float64)

@@ -17,6 +17,10 @@ import torch
 import torch.distributed as dist
 
 
+_HOST_STAGED = True      # collectives over a host-side backend are staged through the host by this module (False: bench.py's lab switch
+                         # --gloo-device-tensors, the path as it was before round 6's hardening -- tools/wd_repeat.sh)
+
+
 def shard_range(B, rank, world):
     """Contiguous, equal shards (the all-gather needs equal sizes): B must divide by world."""
     if B % world:
@@ -39,10 +43,10 @@ def amax_allreduce_async(slots, group=None):
     front-end on another replica) before amax_allreduce_finish."""
     work = None
     if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
-        if not _backend_is_device(group):
+        if _HOST_STAGED and not _backend_is_device(group):
             # host-side backend (gloo: several ranks on ONE GPU, tests only): staged through the host by this module, synchronously, in
-            # stream order -- not handed to gloo as device tensors (round 6: one run in ~14 of the 8-ranks-on-one-GPU scenario came back
-            # with another step's rows, never reproduced; the path now depends on nothing but `.cpu()` / `.copy_()` stream semantics)
+            # stream order -- not handed to gloo as device tensors (round 6: one run in ~45 of the 8-ranks-on-one-GPU scenario failed its
+            # parity check, never reproduced; the path now depends on nothing but `.cpu()` / `.copy_()` stream semantics)
             return amax_allreduce_host(slots, group), None
         work = dist.all_reduce(slots, op=dist.ReduceOp.MAX, group=group, async_op=True)
     return slots, work
@@ -60,7 +64,7 @@ def gather_outputs(local, group=None):
     """[B/R, C] on every rank -> [B, C] on every rank (rank order == row order)."""
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
         return local
-    if local.is_cuda and not _backend_is_device(group):
+    if _HOST_STAGED and local.is_cuda and not _backend_is_device(group):
         return gather_outputs_async(local, group).wait()       # host-side backend: staged through the host (see there)
     world = dist.get_world_size(group)
     out = torch.empty((world * local.shape[0],) + tuple(local.shape[1:]), device=local.device, dtype=local.dtype)
@@ -89,7 +93,7 @@ def gather_outputs_async(local, group=None):
         return GatherHandle(None, local, None)
     world = dist.get_world_size(group)
     local = local.contiguous()
-    if not _backend_is_device(group):
+    if _HOST_STAGED and not _backend_is_device(group):
         # host-side backend (gloo, tests only): `.cpu()` waits for the producing kernels, the collective runs on host tensors, the result
         # returns with a stream-ordered copy -- synchronous, and free of any assumption about a host backend's handling of device tensors
         h = local.detach().cpu()
