@@ -231,3 +231,63 @@ def test_general_engine_refuses_to_grow_its_workspace_inside_a_capture():
         torch.cuda.synchronize()
         with torch.no_grad():
             assert torch.isfinite(m(x)).all()                  # outside a capture the same call allocates and runs
+
+
+def _general_ranks_worker(rank, world, port, q):
+    import os
+    import torch.distributed as dist
+    from uit_mobile_amd.sharded import ShardedUiT
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            m, _ = build(GENERAL_CASES["patch8_token"])
+            pcm = _two_rank_pcm()
+            rows = pcm.shape[0] // world
+            outs = []
+            for gather in ("rccl", "peer"):
+                sh = ShardedUiT(m, gather=gather)
+                out = sh(torch.from_numpy(pcm[rank * rows:(rank + 1) * rows]).cuda())
+                torch.cuda.synchronize()
+                outs.append(out.cpu().numpy())
+        q.put((rank, outs))
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+def _two_rank_pcm():
+    pcm = synth_pcm_i16(8, 16000, seed=21)
+    pcm[[1, 5]] = pcm[[5, 1]]              # the loud tone (clip 1) into rank 1's shard, the clip with a silent tail (2) stays in rank 0's:
+    return pcm                             # rank 0's dB floor is decided on rank 1
+
+
+def test_general_engine_under_the_data_parallel_wrapper():
+    """SURVEY 8e for a general geometry: two ranks sharing the GPU (gloo; the collectives staged through the host), batch shards, the MAX
+    all-reduce of the general engine's amax slots between its two stages, the gather ('rccl' path and the copy-engine PeerGather) --
+    every rank holds the whole batch's output, bit for bit the single-rank result, although rank 0's top_db floor is set by a clip
+    that only rank 1 sees."""
+    import os
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29400 + os.getpid() % 400
+    procs = [ctx.Process(target=_general_ranks_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=300) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        m, _ = build(GENERAL_CASES["patch8_token"])
+        pcm = _two_rank_pcm()
+        with torch.no_grad():
+            single = m(torch.from_numpy(pcm).cuda()).cpu().numpy()
+            alone = m(torch.from_numpy(pcm[:4]).cuda()).cpu().numpy()      # rank 0's shard WITHOUT the other shard's amax
+    assert np.abs(alone - single[:4]).max() > 1e-4                          # (the floor does matter in this batch)
+    for r in range(2):
+        for out in res[r]:
+            assert out.shape == single.shape and np.array_equal(out, single), r
