@@ -23,6 +23,7 @@ CASES = [  # (name, UITBase kwargs, batch, samples)
                                                    target_length=102, patch_size=8, patch_stride=8, outputdim=537), 2048, 16000),
     ("embed 192, 3 heads, MLP x 4, depth 12, full attention, GELU, cls token (25 tokens)", dict(embed_dim=192, depth=12, num_heads=3, mlp_ratio=4.0, pooling="token", target_length=102,
                                                                                                   outputdim=527), 4096, 16000),
+    ("UITBase() with the constructor's own defaults: 768 wide, 12 blocks, 12 heads, MLP x 4, 85.7 M parameters, 10 s clips (249 tokens)", dict(outputdim=527), 64, 160000),
     ("n_fft 400 / hop 160 (DFT path), otherwise uit_xs", dict(embed_dim=128, depth=12, num_heads=2, mlp_ratio=3.0, pooling="mean", attention_type="BNeckAttention", act_layer=nn.ReLU,
                                                               target_length=102, n_fft=400, win_size=400, outputdim=537), 4096, 16000),
 ]
