@@ -291,3 +291,21 @@ def test_general_engine_under_the_data_parallel_wrapper():
     for r in range(2):
         for out in res[r]:
             assert out.shape == single.shape and np.array_equal(out, single), r
+
+
+def test_the_wide_layer_tile_gives_the_same_bits():
+    """Wide models (K >= 512, O >= 256) run their dense layers on a 128 x 128 tile once a call has 8192 tokens (calibrate.hip); every
+    output is the same sum of the same products in the same order as on the 64 x 64 tile: the constructor's default UITBase on one 10 s
+    clip (249 tokens: the small tile) and on the same clip 34 times over (8466 tokens: the large one) -- bit for bit, and the fixture of
+    the imported reference still holds."""
+    case = GENERAL_CASES["default_uitbase"]
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore", UitkSetupWarning)
+        m, _ = build(case)
+        pcm = synth_pcm_i16(1, 160000, seed=19)
+        one = torch.from_numpy(pcm).cuda()
+        many = torch.from_numpy(np.repeat(pcm, 34, 0)).cuda()
+        with torch.no_grad():
+            a = m(one, return_logits=True)[1]
+            b = m(many, return_logits=True)[1]
+    assert torch.equal(a.expand_as(b), b)

@@ -21,6 +21,9 @@ if which == "f32":
     m = models.uit_xs(outputdim=537, target_length=102, precision="f32")
     m.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in make_state_dict("uit_xs", 3).items()})
     B, T = 8192, 16000
+elif which == "default":
+    m = models.UITBase(outputdim=527)                  # the constructor's own defaults: 768 wide, 12 blocks, 12 heads, 85.7 M parameters
+    B, T = 64, 160000
 else:
     m = models.UITBase(embed_dim=128, depth=12, num_heads=2, mlp_ratio=3.0, pooling="mean", attention_type="BNeckAttention", act_layer=nn.ReLU,
                        target_length=102, n_mels=128, n_fft=1024, win_size=1024, outputdim=537)

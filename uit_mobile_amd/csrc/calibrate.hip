@@ -163,6 +163,79 @@ __global__ void __launch_bounds__(256) naive_linear_mfma_kernel(const float* __r
     }
 }
 
+// The same linear on 128 x 128 outputs per workgroup, for WIDE layers only (K >= 512 and O >= 256 at M >= 8192: the general engine on
+// models several hundred wide, e.g. the reference's default UITBase, 768 / 3072): twice the FLOP per byte moved from L2 into LDS.  On the
+// 128-wide layers of the published geometry it LOSES (measured: `f32` rung 826 k -> 719 k clips/s -- three workgroups per CU instead of
+// eight, a padded 96-wide qkv, tails), so they never take it.  Wave w owns rows 32 w .. 32 w + 31 (two row tiles) and all eight 16-wide
+// column tiles.  LDS tiles [row][k] with a row's 16 k of a stage at position 4 (k % 4) + k / 4 (pitch 20 floats): a lane finds its
+// operands of all four k-steps, k = 4 ks + lq, in one 16-byte read; conflict-free.  Every output is the same sum of the same products in
+// the same order as in the 64 x 64 kernel: BIT-IDENTICAL (which tile runs never changes a result; tests/test_gpu_general.py).
+constexpr int BT = 128;
+__global__ void __launch_bounds__(256) naive_linear_mfma_big_kernel(const float* __restrict__ X, const float* __restrict__ W, const float* __restrict__ bias,
+                                                                    float* __restrict__ Y, int M, int K, int O, int act, int accumulate) {
+    constexpr int KP = TS + 4;
+    __shared__ __attribute__((aligned(16))) float xs[2][BT][KP], ws[2][BT][KP];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, lr = lane & 15, lq = lane >> 4;
+    const int m0 = blockIdx.y * BT, o0 = blockIdx.x * BT;
+    const int lrow = tid >> 2, c = tid & 3;                                // this thread's two rows of a tile (lrow, lrow + 64) and its four k of a stage
+    const f4m zero4 = {0.f, 0.f, 0.f, 0.f};
+    f4m xv[2], wv[2];
+    auto fetch = [&](int k0) {
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            const int row = lrow + 64 * r;
+            xv[r] = m0 + row < M ? *(const f4m*)(X + (int64_t)(m0 + row) * K + k0 + 4 * c) : zero4;
+            wv[r] = o0 + row < O ? *(const f4m*)(W + (int64_t)(o0 + row) * K + k0 + 4 * c) : zero4;
+        }
+    };
+    auto stash = [&](int buf) {
+#pragma unroll
+        for (int r = 0; r < 2; ++r)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { xs[buf][lrow + 64 * r][4 * j + c] = xv[r][j]; ws[buf][lrow + 64 * r][4 * j + c] = wv[r][j]; }
+    };
+    f4m acc[2][8] = {};
+    fetch(0);
+    stash(0);
+    __syncthreads();
+    const int nst = K / TS;
+    for (int st = 0; st < nst; ++st) {
+        const int buf = st & 1;
+        if (st + 1 < nst) fetch((st + 1) * TS);
+        f4m a[2], b[8];
+#pragma unroll
+        for (int rt = 0; rt < 2; ++rt) a[rt] = *(const f4m*)&xs[buf][32 * wave + 16 * rt + lr][4 * lq];
+#pragma unroll
+        for (int ot = 0; ot < 8; ++ot) b[ot] = *(const f4m*)&ws[buf][16 * ot + lr][4 * lq];
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+            for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+                for (int ot = 0; ot < 8; ++ot) acc[rt][ot] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[rt][ks], b[ot][ks], acc[rt][ot], 0, 0, 0);
+        if (st + 1 < nst) stash(buf ^ 1);
+        __syncthreads();
+    }
+#pragma unroll
+    for (int ot = 0; ot < 8; ++ot) {
+        const int o = o0 + 16 * ot + lr;
+        if (o >= O) continue;
+        const float bo = bias ? bias[o] : 0.f;
+#pragma unroll
+        for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int m = m0 + 32 * wave + 16 * rt + 4 * lq + r;
+                if (m >= M) continue;
+                float v = acc[rt][ot][r] + bo;
+                if (act == 1) v = fmaxf(v, 0.f);
+                else if (act == 2) v = 0.5f * v * (1.0f + erff(v * 0.70710678118654752f));
+                float* y = Y + (int64_t)m * O + o;
+                *y = accumulate ? *y + v : v;
+            }
+    }
+}
+
 // Xn[m][:] = (R[m][:] - mean) / sqrt(var + eps): one wave per token, two elements per lane (the affine lives in the next linear)
 __global__ void cal_layernorm_kernel(const float* __restrict__ R, float* __restrict__ Xn, int M, float eps) {
     const int m = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6), lane = threadIdx.x & 63;
@@ -247,6 +320,10 @@ __global__ void cal_colmean_kernel(const float* __restrict__ X, float* __restric
 }
 
 static hipError_t linear(const float* X, const float* W, const float* b, float* Y, int M, int K, int O, int act, int accumulate, hipStream_t s) {
+    if (M >= 8192 && K >= 512 && O >= 256) {                                 // wide layers (a speed choice only: both kernels give the same bits)
+        hipLaunchKernelGGL(naive_linear_mfma_big_kernel, dim3((O + BT - 1) / BT, (M + BT - 1) / BT), dim3(256), 0, s, X, W, b, Y, M, K, O, act, accumulate);
+        return hipGetLastError();
+    }
     hipLaunchKernelGGL(naive_linear_mfma_kernel, dim3((O + LT - 1) / LT, (M + LT - 1) / LT), dim3(256), 0, s, X, W, b, Y, M, K, O, act, accumulate);
     return hipGetLastError();
 }

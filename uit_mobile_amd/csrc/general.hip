@@ -202,49 +202,85 @@ __global__ void __launch_bounds__(256) gen_layernorm_kernel(const float* __restr
 
 // softmax attention, thread = one query of one (clip-crop, head): scores (q . k) * scale, max, exp, sum, (p . v) / sum -- two passes over
 // the keys (the reference's order: softmax first, then @ v).  QKV[m][which * inner + h * hd + d] (models/uit.py:110-111 / 147-148).
-// Every thread of a workgroup walks the same keys: the head's k and v rows are staged in LDS once per workgroup (STAGE; every read is
-// a broadcast) when they fit, else read from memory (broadcast loads).  The same arithmetic either way.
-template <int HDP, bool STAGE>
-__global__ void __launch_bounds__(256) gen_attention_kernel(const float* __restrict__ QKV, float* __restrict__ O, int ntok, int heads, int inner, int hd, float scale) {
-    extern __shared__ float kv[];                                          // STAGE: K [ntok][hd], then V [ntok][hd]
-    const int row = blockIdx.x / heads, h = blockIdx.x % heads, t = blockIdx.y * blockDim.x + threadIdx.x;
-    const int lg = 3 * inner;
-    const float* base = QKV + (int64_t)row * ntok * lg;
-    if constexpr (STAGE) {
-        for (int i = threadIdx.x; i < ntok * hd; i += blockDim.x) {
-            const int j = i / hd, d = i - j * hd;
-            kv[i] = base[(int64_t)j * lg + inner + h * hd + d];
-            kv[ntok * hd + i] = base[(int64_t)j * lg + 2 * inner + h * hd + d];
-        }
-        __syncthreads();
+// A workgroup = up to 256 queries of one (clip-crop, head); every thread walks the same keys, so the head's k and v rows are staged in
+// LDS in chunks of CH keys (all of them at once when they fit: one staging serves both passes) and every read is a broadcast.
+// VEC (head widths that are multiples of 4): the staged rows are read 16 bytes at a time -- the kernel is bound by LDS instructions
+// (one broadcast read per multiply-add otherwise); the products are summed in the same order either way.
+typedef float gen_f4 __attribute__((ext_vector_type(4)));
+template <int HDP, bool VEC>
+__device__ __forceinline__ float gen_dot(const float (&q)[HDP], const float* k, int hd) {
+    float s = 0.f;
+    if constexpr (VEC) {
+#pragma unroll
+        for (int d4 = 0; d4 < HDP / 4; ++d4)
+            if (4 * d4 < hd) {
+                const gen_f4 kk = ((const gen_f4*)k)[d4];
+                s = fmaf(q[4 * d4], kk[0], s); s = fmaf(q[4 * d4 + 1], kk[1], s); s = fmaf(q[4 * d4 + 2], kk[2], s); s = fmaf(q[4 * d4 + 3], kk[3], s);
+            }
+    } else {
+#pragma unroll
+        for (int d = 0; d < HDP; ++d) if (d < hd) s = fmaf(q[d], k[d], s);
     }
-    if (t >= ntok) return;
-    const int64_t kstride = STAGE ? hd : lg;
-    const float* kbase = STAGE ? kv : base + inner + h * hd;
-    const float* vbase = STAGE ? kv + ntok * hd : base + 2 * inner + h * hd;
+    return s;
+}
+template <int HDP, bool VEC>
+__global__ void __launch_bounds__(256) gen_attention_kernel(const float* __restrict__ QKV, float* __restrict__ O, int ntok, int heads, int inner, int hd, float scale, int CH) {
+    extern __shared__ __attribute__((aligned(16))) float kv[];             // K [CH][hd], then V [CH][hd]
+    const int row = blockIdx.x / heads, h = blockIdx.x % heads, t = blockIdx.y * blockDim.x + threadIdx.x;
+    const int lg = 3 * inner, nch = (ntok + CH - 1) / CH;
+    const float* base = QKV + (int64_t)row * ntok * lg;
+    const bool active = t < ntok;                                          // (idle lanes still stage and synchronise)
+    auto stage = [&](int j0, int n) {
+        for (int i = threadIdx.x; i < n * hd; i += blockDim.x) {
+            const int j = i / hd, d = i - j * hd;
+            kv[i] = base[(int64_t)(j0 + j) * lg + inner + h * hd + d];
+            kv[CH * hd + i] = base[(int64_t)(j0 + j) * lg + 2 * inner + h * hd + d];
+        }
+    };
     float q[HDP], acc[HDP];
 #pragma unroll
-    for (int d = 0; d < HDP; ++d) { q[d] = d < hd ? base[(int64_t)t * lg + h * hd + d] : 0.f; acc[d] = 0.f; }
+    for (int d = 0; d < HDP; ++d) { q[d] = active && d < hd ? base[(int64_t)t * lg + h * hd + d] : 0.f; acc[d] = 0.f; }
     float mx = -INFINITY;
-    for (int j = 0; j < ntok; ++j) {
-        const float* k = kbase + j * kstride;
-        float s = 0.f;
-#pragma unroll
-        for (int d = 0; d < HDP; ++d) if (d < hd) s = fmaf(q[d], k[d], s);
-        mx = fmaxf(mx, s * scale);
+    for (int c = 0; c < nch; ++c) {
+        const int j0 = c * CH, n = min(CH, ntok - j0);
+        __syncthreads();
+        stage(j0, n);
+        __syncthreads();
+        if (active)
+            for (int j = 0; j < n; ++j) {
+                const float s = gen_dot<HDP, VEC>(q, kv + j * hd, hd);
+                mx = fmaxf(mx, s * scale);
+            }
     }
     float sum = 0.f;
-    for (int j = 0; j < ntok; ++j) {
-        const float* k = kbase + j * kstride;
-        const float* v = vbase + j * kstride;
-        float s = 0.f;
+    for (int c = 0; c < nch; ++c) {
+        const int j0 = c * CH, n = min(CH, ntok - j0);
+        if (nch > 1) {                                                     // (a single chunk is still there from the first pass)
+            __syncthreads();
+            stage(j0, n);
+            __syncthreads();
+        }
+        if (active)
+            for (int j = 0; j < n; ++j) {
+                const float* v = kv + CH * hd + j * hd;
+                const float s = gen_dot<HDP, VEC>(q, kv + j * hd, hd);
+                const float p = expf(s * scale - mx);
+                sum += p;
+                if constexpr (VEC) {
 #pragma unroll
-        for (int d = 0; d < HDP; ++d) if (d < hd) s = fmaf(q[d], k[d], s);
-        const float p = expf(s * scale - mx);
-        sum += p;
+                    for (int d4 = 0; d4 < HDP / 4; ++d4)
+                        if (4 * d4 < hd) {
+                            const gen_f4 vv = ((const gen_f4*)v)[d4];
 #pragma unroll
-        for (int d = 0; d < HDP; ++d) if (d < hd) acc[d] = fmaf(p, v[d], acc[d]);
+                            for (int e = 0; e < 4; ++e) acc[4 * d4 + e] = fmaf(p, vv[e], acc[4 * d4 + e]);
+                        }
+                } else {
+#pragma unroll
+                    for (int d = 0; d < HDP; ++d) if (d < hd) acc[d] = fmaf(p, v[d], acc[d]);
+                }
+            }
     }
+    if (!active) return;
     float* o = O + ((int64_t)row * ntok + t) * inner + h * hd;
 #pragma unroll
     for (int d = 0; d < HDP; ++d) if (d < hd) o[d] = acc[d] / sum;
@@ -437,12 +473,12 @@ static int gen_grow(float** p, size_t* cap, size_t bytes, hipStream_t s) {
 
 template <int HDP>
 static void gen_launch_attention(const float* QKV, float* O, int rows, const GenGeom& g, int ntok, float scale, hipStream_t s) {
-    // a workgroup = up to 256 queries of one (clip-crop, head): one staging of the head's keys and values serves all of them
-    const size_t lds = (size_t)2 * ntok * g.hd * 4;
+    // a workgroup = up to 256 queries of one (clip-crop, head); its keys and values pass through LDS in chunks of CH keys (<= 48 KiB)
+    const int CH = std::min(ntok, std::max(1, (48 * 1024) / (2 * g.hd * 4)));
     const int threads = std::min(256, (ntok + 63) / 64 * 64);
     const dim3 grid(rows * g.heads, (ntok + threads - 1) / threads);
-    if (lds <= 60 * 1024) hipLaunchKernelGGL((gen_attention_kernel<HDP, true>), grid, dim3(threads), lds, s, QKV, O, ntok, g.heads, g.inner, g.hd, scale);
-    else hipLaunchKernelGGL((gen_attention_kernel<HDP, false>), grid, dim3(threads), 0, s, QKV, O, ntok, g.heads, g.inner, g.hd, scale);
+    if (g.hd % 4 == 0) hipLaunchKernelGGL((gen_attention_kernel<HDP, true>), grid, dim3(threads), (size_t)2 * CH * g.hd * 4, s, QKV, O, ntok, g.heads, g.inner, g.hd, scale, CH);
+    else hipLaunchKernelGGL((gen_attention_kernel<HDP, false>), grid, dim3(threads), (size_t)2 * CH * g.hd * 4, s, QKV, O, ntok, g.heads, g.inner, g.hd, scale, CH);
 }
 
 extern "C" {
