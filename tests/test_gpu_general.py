@@ -308,4 +308,9 @@ def test_the_wide_layer_tile_gives_the_same_bits():
         with torch.no_grad():
             a = m(one, return_logits=True)[1]
             b = m(many, return_logits=True)[1]
+            # ... and 400 times over: 8 MB of work buffers per clip-crop of this model, so the engine walks the batch in TWO chunks (384 + 16
+            # rows of its 3 GiB workspace) -- the chunk loop's row offsets (crops, logits, probabilities)
+            c_probs, c = m(torch.from_numpy(np.repeat(pcm, 400, 0)).cuda(), return_logits=True)
+            a_probs = m(one)
     assert torch.equal(a.expand_as(b), b)
+    assert torch.equal(a.expand_as(c), c) and torch.equal(a_probs.expand_as(c_probs), c_probs)
